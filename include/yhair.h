@@ -1,0 +1,263 @@
+/*
+ * yhair.h — C ABI of the MI355X-native hair path-tracing sample loop.
+ *
+ * This is the drop-in boundary for the ONE hot path of dsforza96/yocto-hair:
+ *   trace_samples -> trace_sample -> trace_path -> {BVH traversal, ray-line /
+ *   ray-triangle intersection, hair BSDF eval / sample / pdf, light MIS}.
+ *
+ * The reference has no FFI layer. The narrowest seam it has is the
+ * yocto::pathtrace C++ API (libs/yocto_pathtrace/yocto_pathtrace.h:207-230:
+ * init_bvh, init_lights, init_state, trace_samples) and, one level down, the
+ * four yocto::extension functions (libs/yocto_extension/yocto_extension.h:
+ * 115-125). Every entry point below names the reference interface it replaces.
+ *
+ * Conventions: plain C types only, no exceptions cross the boundary. Every
+ * function returning int returns YH_OK (0) on success or a negative YH_E_*
+ * code; yh_last_error() gives the text. Host arrays passed in are borrowed for
+ * the duration of the call only. A context owns all of its device memory and
+ * is bound to ONE GPU (one process per GPU is the deployment model; image
+ * tiles are sharded across processes with yh_set_shard()).
+ *
+ * All vectors are packed floats; frames are 12 floats x,y,z,o column vectors
+ * exactly as yocto::math::frame3f (libs/yocto/yocto_math.h, frame3f).
+ */
+#ifndef YHAIR_H_
+#define YHAIR_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define YH_OK 0
+#define YH_E_INVALID -1     /* bad argument / unsupported scene feature      */
+#define YH_E_DEVICE -2      /* HIP runtime error (no GPU, launch failure...) */
+#define YH_E_STATE -3       /* call order violated (e.g. trace before init)  */
+#define YH_E_IO -4          /* file not found / parse error                  */
+#define YH_E_SELFTEST -5    /* a Monte-Carlo self-test left its tolerance    */
+
+/* ------------------------------------------------------------------------ */
+/* Scene description (geometry level, no acceleration data).                 */
+/* Mirrors the subset of yocto::pathtrace scene structs reachable from the   */
+/* hair path (yocto_pathtrace.h:272-387).                                    */
+/* ------------------------------------------------------------------------ */
+
+/* ptr::shape (yocto_pathtrace.h:335-366). Exactly one of lines / triangles
+ * is non-empty. For line shapes `normals` holds the hair TANGENTS
+ * (yocto_pbrt.h:1782-1787) and `radius` must be given.                      */
+typedef struct yh_shape {
+  int          num_vertices;
+  const float* positions; /* 3 * num_vertices                              */
+  const float* normals;   /* 3 * num_vertices, or NULL                     */
+  const float* radius;    /* num_vertices, or NULL (triangles)             */
+  int          num_lines;
+  const int*   lines;     /* 2 * num_lines                                 */
+  int          num_triangles;
+  const int*   triangles; /* 3 * num_triangles                             */
+} yh_shape;
+
+/* ptr::material (yocto_pathtrace.h:293-329), restricted to the lobes the hair
+ * configs reach: emission, diffuse colour and the hair parameters
+ * (yocto_extension.h:86-95). Any other lobe (specular, metallic, transmission,
+ * opacity < 1, textures) is rejected by yh_upload_scene with YH_E_INVALID.  */
+typedef struct yh_material {
+  float emission[3];
+  float color[3];
+  float specular, metallic, roughness, transmission, opacity, ior;
+  int   thin;
+  float sigma_a[3];
+  float beta_m, beta_n, alpha, eta, eumelanin, pheomelanin;
+} yh_material;
+
+/* ptr::object (yocto_pathtrace.h:369-373) */
+typedef struct yh_object {
+  float frame[12];
+  int   shape;
+  int   material;
+} yh_object;
+
+/* ptr::environment (yocto_pathtrace.h:376-380); texels = linear float RGB,
+ * row-major, top row first, or NULL for a constant environment.             */
+typedef struct yh_environment {
+  float        frame[12];
+  float        emission[3];
+  int          tex_width, tex_height;
+  const float* texels;
+} yh_environment;
+
+/* ptr::camera (yocto_pathtrace.h:272-278) */
+typedef struct yh_camera {
+  float frame[12];
+  float lens;
+  float film[2];
+  float focus;
+  float aperture;
+} yh_camera;
+
+typedef struct yh_scene_desc {
+  int                   num_shapes;
+  const yh_shape*       shapes;
+  int                   num_materials;
+  const yh_material*    materials;
+  int                   num_objects;
+  const yh_object*      objects;      /* in reference order (alphabetical)  */
+  int                   num_environments;
+  const yh_environment* environments;
+  yh_camera             camera;
+} yh_scene_desc;
+
+/* trace_params (yocto_pathtrace.h:188-197); shader is always `path`.        */
+typedef struct yh_trace_params {
+  int      resolution; /* 720                                               */
+  int      bounces;    /* 8                                                 */
+  float    clamp;      /* 100                                               */
+  uint64_t seed;       /* 961748941                                         */
+} yh_trace_params;
+
+/* Per-sample work counters of the reference algorithm: what
+ * the roofline's algorithmic-bytes figure is built from.                    */
+typedef struct yh_workcounts {
+  uint64_t samples;
+  uint64_t rays;       /* scene-level intersect calls                       */
+  uint64_t nodes;      /* bvh_node visits: scene + shape + instance BVHs    */
+  uint64_t seg_tests;  /* intersect_line calls                              */
+  uint64_t tri_tests;  /* intersect_triangle calls                          */
+  uint64_t hair_shades;
+  uint64_t surf_shades;
+  uint64_t env_lookups;
+  uint64_t env_samples;
+} yh_workcounts;
+
+typedef struct yh_context yh_context;
+
+/* ------------------------------------------------------------------------ */
+/* Context                                                                    */
+/* ------------------------------------------------------------------------ */
+
+/* Creates a context on HIP device `device`. Returns NULL when no usable GPU
+ * or the HIP code object is missing: there is NO CPU fallback.              */
+yh_context* yh_create(int device);
+void        yh_destroy(yh_context* ctx);
+/* Text of the last error on this context (or of the failed yh_create when
+ * ctx == NULL). Never NULL.                                                 */
+const char* yh_last_error(const yh_context* ctx);
+/* Library version string and the code-object architecture it was built for. */
+const char* yh_version(void);
+
+/* ------------------------------------------------------------------------ */
+/* Whole-path API: replaces yocto::pathtrace                                  */
+/* ------------------------------------------------------------------------ */
+
+/* init_bvh + init_lights (yocto_pathtrace.cpp:755-818, 1695-1740): builds the
+ * two-level BVH (reference-identical binary middle-split tree, so that
+ * closest-hit results, including exact-t ties, match the reference), the
+ * area-light triangle CDFs and the environment texel CDF, precomputes inverse
+ * object frames and per-material hair constants, and uploads everything.     */
+int yh_upload_scene(yh_context* ctx, const yh_scene_desc* scene);
+
+/* init_state (yocto_pathtrace.cpp:1931-1946): image size from the camera film
+ * and params->resolution, zeroed accumulators, per-pixel PCG32 streams
+ * make_rng(seed, rand1i(master, 1<<31)/2+1) with master = make_rng(1301081). */
+int yh_init_state(yh_context* ctx, const yh_trace_params* params);
+int yh_image_size(const yh_context* ctx, int* width, int* height);
+
+/* Tile sharding for one-process-per-GPU rendering: this
+ * context renders only the 8x8-pixel tiles with tile_id % world == rank.
+ * Pixel results do not depend on (rank, world). Call before yh_init_state.   */
+int yh_set_shard(yh_context* ctx, int rank, int world);
+
+/* trace_samples called `nsamples` times (yocto_pathtrace.cpp:1992-2007, call
+ * site apps/yscenetrace/yscenetrace.cpp:256-258): adds nsamples samples to
+ * every owned pixel. Blocking.                                               */
+int yh_trace_samples(yh_context* ctx, int nsamples);
+/* Same, but only enqueues the work on the context's stream.                  */
+int yh_trace_samples_async(yh_context* ctx, int nsamples);
+int yh_synchronize(yh_context* ctx);
+
+/* state->render (yocto_pathtrace.h:426-429): accumulated / samples, float4
+ * per pixel, row-major top row first. Non-owned pixels are 0.                */
+int yh_download(yh_context* ctx, float* rgba);
+/* Packs the owned tiles' float4 pixels into a DEVICE buffer (the payload of
+ * the RCCL gather). `capacity` in float4 pixels; *count receives the number
+ * written. Tiles are in increasing tile_id order, 64 pixels per tile.        */
+int yh_pack_tiles_device(yh_context* ctx, void* device_rgba, int64_t capacity,
+    int64_t* count);
+/* Inverse on the gathering rank: scatters rank `src_rank`'s packed tiles into
+ * a full W*H float4 DEVICE image.                                            */
+int yh_unpack_tiles_device(yh_context* ctx, const void* device_packed,
+    int src_rank, int world, void* device_image);
+/* Number of float4 pixels yh_pack_tiles_device writes for (rank, world).     */
+int64_t yh_shard_pixels(const yh_context* ctx, int rank, int world);
+
+/* Per-pixel state (yocto_pathtrace.h:419-423) for checkpoint / parity tests:
+ * rng state words (2 x u64 per pixel) and sample count.                      */
+int yh_download_rng(yh_context* ctx, uint64_t* state_inc);
+
+/* Work counters of the launches since the last reset (instrumented build of
+ * the same kernel; 0 = ok).                                                  */
+int yh_trace_samples_counted(yh_context* ctx, int nsamples, yh_workcounts* out);
+
+/* HIP-event time in milliseconds of the most recent yh_trace_samples launch
+ * sequence on the context's own stream, and the number of kernel launches.   */
+int yh_last_trace_ms(const yh_context* ctx, float* ms, int* launches);
+
+/* ------------------------------------------------------------------------ */
+/* Unit-level API: replaces yocto::extension and the intersect_* functions    */
+/* (batched, host arrays in / host arrays out; device does the arithmetic)    */
+/* ------------------------------------------------------------------------ */
+
+/* hair_brdf as 30 floats: sigma_a[3] alpha eta h v[4] s sin_2k_alpha[3]
+ * cos_2k_alpha[3] gamma_o world_to_brdf[12]  (yocto_extension.h:97-113)      */
+#define YH_HAIR_BRDF_FLOATS 30
+
+/* eval_hair_brdf (yocto_extension.cpp:127-177). materials: n x yh_material
+ * (only hair fields read); v: n; normal, tangent: 3n; out: 30n.              */
+int yh_hair_brdf_batch(yh_context* ctx, int n, const yh_material* materials,
+    const float* v, const float* normal, const float* tangent, float* brdf);
+/* eval_hair_scattering (yocto_extension.cpp:255-336): out 3n.                */
+int yh_hair_eval_batch(yh_context* ctx, int n, const float* brdf,
+    const float* outgoing, const float* incoming, float* f);
+/* sample_hair_scattering (yocto_extension.cpp:399-479): rn 2n -> incoming 3n */
+int yh_hair_sample_batch(yh_context* ctx, int n, const float* brdf,
+    const float* outgoing, const float* rn, float* incoming);
+/* sample_hair_scattering_pdf (yocto_extension.cpp:481-551): out n.           */
+int yh_hair_pdf_batch(yh_context* ctx, int n, const float* brdf,
+    const float* outgoing, const float* incoming, float* pdf);
+/* README.md:20 / BASELINE.json call it eval_hair_scattering_pdf: same entry. */
+int yh_hair_eval_pdf_batch(yh_context* ctx, int n, const float* brdf,
+    const float* outgoing, const float* incoming, float* pdf);
+
+/* intersect_scene_bvh (yocto_pathtrace.cpp:934-1046) on the uploaded scene.
+ * rays: 8n floats (o[3] d[3] tmin tmax). Outputs per ray: object, element
+ * (-1 on miss), uv[2], distance.                                             */
+int yh_intersect_batch(yh_context* ctx, int n, const float* rays, int* object,
+    int* element, float* uv, float* distance);
+
+/* The four Monte-Carlo self-tests of yocto_extension.cpp:555-693 on the
+ * device: 0 white_furnace, 1 white_furnace_sampled, 2 sampling_weights,
+ * 3 sampling_consistency. Same seeds, counts and thresholds. `worst` (may be
+ * NULL) receives the statistic furthest from its target. Returns YH_OK or
+ * YH_E_SELFTEST ("TEST FAILED!").                                            */
+int yh_selftest(yh_context* ctx, int which, float* worst);
+
+/* ------------------------------------------------------------------------ */
+/* Host-side scene I/O (C++ host code, no device work): the minimal JSON +    */
+/* PLY + Radiance-HDR reader for the hair scenes, with the reference loader's */
+/* semantics (yocto_sceneio.cpp:1064-1418: alphabetical objects, lookat,      */
+/* add_radius 0.001, quads_to_triangles).                                     */
+/* ------------------------------------------------------------------------ */
+typedef struct yh_scene_file yh_scene_file;
+yh_scene_file*       yh_scene_load(const char* json_path, const char* camera,
+          char* error, int error_len);
+const yh_scene_desc* yh_scene_get(const yh_scene_file* scene);
+void                 yh_scene_free(yh_scene_file* scene);
+/* save_image for .pfm (3 channels, top row first as the reference writes it,
+ * yocto_image.cpp:1527-1556) and .hdr.                                       */
+int yh_save_image(const char* path, int width, int height, const float* rgba,
+    char* error, int error_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YHAIR_H_ */

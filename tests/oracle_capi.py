@@ -1,0 +1,231 @@
+"""ctypes bindings of the CHECKERS: the CPU oracle (oracle/libyh_oracle.so) and, when it has
+been built in the container that holds /root/reference, the real reference behind
+oracle/_ref/libyh_ref.so. Test infrastructure only — nothing under yocto-hair_amd/ imports this.
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "yocto-hair_amd", "python"))
+import yhair_capi as yh  # noqa: E402  (struct mirrors of include/yhair.h)
+
+ORACLE_SO = os.path.join(ROOT, "oracle", "libyh_oracle.so")
+REF_SO = os.path.join(ROOT, "oracle", "_ref", "libyh_ref.so")
+
+fp, ip = yh.c_float_p, yh.c_int_p
+u64p = C.POINTER(C.c_uint64)
+
+
+def _f(a):
+    return np.ascontiguousarray(a, np.float32)
+
+
+class _UnitApi:
+    """Entry points shared by the oracle (prefix yo_) and the reference shim (prefix ref_)."""
+
+    def __init__(self, lib, prefix):
+        self.lib, self.p = lib, prefix
+        g = lambda n: getattr(lib, prefix + n)  # noqa: E731
+        g("rng_stream").argtypes = [C.c_uint64, C.c_uint64, C.c_int, u64p, fp]
+        g("pixel_seqs").argtypes = [C.c_int, ip]
+        g("hair_brdf").argtypes = [C.c_int, fp, fp, fp, fp, fp]
+        for n in ("hair_eval", "hair_sample", "hair_pdf"):
+            g(n).argtypes = [C.c_int, fp, fp, fp, fp]
+        g("intersect_line").argtypes = [C.c_int, fp, fp, fp, fp, fp, ip, fp, fp]
+        g("intersect_triangle").argtypes = [C.c_int, fp, fp, fp, fp, ip, fp, fp]
+        g("intersect_bbox").argtypes = [C.c_int, fp, fp, ip]
+
+    def _g(self, n):
+        return getattr(self.lib, self.p + n)
+
+    def rng_stream(self, seed, seq, n):
+        si = (C.c_uint64 * 2)()
+        out = np.zeros(n, np.float32)
+        self._g("rng_stream")(seed, seq, n, si, yh.fptr(out))
+        return (int(si[0]), int(si[1])), out
+
+    def pixel_seqs(self, n):
+        out = np.zeros(n, np.int32)
+        self._g("pixel_seqs")(n, yh.iptr(out))
+        return out
+
+    def hair_brdf(self, mats12, v, normal, tangent):
+        mats12, v, normal, tangent = _f(mats12), _f(v), _f(normal), _f(tangent)
+        out = np.zeros((len(v), 30), np.float32)
+        self._g("hair_brdf")(len(v), yh.fptr(mats12), yh.fptr(v), yh.fptr(normal), yh.fptr(tangent), yh.fptr(out))
+        return out
+
+    def _wowi(self, name, brdf, a, b, width):
+        brdf, a, b = _f(brdf), _f(a), _f(b)
+        out = np.zeros((len(brdf), width) if width > 1 else (len(brdf),), np.float32)
+        self._g(name)(len(brdf), yh.fptr(brdf), yh.fptr(a), yh.fptr(b), yh.fptr(out))
+        return out
+
+    def hair_eval(self, brdf, wo, wi):
+        return self._wowi("hair_eval", brdf, wo, wi, 3)
+
+    def hair_sample(self, brdf, wo, rn):
+        return self._wowi("hair_sample", brdf, wo, rn, 3)
+
+    def hair_pdf(self, brdf, wo, wi):
+        return self._wowi("hair_pdf", brdf, wo, wi, 1)
+
+    def intersect_line(self, rays, p0, p1, r0, r1):
+        rays, p0, p1, r0, r1 = _f(rays), _f(p0), _f(p1), _f(r0), _f(r1)
+        n = len(r0)
+        hit, uv, d = np.zeros(n, np.int32), np.zeros((n, 2), np.float32), np.zeros(n, np.float32)
+        self._g("intersect_line")(n, yh.fptr(rays), yh.fptr(p0), yh.fptr(p1), yh.fptr(r0), yh.fptr(r1),
+                                  yh.iptr(hit), yh.fptr(uv), yh.fptr(d))
+        return hit, uv, d
+
+    def intersect_triangle(self, rays, p0, p1, p2):
+        rays, p0, p1, p2 = _f(rays), _f(p0), _f(p1), _f(p2)
+        n = len(p0)
+        hit, uv, d = np.zeros(n, np.int32), np.zeros((n, 2), np.float32), np.zeros(n, np.float32)
+        self._g("intersect_triangle")(n, yh.fptr(rays), yh.fptr(p0), yh.fptr(p1), yh.fptr(p2),
+                                      yh.iptr(hit), yh.fptr(uv), yh.fptr(d))
+        return hit, uv, d
+
+    def intersect_bbox(self, rays, bbox):
+        rays, bbox = _f(rays), _f(bbox)
+        hit = np.zeros(len(bbox), np.int32)
+        self._g("intersect_bbox")(len(bbox), yh.fptr(rays), yh.fptr(bbox), yh.iptr(hit))
+        return hit
+
+
+class Oracle(_UnitApi):
+    def __init__(self):
+        if not os.path.exists(ORACLE_SO):
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "oracle"])
+        lib = C.CDLL(ORACLE_SO)
+        super().__init__(lib, "yo_")
+        lib.yo_selftest.argtypes = [C.c_int, fp]
+        lib.yo_scene_create.restype = C.c_void_p
+        lib.yo_scene_create.argtypes = [C.POINTER(yh.SceneDesc)]
+        lib.yo_scene_free.argtypes = [C.c_void_p]
+        lib.yo_scene_num_lights.argtypes = [C.c_void_p]
+        lib.yo_scene_intersect.argtypes = [C.c_void_p, C.c_int, fp, ip, ip, fp, fp]
+        lib.yo_scene_bvh.argtypes = [C.c_void_p, C.c_int, fp, ip]
+        lib.yo_render.argtypes = [C.c_void_p, C.POINTER(yh.TraceParams), C.c_int, C.c_int, ip, ip, fp, u64p,
+                                  C.POINTER(yh.WorkCounts)]
+
+    def selftest(self, which):
+        worst = C.c_float()
+        ok = self.lib.yo_selftest(which, C.byref(worst))
+        return bool(ok), worst.value
+
+    def scene(self, desc):
+        return OracleScene(self, desc)
+
+
+class OracleScene:
+    def __init__(self, oracle, desc):
+        self.o = oracle
+        self.h = oracle.lib.yo_scene_create(desc)
+
+    def close(self):
+        if self.h:
+            self.o.lib.yo_scene_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def num_lights(self):
+        return self.o.lib.yo_scene_num_lights(self.h)
+
+    def intersect(self, rays):
+        rays = _f(rays).reshape(-1, 8)
+        n = len(rays)
+        obj, elem = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        uv, dist = np.zeros((n, 2), np.float32), np.zeros(n, np.float32)
+        self.o.lib.yo_scene_intersect(self.h, n, yh.fptr(rays), yh.iptr(obj), yh.iptr(elem), yh.fptr(uv), yh.fptr(dist))
+        return obj, elem, uv, dist
+
+    def bvh(self, shape):
+        n = self.o.lib.yo_scene_bvh(self.h, shape, None, None)
+        nodes = np.zeros((n, 8), np.float32)
+        self.o.lib.yo_scene_bvh(self.h, shape, yh.fptr(nodes), None)
+        return nodes
+
+    def render(self, params, samples, nthreads=0, want_rng=False, want_counts=False):
+        w, h = C.c_int(), C.c_int()
+        self.o.lib.yo_render(self.h, C.byref(params), 0, nthreads, C.byref(w), C.byref(h), None, None, None)
+        img = np.zeros((h.value, w.value, 4), np.float32)
+        rng = np.zeros((h.value * w.value, 2), np.uint64) if want_rng else None
+        wc = yh.WorkCounts() if want_counts else None
+        self.o.lib.yo_render(self.h, C.byref(params), samples, nthreads, C.byref(w), C.byref(h), yh.fptr(img),
+                             rng.ctypes.data_as(u64p) if want_rng else None,
+                             C.byref(wc) if want_counts else None)
+        out = [img]
+        if want_rng:
+            out.append(rng)
+        if want_counts:
+            out.append(wc)
+        return out[0] if len(out) == 1 else tuple(out)
+
+
+def have_ref():
+    return os.path.exists(REF_SO)
+
+
+class Ref(_UnitApi):
+    """The real reference (only where oracle/_ref has been built)."""
+
+    def __init__(self):
+        lib = C.CDLL(REF_SO)
+        super().__init__(lib, "ref_")
+        lib.ref_selftest.argtypes = [C.c_int]
+        lib.ref_scene_open.restype = C.c_void_p
+        lib.ref_scene_open.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]
+        lib.ref_scene_close.argtypes = [C.c_void_p]
+        lib.ref_scene_intersect.argtypes = [C.c_void_p, C.c_int, fp, ip, ip, fp, fp]
+        lib.ref_scene_render.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_float, C.c_int,
+                                         ip, ip, fp, u64p]
+        lib.ref_scene_num_lights.argtypes = [C.c_void_p]
+
+    def scene(self, json_path, camera=""):
+        return RefScene(self, json_path, camera)
+
+
+class RefScene:
+    def __init__(self, ref, json_path, camera=""):
+        self.r = ref
+        err = C.create_string_buffer(512)
+        self.h = ref.lib.ref_scene_open(str(json_path).encode(), camera.encode(), err, 512)
+        if not self.h:
+            raise RuntimeError(err.value.decode())
+
+    def close(self):
+        if self.h:
+            self.r.lib.ref_scene_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def num_lights(self):
+        return self.r.lib.ref_scene_num_lights(self.h)
+
+    def intersect(self, rays):
+        rays = _f(rays).reshape(-1, 8)
+        n = len(rays)
+        obj, elem = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        uv, dist = np.zeros((n, 2), np.float32), np.zeros(n, np.float32)
+        self.r.lib.ref_scene_intersect(self.h, n, yh.fptr(rays), yh.iptr(obj), yh.iptr(elem), yh.fptr(uv), yh.fptr(dist))
+        return obj, elem, uv, dist
+
+    def render(self, params, samples, noparallel=False, want_rng=False):
+        w, h = C.c_int(), C.c_int()
+        self.r.lib.ref_scene_render(self.h, params.resolution, 0, params.seed, params.bounces, params.clamp, 0,
+                                    C.byref(w), C.byref(h), None, None)
+        img = np.zeros((h.value, w.value, 4), np.float32)
+        rng = np.zeros((h.value * w.value, 2), np.uint64) if want_rng else None
+        self.r.lib.ref_scene_render(self.h, params.resolution, samples, params.seed, params.bounces, params.clamp,
+                                    int(noparallel), C.byref(w), C.byref(h), yh.fptr(img),
+                                    rng.ctypes.data_as(u64p) if want_rng else None)
+        return (img, rng) if want_rng else img

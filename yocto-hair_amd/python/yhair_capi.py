@@ -1,0 +1,308 @@
+"""ctypes binding of include/yhair.h (the product's C ABI, libyhair.so).
+
+Plumbing only: no arithmetic of the hot path happens in Python. The same
+structures are handed to the CPU oracle (oracle/libyh_oracle.so) by the tests,
+which is why the struct mirrors live here and the oracle loader lives in
+tests/ (tests/oracle_capi.py) — the product never imports the oracle.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+LIB_PATH = os.path.join(ROOT, "yocto-hair_amd", "libyhair.so")
+
+YH_OK, YH_E_INVALID, YH_E_DEVICE, YH_E_STATE, YH_E_IO, YH_E_SELFTEST = 0, -1, -2, -3, -4, -5
+YH_HAIR_BRDF_FLOATS = 30
+
+c_float_p = C.POINTER(C.c_float)
+c_int_p = C.POINTER(C.c_int)
+
+
+class Shape(C.Structure):
+    _fields_ = [("num_vertices", C.c_int), ("positions", c_float_p), ("normals", c_float_p),
+                ("radius", c_float_p), ("num_lines", C.c_int), ("lines", c_int_p),
+                ("num_triangles", C.c_int), ("triangles", c_int_p)]
+
+
+class Material(C.Structure):
+    _fields_ = [("emission", C.c_float * 3), ("color", C.c_float * 3), ("specular", C.c_float),
+                ("metallic", C.c_float), ("roughness", C.c_float), ("transmission", C.c_float),
+                ("opacity", C.c_float), ("ior", C.c_float), ("thin", C.c_int),
+                ("sigma_a", C.c_float * 3), ("beta_m", C.c_float), ("beta_n", C.c_float),
+                ("alpha", C.c_float), ("eta", C.c_float), ("eumelanin", C.c_float),
+                ("pheomelanin", C.c_float)]
+
+
+class Object(C.Structure):
+    _fields_ = [("frame", C.c_float * 12), ("shape", C.c_int), ("material", C.c_int)]
+
+
+class Environment(C.Structure):
+    _fields_ = [("frame", C.c_float * 12), ("emission", C.c_float * 3), ("tex_width", C.c_int),
+                ("tex_height", C.c_int), ("texels", c_float_p)]
+
+
+class Camera(C.Structure):
+    _fields_ = [("frame", C.c_float * 12), ("lens", C.c_float), ("film", C.c_float * 2),
+                ("focus", C.c_float), ("aperture", C.c_float)]
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [("num_shapes", C.c_int), ("shapes", C.POINTER(Shape)),
+                ("num_materials", C.c_int), ("materials", C.POINTER(Material)),
+                ("num_objects", C.c_int), ("objects", C.POINTER(Object)),
+                ("num_environments", C.c_int), ("environments", C.POINTER(Environment)),
+                ("camera", Camera)]
+
+
+class TraceParams(C.Structure):
+    _fields_ = [("resolution", C.c_int), ("bounces", C.c_int), ("clamp", C.c_float),
+                ("seed", C.c_uint64)]
+
+    @staticmethod
+    def default(resolution=720, bounces=8, clamp=100.0, seed=961748941):
+        return TraceParams(resolution, bounces, clamp, seed)
+
+
+class WorkCounts(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("samples", "rays", "nodes", "seg_tests", "tri_tests",
+                                          "hair_shades", "surf_shades", "env_lookups",
+                                          "env_samples")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+    def bytes_per_sample(self, spp_per_launch):
+        """algorithmic bytes per sample of the reference algorithm."""
+        s = max(1, self.samples)
+        return (32 * self.nodes + 44 * self.seg_tests + 52 * self.tri_tests +
+                104 * self.hair_shades + 48 * self.env_lookups + 88 * self.env_samples) / s \
+            + 32.0 / spp_per_launch
+
+
+def fptr(a):
+    return a.ctypes.data_as(c_float_p)
+
+
+def iptr(a):
+    return a.ctypes.data_as(c_int_p)
+
+
+def hair_material_rows(mats12):
+    """(n,12) float rows [sigma_a3 beta_m beta_n alpha eta color3 eumelanin pheomelanin]
+    (yocto_extension.h:86-95 order) -> ctypes array of yh_material."""
+    mats12 = np.ascontiguousarray(mats12, dtype=np.float32).reshape(-1, 12)
+    arr = (Material * len(mats12))()
+    for i, r in enumerate(mats12):
+        m = arr[i]
+        m.sigma_a[:] = r[0:3].tolist()
+        m.beta_m, m.beta_n, m.alpha, m.eta = map(float, r[3:7])
+        m.color[:] = r[7:10].tolist()
+        m.eumelanin, m.pheomelanin = float(r[10]), float(r[11])
+        m.opacity, m.ior, m.thin = 1.0, 1.5, 1
+    return arr
+
+
+_SIGS = {
+    "yh_create": (C.c_void_p, [C.c_int]),
+    "yh_destroy": (None, [C.c_void_p]),
+    "yh_last_error": (C.c_char_p, [C.c_void_p]),
+    "yh_version": (C.c_char_p, []),
+    "yh_upload_scene": (C.c_int, [C.c_void_p, C.POINTER(SceneDesc)]),
+    "yh_init_state": (C.c_int, [C.c_void_p, C.POINTER(TraceParams)]),
+    "yh_image_size": (C.c_int, [C.c_void_p, c_int_p, c_int_p]),
+    "yh_set_shard": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "yh_trace_samples": (C.c_int, [C.c_void_p, C.c_int]),
+    "yh_trace_samples_async": (C.c_int, [C.c_void_p, C.c_int]),
+    "yh_synchronize": (C.c_int, [C.c_void_p]),
+    "yh_download": (C.c_int, [C.c_void_p, c_float_p]),
+    "yh_pack_tiles_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
+    "yh_unpack_tiles_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "yh_shard_pixels": (C.c_int64, [C.c_void_p, C.c_int, C.c_int]),
+    "yh_download_rng": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "yh_trace_samples_counted": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(WorkCounts)]),
+    "yh_last_trace_ms": (C.c_int, [C.c_void_p, c_float_p, c_int_p]),
+    "yh_hair_brdf_batch": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Material), c_float_p,
+                                     c_float_p, c_float_p, c_float_p]),
+    "yh_hair_eval_batch": (C.c_int, [C.c_void_p, C.c_int, c_float_p, c_float_p, c_float_p, c_float_p]),
+    "yh_hair_sample_batch": (C.c_int, [C.c_void_p, C.c_int, c_float_p, c_float_p, c_float_p, c_float_p]),
+    "yh_hair_pdf_batch": (C.c_int, [C.c_void_p, C.c_int, c_float_p, c_float_p, c_float_p, c_float_p]),
+    "yh_hair_eval_pdf_batch": (C.c_int, [C.c_void_p, C.c_int, c_float_p, c_float_p, c_float_p, c_float_p]),
+    "yh_intersect_batch": (C.c_int, [C.c_void_p, C.c_int, c_float_p, c_int_p, c_int_p, c_float_p, c_float_p]),
+    "yh_selftest": (C.c_int, [C.c_void_p, C.c_int, c_float_p]),
+    "yh_scene_load": (C.c_void_p, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]),
+    "yh_scene_get": (C.POINTER(SceneDesc), [C.c_void_p]),
+    "yh_scene_free": (None, [C.c_void_p]),
+    "yh_save_image": (C.c_int, [C.c_char_p, C.c_int, C.c_int, c_float_p, C.c_char_p, C.c_int]),
+}
+EXPORTS = tuple(_SIGS)
+
+_lib = None
+
+
+def load(path=None):
+    """Loads libyhair.so (fails loudly when it has not been built)."""
+    global _lib
+    if _lib is None or path:
+        p = path or LIB_PATH
+        if not os.path.exists(p):
+            raise RuntimeError(f"{p} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(there is no CPU fallback for the product path)")
+        lib = C.CDLL(p)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        if path:
+            return lib
+        _lib = lib
+    return _lib
+
+
+class YhError(RuntimeError):
+    pass
+
+
+class SceneFile:
+    """yh_scene_load / yh_scene_get / yh_scene_free."""
+
+    def __init__(self, json_path, camera=""):
+        lib = load()
+        err = C.create_string_buffer(512)
+        self.handle = lib.yh_scene_load(str(json_path).encode(), camera.encode(), err, 512)
+        if not self.handle:
+            raise YhError(err.value.decode())
+        self.desc = lib.yh_scene_get(self.handle)
+
+    def close(self):
+        if self.handle:
+            load().yh_scene_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        self.close()
+
+
+class Context:
+    """One GPU context (yh_create ... yh_destroy). Raises when no GPU: no fallback."""
+
+    def __init__(self, device=0):
+        self.lib = load()
+        self.h = self.lib.yh_create(device)
+        if not self.h:
+            raise YhError("yh_create failed: " + self.lib.yh_last_error(None).decode())
+
+    def _chk(self, rc):
+        if rc != YH_OK:
+            raise YhError(f"yhair error {rc}: " + self.lib.yh_last_error(self.h).decode())
+
+    def close(self):
+        if self.h:
+            self.lib.yh_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # whole path -----------------------------------------------------------
+    def upload_scene(self, desc):
+        self._chk(self.lib.yh_upload_scene(self.h, desc))
+
+    def set_shard(self, rank, world):
+        self._chk(self.lib.yh_set_shard(self.h, rank, world))
+
+    def init_state(self, params):
+        self._chk(self.lib.yh_init_state(self.h, C.byref(params)))
+        w, h = C.c_int(), C.c_int()
+        self._chk(self.lib.yh_image_size(self.h, C.byref(w), C.byref(h)))
+        self.width, self.height = w.value, h.value
+        return self.width, self.height
+
+    def trace_samples(self, n):
+        self._chk(self.lib.yh_trace_samples(self.h, n))
+
+    def trace_samples_async(self, n):
+        self._chk(self.lib.yh_trace_samples_async(self.h, n))
+
+    def synchronize(self):
+        self._chk(self.lib.yh_synchronize(self.h))
+
+    def trace_samples_counted(self, n):
+        wc = WorkCounts()
+        self._chk(self.lib.yh_trace_samples_counted(self.h, n, C.byref(wc)))
+        return wc
+
+    def last_trace_ms(self):
+        ms, n = C.c_float(), C.c_int()
+        self._chk(self.lib.yh_last_trace_ms(self.h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def download(self):
+        img = np.zeros((self.height, self.width, 4), np.float32)
+        self._chk(self.lib.yh_download(self.h, fptr(img)))
+        return img
+
+    def download_rng(self):
+        rng = np.zeros((self.height * self.width, 2), np.uint64)
+        self._chk(self.lib.yh_download_rng(self.h, rng.ctypes.data_as(C.POINTER(C.c_uint64))))
+        return rng
+
+    def shard_pixels(self, rank, world):
+        return int(self.lib.yh_shard_pixels(self.h, rank, world))
+
+    def pack_tiles_device(self, dev_ptr, capacity):
+        n = C.c_int64()
+        self._chk(self.lib.yh_pack_tiles_device(self.h, C.c_void_p(dev_ptr), capacity, C.byref(n)))
+        return n.value
+
+    def unpack_tiles_device(self, packed_ptr, src_rank, world, image_ptr):
+        self._chk(self.lib.yh_unpack_tiles_device(self.h, C.c_void_p(packed_ptr), src_rank, world,
+                                                  C.c_void_p(image_ptr)))
+
+    # unit level -----------------------------------------------------------
+    def hair_brdf(self, mats12, v, normal, tangent):
+        mats = hair_material_rows(mats12)
+        n = len(mats)
+        v = np.ascontiguousarray(v, np.float32)
+        normal = np.ascontiguousarray(normal, np.float32)
+        tangent = np.ascontiguousarray(tangent, np.float32)
+        out = np.zeros((n, 30), np.float32)
+        self._chk(self.lib.yh_hair_brdf_batch(self.h, n, mats, fptr(v), fptr(normal), fptr(tangent), fptr(out)))
+        return out
+
+    def _wowi(self, fn, brdf, a, b, width):
+        brdf = np.ascontiguousarray(brdf, np.float32)
+        a = np.ascontiguousarray(a, np.float32)
+        b = np.ascontiguousarray(b, np.float32)
+        n = len(brdf)
+        out = np.zeros((n, width) if width > 1 else (n,), np.float32)
+        self._chk(fn(self.h, n, fptr(brdf), fptr(a), fptr(b), fptr(out)))
+        return out
+
+    def hair_eval(self, brdf, wo, wi):
+        return self._wowi(self.lib.yh_hair_eval_batch, brdf, wo, wi, 3)
+
+    def hair_sample(self, brdf, wo, rn):
+        return self._wowi(self.lib.yh_hair_sample_batch, brdf, wo, rn, 3)
+
+    def hair_pdf(self, brdf, wo, wi):
+        return self._wowi(self.lib.yh_hair_pdf_batch, brdf, wo, wi, 1)
+
+    def intersect(self, rays):
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
+        n = len(rays)
+        obj, elem = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        uv, dist = np.zeros((n, 2), np.float32), np.zeros(n, np.float32)
+        self._chk(self.lib.yh_intersect_batch(self.h, n, fptr(rays), iptr(obj), iptr(elem), fptr(uv), fptr(dist)))
+        return obj, elem, uv, dist
+
+    def selftest(self, which):
+        worst = C.c_float()
+        rc = self.lib.yh_selftest(self.h, which, C.byref(worst))
+        if rc not in (YH_OK, YH_E_SELFTEST):
+            self._chk(rc)
+        return rc == YH_OK, worst.value
