@@ -1,0 +1,277 @@
+// dev_hair.h — the hair BSDF on the device (gfx950).
+//
+// Restates libs/yocto_extension/yocto_extension.cpp:90-551 (the pbrt-v3 /
+// Chiang et al. hair model as the reference implements it):
+//   eval_hair_brdf  (127-177)   -> hair_setup (per-hit part) + yhd_material
+//                                  (per-material part, computed at upload)
+//   eval_hair_scattering (255-336), sample_hair_scattering (399-479),
+//   sample_hair_scattering_pdf (481-551) -> hair_eval / hair_sample /
+//   hair_pdf, plus the fused hair_eval_pdf the integrator uses: f and pdf
+//   share Mp and Np (same expressions, so the fused result is bit-identical
+//   to calling the two separately).
+//
+// Reference quirks kept on purpose:
+//   * asin and sinh resolve to the C double overloads in the reference
+//     (ext.cpp:111,206); gamma_o / gamma_t use the double asin here too and
+//     the v > 0.1 branch of Mp divides in double by the host-computed
+//     sinh(1/v) * 2 * v.
+//   * compute_ap_pdf re-derives sin_theta_o as sqrt(1 - cos^2) (ext.cpp:372),
+//     so the Ap used for the pdf is NOT the Ap used for f; both are computed.
+//   * the i0 series divides by int64 products (ext.cpp:179-192); the ten
+//     divisors are exact in float, so they are literal constants here.
+#ifndef YH_DEV_HAIR_H_
+#define YH_DEV_HAIR_H_
+#include "dev_math.h"
+
+namespace yhd {
+
+constexpr int p_max = 3;  // ext.h:84
+
+// Per-hit part of hair_brdf (ext.h:97-113).
+struct hair_hit {
+  float h, gamma_o;
+  frame w2b;  // world_to_brdf: rows of the local frame, o = -0
+};
+
+YH_DEV float sqr(float v) { return v * v; }
+YH_DEV float safe_asin(float x) { return (float)asin((double)fclamp(x, -1.0f, 1.0f)); }
+YH_DEV float safe_sqrt(float x) { return sqrtf(fmax_(0.0f, x)); }
+
+// ext.cpp:148-151,174 with math.h:2898-2903 (frame_fromzx) and the rigid
+// inverse (transpose).
+YH_DEV hair_hit hair_setup(float v, f3 normal, f3 tangent) {
+  hair_hit hh;
+  hh.h       = -1 + 2 * v;
+  hh.gamma_o = safe_asin(hh.h);
+  f3 z       = normalize(normal);
+  f3 x       = orthonormalize(tangent, z);
+  f3 y       = normalize(cross(z, x));
+  hh.w2b     = transpose_rot(frame{x, y, z, mk3(0.0f)});
+  return hh;
+}
+
+// i0 (ext.cpp:179-192): divisors 4^i (i!)^2 as exact floats.
+YH_DEV float i0(float x) {
+  const float den[10] = {1.0f, 4.0f, 64.0f, 2304.0f, 147456.0f, 14745600.0f,
+      2123366400.0f, 416179814400.0f, 106542032486400.0f, 34519618525593600.0f};
+  float val = 0, x2i = 1;
+#pragma unroll
+  for (int i = 0; i < 10; i++) {
+    val += x2i / den[i];
+    x2i *= x * x;
+  }
+  return val;
+}
+YH_DEV float log_i0(float x) {  // ext.cpp:194-199
+  if (x > 12)
+    return x + 0.5f * (-logf(2 * pif) + logf(1 / x) + 1 / (8 * x));
+  else
+    return logf(i0(x));
+}
+// mp (ext.cpp:201-207) for lobe p of material m
+YH_DEV float mp(const yhd_material& m, int p, float cos_theta_i, float cos_theta_o,
+    float sin_theta_i, float sin_theta_o) {
+  float v = m.v[p];
+  float a = cos_theta_i * cos_theta_o / v;
+  float b = sin_theta_i * sin_theta_o / v;
+  if (v <= 0.1f) {
+    return expf(log_i0(a) - b - m.inv_v[p] + 0.6931f + m.log_inv_2v[p]);
+  } else {
+    return (float)((double)(expf(-b) * i0(a)) / m.mp_den[p]);
+  }
+}
+// fresnel_dielectric with dot(normal, outgoing) = cos (math.h:4215-4235)
+YH_DEV float fresnel_dielectric_cos(float eta, float cosw_) {
+  float cosw  = fabs_(cosw_);
+  float sin2  = 1 - cosw * cosw;
+  float eta2  = eta * eta;
+  float cos2t = 1 - sin2 / eta2;
+  if (cos2t < 0) return 1;
+  float t0 = sqrtf(cos2t);
+  float t1 = eta * t0;
+  float t2 = eta * cosw;
+  float rs = (cosw - t1) / (cosw + t1);
+  float rp = (t0 - t2) / (t0 + t2);
+  return (rs * rs + rp * rp) / 2;
+}
+// ap (ext.cpp:209-230)
+YH_DEV void ap(float cos_theta_o, float eta, float h, f3 T, f3 out[p_max + 1]) {
+  float cos_gamma_o = safe_sqrt(1 - h * h);
+  float cos_theta   = cos_theta_o * cos_gamma_o;
+  float f = fresnel_dielectric_cos(eta, 0.0f * 0.0f + 0.0f * 0.0f + 1.0f * cos_theta);
+  out[0]  = mk3(f);
+  out[1]  = sqr(1 - f) * T;
+  out[2]  = out[1] * T * f;
+  out[3]  = out[2] * f * T / (mk3(1.f) - T * f);
+}
+// T for a given (sin_theta_o, cos_theta_o) (ext.cpp:281-291 / 375-384)
+YH_DEV f3 transmittance(const yhd_material& m, float h, float sin_theta_o, float cos_theta_o,
+    float& gamma_t) {
+  float sin_theta_t = sin_theta_o / m.eta;
+  float cos_theta_t = safe_sqrt(1 - sqr(sin_theta_t));
+  float etap        = sqrtf(m.eta * m.eta - sqr(sin_theta_o)) / cos_theta_o;
+  float sin_gamma_t = h / etap;
+  float cos_gamma_t = safe_sqrt(1 - sqr(sin_gamma_t));
+  gamma_t           = safe_asin(sin_gamma_t);
+  float k           = 2 * cos_gamma_t / cos_theta_t;
+  f3    sa          = ld3(m.sigma_a);
+  return f3{expf(-sa.x * k), expf(-sa.y * k), expf(-sa.z * k)};
+}
+YH_DEV float phi_fn(int p, float gamma_o, float gamma_t) {  // ext.cpp:232-234
+  return 2 * p * gamma_t - 2 * gamma_o + p * pif;
+}
+// np (ext.cpp:236-253): trimmed logistic of the wrapped azimuth difference
+YH_DEV float np(const yhd_material& m, float phi, int p, float gamma_o, float gamma_t) {
+  float dphi = phi - phi_fn(p, gamma_o, gamma_t);
+  while (dphi > pif) dphi -= 2 * pif;
+  while (dphi < -pif) dphi += 2 * pif;
+  float x = fabs_(dphi);
+  float e = expf(-x / m.s);
+  return (e / (m.s * sqr(1 + e))) / m.tl_norm;
+}
+// scale tilt of lobe p (ext.cpp:299-322)
+YH_DEV void tilt(const yhd_material& m, int p, float sin_theta_o, float cos_theta_o,
+    float& sin_theta_op, float& cos_theta_op) {
+  if (p == 0) {
+    sin_theta_op = sin_theta_o * m.cos_2k_alpha[1] - cos_theta_o * m.sin_2k_alpha[1];
+    cos_theta_op = cos_theta_o * m.cos_2k_alpha[1] + sin_theta_o * m.sin_2k_alpha[1];
+  } else if (p == 1) {
+    sin_theta_op = sin_theta_o * m.cos_2k_alpha[0] + cos_theta_o * m.sin_2k_alpha[0];
+    cos_theta_op = cos_theta_o * m.cos_2k_alpha[0] - sin_theta_o * m.sin_2k_alpha[0];
+  } else if (p == 2) {
+    sin_theta_op = sin_theta_o * m.cos_2k_alpha[2] + cos_theta_o * m.sin_2k_alpha[2];
+    cos_theta_op = cos_theta_o * m.cos_2k_alpha[2] - sin_theta_o * m.sin_2k_alpha[2];
+  } else {
+    sin_theta_op = sin_theta_o;
+    cos_theta_op = cos_theta_o;
+  }
+}
+// compute_ap_pdf (ext.cpp:365-397)
+YH_DEV void compute_ap_pdf(const yhd_material& m, float h, float cos_theta_o,
+    float ap_pdf[p_max + 1]) {
+  float sin_theta_o = safe_sqrt(1 - cos_theta_o * cos_theta_o);
+  float gamma_t;
+  f3    T = transmittance(m, h, sin_theta_o, cos_theta_o, gamma_t);
+  f3    apv[p_max + 1];
+  ap(cos_theta_o, m.eta, h, T, apv);
+  float sum_y = 0.0f;
+#pragma unroll
+  for (int i = 0; i <= p_max; i++) sum_y += luminance(apv[i]);
+#pragma unroll
+  for (int i = 0; i <= p_max; i++) ap_pdf[i] = luminance(apv[i]) / sum_y;
+}
+
+// Fused eval_hair_scattering + sample_hair_scattering_pdf.
+template <bool WANT_F, bool WANT_PDF>
+YH_DEV void hair_eval_pdf(const yhd_material& m, const hair_hit& hh, f3 outgoing_, f3 incoming_,
+    f3& f, float& pdf) {
+  f3    outgoing    = transform_direction(hh.w2b, outgoing_);
+  f3    incoming    = transform_direction(hh.w2b, incoming_);
+  float sin_theta_o = outgoing.x;
+  float cos_theta_o = safe_sqrt(1 - sqr(sin_theta_o));
+  float phi_o       = atan2f(outgoing.z, outgoing.y);
+  float sin_theta_i = incoming.x;
+  float cos_theta_i = safe_sqrt(1 - sqr(sin_theta_i));
+  float phi_i       = atan2f(incoming.z, incoming.y);
+  float gamma_t;
+  f3    T   = transmittance(m, hh.h, sin_theta_o, cos_theta_o, gamma_t);
+  float phi = phi_i - phi_o;
+  f3    apv[p_max + 1];
+  float ap_pdf[p_max + 1];
+  if (WANT_F) ap(cos_theta_o, m.eta, hh.h, T, apv);
+  if (WANT_PDF) compute_ap_pdf(m, hh.h, cos_theta_o, ap_pdf);
+  f   = mk3(0.0f);
+  pdf = 0.0f;
+#pragma unroll
+  for (int p = 0; p < p_max; p++) {
+    float sin_theta_op, cos_theta_op;
+    tilt(m, p, sin_theta_o, cos_theta_o, sin_theta_op, cos_theta_op);
+    cos_theta_op = fabs_(cos_theta_op);
+    float mpv    = mp(m, p, cos_theta_i, cos_theta_op, sin_theta_i, sin_theta_op);
+    float npv    = np(m, phi, p, hh.gamma_o, gamma_t);
+    if (WANT_F) f = f + mpv * apv[p] * npv;
+    if (WANT_PDF) pdf += mpv * ap_pdf[p] * npv;
+  }
+  float mpl = mp(m, p_max, cos_theta_i, cos_theta_o, sin_theta_i, sin_theta_o);
+  if (WANT_F) f = f + mpl * apv[p_max] / (2 * pif);
+  if (WANT_PDF) pdf += mpl * ap_pdf[p_max] * (1 / (2 * pif));
+}
+
+// ext.cpp:339-357
+YH_DEV uint32_t compact1by1(uint32_t x) {
+  x &= 0x55555555;
+  x = (x ^ (x >> 1)) & 0x33333333;
+  x = (x ^ (x >> 2)) & 0x0f0f0f0f;
+  x = (x ^ (x >> 4)) & 0x00ff00ff;
+  x = (x ^ (x >> 8)) & 0x0000ffff;
+  return x;
+}
+YH_DEV void demux_float(float f, float& a, float& b) {
+  uint64_t v = (uint64_t)(f * 4294967296.0f);
+  a          = (float)compact1by1((uint32_t)v) / 65536.0f;
+  b          = (float)compact1by1((uint32_t)(v >> 1)) / 65536.0f;
+}
+
+// sample_hair_scattering (ext.cpp:399-479)
+YH_DEV f3 hair_sample(const yhd_material& m, const hair_hit& hh, f3 outgoing_, float rnx, float rny) {
+  f3    outgoing    = transform_direction(hh.w2b, outgoing_);
+  float sin_theta_o = outgoing.x;
+  float cos_theta_o = safe_sqrt(1 - sqr(sin_theta_o));
+  float phi_o       = atan2f(outgoing.z, outgoing.y);
+  float u00, u01, u10, u11;
+  demux_float(rnx, u00, u01);
+  demux_float(rny, u10, u11);
+  float ap_pdf[p_max + 1];
+  compute_ap_pdf(m, hh.h, cos_theta_o, ap_pdf);
+  int p = 0;
+  for (p = 0; p < p_max; p++) {
+    if (u00 < ap_pdf[p]) break;
+    u00 -= ap_pdf[p];
+  }
+  float sin_theta_op, cos_theta_op;
+  tilt(m, p, sin_theta_o, cos_theta_o, sin_theta_op, cos_theta_op);
+  u10 = fmax_(u10, 1e-5f);
+  float vp = 0, em2v = 0;
+  // select without dynamic indexing into the struct
+  vp   = p == 0 ? m.v[0] : p == 1 ? m.v[1] : m.v[2];  // v[3] == v[2]
+  em2v = p == 0 ? m.exp_m2_inv_v[0] : p == 1 ? m.exp_m2_inv_v[1] : m.exp_m2_inv_v[2];
+  float cos_theta   = 1 + vp * logf(u10 + (1 - u10) * em2v);
+  float sin_theta   = safe_sqrt(1 - sqr(cos_theta));
+  float cos_phi     = cosf(2 * pif * u11);
+  float sin_theta_i = -cos_theta * sin_theta_op + sin_theta * cos_phi * cos_theta_op;
+  float cos_theta_i = safe_sqrt(1 - sqr(sin_theta_i));
+  float etap        = sqrtf(m.eta * m.eta - sqr(sin_theta_o)) / cos_theta_o;
+  float sin_gamma_t = hh.h / etap;
+  float gamma_t     = safe_asin(sin_gamma_t);
+  float dphi;
+  if (p < p_max) {
+    // sample_trimmed_logistic (ext.cpp:359-363)
+    float x = -m.s * logf(1 / (u01 * m.tl_norm + m.tl_cdf_a) - 1);
+    dphi    = phi_fn(p, hh.gamma_o, gamma_t) + fclamp(x, -pif, pif);
+  } else {
+    dphi = 2 * pif * u01;
+  }
+  float phi_i    = phi_o + dphi;
+  f3    incoming = f3{sin_theta_i, cos_theta_i * cosf(phi_i), cos_theta_i * sinf(phi_i)};
+  return transform_direction(transpose_rot(hh.w2b), incoming);
+}
+
+// Fills the per-material constants from (beta-derived) v[], s on the DEVICE;
+// used by the unit-level batch kernels whose hair_brdf arrives as 30 floats.
+// The integrator uses the host-computed table instead.
+YH_DEV void derive_material(yhd_material& m) {
+#pragma unroll
+  for (int p = 0; p <= p_max; p++) {
+    m.inv_v[p]        = 1 / m.v[p];
+    m.log_inv_2v[p]   = logf(1 / (2 * m.v[p]));
+    m.exp_m2_inv_v[p] = expf(-2 / m.v[p]);
+    m.mp_den[p]       = sinh((double)(1 / m.v[p])) * 2 * m.v[p];
+  }
+  float cb   = 1 / (1 + expf(-pif / m.s));
+  float ca   = 1 / (1 + expf(-(-pif) / m.s));
+  m.tl_cdf_a = ca;
+  m.tl_norm  = cb - ca;
+}
+
+}  // namespace yhd
+#endif

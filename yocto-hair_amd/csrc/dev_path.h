@@ -1,0 +1,327 @@
+// dev_path.h — shading points, lights and the one-sample-MIS path integrator.
+//
+// Restates pt.cpp:211-229 (camera), 232-369 (shading point), 405-492
+// (eval_brdf: only the diffuse and hair lobes are reachable in scope),
+// 536-547 + 148-200 (environment lookup), 1069-1256 (lobe dispatch),
+// 1283-1358 (light sampling and its pdf), 1380-1511 (trace_path) and
+// 1676-1689 (trace_sample).
+//
+// The RNG draw order is the one the g++-built reference executes (SURVEY.md
+// 3.2): lens uv before pixel uv; `rn` (x, y) before `rnl`; `ruv` (x, y), `rel`,
+// `rl` for light sampling.
+#ifndef YH_DEV_PATH_H_
+#define YH_DEV_PATH_H_
+#include "dev_hair.h"
+#include "dev_trace.h"
+
+namespace yhd {
+
+// pt.cpp:211-229 with sample_disk (math.h:4895-4899)
+YH_DEV ray_t sample_camera(const yhd_camera& cam, int i, int j, int w, int h, float pu, float pv,
+    float lu, float lv) {
+  float uvx = ((float)i + pu) / (float)w, uvy = ((float)j + pv) / (float)h;
+  float r   = sqrtf(lv);
+  float phi = 2 * pif * lu;
+  float lx = cosf(phi) * r, ly = sinf(phi) * r;
+  f3    q  = {cam.film_x * (0.5f - uvx), cam.film_y * (uvy - 0.5f), cam.lens};
+  f3    dc = -normalize(q);
+  f3    e  = {lx * cam.aperture / 2, ly * cam.aperture / 2, 0};
+  f3    p  = dc * cam.focus / fabs_(dc.z);
+  f3    d  = normalize(p - e);
+  frame f  = ldframe(cam.frame);
+  return mkray(transform_point(f, e), transform_direction(f, d));
+}
+
+// Geometry of a hit: position, shading normal and (for hair) tangent.
+struct shade_pt {
+  f3 position, normal, tangent;
+};
+YH_DEV f3 transform_normal(const frame& a, f3 b) { return normalize(transform_vector(a, b)); }
+
+// eval_position (pt.cpp:232-250)
+YH_DEV f3 eval_position(const yhd_scene& sc, const yhd_object& o, int element, float u, float v) {
+  frame    fr = ldframe(o.frame);
+  yhd_int4 e  = sc.elems[o.elem_base + element];
+  if (o.kind == YH_KIND_TRIANGLES) {
+    f3 p0 = xyz(sc.vpos[o.vert_base + e.x]), p1 = xyz(sc.vpos[o.vert_base + e.y]),
+       p2 = xyz(sc.vpos[o.vert_base + e.z]);
+    return transform_point(fr, p0 * (1 - u - v) + p1 * u + p2 * v);
+  } else {
+    f3 p0 = xyz(sc.vpos[o.vert_base + e.x]), p1 = xyz(sc.vpos[o.vert_base + e.y]);
+    return transform_point(fr, p0 * (1 - u) + p1 * u);
+  }
+}
+// eval_element_normal (pt.cpp:253-269)
+YH_DEV f3 eval_element_normal(const yhd_scene& sc, const yhd_object& o, int element) {
+  frame    fr = ldframe(o.frame);
+  yhd_int4 e  = sc.elems[o.elem_base + element];
+  f3       p0 = xyz(sc.vpos[o.vert_base + e.x]), p1 = xyz(sc.vpos[o.vert_base + e.y]);
+  if (o.kind == YH_KIND_TRIANGLES) {
+    f3 p2 = xyz(sc.vpos[o.vert_base + e.z]);
+    return transform_normal(fr, normalize(cross(p1 - p0, p2 - p0)));
+  } else {
+    return transform_normal(fr, normalize(p1 - p0));
+  }
+}
+// eval_normal (pt.cpp:272-292)
+YH_DEV f3 eval_normal(const yhd_scene& sc, const yhd_object& o, int element, float u, float v) {
+  if (!o.has_normals) return eval_element_normal(sc, o, element);
+  frame    fr = ldframe(o.frame);
+  yhd_int4 e  = sc.elems[o.elem_base + element];
+  f3       n0 = xyz(sc.vnrm[o.vert_base + e.x]), n1 = xyz(sc.vnrm[o.vert_base + e.y]);
+  if (o.kind == YH_KIND_TRIANGLES) {
+    f3 n2 = xyz(sc.vnrm[o.vert_base + e.z]);
+    return transform_normal(fr, normalize(n0 * (1 - u - v) + n1 * u + n2 * v));
+  } else {
+    return transform_normal(fr, normalize(n0 * (1 - u) + n1 * u));
+  }
+}
+
+// texture lookup of an environment (pt.cpp:167-200), wrap + bilinear
+YH_DEV f3 eval_env_texture(const yhd_scene& sc, const yhd_environment& env, float u_, float v_) {
+  if (env.tex_w == 0) return mk3(1.0f);
+  int   sx = env.tex_w, sy = env.tex_h;
+  float s = fmodf(u_, 1.0f) * sx;
+  if (s < 0) s += sx;
+  float t = fmodf(v_, 1.0f) * sy;
+  if (t < 0) t += sy;
+  int   i = iclamp((int)s, 0, sx - 1), j = iclamp((int)t, 0, sy - 1);
+  int   ii = (i + 1) % sx, jj = (j + 1) % sy;
+  float u = s - i, v = t - j;
+  const yhd_float4* tx = sc.env_texels + env.texel_base;
+  f3 a = xyz(tx[(size_t)j * sx + i]), b = xyz(tx[(size_t)jj * sx + i]);
+  f3 c = xyz(tx[(size_t)j * sx + ii]), d = xyz(tx[(size_t)jj * sx + ii]);
+  return a * (1 - u) * (1 - v) + b * (1 - u) * v + c * u * (1 - v) + d * u * v;
+}
+// eval_environment (pt.cpp:536-547)
+template <bool COUNT>
+YH_DEV f3 eval_environment(const trace_ctx& tc, f3 dir) {
+  const yhd_scene& sc = *tc.sc;
+  f3 emission = mk3(0.0f);
+  for (int k = 0; k < sc.num_environments; k++) {
+    const yhd_environment& env = sc.environments[k];
+    f3    wl = transform_direction(ldframe(env.inv_frame), dir);
+    float tx = atan2f(wl.z, wl.x) / (2 * pif);
+    float ty = acosf(fclamp(wl.y, -1.0f, 1.0f)) / pif;
+    if (tx < 0) tx += 1;
+    if (COUNT) count_add<COUNT>(&tc.counters->envl, 1);
+    emission = emission + ld3(env.emission) * eval_env_texture(sc, env, tx, ty);
+  }
+  return emission;
+}
+
+// sample_discrete_cdf (math.h:4957-4962): std::upper_bound over the cdf
+YH_DEV int sample_discrete_cdf(const float* cdf, int n, float r) {
+  float back = cdf[n - 1];
+  r          = fclamp(r * back, 0.0f, back - 0.00001f);
+  int lo = 0, len = n;
+  while (len > 0) {  // first element > r
+    int half = len >> 1;
+    if (!(r < cdf[lo + half])) {
+      lo += half + 1;
+      len -= half + 1;
+    } else {
+      len = half;
+    }
+  }
+  return iclamp(lo, 0, n - 1);
+}
+
+// sample_lights (pt.cpp:1283-1308)
+template <bool COUNT>
+YH_DEV f3 sample_lights(const trace_ctx& tc, f3 position, float rl, float rel, float ruvx,
+    float ruvy) {
+  const yhd_scene& sc = *tc.sc;
+  int n        = sc.num_lights;
+  int light_id = iclamp((int)(rl * n), 0, n - 1);
+  const yhd_light& light = sc.lights[light_id];
+  if (light.object >= 0) {
+    int   element = sample_discrete_cdf(sc.light_cdf + light.cdf_base, light.cdf_count, rel);
+    float su      = sqrtf(ruvx);
+    float u = 1 - su, v = ruvy * su;  // sample_triangle, math.h:4910-4912
+    f3 lposition = eval_position(sc, sc.objects[light.object], element, u, v);
+    return normalize(lposition - position);
+  } else if (light.environment >= 0) {
+    const yhd_environment& env = sc.environments[light.environment];
+    if (env.tex_w) {
+      if (COUNT) count_add<COUNT>(&tc.counters->envs, 1);
+      int   idx = sample_discrete_cdf(sc.light_cdf + light.cdf_base, light.cdf_count, rel);
+      float ux  = (idx % env.tex_w + 0.5f) / env.tex_w;
+      float uy  = (idx / env.tex_w + 0.5f) / env.tex_h;
+      return transform_direction(ldframe(env.frame),
+          f3{cosf(ux * 2 * pif) * sinf(uy * pif), cosf(uy * pif), sinf(ux * 2 * pif) * sinf(uy * pif)});
+    } else {
+      // sample_sphere (math.h:4847-4852)
+      float z   = 2 * ruvy - 1;
+      float r   = sqrtf(fclamp(1 - z * z, 0.0f, 1.0f));
+      float phi = 2 * pif * ruvx;
+      return f3{r * cosf(phi), r * sinf(phi), z};
+    }
+  }
+  return mk3(0.0f);
+}
+
+// sample_lights_pdf (pt.cpp:1311-1358)
+template <bool COUNT>
+YH_DEV float sample_lights_pdf(const trace_ctx& tc, f3 position, f3 direction) {
+  const yhd_scene& sc = *tc.sc;
+  float pdf = 0.0f;
+  for (int k = 0; k < sc.num_lights; k++) {
+    const yhd_light& light = sc.lights[k];
+    if (light.object >= 0) {
+      const yhd_object& o = sc.objects[light.object];
+      float lpdf = 0.0f;
+      f3    next_position = position;
+      for (int bounce = 0; bounce < 100; bounce++) {
+        hit_t isec = trace_ray<COUNT>(tc, mkray(next_position, direction), light.object);
+        if (isec.object < 0) break;
+        f3    lposition = eval_position(sc, o, isec.element, isec.u, isec.v);
+        f3    lnormal   = eval_element_normal(sc, o, isec.element);
+        float area      = sc.light_cdf[light.cdf_base + light.cdf_count - 1];
+        f3    dp        = lposition - position;
+        lpdf += dot(dp, dp) / (fabs_(dot(lnormal, direction)) * area);
+        next_position = lposition + direction * 1e-3f;
+      }
+      pdf += lpdf;
+    } else if (light.environment >= 0) {
+      const yhd_environment& env = sc.environments[light.environment];
+      if (env.tex_w) {
+        f3    wl = transform_direction(ldframe(env.inv_frame), direction);
+        float tx = atan2f(wl.z, wl.x) / (2 * pif);
+        float ty = acosf(fclamp(wl.y, -1.0f, 1.0f)) / pif;
+        if (tx < 0) tx += 1;
+        int   i   = iclamp((int)(tx * env.tex_w), 0, env.tex_w - 1);
+        int   j   = iclamp((int)(ty * env.tex_h), 0, env.tex_h - 1);
+        int   idx = j * env.tex_w + i;
+        const float* cdf = sc.light_cdf + light.cdf_base;
+        float prob = (idx == 0 ? cdf[0] : cdf[idx] - cdf[idx - 1]) / cdf[light.cdf_count - 1];
+        float angle = (2 * pif / env.tex_w) * (pif / env.tex_h) * sinf(pif * (j + 0.5f) / env.tex_h);
+        pdf += prob / angle;
+      } else {
+        pdf += 1 / (4 * pif);
+      }
+    }
+  }
+  pdf *= (float)1 / (float)sc.num_lights;
+  return pdf;
+}
+
+// sample_hemisphere_cos(normal, ruv) with basis_fromz (math.h:4867-4878,2743)
+YH_DEV f3 sample_hemisphere_cos(f3 normal, float rx, float ry) {
+  float z     = sqrtf(ry);
+  float r     = sqrtf(1 - z * z);
+  float phi   = 2 * pif * rx;
+  f3    local = {r * cosf(phi), r * sinf(phi), z};
+  f3    zz    = normalize(normal);
+  float sign  = copysignf(1.0f, zz.z);
+  float a     = -1.0f / (sign + zz.z);
+  float b     = zz.x * zz.y * a;
+  f3    x     = {1.0f + sign * zz.x * zz.x * a, sign * b, -sign * zz.x};
+  f3    y     = {b, sign + zz.y * zz.y * a, -zz.y};
+  return normalize(x * local.x + y * local.y + zz * local.z);
+}
+
+// trace_path (pt.cpp:1380-1511) for one camera ray
+template <bool COUNT>
+YH_DEV void trace_path(const trace_ctx& tc, ray_t ray, rng_t& rng, int bounces, f3& radiance_out,
+    float& hit_out) {
+  const yhd_scene& sc = *tc.sc;
+  f3   radiance = mk3(0.0f), weight = mk3(1.0f);
+  bool hit = false;
+  for (int bounce = 0; bounce < bounces; bounce++) {
+    if (COUNT) count_add<COUNT>(&tc.counters->rays, 1);
+    hit_t isec = trace_ray<COUNT>(tc, ray, -1);
+    if (isec.object < 0) {
+      radiance = radiance + weight * eval_environment<COUNT>(tc, ray.d);
+      break;
+    }
+    const yhd_object&   o   = sc.objects[isec.object];
+    const yhd_material& mat = sc.materials[o.material];
+    f3 outgoing = -ray.d;
+    f3 position = eval_position(sc, o, isec.element, isec.u, isec.v);
+    f3 nrm      = eval_normal(sc, o, isec.element, isec.u, isec.v);
+    f3 normal;  // eval_shading_normal (pt.cpp:350-369)
+    bool is_hair = o.kind == YH_KIND_LINES;
+    if (is_hair) {
+      normal = orthonormalize(outgoing, nrm);
+    } else {
+      normal = (!mat.thin || dot(nrm, outgoing) >= 0) ? nrm : -nrm;
+    }
+    if (COUNT) count_add<COUNT>(is_hair ? &tc.counters->hair : &tc.counters->surf, 1);
+    hit      = true;
+    radiance = radiance + weight * (ld3(mat.emission) * mk3(1.0f));
+    hair_hit hh;
+    if (is_hair) hh = hair_setup(isec.v, normal, nrm);  // tangent = eval_normal (pt.cpp:487)
+
+    f3 incoming;
+    if (rand1f(rng) < 0.5f) {
+      float rnx = rand1f(rng), rny = rand1f(rng);
+      float rnl = rand1f(rng);
+      if (is_hair) {
+        incoming = hair_sample(mat, hh, outgoing, rnx, rny);
+      } else {  // sample_brdfcos (pt.cpp:1139-1174): only the diffuse lobe
+        incoming = mk3(0.0f);
+        if (mat.diffuse_pdf != 0 && rnl < 0.0f + mat.diffuse_pdf) {
+          if (!(dot(normal, outgoing) <= 0)) incoming = sample_hemisphere_cos(normal, rnx, rny);
+        }
+      }
+    } else {
+      float ruvx = rand1f(rng), ruvy = rand1f(rng);
+      float rel = rand1f(rng);
+      float rl  = rand1f(rng);
+      incoming  = sample_lights<COUNT>(tc, position, rl, rel, ruvx, ruvy);
+    }
+    f3    brdfcos;
+    float brdf_pdf;
+    if (is_hair) {
+      hair_eval_pdf<true, true>(mat, hh, outgoing, incoming, brdfcos, brdf_pdf);
+    } else {  // eval_brdfcos / sample_brdfcos_pdf, diffuse lobe (math.h:4427,4572)
+      brdfcos  = mk3(0.0f);
+      brdf_pdf = 0.0f;
+      f3 diffuse = ld3(mat.color);
+      bool below = dot(normal, incoming) <= 0 || dot(normal, outgoing) <= 0;
+      if (!is_zero(diffuse)) {
+        f3 lobe = below ? mk3(0.0f) : mk3(1.0f) / pif * dot(normal, incoming);
+        brdfcos = brdfcos + diffuse * lobe;
+      }
+      if (mat.diffuse_pdf != 0) {
+        float lobe = 0.0f;
+        if (!below) {
+          float cosw = dot(normal, incoming);
+          lobe       = (cosw <= 0) ? 0 : cosw / pif;
+        }
+        brdf_pdf += mat.diffuse_pdf * lobe;
+      }
+    }
+    float light_pdf = sample_lights_pdf<COUNT>(tc, position, incoming);
+    weight = weight * (brdfcos / (0.5f * brdf_pdf + 0.5f * light_pdf));
+    ray    = mkray(position, incoming);
+    if (is_zero(weight) || !finite3(weight)) break;
+    if (bounce > 3) {
+      float rr_prob = fmin_(0.99f, hmax(weight));
+      if (rand1f(rng) >= rr_prob) break;
+      weight = weight * (1 / rr_prob);
+    }
+  }
+  radiance_out = radiance;
+  hit_out      = hit ? 1.0f : 0.0f;
+}
+
+// trace_sample (pt.cpp:1676-1689): returns the value added to the accumulator
+template <bool COUNT>
+YH_DEV yhd_float4 trace_sample(const trace_ctx& tc, rng_t& rng, int i, int j, int w, int h,
+    int bounces, float clamp) {
+  float lu = rand1f(rng), lv = rand1f(rng);
+  float pu = rand1f(rng), pv = rand1f(rng);
+  ray_t ray = sample_camera(tc.sc->camera, i, j, w, h, pu, pv, lu, lv);
+  f3    rgb;
+  float a;
+  trace_path<COUNT>(tc, ray, rng, bounces, rgb, a);
+  if (!finite3(rgb)) rgb = mk3(0.0f);
+  if (hmax(rgb) > clamp) rgb = rgb * (clamp / hmax(rgb));
+  if (COUNT) count_add<COUNT>(&tc.counters->samples, 1);
+  return yhd_float4{rgb.x, rgb.y, rgb.z, a};
+}
+
+}  // namespace yhd
+#endif

@@ -1,0 +1,387 @@
+// kernels.hip — gfx950 kernels of the hair path and their launchers.
+//
+//   k_trace          the sample loop (trace_samples, pt.cpp:1992-2007): one
+//                    64-lane wavefront owns one 8x8 pixel tile, each lane one
+//                    pixel with its own PCG32 stream; tiles are pulled from the
+//                    owned-tile list; the top of the hair BVH and nothing else
+//                    lives in LDS.
+//   k_hair_*         unit-level batches of the four yocto::extension functions
+//   k_intersect      unit-level closest-hit batch
+//   k_selftest       the four Monte-Carlo self-tests (ext.cpp:555-693), made
+//                    data-parallel with PCG32 jump-ahead (draw counts per
+//                    iteration are fixed, so sample i's stream offset is known)
+//   k_pack / k_unpack  tile-packed float4 framebuffer for the RCCL gather
+//
+// Compiled with -ffp-contract=off (see dev_math.h).
+#include <hip/hip_runtime.h>
+
+#include "dev_path.h"
+
+using namespace yhd;
+
+#define YH_BLOCK 512
+
+// ---------------------------------------------------------------------------
+// The sample loop
+// ---------------------------------------------------------------------------
+template <bool COUNT>
+__global__ __launch_bounds__(YH_BLOCK) void k_trace(const yhd_scene sc, const yhd_state st,
+    int nsamples, yhd_counters* counters) {
+  extern __shared__ yhd_float4 lds_nodes[];
+  // stage the nodelets: the first lds_node_count nodes (breadth-first = top
+  // levels) of the dominant hair shape, 32 B each, coalesced dwordx4 loads
+  for (int i = threadIdx.x; i < 2 * sc.lds_node_count; i += blockDim.x)
+    lds_nodes[i] = sc.nodes[2 * (size_t)sc.lds_node_base + i];
+  __syncthreads();
+
+  trace_ctx tc;
+  tc.sc        = &sc;
+  tc.lds_nodes = sc.lds_node_count ? lds_nodes : nullptr;
+  tc.counters  = counters;
+
+  const int lane        = threadIdx.x & 63;
+  const int wave        = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int total_waves = (gridDim.x * blockDim.x) >> 6;
+  for (int t = wave; t < st.num_tiles; t += total_waves) {
+    int tile = st.tiles[t];
+    int i    = (tile % st.tiles_x) * YH_TILE + (lane & 7);
+    int j    = (tile / st.tiles_x) * YH_TILE + (lane >> 3);
+    if (i >= st.width || j >= st.height) continue;
+    size_t pix = (size_t)j * st.width + i;
+    rng_t  rng;
+    rng.state      = st.rng_state[pix];
+    rng.inc        = st.rng_inc[pix];
+    yhd_float4 acc = st.accum[pix];
+    for (int s = 0; s < nsamples; s++) {
+      yhd_float4 v = trace_sample<COUNT>(tc, rng, i, j, st.width, st.height, st.bounces, st.clamp);
+      acc.x += v.x, acc.y += v.y, acc.z += v.z, acc.w += v.w;
+    }
+    st.rng_state[pix] = rng.state;
+    st.accum[pix]     = acc;
+  }
+}
+
+// render[ij] = accumulated / samples (pt.cpp:1688) into a full W*H image
+__global__ void k_resolve(const yhd_state st, int samples, yhd_float4* image) {
+  int t = blockIdx.x, lane = threadIdx.x;
+  if (t >= st.num_tiles) return;
+  int tile = st.tiles[t];
+  int i    = (tile % st.tiles_x) * YH_TILE + (lane & 7);
+  int j    = (tile / st.tiles_x) * YH_TILE + (lane >> 3);
+  if (i >= st.width || j >= st.height) return;
+  size_t     pix = (size_t)j * st.width + i;
+  yhd_float4 a   = st.accum[pix];
+  float      n   = (float)samples;
+  image[pix]     = samples > 0 ? yhd_float4{a.x / n, a.y / n, a.z / n, a.w / n} : yhd_float4{0, 0, 0, 0};
+}
+// tile-packed variant: 64 float4 per owned tile, tiles in increasing id order
+__global__ void k_pack(const yhd_state st, int samples, yhd_float4* packed) {
+  int t = blockIdx.x, lane = threadIdx.x;
+  if (t >= st.num_tiles) return;
+  int tile = st.tiles[t];
+  int i    = (tile % st.tiles_x) * YH_TILE + (lane & 7);
+  int j    = (tile / st.tiles_x) * YH_TILE + (lane >> 3);
+  yhd_float4 out = {0, 0, 0, 0};
+  if (i < st.width && j < st.height && samples > 0) {
+    yhd_float4 a = st.accum[(size_t)j * st.width + i];
+    float      n = (float)samples;
+    out          = yhd_float4{a.x / n, a.y / n, a.z / n, a.w / n};
+  }
+  packed[(size_t)t * 64 + lane] = out;
+}
+__global__ void k_unpack(const yhd_float4* packed, int src_rank, int world, int num_tiles_total,
+    int tiles_x, int width, int height, yhd_float4* image) {
+  // the k-th tile owned by src_rank is tile id src_rank + k * world
+  int k = blockIdx.x, lane = threadIdx.x;
+  int tile = src_rank + k * world;
+  if (tile >= num_tiles_total) return;
+  int i = (tile % tiles_x) * YH_TILE + (lane & 7);
+  int j = (tile / tiles_x) * YH_TILE + (lane >> 3);
+  if (i < width && j < height) image[(size_t)j * width + i] = packed[(size_t)k * 64 + lane];
+}
+
+// ---------------------------------------------------------------------------
+// Unit-level batches
+// ---------------------------------------------------------------------------
+// hair_brdf as 30 floats (yhair.h): sigma_a[3] alpha eta h v[4] s sin[3]
+// cos[3] gamma_o world_to_brdf[12]
+YH_DEV void unpack_brdf(const float* b, yhd_material& m, hair_hit& hh) {
+  m.sigma_a[0] = b[0], m.sigma_a[1] = b[1], m.sigma_a[2] = b[2];
+  m.alpha = b[3], m.eta = b[4];
+  hh.h = b[5];
+  for (int p = 0; p < 4; p++) m.v[p] = b[6 + p];
+  m.s = b[10];
+  for (int k = 0; k < 3; k++) m.sin_2k_alpha[k] = b[11 + k], m.cos_2k_alpha[k] = b[14 + k];
+  hh.gamma_o = b[17];
+  hh.w2b     = ldframe(b + 18);
+  derive_material(m);
+}
+
+// eval_hair_brdf (ext.cpp:127-177) entirely on the device
+struct yh_material_in {  // mirrors yh_material of include/yhair.h
+  float emission[3], color[3];
+  float specular, metallic, roughness, transmission, opacity, ior;
+  int   thin;
+  float sigma_a[3];
+  float beta_m, beta_n, alpha, eta, eumelanin, pheomelanin;
+};
+template <int N>
+YH_DEV float powt(float v) {  // ext.cpp:95-109
+  if constexpr (N == 0) return 1;
+  else if constexpr (N == 1) return v;
+  else {
+    float n2 = powt<N / 2>(v);
+    return n2 * n2 * powt<(N & 1)>(v);
+  }
+}
+__global__ void k_hair_brdf(int n, const yh_material_in* mats, const float* v, const float* nrm,
+    const float* tng, float* out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const yh_material_in& m = mats[i];
+  f3 sigma_a = mk3(0.0f);
+  f3 msa = ld3(m.sigma_a), col = ld3(m.color);
+  if (!is_zero(msa)) {
+    sigma_a = msa;
+  } else if (!is_zero(col)) {  // sigma_a_from_reflectance (ext.cpp:121-125)
+    float bn  = m.beta_n;
+    float den = 5.969f - 0.215f * bn + 2.532f * sqr(bn) - 10.73f * powt<3>(bn) +
+                5.574f * powt<4>(bn) + 0.245f * powt<5>(bn);
+    f3 q    = f3{logf(col.x), logf(col.y), logf(col.z)} / den;
+    sigma_a = q * q;
+  } else if (m.eumelanin != 0 || m.pheomelanin != 0) {  // ext.cpp:115-119
+    sigma_a = m.eumelanin * f3{0.419f, 0.697f, 1.37f} + m.pheomelanin * f3{0.187f, 0.4f, 1.05f};
+  }
+  float bm = m.beta_m, bn = m.beta_n;
+  float* o = out + 30 * (size_t)i;
+  o[0] = sigma_a.x, o[1] = sigma_a.y, o[2] = sigma_a.z;
+  o[3] = m.alpha, o[4] = m.eta;
+  hair_hit hh = hair_setup(v[i], ld3(nrm + 3 * i), ld3(tng + 3 * i));
+  o[5]     = hh.h;
+  float v0 = sqr(0.726f * bm + 0.812f * sqr(bm) + 3.7f * powt<20>(bm));
+  o[6] = v0, o[7] = 0.25f * v0, o[8] = 4 * v0, o[9] = 4 * v0;
+  o[10] = 0.626657069f * (0.265f * bn + 1.194f * sqr(bn) + 5.372f * powt<22>(bn));
+  float s0 = sinf(pif / 180 * m.alpha);
+  float c0 = safe_sqrt(1 - sqr(s0));
+  float s1 = 2 * c0 * s0, c1 = sqr(c0) - sqr(s0);
+  float s2 = 2 * c1 * s1, c2 = sqr(c1) - sqr(s1);
+  o[11] = s0, o[12] = s1, o[13] = s2, o[14] = c0, o[15] = c1, o[16] = c2;
+  o[17] = hh.gamma_o;
+  const frame& w = hh.w2b;
+  o[18] = w.x.x, o[19] = w.x.y, o[20] = w.x.z, o[21] = w.y.x, o[22] = w.y.y, o[23] = w.y.z;
+  o[24] = w.z.x, o[25] = w.z.y, o[26] = w.z.z, o[27] = w.o.x, o[28] = w.o.y, o[29] = w.o.z;
+}
+__global__ void k_hair_eval(int n, const float* brdf, const float* wo, const float* wi, float* out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  yhd_material m;
+  hair_hit     hh;
+  unpack_brdf(brdf + 30 * (size_t)i, m, hh);
+  f3    f;
+  float pdf;
+  hair_eval_pdf<true, false>(m, hh, ld3(wo + 3 * i), ld3(wi + 3 * i), f, pdf);
+  out[3 * i] = f.x, out[3 * i + 1] = f.y, out[3 * i + 2] = f.z;
+}
+__global__ void k_hair_pdf(int n, const float* brdf, const float* wo, const float* wi, float* out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  yhd_material m;
+  hair_hit     hh;
+  unpack_brdf(brdf + 30 * (size_t)i, m, hh);
+  f3    f;
+  float pdf;
+  hair_eval_pdf<false, true>(m, hh, ld3(wo + 3 * i), ld3(wi + 3 * i), f, pdf);
+  out[i] = pdf;
+}
+__global__ void k_hair_sample(int n, const float* brdf, const float* wo, const float* rn, float* out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  yhd_material m;
+  hair_hit     hh;
+  unpack_brdf(brdf + 30 * (size_t)i, m, hh);
+  f3 w = hair_sample(m, hh, ld3(wo + 3 * i), rn[2 * i], rn[2 * i + 1]);
+  out[3 * i] = w.x, out[3 * i + 1] = w.y, out[3 * i + 2] = w.z;
+}
+__global__ void k_intersect(const yhd_scene sc, int n, const float* rays, int* object, int* element,
+    float* uv, float* dist) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  trace_ctx tc;
+  tc.sc = &sc, tc.lds_nodes = nullptr, tc.counters = nullptr;
+  const float* r = rays + 8 * (size_t)i;
+  ray_t ray      = ray_t{ld3(r), ld3(r + 3), r[6], r[7]};
+  hit_t h        = trace_ray<false>(tc, ray, -1);
+  object[i] = h.object, element[i] = h.object < 0 ? -1 : h.element;
+  uv[2 * i] = h.u, uv[2 * i + 1] = h.v, dist[i] = h.distance;
+}
+
+// ---------------------------------------------------------------------------
+// Self-tests (ext.cpp:555-693)
+// ---------------------------------------------------------------------------
+// PCG32 jump-ahead: state after `delta` steps of the LCG (Brown, "Random
+// number generation with arbitrary strides").
+YH_DEV uint64_t pcg_advance(uint64_t state, uint64_t inc, uint64_t delta) {
+  uint64_t cur_mult = 6364136223846793005ULL, cur_plus = inc, acc_mult = 1u, acc_plus = 0u;
+  while (delta > 0) {
+    if (delta & 1) {
+      acc_mult *= cur_mult;
+      acc_plus = acc_plus * cur_mult + cur_plus;
+    }
+    cur_plus = (cur_mult + 1) * cur_plus;
+    cur_mult *= cur_mult;
+    delta /= 2;
+  }
+  return acc_mult * state + acc_plus;
+}
+YH_DEV f3 sample_sphere(float rx, float ry) {  // math.h:4847-4852
+  float z   = 2 * ry - 1;
+  float r   = sqrtf(fclamp(1 - z * z, 0.0f, 1.0f));
+  float phi = 2 * pif * rx;
+  return f3{r * cosf(phi), r * sinf(phi), z};
+}
+struct selftest_args {
+  int      which;
+  float    beta_m, beta_n;
+  uint64_t state, inc;   // rng state at the start of this (beta_m, beta_n) block's sample loop
+  int      count;
+  float    wo[3];        // tests 0, 1, 3
+};
+// out (double): [0..2] first sum, [3..5] second sum, [6] max |lum(f)/pdf - 1| as float bits via atomicMax
+__global__ void k_selftest(selftest_args a, double* sums, unsigned int* worst_bits) {
+  int   i = blockIdx.x * blockDim.x + threadIdx.x;
+  float s0[3] = {0, 0, 0}, s1[3] = {0, 0, 0};
+  float dev = 0.0f;
+  if (i < a.count) {
+    int   per_iter = a.which == 2 ? 5 : 3;
+    rng_t rng;
+    rng.inc   = a.inc;
+    rng.state = pcg_advance(a.state, a.inc, (uint64_t)per_iter * (uint64_t)i);
+    float h   = rand1f(rng);
+    if (a.which == 0 && h == 0) h += 1.1920929e-07f;  // flt_eps
+    // eval_hair_brdf(mat{beta_m, beta_n, alpha 0}, h, {0,0,1}, {1,0,0})
+    yhd_material m;
+    m.sigma_a[0] = m.sigma_a[1] = m.sigma_a[2] = 0;
+    m.alpha = 0, m.eta = 1.55f;
+    float bm = a.beta_m, bn = a.beta_n;
+    m.v[0] = sqr(0.726f * bm + 0.812f * sqr(bm) + 3.7f * powt<20>(bm));
+    m.v[1] = 0.25f * m.v[0], m.v[2] = 4 * m.v[0], m.v[3] = m.v[2];
+    m.s    = 0.626657069f * (0.265f * bn + 1.194f * sqr(bn) + 5.372f * powt<22>(bn));
+    float s_0 = sinf(pif / 180 * m.alpha), c_0 = safe_sqrt(1 - sqr(s_0));
+    m.sin_2k_alpha[0] = s_0, m.cos_2k_alpha[0] = c_0;
+    for (int k = 1; k < 3; k++) {
+      m.sin_2k_alpha[k] = 2 * m.cos_2k_alpha[k - 1] * m.sin_2k_alpha[k - 1];
+      m.cos_2k_alpha[k] = sqr(m.cos_2k_alpha[k - 1]) - sqr(m.sin_2k_alpha[k - 1]);
+    }
+    derive_material(m);
+    hair_hit hh = hair_setup(h, f3{0, 0, 1}, f3{1, 0, 0});
+    f3 wo = ld3(a.wo);
+    if (a.which == 2) {
+      float wx = rand1f(rng), wy = rand1f(rng);
+      wo = sample_sphere(wx, wy);
+    }
+    float rx = rand1f(rng), ry = rand1f(rng);
+    f3    f;
+    float pdf;
+    if (a.which == 0) {
+      f3 wi = sample_sphere(rx, ry);
+      hair_eval_pdf<true, false>(m, hh, wo, wi, f, pdf);
+      s0[0] = f.x, s0[1] = f.y, s0[2] = f.z;
+    } else {
+      f3 wi = hair_sample(m, hh, wo, rx, ry);
+      hair_eval_pdf<true, true>(m, hh, wo, wi, f, pdf);
+      if (a.which == 1) {
+        if (pdf > 0) s0[0] = f.x / pdf, s0[1] = f.y / pdf, s0[2] = f.z / pdf;
+      } else if (a.which == 2) {
+        if (pdf > 0) dev = fabs_(luminance(f) / pdf - 1);
+      } else {
+        float li = wi.z * wi.z;  // Li(w) = w.z^2 (ext.cpp:662)
+        if (pdf > 0) s0[0] = f.x * li / pdf, s0[1] = f.y * li / pdf, s0[2] = f.z * li / pdf;
+        f3 wu = sample_sphere(rx, ry);
+        f3 fu;
+        hair_eval_pdf<true, false>(m, hh, wo, wu, fu, pdf);
+        float lu = wu.z * wu.z;
+        s1[0] = fu.x * lu, s1[1] = fu.y * lu, s1[2] = fu.z * lu;
+      }
+    }
+  }
+  // wave reduction, then one atomic per wave (sums are tiny: double atomics)
+  for (int k = 0; k < 3; k++) {
+    double a0 = s0[k], a1 = s1[k];
+    for (int off = 32; off > 0; off >>= 1) {
+      a0 += __shfl_down(a0, off, 64);
+      a1 += __shfl_down(a1, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+      atomicAdd(&sums[k], a0);
+      atomicAdd(&sums[3 + k], a1);
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) dev = fmaxf(dev, __shfl_down(dev, off, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(worst_bits, __float_as_uint(dev));
+}
+
+// ---------------------------------------------------------------------------
+// Launchers (called from the g++-compiled host code)
+// ---------------------------------------------------------------------------
+extern "C" {
+
+int yhk_trace(const yhd_scene* sc, const yhd_state* st, int nsamples, yhd_counters* counters,
+    int grid_blocks, hipStream_t stream) {
+  size_t lds = (size_t)sc->lds_node_count * 32;
+  if (counters)
+    hipLaunchKernelGGL(k_trace<true>, dim3(grid_blocks), dim3(YH_BLOCK), lds, stream, *sc, *st, nsamples, counters);
+  else
+    hipLaunchKernelGGL(k_trace<false>, dim3(grid_blocks), dim3(YH_BLOCK), lds, stream, *sc, *st, nsamples, counters);
+  return (int)hipGetLastError();
+}
+int yhk_block_threads(void) { return YH_BLOCK; }
+int yhk_trace_occupancy(int lds_bytes) {
+  int blocks = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_trace<false>, YH_BLOCK, lds_bytes) != hipSuccess) return 1;
+  return blocks < 1 ? 1 : blocks;
+}
+int yhk_resolve(const yhd_state* st, int samples, void* image, hipStream_t stream) {
+  if (st->num_tiles) hipLaunchKernelGGL(k_resolve, dim3(st->num_tiles), dim3(64), 0, stream, *st, samples, (yhd_float4*)image);
+  return (int)hipGetLastError();
+}
+int yhk_pack(const yhd_state* st, int samples, void* packed, hipStream_t stream) {
+  if (st->num_tiles) hipLaunchKernelGGL(k_pack, dim3(st->num_tiles), dim3(64), 0, stream, *st, samples, (yhd_float4*)packed);
+  return (int)hipGetLastError();
+}
+int yhk_unpack(const void* packed, int src_rank, int world, int ntiles_src, int num_tiles_total, int tiles_x,
+    int width, int height, void* image, hipStream_t stream) {
+  if (ntiles_src)
+    hipLaunchKernelGGL(k_unpack, dim3(ntiles_src), dim3(64), 0, stream, (const yhd_float4*)packed, src_rank, world,
+        num_tiles_total, tiles_x, width, height, (yhd_float4*)image);
+  return (int)hipGetLastError();
+}
+int yhk_hair_brdf(int n, const void* mats, const float* v, const float* nrm, const float* tng, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_hair_brdf, dim3((n + 255) / 256), dim3(256), 0, s, n, (const yh_material_in*)mats, v, nrm, tng, out);
+  return (int)hipGetLastError();
+}
+int yhk_hair_eval(int n, const float* brdf, const float* wo, const float* wi, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_hair_eval, dim3((n + 255) / 256), dim3(256), 0, s, n, brdf, wo, wi, out);
+  return (int)hipGetLastError();
+}
+int yhk_hair_pdf(int n, const float* brdf, const float* wo, const float* wi, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_hair_pdf, dim3((n + 255) / 256), dim3(256), 0, s, n, brdf, wo, wi, out);
+  return (int)hipGetLastError();
+}
+int yhk_hair_sample(int n, const float* brdf, const float* wo, const float* rn, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_hair_sample, dim3((n + 255) / 256), dim3(256), 0, s, n, brdf, wo, rn, out);
+  return (int)hipGetLastError();
+}
+int yhk_intersect(const yhd_scene* sc, int n, const float* rays, int* object, int* element, float* uv, float* dist,
+    hipStream_t s) {
+  hipLaunchKernelGGL(k_intersect, dim3((n + 255) / 256), dim3(256), 0, s, *sc, n, rays, object, element, uv, dist);
+  return (int)hipGetLastError();
+}
+int yhk_selftest(int which, float beta_m, float beta_n, uint64_t state, uint64_t inc, int count, const float* wo,
+    double* sums, unsigned int* worst_bits, hipStream_t s) {
+  selftest_args a;
+  a.which = which, a.beta_m = beta_m, a.beta_n = beta_n, a.state = state, a.inc = inc, a.count = count;
+  a.wo[0] = wo[0], a.wo[1] = wo[1], a.wo[2] = wo[2];
+  hipLaunchKernelGGL(k_selftest, dim3((count + 255) / 256), dim3(256), 0, s, a, sums, worst_bits);
+  return (int)hipGetLastError();
+}
+}

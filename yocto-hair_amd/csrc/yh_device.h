@@ -1,0 +1,138 @@
+// yh_device.h — layout of the scene and render state in HBM, shared by the
+// host upload code (g++) and the HIP kernels (hipcc). Plain C structs only.
+//
+// Everything a ray touches is stored in 16-byte records so that every fetch
+// is one or two `global_load_dwordx4`:
+//   * BVH node (32 B): {min.xyz, start} {max.xyz, meta}; meta = num |
+//     internal << 16 | axis << 24 — the reference's bvh_node (pt.h:243-249).
+//     Nodes keep the reference's breadth-first order, so the first N nodes are
+//     the top of the tree (the "nodelets" staged in LDS).
+//   * hair segment (32 B), stored in BVH LEAF ORDER (no primitives[] / lines[]
+//     / positions[] / radius[] indirection in the inner loop):
+//     {p0.xyz, r0} {p1.xyz, r1}; the element id is in a parallel int array
+//     read only on a hit.
+//   * triangle (48 B) in leaf order: {p0.xyz, elem} {p1.xyz, 0} {p2.xyz, 0}.
+//   * shading data per vertex: float4 {pos.xyz, radius}, float4 {normal.xyz,0}
+//     (normal = hair tangent for line shapes), and int4 element indices.
+#ifndef YH_DEVICE_H_
+#define YH_DEVICE_H_
+#include <stdint.h>
+
+#define YH_KIND_LINES 1
+#define YH_KIND_TRIANGLES 2
+#define YH_TILE 8          /* tiles are 8x8 pixels = one 64-lane wavefront  */
+#define YH_STACK_MAX 96    /* traversal stack entries per lane               */
+#define YH_MAX_LIGHTS 16
+#define YH_MAX_ENVS 4
+
+typedef struct yhd_float4 { float x, y, z, w; } yhd_float4;
+typedef struct yhd_int4 { int x, y, z, w; } yhd_int4;
+
+// One instance (ptr::object) with its shape's array offsets folded in.
+typedef struct yhd_object {
+  float frame[12];      // object -> world
+  float inv_frame[12];  // inverse(frame, non_rigid = true), pt.cpp:1012-1013
+  int   kind;           // YH_KIND_*
+  int   node_base;      // first BVH node of the shape in `nodes`
+  int   prim_base;      // first leaf-ordered primitive record of the shape
+  int   vert_base;      // first vertex in vpos / vnrm
+  int   elem_base;      // first element in elems
+  int   has_normals;
+  int   material;
+  int   slot_base;      // first leaf slot of the shape in prim_elem
+} yhd_object;
+
+// ptr::material + everything of hair_brdf that depends on the material only
+// (ext.cpp:131-172), computed ONCE on the host at upload.
+typedef struct yhd_material {
+  float  emission[3];
+  float  color[3];
+  float  diffuse_pdf;  // 1 if any colour channel is non-zero, else 0
+  int    thin;
+  // hair constants
+  float  sigma_a[3];
+  float  alpha, eta;
+  float  v[4];
+  float  s;
+  float  sin_2k_alpha[3], cos_2k_alpha[3];
+  // derived per-lobe constants used by mp() / np() / sampling
+  float  inv_v[4];         // 1 / v[p]
+  float  log_inv_2v[4];    // log(1 / (2 v[p]))
+  float  exp_m2_inv_v[4];  // exp(-2 / v[p])
+  double mp_den[4];        // sinh(1 / v[p]) * 2 * v[p]   (double, ext.cpp:206)
+  float  tl_cdf_a;         // logistic_cdf(-pi, s)
+  float  tl_norm;          // logistic_cdf(pi, s) - logistic_cdf(-pi, s)
+  float  pad0, pad1;
+} yhd_material;
+
+typedef struct yhd_light {
+  int object;       // >= 0: area light on that object
+  int environment;  // >= 0: environment light
+  int cdf_base;     // offset into light_cdf
+  int cdf_count;    // triangles / texels (0 for a constant environment)
+} yhd_light;
+
+typedef struct yhd_environment {
+  float frame[12];
+  float inv_frame[12];  // rigid inverse (transpose), pt.cpp:539
+  float emission[3];
+  int   tex_w, tex_h;   // 0 when constant
+  int   texel_base;     // offset into env_texels (float4 per texel)
+  int   pad0, pad1;
+} yhd_environment;
+
+typedef struct yhd_camera {
+  float frame[12];
+  float lens, film_x, film_y, focus, aperture;
+} yhd_camera;
+
+typedef struct yhd_scene {
+  // geometry
+  const yhd_float4* nodes;      // 2 float4 per node
+  const yhd_float4* prims;      // leaf-ordered records (2 or 3 float4 each)
+  const int*        prim_elem;  // element id of each leaf-ordered hair segment
+  const yhd_float4* vpos;       // per vertex {pos, radius}
+  const yhd_float4* vnrm;       // per vertex {normal/tangent, 0}
+  const yhd_int4*   elems;      // per element vertex indices (shape-local)
+  const yhd_object* objects;
+  const yhd_material* materials;
+  // scene-level BVH over instances
+  const yhd_float4* scene_nodes;
+  const int*        scene_prims;
+  int               num_scene_nodes;
+  int               num_objects;
+  // lights
+  int               num_lights;
+  int               num_environments;
+  yhd_light         lights[YH_MAX_LIGHTS];
+  yhd_environment   environments[YH_MAX_ENVS];
+  const float*      light_cdf;
+  const yhd_float4* env_texels;
+  yhd_camera        camera;
+  // number of leading nodes of the largest line shape staged in LDS
+  int               lds_node_base;   // global index of that shape's root
+  int               lds_node_count;
+} yhd_scene;
+
+// Render state (pt.h:419-429) in SoA form.
+typedef struct yhd_state {
+  uint64_t*   rng_state;  // per pixel
+  uint64_t*   rng_inc;    // per pixel
+  yhd_float4* accum;      // per pixel: sum of clamped radiance, w = hit count
+  const int*  tiles;      // owned tile ids (increasing)
+  int         num_tiles;
+  int         width, height;
+  int         tiles_x;
+  int         samples_done;
+  int         bounces;
+  float       clamp;
+  int         pad;
+} yhd_state;
+
+// Work counters (one 64-bit slot each), accumulated with atomics by the
+// instrumented kernel variant only.
+typedef struct yhd_counters {
+  unsigned long long samples, rays, nodes, seg, tri, hair, surf, envl, envs;
+} yhd_counters;
+
+#endif

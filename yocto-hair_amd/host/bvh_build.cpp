@@ -1,0 +1,96 @@
+// bvh_build.cpp — see bvh_build.h. Restates pt.cpp:557-650.
+#include "bvh_build.h"
+
+#include <algorithm>
+#include <deque>
+#include <limits>
+
+namespace yhh {
+
+namespace {
+struct Prim {
+  Box   bbox;
+  float center[3];
+  int   primitive;
+};
+inline float fmin_(float a, float b) { return (a < b) ? a : b; }  // math.h:1779
+inline float fmax_(float a, float b) { return (a > b) ? a : b; }
+const float flt_max = std::numeric_limits<float>::max();
+const float flt_min = std::numeric_limits<float>::lowest();
+
+// split_middle (pt.cpp:564-595)
+void split_middle(std::vector<Prim>& prims, int start, int end, int& mid, int& axis) {
+  axis = 0;
+  mid  = (start + end) / 2;
+  float cmin[3] = {flt_max, flt_max, flt_max}, cmax[3] = {flt_min, flt_min, flt_min};
+  for (int i = start; i < end; i++)
+    for (int k = 0; k < 3; k++) {
+      cmin[k] = fmin_(cmin[k], prims[i].center[k]);
+      cmax[k] = fmax_(cmax[k], prims[i].center[k]);
+    }
+  float cs[3] = {cmax[0] - cmin[0], cmax[1] - cmin[1], cmax[2] - cmin[2]};
+  if (cs[0] == 0 && cs[1] == 0 && cs[2] == 0) return;
+  if (cs[0] >= cs[1] && cs[0] >= cs[2]) axis = 0;
+  if (cs[1] >= cs[0] && cs[1] >= cs[2]) axis = 1;
+  if (cs[2] >= cs[0] && cs[2] >= cs[1]) axis = 2;
+  int   ax     = axis;
+  float middle = (cmin[ax] + cmax[ax]) / 2;
+  mid = (int)(std::partition(prims.data() + start, prims.data() + end,
+                  [ax, middle](const Prim& p) { return p.center[ax] < middle; }) -
+              prims.data());
+  if (mid == start || mid == end) mid = (start + end) / 2;
+}
+}  // namespace
+
+void build_bvh(Tree& tree, const std::vector<Box>& boxes) {
+  std::vector<Prim> prims(boxes.size());
+  for (size_t i = 0; i < boxes.size(); i++) {
+    prims[i].bbox = boxes[i];
+    for (int k = 0; k < 3; k++) prims[i].center[k] = (boxes[i].min[k] + boxes[i].max[k]) / 2;
+    prims[i].primitive = (int)i;
+  }
+  auto& nodes = tree.nodes;
+  nodes.clear();
+  nodes.reserve(prims.size() * 2 + 1);
+  struct Item {
+    int node, start, end, depth;
+  };
+  std::deque<Item> queue{{0, 0, (int)prims.size(), 1}};
+  nodes.emplace_back();
+  tree.max_depth = 0;
+  while (!queue.empty()) {
+    Item it = queue.front();
+    queue.pop_front();
+    tree.max_depth = std::max(tree.max_depth, it.depth);
+    Node node;
+    for (int k = 0; k < 3; k++) node.bbox.min[k] = flt_max, node.bbox.max[k] = flt_min;
+    for (int i = it.start; i < it.end; i++)
+      for (int k = 0; k < 3; k++) {
+        node.bbox.min[k] = fmin_(node.bbox.min[k], prims[i].bbox.min[k]);
+        node.bbox.max[k] = fmax_(node.bbox.max[k], prims[i].bbox.max[k]);
+      }
+    if (it.end - it.start > 4) {  // bvh_max_prims (pt.cpp:598)
+      int mid, axis;
+      split_middle(prims, it.start, it.end, mid, axis);
+      node.internal = true;
+      node.axis     = (unsigned char)axis;
+      node.num      = 2;
+      node.start    = (int)nodes.size();
+      nodes.emplace_back();
+      nodes.emplace_back();
+      queue.push_back({node.start + 0, it.start, mid, it.depth + 1});
+      queue.push_back({node.start + 1, mid, it.end, it.depth + 1});
+    } else {
+      node.internal = false;
+      node.axis     = 0;
+      node.num      = (short)(it.end - it.start);
+      node.start    = it.start;
+    }
+    nodes[it.node] = node;
+  }
+  nodes.shrink_to_fit();
+  tree.primitives.resize(prims.size());
+  for (size_t i = 0; i < prims.size(); i++) tree.primitives[i] = prims[i].primitive;
+}
+
+}  // namespace yhh

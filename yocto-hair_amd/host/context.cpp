@@ -1,0 +1,876 @@
+// context.cpp — the C ABI of include/yhair.h on top of the HIP kernels.
+//
+// Host responsibilities (all once per scene / per image, never per sample):
+//   yh_upload_scene = init_bvh + init_lights (pt.cpp:755-818,1695-1740):
+//     reference-identical BVHs, leaf-ordered primitive records, inverse object
+//     frames, per-material hair constants (the material-only part of
+//     eval_hair_brdf, ext.cpp:131-172), light CDFs, float4 env texels;
+//   yh_init_state (pt.cpp:1931-1946): image size, tile list of this shard,
+//     per-pixel PCG32 streams (the sequence ids come from ONE serial master
+//     generator, so they are produced on the host and uploaded: 16 B/pixel);
+//   yh_trace_samples: one k_trace launch on the context's stream, HIP-event
+//     timed.
+// There is no CPU fallback: without a GPU yh_create returns NULL.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "../csrc/yh_device.h"
+#include "bvh_build.h"
+#include "yhair.h"
+
+// launchers in csrc/kernels.hip
+extern "C" {
+int yhk_trace(const yhd_scene*, const yhd_state*, int, yhd_counters*, int, hipStream_t);
+int yhk_block_threads(void);
+int yhk_trace_occupancy(int lds_bytes);
+int yhk_resolve(const yhd_state*, int, void*, hipStream_t);
+int yhk_pack(const yhd_state*, int, void*, hipStream_t);
+int yhk_unpack(const void*, int, int, int, int, int, int, int, void*, hipStream_t);
+int yhk_hair_brdf(int, const void*, const float*, const float*, const float*, float*, hipStream_t);
+int yhk_hair_eval(int, const float*, const float*, const float*, float*, hipStream_t);
+int yhk_hair_pdf(int, const float*, const float*, const float*, float*, hipStream_t);
+int yhk_hair_sample(int, const float*, const float*, const float*, float*, hipStream_t);
+int yhk_intersect(const yhd_scene*, int, const float*, int*, int*, float*, float*, hipStream_t);
+int yhk_selftest(int, float, float, uint64_t, uint64_t, int, const float*, double*, unsigned int*, hipStream_t);
+}
+
+namespace {
+
+std::string g_create_error = "no error";
+
+struct DevBuf {
+  void*  p = nullptr;
+  size_t bytes = 0;
+  ~DevBuf() { reset(); }
+  void reset() {
+    if (p) (void)hipFree(p);
+    p = nullptr, bytes = 0;
+  }
+};
+
+const float pif = (float)3.14159265358979323846;
+
+// ---- tiny host vector helpers with the reference's operation order --------
+struct F3 {
+  float x, y, z;
+};
+F3    operator+(F3 a, F3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+F3    operator-(F3 a, F3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+F3    operator-(F3 a) { return {-a.x, -a.y, -a.z}; }
+F3    operator*(F3 a, float b) { return {a.x * b, a.y * b, a.z * b}; }
+float dot(F3 a, F3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+F3    cross(F3 a, F3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+float fmin_(float a, float b) { return (a < b) ? a : b; }
+float fmax_(float a, float b) { return (a > b) ? a : b; }
+F3    ld3(const float* p) { return {p[0], p[1], p[2]}; }
+void  st3(float* p, F3 a) { p[0] = a.x, p[1] = a.y, p[2] = a.z; }
+
+// inverse(frame, non_rigid = true) (math.h:2877-2885, 2721-2741)
+void inverse_frame(const float* f, bool non_rigid, float* out) {
+  F3 x = ld3(f), y = ld3(f + 3), z = ld3(f + 6), o = ld3(f + 9);
+  F3 rx, ry, rz;
+  if (non_rigid) {
+    F3    c0 = cross(y, z), c1 = cross(z, x), c2 = cross(x, y);
+    float det = dot(x, cross(y, z));
+    float s   = 1 / det;
+    rx = F3{c0.x, c1.x, c2.x} * s, ry = F3{c0.y, c1.y, c2.y} * s, rz = F3{c0.z, c1.z, c2.z} * s;
+  } else {
+    rx = {x.x, y.x, z.x}, ry = {x.y, y.y, z.y}, rz = {x.z, y.z, z.z};
+  }
+  F3 ro = -(rx * o.x + ry * o.y + rz * o.z);
+  st3(out, rx), st3(out + 3, ry), st3(out + 6, rz), st3(out + 9, ro);
+}
+F3 transform_point(const float* f, F3 b) {
+  return ld3(f) * b.x + ld3(f + 3) * b.y + ld3(f + 6) * b.z + ld3(f + 9);
+}
+
+// PCG32 (math.h:1396-1442) for init_state and the self-test drivers
+struct Rng {
+  uint64_t state, inc;
+};
+uint32_t advance_rng(Rng& rng) {
+  uint64_t old        = rng.state;
+  rng.state           = old * 6364136223846793005ULL + rng.inc;
+  uint32_t xorshifted = (uint32_t)(((old >> 18u) ^ old) >> 27u);
+  uint32_t rot        = (uint32_t)(old >> 59u);
+  return (xorshifted >> rot) | (xorshifted << ((-rot) & 31));
+}
+Rng make_rng(uint64_t seed, uint64_t seq = 1) {
+  Rng rng{0, (seq << 1u) | 1u};
+  advance_rng(rng);
+  rng.state += seed;
+  advance_rng(rng);
+  return rng;
+}
+float rand1f(Rng& rng) {
+  uint32_t u = (advance_rng(rng) >> 9) | 0x3f800000u;
+  float    f;
+  memcpy(&f, &u, 4);
+  return f - 1.0f;
+}
+void skip_rng(Rng& rng, uint64_t delta) {  // LCG jump-ahead
+  uint64_t cur_mult = 6364136223846793005ULL, cur_plus = rng.inc, acc_mult = 1u, acc_plus = 0u;
+  while (delta > 0) {
+    if (delta & 1) acc_mult *= cur_mult, acc_plus = acc_plus * cur_mult + cur_plus;
+    cur_plus = (cur_mult + 1) * cur_plus;
+    cur_mult *= cur_mult;
+    delta /= 2;
+  }
+  rng.state = acc_mult * rng.state + acc_plus;
+}
+
+float sqr(float v) { return v * v; }
+template <int N>
+float powt(float v) {  // ext.cpp:95-109
+  if constexpr (N == 0) return 1;
+  else if constexpr (N == 1) return v;
+  else {
+    float n2 = powt<N / 2>(v);
+    return n2 * n2 * powt<(N & 1)>(v);
+  }
+}
+
+// The material-only part of eval_hair_brdf (ext.cpp:131-172) plus the
+// per-lobe constants the kernels use (dev_hair.h). Same libm as the reference
+// (this runs on the host), so these values are bit-identical to what the
+// reference recomputes at every hit.
+void make_material(const yh_material& m, yhd_material& d) {
+  memset(&d, 0, sizeof(d));
+  memcpy(d.emission, m.emission, 12);
+  memcpy(d.color, m.color, 12);
+  float dmax    = fmax_(fmax_(m.color[0], m.color[1]), m.color[2]);
+  d.diffuse_pdf = dmax ? dmax / dmax : 0.0f;  // pt.cpp:456-471 with one lobe
+  d.thin        = m.thin;
+  F3 sa{0, 0, 0};
+  if (m.sigma_a[0] || m.sigma_a[1] || m.sigma_a[2]) {
+    sa = ld3(m.sigma_a);
+  } else if (m.color[0] || m.color[1] || m.color[2]) {  // ext.cpp:121-125
+    float bn  = m.beta_n;
+    float den = 5.969f - 0.215f * bn + 2.532f * sqr(bn) - 10.73f * powt<3>(bn) + 5.574f * powt<4>(bn) +
+                0.245f * powt<5>(bn);
+    F3 q = {std::log(m.color[0]) / den, std::log(m.color[1]) / den, std::log(m.color[2]) / den};
+    sa   = {q.x * q.x, q.y * q.y, q.z * q.z};
+  } else if (m.eumelanin || m.pheomelanin) {  // ext.cpp:115-119
+    F3 e = F3{0.419f, 0.697f, 1.37f}, p = F3{0.187f, 0.4f, 1.05f};
+    sa   = F3{m.eumelanin * e.x, m.eumelanin * e.y, m.eumelanin * e.z} +
+         F3{m.pheomelanin * p.x, m.pheomelanin * p.y, m.pheomelanin * p.z};
+  }
+  st3(d.sigma_a, sa);
+  d.alpha = m.alpha, d.eta = m.eta;
+  float bm = m.beta_m, bn = m.beta_n;
+  d.v[0] = sqr(0.726f * bm + 0.812f * sqr(bm) + 3.7f * powt<20>(bm));
+  d.v[1] = 0.25f * d.v[0];
+  d.v[2] = 4 * d.v[0];
+  d.v[3] = d.v[2];
+  d.s    = 0.626657069f * (0.265f * bn + 1.194f * sqr(bn) + 5.372f * powt<22>(bn));
+  d.sin_2k_alpha[0] = std::sin(pif / 180 * d.alpha);
+  d.cos_2k_alpha[0] = std::sqrt(fmax_(0.0f, 1 - sqr(d.sin_2k_alpha[0])));
+  for (int i = 1; i < 3; i++) {
+    d.sin_2k_alpha[i] = 2 * d.cos_2k_alpha[i - 1] * d.sin_2k_alpha[i - 1];
+    d.cos_2k_alpha[i] = sqr(d.cos_2k_alpha[i - 1]) - sqr(d.sin_2k_alpha[i - 1]);
+  }
+  for (int p = 0; p < 4; p++) {
+    d.inv_v[p]        = 1 / d.v[p];
+    d.log_inv_2v[p]   = std::log(1 / (2 * d.v[p]));
+    d.exp_m2_inv_v[p] = std::exp(-2 / d.v[p]);
+    d.mp_den[p]       = ::sinh((double)(1 / d.v[p])) * 2 * d.v[p];
+  }
+  float cb   = 1 / (1 + std::exp(-pif / d.s));
+  float ca   = 1 / (1 + std::exp(-(-pif) / d.s));
+  d.tl_cdf_a = ca;
+  d.tl_norm  = cb - ca;
+}
+
+}  // namespace
+
+struct yh_context {
+  int         device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t  ev0 = nullptr, ev1 = nullptr;
+  int         num_cus = 0;
+  std::string error = "no error";
+  // scene
+  bool      have_scene = false;
+  yhd_scene scene{};
+  DevBuf    d_nodes, d_prims, d_prim_elem, d_vpos, d_vnrm, d_elems, d_objects, d_materials, d_scene_nodes,
+      d_scene_prims, d_light_cdf, d_env_texels;
+  int       stack_need = 0;
+  // state
+  bool             have_state = false;
+  yhd_state        state{};
+  yh_trace_params  params{};
+  DevBuf           d_rng_state, d_rng_inc, d_accum, d_tiles, d_image, d_counters;
+  int              rank = 0, world = 1;
+  int              num_tiles_total = 0;
+  float            last_ms = 0;
+  int              last_launches = 0;
+};
+
+namespace {
+
+int fail(yh_context* ctx, int code, const char* fmt, ...) {
+  char    buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (ctx) ctx->error = buf;
+  else g_create_error = buf;
+  return code;
+}
+#define HIPCHK(ctx, call)                                                                               \
+  do {                                                                                                  \
+    hipError_t e_ = (call);                                                                             \
+    if (e_ != hipSuccess) return fail(ctx, YH_E_DEVICE, "%s: %s", #call, hipGetErrorString(e_));       \
+  } while (0)
+
+int upload(yh_context* ctx, DevBuf& buf, const void* src, size_t bytes) {
+  buf.reset();
+  size_t alloc = std::max<size_t>(bytes, 16);
+  HIPCHK(ctx, hipMalloc(&buf.p, alloc));
+  buf.bytes = alloc;
+  if (bytes) HIPCHK(ctx, hipMemcpy(buf.p, src, bytes, hipMemcpyHostToDevice));
+  return YH_OK;
+}
+int alloc_zero(yh_context* ctx, DevBuf& buf, size_t bytes) {
+  buf.reset();
+  size_t alloc = std::max<size_t>(bytes, 16);
+  HIPCHK(ctx, hipMalloc(&buf.p, alloc));
+  buf.bytes = alloc;
+  HIPCHK(ctx, hipMemset(buf.p, 0, alloc));
+  return YH_OK;
+}
+
+yhd_float4 node_lo(const yhh::Node& n) {
+  yhd_float4 r{n.bbox.min[0], n.bbox.min[1], n.bbox.min[2], 0};
+  memcpy(&r.w, &n.start, 4);
+  return r;
+}
+yhd_float4 node_hi(const yhh::Node& n) {
+  yhd_float4 r{n.bbox.max[0], n.bbox.max[1], n.bbox.max[2], 0};
+  int        meta = ((int)(unsigned short)n.num) | ((int)n.internal << 16) | ((int)n.axis << 24);
+  memcpy(&r.w, &meta, 4);
+  return r;
+}
+
+int tiles_of(int n) { return (n + YH_TILE - 1) / YH_TILE; }
+
+}  // namespace
+
+extern "C" {
+
+const char* yh_version(void) { return "yhair 0.1 (gfx950, HIP)"; }
+
+yh_context* yh_create(int device) {
+  int        count = 0;
+  hipError_t e     = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0) {
+    fail(nullptr, YH_E_DEVICE, "no HIP device available (%s): the hair path has no CPU fallback",
+        e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    return nullptr;
+  }
+  if (device < 0 || device >= count) {
+    fail(nullptr, YH_E_INVALID, "device %d out of range (%d devices)", device, count);
+    return nullptr;
+  }
+  auto ctx    = new yh_context{};
+  ctx->device = device;
+  hipDeviceProp_t prop;
+  if ((e = hipSetDevice(device)) != hipSuccess || (e = hipGetDeviceProperties(&prop, device)) != hipSuccess ||
+      (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
+      (e = hipEventCreate(&ctx->ev0)) != hipSuccess || (e = hipEventCreate(&ctx->ev1)) != hipSuccess) {
+    fail(nullptr, YH_E_DEVICE, "device %d setup failed: %s", device, hipGetErrorString(e));
+    delete ctx;
+    return nullptr;
+  }
+  ctx->num_cus = prop.multiProcessorCount;
+  return ctx;
+}
+
+void yh_destroy(yh_context* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+  if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char* yh_last_error(const yh_context* ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
+
+int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
+  if (!ctx) return YH_E_INVALID;
+  if (!sd) return fail(ctx, YH_E_INVALID, "scene is NULL");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  if (sd->num_objects <= 0) return fail(ctx, YH_E_INVALID, "scene has no objects");
+  if (sd->num_environments > YH_MAX_ENVS) return fail(ctx, YH_E_INVALID, "more than %d environments", YH_MAX_ENVS);
+  // ---- validate the material scope (yhair.h: yh_material) ----------------
+  for (int i = 0; i < sd->num_materials; i++) {
+    auto& m = sd->materials[i];
+    if (m.specular != 0 || m.metallic != 0 || m.transmission != 0 || m.opacity < 1)
+      return fail(ctx, YH_E_INVALID,
+          "material %d uses a lobe outside the hair path (specular/metallic/transmission/opacity): "
+          "only emission, diffuse colour and hair parameters are supported",
+          i);
+  }
+  // ---- per-shape BVHs and flattened arrays --------------------------------
+  struct ShapeInfo {
+    int kind, node_base, prim_base, vert_base, elem_base, slot_base, has_normals, depth;
+    yhh::Box root;
+    int num_nodes;
+  };
+  std::vector<ShapeInfo>  info(sd->num_shapes);
+  std::vector<yhd_float4> nodes, prims, vpos, vnrm;
+  std::vector<int>        prim_elem;
+  std::vector<yhd_int4>   elems;
+  int                     best_lines = -1, best_shape = -1;
+  for (int si = 0; si < sd->num_shapes; si++) {
+    auto& s = sd->shapes[si];
+    if (s.num_vertices <= 0 || !s.positions) return fail(ctx, YH_E_INVALID, "shape %d has no vertices", si);
+    bool lines = s.num_lines > 0;
+    if (!lines && s.num_triangles <= 0) return fail(ctx, YH_E_INVALID, "shape %d has no lines or triangles", si);
+    int nel = lines ? s.num_lines : s.num_triangles;
+    const int* idx = lines ? s.lines : s.triangles;
+    for (int k = 0; k < nel * (lines ? 2 : 3); k++)
+      if (idx[k] < 0 || idx[k] >= s.num_vertices) return fail(ctx, YH_E_INVALID, "shape %d: vertex index out of range", si);
+    auto& I       = info[si];
+    I.kind        = lines ? YH_KIND_LINES : YH_KIND_TRIANGLES;
+    I.node_base   = (int)nodes.size() / 2;
+    I.prim_base   = (int)prims.size();
+    I.vert_base   = (int)vpos.size();
+    I.elem_base   = (int)elems.size();
+    I.slot_base   = (int)prim_elem.size();
+    I.has_normals = s.normals != nullptr;
+    auto pos = [&](int v) { return ld3(s.positions + 3 * (size_t)v); };
+    auto rad = [&](int v) { return s.radius ? s.radius[v] : 0.001f; };  // add_radius, sceneio.cpp:390
+    std::vector<yhh::Box> boxes(nel);
+    for (int e = 0; e < nel; e++) {
+      if (lines) {  // line_bounds (math.h:3037-3040)
+        int a = idx[2 * e], b = idx[2 * e + 1];
+        F3  p0 = pos(a), p1 = pos(b);
+        float r0 = rad(a), r1 = rad(b);
+        float lo0[3] = {p0.x - r0, p0.y - r0, p0.z - r0}, lo1[3] = {p1.x - r1, p1.y - r1, p1.z - r1};
+        float hi0[3] = {p0.x + r0, p0.y + r0, p0.z + r0}, hi1[3] = {p1.x + r1, p1.y + r1, p1.z + r1};
+        for (int k = 0; k < 3; k++) boxes[e].min[k] = fmin_(lo0[k], lo1[k]), boxes[e].max[k] = fmax_(hi0[k], hi1[k]);
+      } else {  // triangle_bounds (math.h:3041-3044)
+        const float* p0 = s.positions + 3 * (size_t)idx[3 * e];
+        const float* p1 = s.positions + 3 * (size_t)idx[3 * e + 1];
+        const float* p2 = s.positions + 3 * (size_t)idx[3 * e + 2];
+        for (int k = 0; k < 3; k++) {
+          boxes[e].min[k] = fmin_(p0[k], fmin_(p1[k], p2[k]));
+          boxes[e].max[k] = fmax_(p0[k], fmax_(p1[k], p2[k]));
+        }
+      }
+    }
+    yhh::Tree tree;
+    yhh::build_bvh(tree, boxes);
+    I.depth = tree.max_depth, I.root = tree.nodes[0].bbox, I.num_nodes = (int)tree.nodes.size();
+    for (auto& n : tree.nodes) nodes.push_back(node_lo(n)), nodes.push_back(node_hi(n));
+    for (int slot = 0; slot < nel; slot++) {  // leaf-ordered records
+      int e = tree.primitives[slot];
+      if (lines) {
+        int a = idx[2 * e], b = idx[2 * e + 1];
+        F3  p0 = pos(a), p1 = pos(b);
+        prims.push_back({p0.x, p0.y, p0.z, rad(a)});
+        prims.push_back({p1.x, p1.y, p1.z, rad(b)});
+        prim_elem.push_back(e);
+      } else {
+        F3    p0 = pos(idx[3 * e]), p1 = pos(idx[3 * e + 1]), p2 = pos(idx[3 * e + 2]);
+        float ew;
+        memcpy(&ew, &e, 4);
+        prims.push_back({p0.x, p0.y, p0.z, ew});
+        prims.push_back({p1.x, p1.y, p1.z, 0});
+        prims.push_back({p2.x, p2.y, p2.z, 0});
+      }
+    }
+    for (int v = 0; v < s.num_vertices; v++) {
+      F3 p = pos(v);
+      vpos.push_back({p.x, p.y, p.z, lines ? rad(v) : 0.0f});
+      if (s.normals) vnrm.push_back({s.normals[3 * v], s.normals[3 * v + 1], s.normals[3 * v + 2], 0});
+      else vnrm.push_back({0, 0, 0, 0});
+    }
+    for (int e = 0; e < nel; e++)
+      elems.push_back(lines ? yhd_int4{idx[2 * e], idx[2 * e + 1], 0, 0}
+                            : yhd_int4{idx[3 * e], idx[3 * e + 1], idx[3 * e + 2], 0});
+    if (lines && s.num_lines > best_lines) best_lines = s.num_lines, best_shape = si;
+  }
+  // ---- objects and the scene-level BVH (pt.cpp:792-814) -------------------
+  std::vector<yhd_object> objects(sd->num_objects);
+  std::vector<yhh::Box>   obj_boxes(sd->num_objects);
+  for (int oi = 0; oi < sd->num_objects; oi++) {
+    auto& o = sd->objects[oi];
+    if (o.shape < 0 || o.shape >= sd->num_shapes || o.material < 0 || o.material >= sd->num_materials)
+      return fail(ctx, YH_E_INVALID, "object %d references a missing shape or material", oi);
+    auto& I = info[o.shape];
+    auto& d = objects[oi];
+    memcpy(d.frame, o.frame, 48);
+    inverse_frame(o.frame, true, d.inv_frame);
+    d.kind = I.kind, d.node_base = I.node_base, d.prim_base = I.prim_base, d.vert_base = I.vert_base;
+    d.elem_base = I.elem_base, d.has_normals = I.has_normals, d.material = o.material, d.slot_base = I.slot_base;
+    // transform_bbox (math.h:3174-3185)
+    const yhh::Box& b = I.root;
+    float lo[3] = {std::numeric_limits<float>::max(), std::numeric_limits<float>::max(), std::numeric_limits<float>::max()};
+    float hi[3] = {std::numeric_limits<float>::lowest(), std::numeric_limits<float>::lowest(),
+        std::numeric_limits<float>::lowest()};
+    for (int c = 0; c < 8; c++) {
+      F3 corner = {(c & 4) ? b.max[0] : b.min[0], (c & 2) ? b.max[1] : b.min[1], (c & 1) ? b.max[2] : b.min[2]};
+      F3 t      = transform_point(o.frame, corner);
+      float tv[3] = {t.x, t.y, t.z};
+      for (int k = 0; k < 3; k++) lo[k] = fmin_(lo[k], tv[k]), hi[k] = fmax_(hi[k], tv[k]);
+    }
+    for (int k = 0; k < 3; k++) obj_boxes[oi].min[k] = lo[k], obj_boxes[oi].max[k] = hi[k];
+  }
+  yhh::Tree scene_tree;
+  yhh::build_bvh(scene_tree, obj_boxes);
+  std::vector<yhd_float4> scene_nodes;
+  for (auto& n : scene_tree.nodes) scene_nodes.push_back(node_lo(n)), scene_nodes.push_back(node_hi(n));
+  int max_shape_depth = 0;
+  for (auto& I : info) max_shape_depth = std::max(max_shape_depth, I.depth);
+  ctx->stack_need = scene_tree.max_depth + 4 + max_shape_depth + 2;
+  if (ctx->stack_need > YH_STACK_MAX)
+    return fail(ctx, YH_E_INVALID, "BVH too deep for the traversal stack (%d > %d)", ctx->stack_need, YH_STACK_MAX);
+  // ---- materials ---------------------------------------------------------
+  std::vector<yhd_material> materials(sd->num_materials);
+  for (int i = 0; i < sd->num_materials; i++) make_material(sd->materials[i], materials[i]);
+  // ---- lights (pt.cpp:1695-1740) -----------------------------------------
+  yhd_scene sc{};
+  std::vector<float>      light_cdf;
+  std::vector<yhd_float4> env_texels;
+  for (int oi = 0; oi < sd->num_objects; oi++) {
+    auto& o = sd->objects[oi];
+    auto& m = sd->materials[o.material];
+    if (m.emission[0] == 0 && m.emission[1] == 0 && m.emission[2] == 0) continue;
+    auto& s = sd->shapes[o.shape];
+    if (s.num_lines > 0 || s.num_triangles <= 0) continue;
+    if (sc.num_lights >= YH_MAX_LIGHTS) return fail(ctx, YH_E_INVALID, "more than %d lights", YH_MAX_LIGHTS);
+    auto& L = sc.lights[sc.num_lights++];
+    L.object = oi, L.environment = -1, L.cdf_base = (int)light_cdf.size(), L.cdf_count = s.num_triangles;
+    for (int t = 0; t < s.num_triangles; t++) {
+      F3 p0 = ld3(s.positions + 3 * (size_t)s.triangles[3 * t]), p1 = ld3(s.positions + 3 * (size_t)s.triangles[3 * t + 1]),
+         p2 = ld3(s.positions + 3 * (size_t)s.triangles[3 * t + 2]);
+      F3    c    = cross(p1 - p0, p2 - p0);
+      float area = std::sqrt(dot(c, c)) / 2;  // triangle_area (math.h:3306)
+      if (t) area += light_cdf.back();
+      light_cdf.push_back(area);
+    }
+  }
+  sc.num_environments = sd->num_environments;
+  for (int ei = 0; ei < sd->num_environments; ei++) {
+    auto& e = sd->environments[ei];
+    auto& d = sc.environments[ei];
+    memcpy(d.frame, e.frame, 48);
+    inverse_frame(e.frame, false, d.inv_frame);
+    memcpy(d.emission, e.emission, 12);
+    d.tex_w = e.texels ? e.tex_width : 0, d.tex_h = e.texels ? e.tex_height : 0;
+    d.texel_base = (int)env_texels.size();
+    if (e.texels)
+      for (size_t t = 0; t < (size_t)e.tex_width * e.tex_height; t++)
+        env_texels.push_back({e.texels[3 * t], e.texels[3 * t + 1], e.texels[3 * t + 2], 0});
+    if (e.emission[0] == 0 && e.emission[1] == 0 && e.emission[2] == 0) continue;
+    if (sc.num_lights >= YH_MAX_LIGHTS) return fail(ctx, YH_E_INVALID, "more than %d lights", YH_MAX_LIGHTS);
+    auto& L = sc.lights[sc.num_lights++];
+    L.object = -1, L.environment = ei, L.cdf_base = (int)light_cdf.size(), L.cdf_count = 0;
+    if (e.texels) {
+      size_t n    = (size_t)e.tex_width * e.tex_height;
+      L.cdf_count = (int)n;
+      for (size_t i = 0; i < n; i++) {
+        int   iy    = (int)(i / e.tex_width);
+        float th    = (iy + 0.5f) * pif / e.tex_height;
+        float mx    = fmax_(fmax_(e.texels[3 * i], e.texels[3 * i + 1]), e.texels[3 * i + 2]);
+        float value = mx * std::sin(th);
+        if (i) value += light_cdf.back();
+        light_cdf.push_back(value);
+      }
+    }
+  }
+  if (sc.num_lights == 0) return fail(ctx, YH_E_INVALID, "scene has no lights (the path sampler needs at least one)");
+  // ---- upload ------------------------------------------------------------
+  int rc;
+  if ((rc = upload(ctx, ctx->d_nodes, nodes.data(), nodes.size() * 16))) return rc;
+  if ((rc = upload(ctx, ctx->d_prims, prims.data(), prims.size() * 16))) return rc;
+  if ((rc = upload(ctx, ctx->d_prim_elem, prim_elem.data(), prim_elem.size() * 4))) return rc;
+  if ((rc = upload(ctx, ctx->d_vpos, vpos.data(), vpos.size() * 16))) return rc;
+  if ((rc = upload(ctx, ctx->d_vnrm, vnrm.data(), vnrm.size() * 16))) return rc;
+  if ((rc = upload(ctx, ctx->d_elems, elems.data(), elems.size() * 16))) return rc;
+  if ((rc = upload(ctx, ctx->d_objects, objects.data(), objects.size() * sizeof(yhd_object)))) return rc;
+  if ((rc = upload(ctx, ctx->d_materials, materials.data(), materials.size() * sizeof(yhd_material)))) return rc;
+  if ((rc = upload(ctx, ctx->d_scene_nodes, scene_nodes.data(), scene_nodes.size() * 16))) return rc;
+  if ((rc = upload(ctx, ctx->d_scene_prims, scene_tree.primitives.data(), scene_tree.primitives.size() * 4))) return rc;
+  if ((rc = upload(ctx, ctx->d_light_cdf, light_cdf.data(), light_cdf.size() * 4))) return rc;
+  if ((rc = upload(ctx, ctx->d_env_texels, env_texels.data(), env_texels.size() * 16))) return rc;
+  sc.nodes = (const yhd_float4*)ctx->d_nodes.p, sc.prims = (const yhd_float4*)ctx->d_prims.p;
+  sc.prim_elem = (const int*)ctx->d_prim_elem.p, sc.vpos = (const yhd_float4*)ctx->d_vpos.p;
+  sc.vnrm = (const yhd_float4*)ctx->d_vnrm.p, sc.elems = (const yhd_int4*)ctx->d_elems.p;
+  sc.objects = (const yhd_object*)ctx->d_objects.p, sc.materials = (const yhd_material*)ctx->d_materials.p;
+  sc.scene_nodes = (const yhd_float4*)ctx->d_scene_nodes.p, sc.scene_prims = (const int*)ctx->d_scene_prims.p;
+  sc.num_scene_nodes = (int)scene_tree.nodes.size(), sc.num_objects = sd->num_objects;
+  sc.light_cdf = (const float*)ctx->d_light_cdf.p, sc.env_texels = (const yhd_float4*)ctx->d_env_texels.p;
+  memcpy(sc.camera.frame, sd->camera.frame, 48);
+  sc.camera.lens = sd->camera.lens, sc.camera.film_x = sd->camera.film[0], sc.camera.film_y = sd->camera.film[1];
+  sc.camera.focus = sd->camera.focus, sc.camera.aperture = sd->camera.aperture;
+  // nodelets: the top (breadth-first prefix) of the largest hair shape's BVH
+  sc.lds_node_base = 0, sc.lds_node_count = 0;
+  if (best_shape >= 0) {
+    sc.lds_node_base  = info[best_shape].node_base;
+    sc.lds_node_count = std::min(info[best_shape].num_nodes, 2047);
+  }
+  ctx->scene      = sc;
+  ctx->have_scene = true;
+  ctx->have_state = false;
+  return YH_OK;
+}
+
+int yh_set_shard(yh_context* ctx, int rank, int world) {
+  if (!ctx) return YH_E_INVALID;
+  if (world < 1 || rank < 0 || rank >= world) return fail(ctx, YH_E_INVALID, "bad shard %d of %d", rank, world);
+  ctx->rank = rank, ctx->world = world;
+  ctx->have_state = false;
+  return YH_OK;
+}
+
+int yh_init_state(yh_context* ctx, const yh_trace_params* params) {
+  if (!ctx) return YH_E_INVALID;
+  if (!ctx->have_scene) return fail(ctx, YH_E_STATE, "yh_init_state before yh_upload_scene");
+  if (!params || params->resolution <= 0 || params->bounces < 0)
+    return fail(ctx, YH_E_INVALID, "bad trace params");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  ctx->params = *params;
+  // image size (pt.cpp:1933-1939)
+  auto& cam = ctx->scene.camera;
+  int   w, h;
+  if (cam.film_x > cam.film_y) {
+    w = params->resolution;
+    h = (int)round(params->resolution * cam.film_y / cam.film_x);
+  } else {
+    w = (int)round(params->resolution * cam.film_x / cam.film_y);
+    h = params->resolution;
+  }
+  if (w <= 0 || h <= 0) return fail(ctx, YH_E_INVALID, "empty image");
+  size_t npix = (size_t)w * h;
+  // per-pixel streams (pt.cpp:1942-1945), pixel order j * W + i
+  std::vector<uint64_t> st(npix), inc(npix);
+  Rng master = make_rng(1301081);
+  for (size_t i = 0; i < npix; i++) {
+    int seq = (int)(advance_rng(master) % 2147483648u) / 2 + 1;  // rand1i(rng, 1 << 31) / 2 + 1
+    Rng r   = make_rng(params->seed, (uint64_t)seq);
+    st[i] = r.state, inc[i] = r.inc;
+  }
+  int tx = tiles_of(w), ty = tiles_of(h);
+  ctx->num_tiles_total = tx * ty;
+  std::vector<int> tiles;
+  for (int t = ctx->rank; t < ctx->num_tiles_total; t += ctx->world) tiles.push_back(t);
+  int rc;
+  if ((rc = upload(ctx, ctx->d_rng_state, st.data(), npix * 8))) return rc;
+  if ((rc = upload(ctx, ctx->d_rng_inc, inc.data(), npix * 8))) return rc;
+  if ((rc = alloc_zero(ctx, ctx->d_accum, npix * 16))) return rc;
+  if ((rc = alloc_zero(ctx, ctx->d_image, npix * 16))) return rc;
+  if ((rc = upload(ctx, ctx->d_tiles, tiles.data(), tiles.size() * 4))) return rc;
+  if ((rc = alloc_zero(ctx, ctx->d_counters, sizeof(yhd_counters)))) return rc;
+  auto& s = ctx->state;
+  s.rng_state = (uint64_t*)ctx->d_rng_state.p, s.rng_inc = (uint64_t*)ctx->d_rng_inc.p;
+  s.accum = (yhd_float4*)ctx->d_accum.p, s.tiles = (const int*)ctx->d_tiles.p;
+  s.num_tiles = (int)tiles.size(), s.width = w, s.height = h, s.tiles_x = tx;
+  s.samples_done = 0, s.bounces = params->bounces, s.clamp = params->clamp;
+  ctx->have_state = true;
+  return YH_OK;
+}
+
+int yh_image_size(const yh_context* ctx, int* width, int* height) {
+  if (!ctx || !ctx->have_state) return YH_E_STATE;
+  if (width) *width = ctx->state.width;
+  if (height) *height = ctx->state.height;
+  return YH_OK;
+}
+
+static int trace_impl(yh_context* ctx, int nsamples, bool counted, bool sync) {
+  if (!ctx) return YH_E_INVALID;
+  if (!ctx->have_state) return fail(ctx, YH_E_STATE, "yh_trace_samples before yh_init_state");
+  if (nsamples < 0) return fail(ctx, YH_E_INVALID, "negative sample count");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  if (nsamples == 0 || ctx->state.num_tiles == 0) {
+    ctx->state.samples_done += nsamples;
+    ctx->last_ms = 0, ctx->last_launches = 0;
+    return YH_OK;
+  }
+  int waves_per_block = yhk_block_threads() / 64;
+  int lds_bytes       = ctx->scene.lds_node_count * 32;
+  int resident        = ctx->num_cus * yhk_trace_occupancy(lds_bytes);
+  int want            = (ctx->state.num_tiles + waves_per_block - 1) / waves_per_block;
+  int grid            = std::max(1, std::min(want, resident));
+  HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  int e = yhk_trace(&ctx->scene, &ctx->state, nsamples, counted ? (yhd_counters*)ctx->d_counters.p : nullptr, grid,
+      ctx->stream);
+  if (e) return fail(ctx, YH_E_DEVICE, "k_trace launch: %s", hipGetErrorString((hipError_t)e));
+  HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  ctx->state.samples_done += nsamples;
+  ctx->last_launches = 1;
+  if (sync) {
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipEventElapsedTime(&ctx->last_ms, ctx->ev0, ctx->ev1));
+  }
+  return YH_OK;
+}
+int yh_trace_samples(yh_context* ctx, int nsamples) { return trace_impl(ctx, nsamples, false, true); }
+int yh_trace_samples_async(yh_context* ctx, int nsamples) { return trace_impl(ctx, nsamples, false, false); }
+int yh_synchronize(yh_context* ctx) {
+  if (!ctx) return YH_E_INVALID;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->last_launches) (void)hipEventElapsedTime(&ctx->last_ms, ctx->ev0, ctx->ev1);
+  return YH_OK;
+}
+int yh_last_trace_ms(const yh_context* ctx, float* ms, int* launches) {
+  if (!ctx) return YH_E_INVALID;
+  if (ms) *ms = ctx->last_ms;
+  if (launches) *launches = ctx->last_launches;
+  return YH_OK;
+}
+int yh_trace_samples_counted(yh_context* ctx, int nsamples, yh_workcounts* out) {
+  if (!ctx || !out) return YH_E_INVALID;
+  if (!ctx->have_state) return fail(ctx, YH_E_STATE, "yh_trace_samples_counted before yh_init_state");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipMemsetAsync(ctx->d_counters.p, 0, sizeof(yhd_counters), ctx->stream));
+  int rc = trace_impl(ctx, nsamples, true, true);
+  if (rc) return rc;
+  yhd_counters c;
+  HIPCHK(ctx, hipMemcpy(&c, ctx->d_counters.p, sizeof(c), hipMemcpyDeviceToHost));
+  out->samples = c.samples, out->rays = c.rays, out->nodes = c.nodes, out->seg_tests = c.seg, out->tri_tests = c.tri;
+  out->hair_shades = c.hair, out->surf_shades = c.surf, out->env_lookups = c.envl, out->env_samples = c.envs;
+  return YH_OK;
+}
+
+int yh_download(yh_context* ctx, float* rgba) {
+  if (!ctx || !rgba) return YH_E_INVALID;
+  if (!ctx->have_state) return fail(ctx, YH_E_STATE, "yh_download before yh_init_state");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  size_t bytes = (size_t)ctx->state.width * ctx->state.height * 16;
+  HIPCHK(ctx, hipMemsetAsync(ctx->d_image.p, 0, bytes, ctx->stream));
+  int e = yhk_resolve(&ctx->state, ctx->state.samples_done, ctx->d_image.p, ctx->stream);
+  if (e) return fail(ctx, YH_E_DEVICE, "k_resolve launch: %s", hipGetErrorString((hipError_t)e));
+  HIPCHK(ctx, hipMemcpyAsync(rgba, ctx->d_image.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return YH_OK;
+}
+
+int64_t yh_shard_pixels(const yh_context* ctx, int rank, int world) {
+  if (!ctx || !ctx->have_state || world < 1 || rank < 0 || rank >= world) return -1;
+  int64_t n = ctx->num_tiles_total > rank ? (ctx->num_tiles_total - rank + world - 1) / world : 0;
+  return n * 64;
+}
+int yh_pack_tiles_device(yh_context* ctx, void* device_rgba, int64_t capacity, int64_t* count) {
+  if (!ctx || !device_rgba) return YH_E_INVALID;
+  if (!ctx->have_state) return fail(ctx, YH_E_STATE, "yh_pack_tiles_device before yh_init_state");
+  int64_t need = (int64_t)ctx->state.num_tiles * 64;
+  if (capacity < need) return fail(ctx, YH_E_INVALID, "pack buffer too small (%lld < %lld pixels)", (long long)capacity, (long long)need);
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  int e = yhk_pack(&ctx->state, ctx->state.samples_done, device_rgba, ctx->stream);
+  if (e) return fail(ctx, YH_E_DEVICE, "k_pack launch: %s", hipGetErrorString((hipError_t)e));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (count) *count = need;
+  return YH_OK;
+}
+int yh_unpack_tiles_device(yh_context* ctx, const void* device_packed, int src_rank, int world, void* device_image) {
+  if (!ctx || !device_packed || !device_image) return YH_E_INVALID;
+  if (!ctx->have_state) return fail(ctx, YH_E_STATE, "yh_unpack_tiles_device before yh_init_state");
+  if (world < 1 || src_rank < 0 || src_rank >= world) return fail(ctx, YH_E_INVALID, "bad shard %d of %d", src_rank, world);
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  int n = (int)(yh_shard_pixels(ctx, src_rank, world) / 64);
+  int e = yhk_unpack(device_packed, src_rank, world, n, ctx->num_tiles_total, ctx->state.tiles_x, ctx->state.width,
+      ctx->state.height, device_image, ctx->stream);
+  if (e) return fail(ctx, YH_E_DEVICE, "k_unpack launch: %s", hipGetErrorString((hipError_t)e));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return YH_OK;
+}
+
+int yh_download_rng(yh_context* ctx, uint64_t* state_inc) {
+  if (!ctx || !state_inc) return YH_E_INVALID;
+  if (!ctx->have_state) return fail(ctx, YH_E_STATE, "yh_download_rng before yh_init_state");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  size_t npix = (size_t)ctx->state.width * ctx->state.height;
+  std::vector<uint64_t> st(npix), inc(npix);
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, hipMemcpy(st.data(), ctx->d_rng_state.p, npix * 8, hipMemcpyDeviceToHost));
+  HIPCHK(ctx, hipMemcpy(inc.data(), ctx->d_rng_inc.p, npix * 8, hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < npix; i++) state_inc[2 * i] = st[i], state_inc[2 * i + 1] = inc[i];
+  return YH_OK;
+}
+
+// ---- unit-level batches ----------------------------------------------------
+namespace {
+struct Staged {
+  std::vector<DevBuf> bufs;
+  yh_context*         ctx;
+  int                 rc = YH_OK;
+  explicit Staged(yh_context* c) : ctx(c) { bufs.reserve(8); }
+  void* in(const void* src, size_t bytes) {
+    bufs.emplace_back();
+    if (rc == YH_OK) rc = upload(ctx, bufs.back(), src, bytes);
+    return bufs.back().p;
+  }
+  void* out(size_t bytes) {
+    bufs.emplace_back();
+    if (rc == YH_OK) rc = alloc_zero(ctx, bufs.back(), bytes);
+    return bufs.back().p;
+  }
+};
+int finish(yh_context* ctx, int launch_err, void* dst, const void* src, size_t bytes) {
+  if (launch_err) return fail(ctx, YH_E_DEVICE, "kernel launch: %s", hipGetErrorString((hipError_t)launch_err));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+  return YH_OK;
+}
+}  // namespace
+
+int yh_hair_brdf_batch(yh_context* ctx, int n, const yh_material* materials, const float* v, const float* normal,
+    const float* tangent, float* brdf) {
+  if (!ctx || n < 0 || (n && (!materials || !v || !normal || !tangent || !brdf))) return YH_E_INVALID;
+  if (n == 0) return YH_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  Staged s(ctx);
+  auto   dm = s.in(materials, sizeof(yh_material) * (size_t)n);
+  auto   dv = (float*)s.in(v, 4 * (size_t)n);
+  auto   dn = (float*)s.in(normal, 12 * (size_t)n);
+  auto   dt = (float*)s.in(tangent, 12 * (size_t)n);
+  auto   o  = (float*)s.out(120 * (size_t)n);
+  if (s.rc) return s.rc;
+  return finish(ctx, yhk_hair_brdf(n, dm, dv, dn, dt, o, ctx->stream), brdf, o, 120 * (size_t)n);
+}
+static int wowi(yh_context* ctx, int n, const float* brdf, const float* a, size_t a_floats, const float* b,
+    size_t b_floats, float* out, size_t out_floats, int which) {
+  if (!ctx || n < 0 || (n && (!brdf || !a || !b || !out))) return YH_E_INVALID;
+  if (n == 0) return YH_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  Staged s(ctx);
+  auto   db = (float*)s.in(brdf, 120 * (size_t)n);
+  auto   da = (float*)s.in(a, 4 * a_floats * n);
+  auto   dbb = (float*)s.in(b, 4 * b_floats * n);
+  auto   o  = (float*)s.out(4 * out_floats * n);
+  if (s.rc) return s.rc;
+  int e = which == 0   ? yhk_hair_eval(n, db, da, dbb, o, ctx->stream)
+          : which == 1 ? yhk_hair_sample(n, db, da, dbb, o, ctx->stream)
+                       : yhk_hair_pdf(n, db, da, dbb, o, ctx->stream);
+  return finish(ctx, e, out, o, 4 * out_floats * n);
+}
+int yh_hair_eval_batch(yh_context* ctx, int n, const float* brdf, const float* wo, const float* wi, float* f) {
+  return wowi(ctx, n, brdf, wo, 3, wi, 3, f, 3, 0);
+}
+int yh_hair_sample_batch(yh_context* ctx, int n, const float* brdf, const float* wo, const float* rn, float* wi) {
+  return wowi(ctx, n, brdf, wo, 3, rn, 2, wi, 3, 1);
+}
+int yh_hair_pdf_batch(yh_context* ctx, int n, const float* brdf, const float* wo, const float* wi, float* pdf) {
+  return wowi(ctx, n, brdf, wo, 3, wi, 3, pdf, 1, 2);
+}
+int yh_hair_eval_pdf_batch(yh_context* ctx, int n, const float* brdf, const float* wo, const float* wi, float* pdf) {
+  return yh_hair_pdf_batch(ctx, n, brdf, wo, wi, pdf);
+}
+
+int yh_intersect_batch(yh_context* ctx, int n, const float* rays, int* object, int* element, float* uv,
+    float* distance) {
+  if (!ctx || n < 0 || (n && (!rays || !object || !element || !uv || !distance))) return YH_E_INVALID;
+  if (!ctx->have_scene) return fail(ctx, YH_E_STATE, "yh_intersect_batch before yh_upload_scene");
+  if (n == 0) return YH_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  Staged s(ctx);
+  auto   dr = (float*)s.in(rays, 32 * (size_t)n);
+  auto   dob = (int*)s.out(4 * (size_t)n);
+  auto   del = (int*)s.out(4 * (size_t)n);
+  auto   duv = (float*)s.out(8 * (size_t)n);
+  auto   dd  = (float*)s.out(4 * (size_t)n);
+  if (s.rc) return s.rc;
+  int e = yhk_intersect(&ctx->scene, n, dr, dob, del, duv, dd, ctx->stream);
+  if (e) return fail(ctx, YH_E_DEVICE, "k_intersect launch: %s", hipGetErrorString((hipError_t)e));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, hipMemcpy(object, dob, 4 * (size_t)n, hipMemcpyDeviceToHost));
+  HIPCHK(ctx, hipMemcpy(element, del, 4 * (size_t)n, hipMemcpyDeviceToHost));
+  HIPCHK(ctx, hipMemcpy(uv, duv, 8 * (size_t)n, hipMemcpyDeviceToHost));
+  HIPCHK(ctx, hipMemcpy(distance, dd, 4 * (size_t)n, hipMemcpyDeviceToHost));
+  return YH_OK;
+}
+
+// ---- the four self-tests (ext.cpp:555-693) ---------------------------------
+// The host replays the reference's serial structure (seed, loop bounds with
+// the accumulating float counters, per-block draw counts) and hands every
+// (beta_m, beta_n) block to the device with the generator state at its start.
+int yh_selftest(yh_context* ctx, int which, float* worst) {
+  if (!ctx) return YH_E_INVALID;
+  if (which < 0 || which > 3) return fail(ctx, YH_E_INVALID, "unknown self-test %d", which);
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  DevBuf sums, wbits;
+  int    rc;
+  if ((rc = alloc_zero(ctx, sums, 6 * sizeof(double)))) return rc;
+  if ((rc = alloc_zero(ctx, wbits, 4))) return rc;
+  auto lum = [](const double* s) { return (float)(0.2126 * s[0] + 0.7152 * s[1] + 0.0722 * s[2]); };
+  auto sample_sphere = [](float rx, float ry, float* w) {  // math.h:4847-4852
+    float z = 2 * ry - 1;
+    float r = std::sqrt(fmin_(fmax_(1 - z * z, 0.0f), 1.0f));
+    float phi = 2 * pif * rx;
+    w[0] = r * std::cos(phi), w[1] = r * std::sin(phi), w[2] = z;
+  };
+  Rng   rng = make_rng(199382389514ULL);
+  float wo[3] = {0, 0, 1};
+  if (which == 0 || which == 1) {
+    float x = rand1f(rng), y = rand1f(rng);
+    sample_sphere(x, y, wo);
+  }
+  bool  ok  = true;
+  float dev = 0;
+  auto run = [&](float bm, float bn, int count, int per_iter, double* out, float* dmax) -> int {
+    HIPCHK(ctx, hipMemsetAsync(sums.p, 0, 6 * sizeof(double), ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(wbits.p, 0, 4, ctx->stream));
+    int e = yhk_selftest(which, bm, bn, rng.state, rng.inc, count, wo, (double*)sums.p, (unsigned int*)wbits.p, ctx->stream);
+    if (e) return fail(ctx, YH_E_DEVICE, "k_selftest launch: %s", hipGetErrorString((hipError_t)e));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipMemcpy(out, sums.p, 6 * sizeof(double), hipMemcpyDeviceToHost));
+    unsigned int bits;
+    HIPCHK(ctx, hipMemcpy(&bits, wbits.p, 4, hipMemcpyDeviceToHost));
+    memcpy(dmax, &bits, 4);
+    skip_rng(rng, (uint64_t)count * per_iter);
+    return YH_OK;
+  };
+  double s[6];
+  float  d;
+  if (which == 0 || which == 1) {
+    for (float bm = 0.1f; bm < 1.0f; bm += 0.2f)
+      for (float bn = 0.1f; bn < 1.0f; bn += 0.2f) {
+        const int count = 300000;
+        if ((rc = run(bm, bn, count, 3, s, &d))) return rc;
+        float avg = which == 0 ? lum(s) / (count * (1 / (4 * pif))) : lum(s) / count;
+        float lo = which == 0 ? 0.95f : 0.99f, hi = which == 0 ? 1.05f : 1.01f;
+        if (!(avg >= lo && avg <= hi)) ok = false;
+        dev = fmax_(dev, std::fabs(avg - 1));
+      }
+  } else if (which == 2) {
+    for (float bm = 0.1f; bm < 1.0f; bm += 0.2f)
+      for (float bn = 0.4f; bn < 1.0f; bn += 0.2f) {
+        if ((rc = run(bm, bn, 10000, 5, s, &d))) return rc;
+        if (!(d <= 0.001f)) ok = false;
+        dev = fmax_(dev, d);
+      }
+  } else {
+    for (float bm = 0.2f; bm < 1.0f; bm += 0.2f)
+      for (float bn = 0.4f; bn < 1.0f; bn += 0.2f) {
+        const int count = 64 * 1024;
+        float x = rand1f(rng), y = rand1f(rng);
+        sample_sphere(x, y, wo);
+        if ((rc = run(bm, bn, count, 3, s, &d))) return rc;
+        float fi = lum(s) / count, fu = lum(s + 3) / (count * (1 / (4 * pif)));
+        float err = std::fabs(fi - fu) / fu;
+        if (err >= 0.05f) ok = false;
+        dev = fmax_(dev, err);
+      }
+  }
+  if (worst) *worst = dev;
+  if (!ok) return fail(ctx, YH_E_SELFTEST, "TEST FAILED! (self-test %d, worst deviation %g)", which, dev);
+  return YH_OK;
+}
+
+}  // extern "C"
