@@ -1,0 +1,67 @@
+"""The N>1 path on CPU: world_size-2 (and 3) gloo runs of the tile shard + single gather +
+un-interleave used by bench.py --gpus N (yocto-hair_amd/python/yhair_dist.py). No GPU needed:
+the per-rank payload is produced by the host restatement of k_pack from a known image."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "yocto-hair_amd", "python"))
+import yhair_dist  # noqa: E402
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, w, h, out_path):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(5)
+    image = rng.uniform(0, 1, (h, w, 4)).astype(np.float32)  # same on every rank
+    packed = torch.from_numpy(yhair_dist.pack_tiles_host(image, rank, world))
+    assert packed.shape[0] == yhair_dist.shard_pixels(w, h, rank, world)
+    dist.barrier()
+    full = yhair_dist.gather_framebuffer(packed, w, h, rank, world)
+    if rank == 0:
+        np.save(out_path, np.stack([full.numpy(), image]))
+    else:
+        assert full is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,w,h", [(2, 72, 40), (3, 37, 21), (2, 8, 8)])
+def test_gather_framebuffer_gloo(tmp_path, world, w, h):
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "img.npy")
+    mp.spawn(_worker, args=(world, _free_port(), w, h, out), nprocs=world, join=True)
+    got, want = np.load(out)
+    assert np.array_equal(got, want)
+
+
+def test_shards_partition_the_image():
+    for w, h in ((720, 720), (720, 405), (13, 7)):
+        tx, ty = yhair_dist.tiles_xy(w, h)
+        for world in (1, 2, 3, 8):
+            tiles = np.concatenate([yhair_dist.shard_tiles(w, h, r, world) for r in range(world)])
+            assert sorted(tiles.tolist()) == list(range(tx * ty))
+            sizes = [yhair_dist.shard_pixels(w, h, r, world) for r in range(world)]
+            assert max(sizes) - min(sizes) <= 64  # interleaving balances the shards
+
+
+def test_pack_unpack_roundtrip_host():
+    rng = np.random.default_rng(1)
+    img = rng.uniform(0, 1, (21, 37, 4)).astype(np.float32)
+    out = np.zeros_like(img)
+    for r in range(3):
+        yhair_dist.unpack_tiles_host(yhair_dist.pack_tiles_host(img, r, 3), r, 3, out)
+    assert np.array_equal(out, img)

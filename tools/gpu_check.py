@@ -23,7 +23,7 @@ def rel(a, b):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--scenes", default=os.path.join(ROOT, "gpurun_out", "scenes"))
+    ap.add_argument("--scenes", default="/tmp/yhair_scenes")
     ap.add_argument("--big", action="store_true")
     a = ap.parse_args()
     o = oc.Oracle()
