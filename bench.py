@@ -55,7 +55,7 @@ def cpu_baseline(scene_json, resolution, budget_s=15.0):
     t0 = time.time()
     img = sc.render(p, 1, nthreads=threads)
     t1 = time.time() - t0
-    spp = int(max(1, min(64, budget_s / max(t1, 1e-3))))
+    spp = int(max(1, min(1024, budget_s / max(t1, 1e-3))))
     t0 = time.time()
     img = sc.render(p, spp, nthreads=threads)
     dt = time.time() - t0

