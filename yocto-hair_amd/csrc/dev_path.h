@@ -221,106 +221,111 @@ YH_DEV f3 sample_hemisphere_cos(f3 normal, float rx, float ry) {
   return normalize(x * local.x + y * local.y + zz * local.z);
 }
 
-// trace_path (pt.cpp:1380-1511) for one camera ray
-template <bool COUNT>
-YH_DEV void trace_path(const trace_ctx& tc, ray_t ray, rng_t& rng, int bounces, f3& radiance_out,
-    float& hit_out) {
-  const yhd_scene& sc = *tc.sc;
-  f3   radiance = mk3(0.0f), weight = mk3(1.0f);
-  bool hit = false;
-  for (int bounce = 0; bounce < bounces; bounce++) {
-    if (COUNT) count_add<COUNT>(&tc.counters->rays, 1);
-    hit_t isec = trace_ray<COUNT>(tc, ray, -1);
-    if (isec.object < 0) {
-      radiance = radiance + weight * eval_environment<COUNT>(tc, ray.d);
-      break;
-    }
-    const yhd_object&   o   = sc.objects[isec.object];
-    const yhd_material& mat = sc.materials[o.material];
-    f3 outgoing = -ray.d;
-    f3 position = eval_position(sc, o, isec.element, isec.u, isec.v);
-    f3 nrm      = eval_normal(sc, o, isec.element, isec.u, isec.v);
-    f3 normal;  // eval_shading_normal (pt.cpp:350-369)
-    bool is_hair = o.kind == YH_KIND_LINES;
-    if (is_hair) {
-      normal = orthonormalize(outgoing, nrm);
-    } else {
-      normal = (!mat.thin || dot(nrm, outgoing) >= 0) ? nrm : -nrm;
-    }
-    if (COUNT) count_add<COUNT>(is_hair ? &tc.counters->hair : &tc.counters->surf, 1);
-    hit      = true;
-    radiance = radiance + weight * (ld3(mat.emission) * mk3(1.0f));
-    hair_hit hh;
-    if (is_hair) hh = hair_setup(isec.v, normal, nrm);  // tangent = eval_normal (pt.cpp:487)
+// State of one path in flight (the locals of trace_path, pt.cpp:1383-1387).
+struct path_t {
+  ray_t ray;
+  f3    radiance, weight;
+  int   bounce;
+  bool  hit;
+};
 
-    f3 incoming;
-    if (rand1f(rng) < 0.5f) {
-      float rnx = rand1f(rng), rny = rand1f(rng);
-      float rnl = rand1f(rng);
-      if (is_hair) {
-        incoming = hair_sample(mat, hh, outgoing, rnx, rny);
-      } else {  // sample_brdfcos (pt.cpp:1139-1174): only the diffuse lobe
-        incoming = mk3(0.0f);
-        if (mat.diffuse_pdf != 0 && rnl < 0.0f + mat.diffuse_pdf) {
-          if (!(dot(normal, outgoing) <= 0)) incoming = sample_hemisphere_cos(normal, rnx, rny);
-        }
-      }
-    } else {
-      float ruvx = rand1f(rng), ruvy = rand1f(rng);
-      float rel = rand1f(rng);
-      float rl  = rand1f(rng);
-      incoming  = sample_lights<COUNT>(tc, position, rl, rel, ruvx, ruvy);
-    }
-    f3    brdfcos;
-    float brdf_pdf;
+// One iteration of trace_path's bounce loop (pt.cpp:1395-1508) given the
+// closest hit of ps.ray. Returns true when the path continues with the new
+// ps.ray, false when it ended (miss, zero / non-finite weight, Russian
+// roulette or the bounce limit).
+template <bool COUNT>
+YH_DEV bool path_step(const trace_ctx& tc, path_t& ps, const hit_t& isec, rng_t& rng, int bounces) {
+  const yhd_scene& sc = *tc.sc;
+  if (isec.object < 0) {
+    ps.radiance = ps.radiance + ps.weight * eval_environment<COUNT>(tc, ps.ray.d);
+    return false;
+  }
+  const yhd_object&   o   = sc.objects[isec.object];
+  const yhd_material& mat = sc.materials[o.material];
+  f3 outgoing = -ps.ray.d;
+  f3 position = eval_position(sc, o, isec.element, isec.u, isec.v);
+  f3 nrm      = eval_normal(sc, o, isec.element, isec.u, isec.v);
+  f3 normal;  // eval_shading_normal (pt.cpp:350-369)
+  bool is_hair = o.kind == YH_KIND_LINES;
+  if (is_hair) {
+    normal = orthonormalize(outgoing, nrm);
+  } else {
+    normal = (!mat.thin || dot(nrm, outgoing) >= 0) ? nrm : -nrm;
+  }
+  if (COUNT) count_add<COUNT>(is_hair ? &tc.counters->hair : &tc.counters->surf, 1);
+  ps.hit      = true;
+  ps.radiance = ps.radiance + ps.weight * (ld3(mat.emission) * mk3(1.0f));
+  hair_hit hh;
+  if (is_hair) hh = hair_setup(isec.v, normal, nrm);  // tangent = eval_normal (pt.cpp:487)
+
+  f3 incoming;
+  if (rand1f(rng) < 0.5f) {
+    float rnx = rand1f(rng), rny = rand1f(rng);
+    float rnl = rand1f(rng);
     if (is_hair) {
-      hair_eval_pdf<true, true>(mat, hh, outgoing, incoming, brdfcos, brdf_pdf);
-    } else {  // eval_brdfcos / sample_brdfcos_pdf, diffuse lobe (math.h:4427,4572)
-      brdfcos  = mk3(0.0f);
-      brdf_pdf = 0.0f;
-      f3 diffuse = ld3(mat.color);
-      bool below = dot(normal, incoming) <= 0 || dot(normal, outgoing) <= 0;
-      if (!is_zero(diffuse)) {
-        f3 lobe = below ? mk3(0.0f) : mk3(1.0f) / pif * dot(normal, incoming);
-        brdfcos = brdfcos + diffuse * lobe;
-      }
-      if (mat.diffuse_pdf != 0) {
-        float lobe = 0.0f;
-        if (!below) {
-          float cosw = dot(normal, incoming);
-          lobe       = (cosw <= 0) ? 0 : cosw / pif;
-        }
-        brdf_pdf += mat.diffuse_pdf * lobe;
+      incoming = hair_sample(mat, hh, outgoing, rnx, rny);
+    } else {  // sample_brdfcos (pt.cpp:1139-1174): only the diffuse lobe
+      incoming = mk3(0.0f);
+      if (mat.diffuse_pdf != 0 && rnl < 0.0f + mat.diffuse_pdf) {
+        if (!(dot(normal, outgoing) <= 0)) incoming = sample_hemisphere_cos(normal, rnx, rny);
       }
     }
-    float light_pdf = sample_lights_pdf<COUNT>(tc, position, incoming);
-    weight = weight * (brdfcos / (0.5f * brdf_pdf + 0.5f * light_pdf));
-    ray    = mkray(position, incoming);
-    if (is_zero(weight) || !finite3(weight)) break;
-    if (bounce > 3) {
-      float rr_prob = fmin_(0.99f, hmax(weight));
-      if (rand1f(rng) >= rr_prob) break;
-      weight = weight * (1 / rr_prob);
+  } else {
+    float ruvx = rand1f(rng), ruvy = rand1f(rng);
+    float rel = rand1f(rng);
+    float rl  = rand1f(rng);
+    incoming  = sample_lights<COUNT>(tc, position, rl, rel, ruvx, ruvy);
+  }
+  f3    brdfcos;
+  float brdf_pdf;
+  if (is_hair) {
+    hair_eval_pdf<true, true>(mat, hh, outgoing, incoming, brdfcos, brdf_pdf);
+  } else {  // eval_brdfcos / sample_brdfcos_pdf, diffuse lobe (math.h:4427,4572)
+    brdfcos  = mk3(0.0f);
+    brdf_pdf = 0.0f;
+    f3 diffuse = ld3(mat.color);
+    bool below = dot(normal, incoming) <= 0 || dot(normal, outgoing) <= 0;
+    if (!is_zero(diffuse)) {
+      f3 lobe = below ? mk3(0.0f) : mk3(1.0f) / pif * dot(normal, incoming);
+      brdfcos = brdfcos + diffuse * lobe;
+    }
+    if (mat.diffuse_pdf != 0) {
+      float lobe = 0.0f;
+      if (!below) {
+        float cosw = dot(normal, incoming);
+        lobe       = (cosw <= 0) ? 0 : cosw / pif;
+      }
+      brdf_pdf += mat.diffuse_pdf * lobe;
     }
   }
-  radiance_out = radiance;
-  hit_out      = hit ? 1.0f : 0.0f;
+  float light_pdf = sample_lights_pdf<COUNT>(tc, position, incoming);
+  ps.weight = ps.weight * (brdfcos / (0.5f * brdf_pdf + 0.5f * light_pdf));
+  ps.ray    = mkray(position, incoming);
+  if (is_zero(ps.weight) || !finite3(ps.weight)) return false;
+  if (ps.bounce > 3) {
+    float rr_prob = fmin_(0.99f, hmax(ps.weight));
+    if (rand1f(rng) >= rr_prob) return false;
+    ps.weight = ps.weight * (1 / rr_prob);
+  }
+  ps.bounce++;
+  return ps.bounce < bounces;
 }
 
-// trace_sample (pt.cpp:1676-1689): returns the value added to the accumulator
-template <bool COUNT>
-YH_DEV yhd_float4 trace_sample(const trace_ctx& tc, rng_t& rng, int i, int j, int w, int h,
-    int bounces, float clamp) {
+// Start of trace_sample (pt.cpp:1676-1682): the four draws and the camera ray.
+YH_DEV void path_begin(const yhd_camera& cam, path_t& ps, rng_t& rng, int i, int j, int w, int h) {
   float lu = rand1f(rng), lv = rand1f(rng);
   float pu = rand1f(rng), pv = rand1f(rng);
-  ray_t ray = sample_camera(tc.sc->camera, i, j, w, h, pu, pv, lu, lv);
-  f3    rgb;
-  float a;
-  trace_path<COUNT>(tc, ray, rng, bounces, rgb, a);
+  ps.ray      = sample_camera(cam, i, j, w, h, pu, pv, lu, lv);
+  ps.radiance = mk3(0.0f), ps.weight = mk3(1.0f);
+  ps.bounce   = 0;
+  ps.hit      = false;
+}
+// End of trace_sample (pt.cpp:1683-1686): sanitize, clamp, accumulate.
+YH_DEV void path_end(const path_t& ps, float clamp, yhd_float4& acc) {
+  f3 rgb = ps.radiance;
   if (!finite3(rgb)) rgb = mk3(0.0f);
   if (hmax(rgb) > clamp) rgb = rgb * (clamp / hmax(rgb));
-  if (COUNT) count_add<COUNT>(&tc.counters->samples, 1);
-  return yhd_float4{rgb.x, rgb.y, rgb.z, a};
+  acc.x += rgb.x, acc.y += rgb.y, acc.z += rgb.z, acc.w += ps.hit ? 1.0f : 0.0f;
 }
 
 }  // namespace yhd

@@ -123,10 +123,37 @@ YH_DEV bool intersect_bbox(f3 ro, f3 dinv, float tmin_, float tmax_, f3 bmin, f3
 #define YH_TAG_SCENE 0x40000000u /* entry = scene-node index                 */
 #define YH_TAG_ENTER 0x80000000u /* entry = object id to enter               */
 #define YH_TAG_MASK 0xC0000000u
+#define YH_NONE 0xFFFFFFFFu
+
+// Traversal stack. The first YH_LDS_STACK entries of every lane live in LDS
+// (column `tid` of a [depth][block] array: conflict-free, one ds_read/ds_write
+// per push/pop); deeper entries overflow to scratch. Kernels without an LDS
+// carve-out (unit-level batches) pass lds == nullptr and use scratch only.
+#ifndef YH_LDS_STACK
+#define YH_LDS_STACK 24
+#endif
+struct stack_t {
+  unsigned int* lds;     // &lds_stack[tid] or nullptr
+  int           stride;  // block size
+  int           sp;
+  unsigned int  ovf[YH_STACK_MAX];  // only entries beyond the LDS part are ever touched
+  YH_DEV void push(unsigned int v) {
+    if (lds && sp < YH_LDS_STACK) lds[sp * stride] = v;
+    else ovf[lds ? sp - YH_LDS_STACK : sp] = v;
+    sp++;
+  }
+  YH_DEV unsigned int pop() {
+    sp--;
+    if (lds && sp < YH_LDS_STACK) return lds[sp * stride];
+    return ovf[lds ? sp - YH_LDS_STACK : sp];
+  }
+};
 
 struct trace_ctx {
   const yhd_scene*  sc;
   const yhd_float4* lds_nodes;  // LDS copy of nodes[lds_node_base ..+count)
+  unsigned int*     lds_stack;  // this lane's LDS stack column (or nullptr)
+  int               lds_stride;
   yhd_counters*     counters;   // NULL in the production kernel
 };
 
@@ -137,34 +164,42 @@ YH_DEV void count_add(unsigned long long* slot, unsigned long long n) {
 
 // Closest hit against the whole scene (first_object < 0) or against a single
 // instance (intersect_instance_bvh, pt.cpp:1031-1037).
+//
+// The node being visited is kept in a register (`cur`): at an internal node
+// the near child becomes `cur` directly and only the far child is pushed —
+// the same visiting order as the reference's push(far), push(near), pop().
 template <bool COUNT>
 YH_DEV hit_t trace_ray(const trace_ctx& tc, const ray_t& ray, int first_object) {
   const yhd_scene& sc = *tc.sc;
-  unsigned int     stack[YH_STACK_MAX];
-  int              sp = 0;
-  hit_t            hit;
+  stack_t          stk;
+  stk.lds = tc.lds_stack, stk.stride = tc.lds_stride, stk.sp = 0;
+  hit_t hit;
   hit.object = -1, hit.element = -1, hit.u = 0, hit.v = 0, hit.distance = 0;
   float tmax = ray.tmax;
   // world-space ray data for the scene level
-  f3 wdinv = {1 / ray.d.x, 1 / ray.d.y, 1 / ray.d.z};
+  f3  wdinv = {1 / ray.d.x, 1 / ray.d.y, 1 / ray.d.z};
   int wsign = (wdinv.x < 0 ? 1 : 0) | (wdinv.y < 0 ? 2 : 0) | (wdinv.z < 0 ? 4 : 0);
   // instance-space ray data
   f3  lo = ray.o, ld = ray.d, ldinv = wdinv;
   int lsign = wsign, cur_obj = -1, kind = 0, node_base = 0, prim_base = 0;
   unsigned long long n_nodes = 0, n_seg = 0, n_tri = 0;
 
+  unsigned int cur;
   if (first_object >= 0) {
-    stack[sp++] = YH_TAG_ENTER | (unsigned)first_object;
+    cur = YH_TAG_ENTER | (unsigned)first_object;
   } else {
     if (sc.num_scene_nodes == 0) return hit;
-    stack[sp++] = YH_TAG_SCENE | 0u;
+    cur = YH_TAG_SCENE | 0u;
   }
-  while (sp) {
-    unsigned int e   = stack[--sp];
-    unsigned int tag = e & YH_TAG_MASK;
+  while (true) {
+    if (cur == YH_NONE) {
+      if (stk.sp == 0) break;
+      cur = stk.pop();
+    }
+    unsigned int tag = cur & YH_TAG_MASK;
     if (tag == YH_TAG_ENTER) {
       // transform_ray(inverse(object.frame, true), ray) (pt.cpp:1012-1013)
-      cur_obj             = (int)(e & ~YH_TAG_MASK);
+      cur_obj             = (int)(cur & ~YH_TAG_MASK);
       const yhd_object& o = sc.objects[cur_obj];
       frame inv           = ldframe(o.inv_frame);
       lo                  = transform_point(inv, ray.o);
@@ -172,33 +207,30 @@ YH_DEV hit_t trace_ray(const trace_ctx& tc, const ray_t& ray, int first_object) 
       ldinv               = {1 / ld.x, 1 / ld.y, 1 / ld.z};
       lsign = (ldinv.x < 0 ? 1 : 0) | (ldinv.y < 0 ? 2 : 0) | (ldinv.z < 0 ? 4 : 0);
       kind = o.kind, node_base = o.node_base, prim_base = o.prim_base;
-      stack[sp++] = YH_TAG_SHAPE | (unsigned)node_base;  // shape root
+      cur = YH_TAG_SHAPE | (unsigned)node_base;  // shape root
       continue;
     }
     if (tag == YH_TAG_SCENE) {
-      int        idx = (int)(e & ~YH_TAG_MASK);
+      int        idx = (int)(cur & ~YH_TAG_MASK);
       yhd_float4 n0 = sc.scene_nodes[2 * idx], n1 = sc.scene_nodes[2 * idx + 1];
       n_nodes++;
+      cur = YH_NONE;
       if (!intersect_bbox(ray.o, wdinv, ray.tmin, tmax, xyz(n0), xyz(n1))) continue;
       int start = __float_as_int(n0.w), meta = __float_as_int(n1.w);
       if (meta & 0x10000) {  // internal
         int axis = (meta >> 24) & 3;
-        if ((wsign >> axis) & 1) {
-          stack[sp++] = YH_TAG_SCENE | (unsigned)(start + 0);
-          stack[sp++] = YH_TAG_SCENE | (unsigned)(start + 1);
-        } else {
-          stack[sp++] = YH_TAG_SCENE | (unsigned)(start + 1);
-          stack[sp++] = YH_TAG_SCENE | (unsigned)(start + 0);
-        }
+        int near = (wsign >> axis) & 1;  // dsign set: visit start+1 first
+        stk.push(YH_TAG_SCENE | (unsigned)(start + 1 - near));
+        cur = YH_TAG_SCENE | (unsigned)(start + near);
       } else {
         int num = meta & 0xffff;
-        for (int i = num - 1; i >= 0; i--)
-          stack[sp++] = YH_TAG_ENTER | (unsigned)sc.scene_prims[start + i];
+        for (int i = num - 1; i >= 1; i--) stk.push(YH_TAG_ENTER | (unsigned)sc.scene_prims[start + i]);
+        if (num > 0) cur = YH_TAG_ENTER | (unsigned)sc.scene_prims[start];
       }
       continue;
     }
     // shape node
-    int        idx = (int)e;
+    int        idx = (int)cur;
     yhd_float4 n0, n1;
     int        rel = idx - sc.lds_node_base;
     if (tc.lds_nodes && rel >= 0 && rel < sc.lds_node_count) {
@@ -207,23 +239,20 @@ YH_DEV hit_t trace_ray(const trace_ctx& tc, const ray_t& ray, int first_object) 
       n0 = sc.nodes[2 * (size_t)idx], n1 = sc.nodes[2 * (size_t)idx + 1];
     }
     n_nodes++;
+    cur = YH_NONE;
     if (!intersect_bbox(lo, ldinv, ray.tmin, tmax, xyz(n0), xyz(n1))) continue;
     int start = __float_as_int(n0.w), meta = __float_as_int(n1.w);
     if (meta & 0x10000) {
       int axis = (meta >> 24) & 3;
-      int a = node_base + start, b = a + 1;
-      if ((lsign >> axis) & 1) {
-        stack[sp++] = (unsigned)a;
-        stack[sp++] = (unsigned)b;
-      } else {
-        stack[sp++] = (unsigned)b;
-        stack[sp++] = (unsigned)a;
-      }
+      int near = (lsign >> axis) & 1;
+      int a    = node_base + start;
+      stk.push((unsigned)(a + 1 - near));
+      cur = (unsigned)(a + near);
     } else {
       int num = meta & 0xffff;
       if (kind == YH_KIND_LINES) {
         for (int i = 0; i < num; i++) {
-          size_t     r  = (size_t)prim_base + (size_t)(start + i) * 2;
+          size_t     r = (size_t)prim_base + (size_t)(start + i) * 2;
           yhd_float4 a = sc.prims[r], b = sc.prims[r + 1];
           n_seg++;
           float uu, vv, dist;
@@ -235,7 +264,7 @@ YH_DEV hit_t trace_ray(const trace_ctx& tc, const ray_t& ray, int first_object) 
         }
       } else {
         for (int i = 0; i < num; i++) {
-          size_t     r  = (size_t)prim_base + (size_t)(start + i) * 3;
+          size_t     r = (size_t)prim_base + (size_t)(start + i) * 3;
           yhd_float4 a = sc.prims[r], b = sc.prims[r + 1], c = sc.prims[r + 2];
           n_tri++;
           float uu, vv, dist;

@@ -19,15 +19,31 @@
 
 using namespace yhd;
 
+#ifndef YH_BLOCK
 #define YH_BLOCK 512
+#endif
+#ifndef YH_MIN_WAVES
+#define YH_MIN_WAVES 4 /* waves per SIMD the register allocator must allow */
+#endif
 
 // ---------------------------------------------------------------------------
 // The sample loop
 // ---------------------------------------------------------------------------
+// Persistent wavefronts with path regeneration. A wave pulls an 8x8 tile from
+// the launch's tile queue (tiles are queued most-expensive-first using the
+// cost each tile reported in the previous launch); each lane owns one pixel
+// and keeps ONE path in flight. Every iteration traces the current segment of
+// all live lanes, shades it, and a lane whose path ended starts its pixel's
+// next sample in the same iteration (its PCG32 stream is sequential per pixel,
+// pt.cpp:1942-1945, so samples of one pixel cannot run side by side) — lanes
+// never wait for the longest path of a sample, only for the tile's last lane.
 template <bool COUNT>
-__global__ __launch_bounds__(YH_BLOCK) void k_trace(const yhd_scene sc, const yhd_state st,
+__global__ __launch_bounds__(YH_BLOCK, YH_MIN_WAVES) void k_trace(const yhd_scene sc, const yhd_state st,
     int nsamples, yhd_counters* counters) {
-  extern __shared__ yhd_float4 lds_nodes[];
+  extern __shared__ yhd_float4 lds_dyn[];
+  // LDS carve-out: [nodelets: 2 * lds_node_count float4][stack: YH_LDS_STACK x blockDim uint]
+  yhd_float4*   lds_nodes = lds_dyn;
+  unsigned int* lds_stack = (unsigned int*)(lds_dyn + 2 * sc.lds_node_count);
   // stage the nodelets: the first lds_node_count nodes (breadth-first = top
   // levels) of the dominant hair shape, 32 B each, coalesced dwordx4 loads
   for (int i = threadIdx.x; i < 2 * sc.lds_node_count; i += blockDim.x)
@@ -35,29 +51,54 @@ __global__ __launch_bounds__(YH_BLOCK) void k_trace(const yhd_scene sc, const yh
   __syncthreads();
 
   trace_ctx tc;
-  tc.sc        = &sc;
-  tc.lds_nodes = sc.lds_node_count ? lds_nodes : nullptr;
-  tc.counters  = counters;
+  tc.sc         = &sc;
+  tc.lds_nodes  = sc.lds_node_count ? lds_nodes : nullptr;
+  tc.lds_stack  = lds_stack + threadIdx.x;
+  tc.lds_stride = blockDim.x;
+  tc.counters   = counters;
 
-  const int lane        = threadIdx.x & 63;
-  const int wave        = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int total_waves = (gridDim.x * blockDim.x) >> 6;
-  for (int t = wave; t < st.num_tiles; t += total_waves) {
-    int tile = st.tiles[t];
-    int i    = (tile % st.tiles_x) * YH_TILE + (lane & 7);
-    int j    = (tile / st.tiles_x) * YH_TILE + (lane >> 3);
-    if (i >= st.width || j >= st.height) continue;
-    size_t pix = (size_t)j * st.width + i;
+  const int lane = threadIdx.x & 63;
+  while (true) {
+    int t = 0;
+    if (lane == 0) t = atomicAdd(st.tile_cursor, 1);
+    t = __builtin_amdgcn_readfirstlane(t);
+    if (t >= st.num_tiles) break;
+    unsigned long long t0 = wall_clock64();
+    int  tile  = st.tiles[t];
+    int  i     = (tile % st.tiles_x) * YH_TILE + (lane & 7);
+    int  j     = (tile / st.tiles_x) * YH_TILE + (lane >> 3);
+    bool owner = i < st.width && j < st.height;
+    size_t pix = owner ? (size_t)j * st.width + i : 0;
     rng_t  rng;
     rng.state      = st.rng_state[pix];
     rng.inc        = st.rng_inc[pix];
     yhd_float4 acc = st.accum[pix];
-    for (int s = 0; s < nsamples; s++) {
-      yhd_float4 v = trace_sample<COUNT>(tc, rng, i, j, st.width, st.height, st.bounces, st.clamp);
-      acc.x += v.x, acc.y += v.y, acc.z += v.z, acc.w += v.w;
+    int    left    = owner ? nsamples : 0;  // samples this lane still has to start
+    bool   alive   = false;
+    path_t ps;
+    ps.bounce = 0, ps.hit = false;
+    while (true) {
+      if (!alive && left > 0) {
+        path_begin(sc.camera, ps, rng, i, j, st.width, st.height);
+        left--;
+        alive = true;
+      }
+      if (!__any(alive)) break;
+      if (alive) {
+        if (COUNT) count_add<COUNT>(&counters->rays, 1);
+        hit_t isec = trace_ray<COUNT>(tc, ps.ray, -1);
+        alive      = path_step<COUNT>(tc, ps, isec, rng, st.bounces);
+        if (!alive) {
+          path_end(ps, st.clamp, acc);
+          if (COUNT) count_add<COUNT>(&counters->samples, 1);
+        }
+      }
     }
-    st.rng_state[pix] = rng.state;
-    st.accum[pix]     = acc;
+    if (owner) {
+      st.rng_state[pix] = rng.state;
+      st.accum[pix]     = acc;
+    }
+    if (lane == 0) st.tile_cost[tile] = (unsigned int)(wall_clock64() - t0);
   }
 }
 
@@ -87,7 +128,9 @@ __global__ void k_pack(const yhd_state st, int samples, yhd_float4* packed) {
     float      n = (float)samples;
     out          = yhd_float4{a.x / n, a.y / n, a.z / n, a.w / n};
   }
-  packed[(size_t)t * 64 + lane] = out;
+  // position in the packed buffer = rank of the tile id within this shard (the
+  // hand-out order of `tiles` changes from launch to launch)
+  packed[(size_t)((tile - st.shard_rank) / st.shard_world) * 64 + lane] = out;
 }
 __global__ void k_unpack(const yhd_float4* packed, int src_rank, int world, int num_tiles_total,
     int tiles_x, int width, int height, yhd_float4* image) {
@@ -207,7 +250,7 @@ __global__ void k_intersect(const yhd_scene sc, int n, const float* rays, int* o
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   trace_ctx tc;
-  tc.sc = &sc, tc.lds_nodes = nullptr, tc.counters = nullptr;
+  tc.sc = &sc, tc.lds_nodes = nullptr, tc.lds_stack = nullptr, tc.lds_stride = 0, tc.counters = nullptr;
   const float* r = rays + 8 * (size_t)i;
   ray_t ray      = ray_t{ld3(r), ld3(r + 3), r[6], r[7]};
   hit_t h        = trace_ray<false>(tc, ray, -1);
@@ -327,7 +370,14 @@ extern "C" {
 
 int yhk_trace(const yhd_scene* sc, const yhd_state* st, int nsamples, yhd_counters* counters,
     int grid_blocks, hipStream_t stream) {
-  size_t lds = (size_t)sc->lds_node_count * 32;
+  size_t lds = (size_t)sc->lds_node_count * 32 + (size_t)YH_LDS_STACK * YH_BLOCK * 4;
+  static size_t lds_set[2] = {0, 0};
+  if (lds > lds_set[counters ? 1 : 0]) {  // above 64 KB the dynamic-LDS limit must be raised explicitly
+    hipError_t e = counters ? hipFuncSetAttribute((const void*)k_trace<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                            : hipFuncSetAttribute((const void*)k_trace<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    lds_set[counters ? 1 : 0] = lds;
+  }
   if (counters)
     hipLaunchKernelGGL(k_trace<true>, dim3(grid_blocks), dim3(YH_BLOCK), lds, stream, *sc, *st, nsamples, counters);
   else
@@ -335,8 +385,10 @@ int yhk_trace(const yhd_scene* sc, const yhd_state* st, int nsamples, yhd_counte
   return (int)hipGetLastError();
 }
 int yhk_block_threads(void) { return YH_BLOCK; }
+int yhk_trace_lds_bytes(int lds_node_count) { return lds_node_count * 32 + YH_LDS_STACK * YH_BLOCK * 4; }
 int yhk_trace_occupancy(int lds_bytes) {
   int blocks = 0;
+  (void)hipFuncSetAttribute((const void*)k_trace<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_trace<false>, YH_BLOCK, lds_bytes) != hipSuccess) return 1;
   return blocks < 1 ? 1 : blocks;
 }

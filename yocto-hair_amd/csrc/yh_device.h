@@ -119,14 +119,16 @@ typedef struct yhd_state {
   uint64_t*   rng_state;  // per pixel
   uint64_t*   rng_inc;    // per pixel
   yhd_float4* accum;      // per pixel: sum of clamped radiance, w = hit count
-  const int*  tiles;      // owned tile ids (increasing)
+  const int*  tiles;      // owned tile ids, in the order the launch hands them out
+  int*        tile_cursor;  // next position in `tiles` (zeroed before every launch)
+  unsigned int* tile_cost;  // per tile id: wall-clock ticks its last launch took
   int         num_tiles;
   int         width, height;
   int         tiles_x;
   int         samples_done;
   int         bounces;
   float       clamp;
-  int         pad;
+  int         shard_rank, shard_world;  // tile ids owned: rank, rank + world, ...
 } yhd_state;
 
 // Work counters (one 64-bit slot each), accumulated with atomics by the

@@ -17,6 +17,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <string>
@@ -31,6 +32,7 @@ extern "C" {
 int yhk_trace(const yhd_scene*, const yhd_state*, int, yhd_counters*, int, hipStream_t);
 int yhk_block_threads(void);
 int yhk_trace_occupancy(int lds_bytes);
+int yhk_trace_lds_bytes(int lds_node_count);
 int yhk_resolve(const yhd_state*, int, void*, hipStream_t);
 int yhk_pack(const yhd_state*, int, void*, hipStream_t);
 int yhk_unpack(const void*, int, int, int, int, int, int, int, void*, hipStream_t);
@@ -207,7 +209,8 @@ struct yh_context {
   bool             have_state = false;
   yhd_state        state{};
   yh_trace_params  params{};
-  DevBuf           d_rng_state, d_rng_inc, d_accum, d_tiles, d_image, d_counters;
+  DevBuf           d_rng_state, d_rng_inc, d_accum, d_tiles, d_image, d_counters, d_tile_cursor, d_tile_cost;
+  std::vector<int> tiles;  // owned tile ids in hand-out order (most expensive first)
   int              rank = 0, world = 1;
   int              num_tiles_total = 0;
   float            last_ms = 0;
@@ -521,7 +524,9 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
   sc.lds_node_base = 0, sc.lds_node_count = 0;
   if (best_shape >= 0) {
     sc.lds_node_base  = info[best_shape].node_base;
-    sc.lds_node_count = std::min(info[best_shape].num_nodes, 2047);
+    int want = 1023;  // 32 KB of nodelets + 48 KB of stacks = 80 KB: two 512-thread blocks per CU
+    if (const char* env = getenv("YHAIR_LDS_NODES")) want = std::max(0, std::min(atoi(env), 3000));
+    sc.lds_node_count = std::min(info[best_shape].num_nodes, want);
   }
   ctx->scene      = sc;
   ctx->have_scene = true;
@@ -566,7 +571,8 @@ int yh_init_state(yh_context* ctx, const yh_trace_params* params) {
   }
   int tx = tiles_of(w), ty = tiles_of(h);
   ctx->num_tiles_total = tx * ty;
-  std::vector<int> tiles;
+  auto& tiles = ctx->tiles;
+  tiles.clear();
   for (int t = ctx->rank; t < ctx->num_tiles_total; t += ctx->world) tiles.push_back(t);
   int rc;
   if ((rc = upload(ctx, ctx->d_rng_state, st.data(), npix * 8))) return rc;
@@ -575,11 +581,15 @@ int yh_init_state(yh_context* ctx, const yh_trace_params* params) {
   if ((rc = alloc_zero(ctx, ctx->d_image, npix * 16))) return rc;
   if ((rc = upload(ctx, ctx->d_tiles, tiles.data(), tiles.size() * 4))) return rc;
   if ((rc = alloc_zero(ctx, ctx->d_counters, sizeof(yhd_counters)))) return rc;
+  if ((rc = alloc_zero(ctx, ctx->d_tile_cursor, 4))) return rc;
+  if ((rc = alloc_zero(ctx, ctx->d_tile_cost, (size_t)ctx->num_tiles_total * 4))) return rc;
   auto& s = ctx->state;
+  s.tile_cursor = (int*)ctx->d_tile_cursor.p, s.tile_cost = (unsigned int*)ctx->d_tile_cost.p;
   s.rng_state = (uint64_t*)ctx->d_rng_state.p, s.rng_inc = (uint64_t*)ctx->d_rng_inc.p;
   s.accum = (yhd_float4*)ctx->d_accum.p, s.tiles = (const int*)ctx->d_tiles.p;
   s.num_tiles = (int)tiles.size(), s.width = w, s.height = h, s.tiles_x = tx;
   s.samples_done = 0, s.bounces = params->bounces, s.clamp = params->clamp;
+  s.shard_rank = ctx->rank, s.shard_world = ctx->world;
   ctx->have_state = true;
   return YH_OK;
 }
@@ -602,10 +612,11 @@ static int trace_impl(yh_context* ctx, int nsamples, bool counted, bool sync) {
     return YH_OK;
   }
   int waves_per_block = yhk_block_threads() / 64;
-  int lds_bytes       = ctx->scene.lds_node_count * 32;
+  int lds_bytes       = yhk_trace_lds_bytes(ctx->scene.lds_node_count);
   int resident        = ctx->num_cus * yhk_trace_occupancy(lds_bytes);
   int want            = (ctx->state.num_tiles + waves_per_block - 1) / waves_per_block;
   int grid            = std::max(1, std::min(want, resident));
+  HIPCHK(ctx, hipMemsetAsync(ctx->d_tile_cursor.p, 0, 4, ctx->stream));
   HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   int e = yhk_trace(&ctx->scene, &ctx->state, nsamples, counted ? (yhd_counters*)ctx->d_counters.p : nullptr, grid,
       ctx->stream);
@@ -616,6 +627,14 @@ static int trace_impl(yh_context* ctx, int nsamples, bool counted, bool sync) {
   if (sync) {
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     HIPCHK(ctx, hipEventElapsedTime(&ctx->last_ms, ctx->ev0, ctx->ev1));
+    // Longest-processing-time-first: hand the tiles out in decreasing order of
+    // the cost they just reported (hair tiles cost 10-100x background tiles and
+    // a pixel's samples are sequential, so the last tile to start bounds the
+    // launch). Pixel results do not depend on the order.
+    std::vector<unsigned int> cost(ctx->num_tiles_total);
+    HIPCHK(ctx, hipMemcpy(cost.data(), ctx->d_tile_cost.p, cost.size() * 4, hipMemcpyDeviceToHost));
+    std::stable_sort(ctx->tiles.begin(), ctx->tiles.end(), [&](int a, int b) { return cost[a] > cost[b]; });
+    HIPCHK(ctx, hipMemcpy(ctx->d_tiles.p, ctx->tiles.data(), ctx->tiles.size() * 4, hipMemcpyHostToDevice));
   }
   return YH_OK;
 }

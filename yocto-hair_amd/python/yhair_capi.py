@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-LIB_PATH = os.path.join(ROOT, "yocto-hair_amd", "libyhair.so")
+LIB_PATH = os.environ.get("YHAIR_LIB", os.path.join(ROOT, "yocto-hair_amd", "libyhair.so"))
 
 YH_OK, YH_E_INVALID, YH_E_DEVICE, YH_E_STATE, YH_E_IO, YH_E_SELFTEST = 0, -1, -2, -3, -4, -5
 YH_HAIR_BRDF_FLOATS = 30
