@@ -202,6 +202,12 @@ int yh_trace_samples_counted(yh_context* ctx, int nsamples, yh_workcounts* out);
  * sequence on the context's own stream, and the number of kernel launches.   */
 int yh_last_trace_ms(const yh_context* ctx, float* ms, int* launches);
 
+/* Load-balance telemetry: for every tile id (row-major over ceil(W/8) x
+ * ceil(H/8) tiles) the time its wavefront spent on it in the most recent
+ * launch, in ticks of the 100 MHz device wall clock (0 for tiles of other
+ * shards). `count` = number of tiles the caller's buffer holds.               */
+int yh_tile_costs(yh_context* ctx, uint32_t* ticks, int count);
+
 /* ------------------------------------------------------------------------ */
 /* Unit-level API: replaces yocto::extension and the intersect_* functions    */
 /* (batched, host arrays in / host arrays out; device does the arithmetic)    */

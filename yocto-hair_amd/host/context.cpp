@@ -723,6 +723,16 @@ int yh_download_rng(yh_context* ctx, uint64_t* state_inc) {
   return YH_OK;
 }
 
+int yh_tile_costs(yh_context* ctx, uint32_t* ticks, int count) {
+  if (!ctx || !ticks) return YH_E_INVALID;
+  if (!ctx->have_state) return fail(ctx, YH_E_STATE, "yh_tile_costs before yh_init_state");
+  if (count < ctx->num_tiles_total) return fail(ctx, YH_E_INVALID, "buffer holds %d tiles, image has %d", count, ctx->num_tiles_total);
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, hipMemcpy(ticks, ctx->d_tile_cost.p, (size_t)ctx->num_tiles_total * 4, hipMemcpyDeviceToHost));
+  return YH_OK;
+}
+
 // ---- unit-level batches ----------------------------------------------------
 namespace {
 struct Staged {

@@ -124,6 +124,7 @@ _SIGS = {
     "yh_download_rng": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "yh_trace_samples_counted": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(WorkCounts)]),
     "yh_last_trace_ms": (C.c_int, [C.c_void_p, c_float_p, c_int_p]),
+    "yh_tile_costs": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_int]),
     "yh_hair_brdf_batch": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Material), c_float_p,
                                      c_float_p, c_float_p, c_float_p]),
     "yh_hair_eval_batch": (C.c_int, [C.c_void_p, C.c_int, c_float_p, c_float_p, c_float_p, c_float_p]),
@@ -240,6 +241,12 @@ class Context:
         ms, n = C.c_float(), C.c_int()
         self._chk(self.lib.yh_last_trace_ms(self.h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def tile_costs(self):
+        tx, ty = (self.width + 7) // 8, (self.height + 7) // 8
+        out = np.zeros(tx * ty, np.uint32)
+        self._chk(self.lib.yh_tile_costs(self.h, out.ctypes.data_as(C.POINTER(C.c_uint32)), len(out)))
+        return out.reshape(ty, tx)
 
     def download(self):
         img = np.zeros((self.height, self.width, 4), np.float32)
