@@ -162,7 +162,7 @@ YH_DEV f3 sample_lights(const trace_ctx& tc, f3 position, float rl, float rel, f
 }
 
 // sample_lights_pdf (pt.cpp:1311-1358)
-template <bool COUNT>
+template <bool COUNT, bool LDS, int STRIDE>
 YH_DEV float sample_lights_pdf(const trace_ctx& tc, f3 position, f3 direction) {
   const yhd_scene& sc = *tc.sc;
   float pdf = 0.0f;
@@ -173,7 +173,7 @@ YH_DEV float sample_lights_pdf(const trace_ctx& tc, f3 position, f3 direction) {
       float lpdf = 0.0f;
       f3    next_position = position;
       for (int bounce = 0; bounce < 100; bounce++) {
-        hit_t isec = trace_ray<COUNT>(tc, mkray(next_position, direction), light.object);
+        hit_t isec = trace_ray<COUNT, LDS, STRIDE>(tc, mkray(next_position, direction), light.object);
         if (isec.object < 0) break;
         f3    lposition = eval_position(sc, o, isec.element, isec.u, isec.v);
         f3    lnormal   = eval_element_normal(sc, o, isec.element);
@@ -233,7 +233,7 @@ struct path_t {
 // closest hit of ps.ray. Returns true when the path continues with the new
 // ps.ray, false when it ended (miss, zero / non-finite weight, Russian
 // roulette or the bounce limit).
-template <bool COUNT>
+template <bool COUNT, bool LDS, int STRIDE>
 YH_DEV bool path_step(const trace_ctx& tc, path_t& ps, const hit_t& isec, rng_t& rng, int bounces) {
   const yhd_scene& sc = *tc.sc;
   if (isec.object < 0) {
@@ -298,7 +298,7 @@ YH_DEV bool path_step(const trace_ctx& tc, path_t& ps, const hit_t& isec, rng_t&
       brdf_pdf += mat.diffuse_pdf * lobe;
     }
   }
-  float light_pdf = sample_lights_pdf<COUNT>(tc, position, incoming);
+  float light_pdf = sample_lights_pdf<COUNT, LDS, STRIDE>(tc, position, incoming);
   ps.weight = ps.weight * (brdfcos / (0.5f * brdf_pdf + 0.5f * light_pdf));
   ps.ray    = mkray(position, incoming);
   if (is_zero(ps.weight) || !finite3(ps.weight)) return false;

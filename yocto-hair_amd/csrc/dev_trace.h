@@ -125,37 +125,27 @@ YH_DEV bool intersect_bbox(f3 ro, f3 dinv, float tmin_, float tmax_, f3 bmin, f3
 #define YH_TAG_MASK 0xC0000000u
 #define YH_NONE 0xFFFFFFFFu
 
-// Traversal stack. The first YH_LDS_STACK entries of every lane live in LDS
-// (column `tid` of a [depth][block] array: conflict-free, one ds_read/ds_write
-// per push/pop); deeper entries overflow to scratch. Kernels without an LDS
-// carve-out (unit-level batches) pass lds == nullptr and use scratch only.
+// Traversal stack. In k_trace the first YH_LDS_STACK entries of every lane
+// live in LDS (column `tid` of a [depth][block] array: conflict-free, one
+// ds_write_b32 / ds_read_b32 per push / pop) and only deeper entries overflow
+// to scratch; kernels without an LDS carve-out (unit-level batches) use
+// scratch only. Pointers into LDS carry the LDS address space so that the
+// compiler emits ds_* instructions instead of flat ones.
 #ifndef YH_LDS_STACK
 #define YH_LDS_STACK 24
 #endif
-struct stack_t {
-  unsigned int* lds;     // &lds_stack[tid] or nullptr
-  int           stride;  // block size
-  int           sp;
-  unsigned int  ovf[YH_STACK_MAX];  // only entries beyond the LDS part are ever touched
-  YH_DEV void push(unsigned int v) {
-    if (lds && sp < YH_LDS_STACK) lds[sp * stride] = v;
-    else ovf[lds ? sp - YH_LDS_STACK : sp] = v;
-    sp++;
-  }
-  YH_DEV unsigned int pop() {
-    sp--;
-    if (lds && sp < YH_LDS_STACK) return lds[sp * stride];
-    return ovf[lds ? sp - YH_LDS_STACK : sp];
-  }
-};
+#define YH_LDS __attribute__((address_space(3)))
+typedef float v4f __attribute__((ext_vector_type(4)));
 
 struct trace_ctx {
-  const yhd_scene*  sc;
-  const yhd_float4* lds_nodes;  // LDS copy of nodes[lds_node_base ..+count)
-  unsigned int*     lds_stack;  // this lane's LDS stack column (or nullptr)
-  int               lds_stride;
-  yhd_counters*     counters;   // NULL in the production kernel
+  const yhd_scene*      sc;
+  const YH_LDS v4f*     lds_nodes;  // LDS copy of nodes[lds_node_base ..+count)
+  YH_LDS unsigned int*  lds_stack;  // this lane's LDS stack column
+  yhd_counters*         counters;   // NULL in the production kernel
 };
+// one 16-byte load (never split into dwordx3 + dword)
+YH_DEV v4f ldg4(const yhd_float4* p) { return *(const v4f*)p; }
+YH_DEV f3  xyz(v4f a) { return f3{a.x, a.y, a.z}; }
 
 template <bool COUNT>
 YH_DEV void count_add(unsigned long long* slot, unsigned long long n) {
@@ -168,11 +158,25 @@ YH_DEV void count_add(unsigned long long* slot, unsigned long long n) {
 // The node being visited is kept in a register (`cur`): at an internal node
 // the near child becomes `cur` directly and only the far child is pushed —
 // the same visiting order as the reference's push(far), push(near), pop().
-template <bool COUNT>
+template <bool COUNT, bool LDS, int STRIDE>
 YH_DEV hit_t trace_ray(const trace_ctx& tc, const ray_t& ray, int first_object) {
   const yhd_scene& sc = *tc.sc;
-  stack_t          stk;
-  stk.lds = tc.lds_stack, stk.stride = tc.lds_stride, stk.sp = 0;
+  // stack: `sp` and the LDS column pointer stay in registers; only the
+  // overflow array is addressable memory
+  constexpr int         kLds = LDS ? YH_LDS_STACK : 0;
+  unsigned int          ovf[YH_STACK_MAX - kLds];
+  int                   sp   = 0;
+  YH_LDS unsigned int*  lstk = tc.lds_stack;
+  auto push = [&](unsigned int v) {
+    if (LDS && sp < kLds) lstk[sp * STRIDE] = v;
+    else ovf[sp - kLds] = v;
+    sp++;
+  };
+  auto pop = [&]() -> unsigned int {
+    sp--;
+    if (LDS && sp < kLds) return lstk[sp * STRIDE];
+    return ovf[sp - kLds];
+  };
   hit_t hit;
   hit.object = -1, hit.element = -1, hit.u = 0, hit.v = 0, hit.distance = 0;
   float tmax = ray.tmax;
@@ -193,8 +197,8 @@ YH_DEV hit_t trace_ray(const trace_ctx& tc, const ray_t& ray, int first_object) 
   }
   while (true) {
     if (cur == YH_NONE) {
-      if (stk.sp == 0) break;
-      cur = stk.pop();
+      if (sp == 0) break;
+      cur = pop();
     }
     unsigned int tag = cur & YH_TAG_MASK;
     if (tag == YH_TAG_ENTER) {
@@ -211,8 +215,8 @@ YH_DEV hit_t trace_ray(const trace_ctx& tc, const ray_t& ray, int first_object) 
       continue;
     }
     if (tag == YH_TAG_SCENE) {
-      int        idx = (int)(cur & ~YH_TAG_MASK);
-      yhd_float4 n0 = sc.scene_nodes[2 * idx], n1 = sc.scene_nodes[2 * idx + 1];
+      int idx = (int)(cur & ~YH_TAG_MASK);
+      v4f n0 = ldg4(sc.scene_nodes + 2 * idx), n1 = ldg4(sc.scene_nodes + 2 * idx + 1);
       n_nodes++;
       cur = YH_NONE;
       if (!intersect_bbox(ray.o, wdinv, ray.tmin, tmax, xyz(n0), xyz(n1))) continue;
@@ -220,23 +224,23 @@ YH_DEV hit_t trace_ray(const trace_ctx& tc, const ray_t& ray, int first_object) 
       if (meta & 0x10000) {  // internal
         int axis = (meta >> 24) & 3;
         int near = (wsign >> axis) & 1;  // dsign set: visit start+1 first
-        stk.push(YH_TAG_SCENE | (unsigned)(start + 1 - near));
+        push(YH_TAG_SCENE | (unsigned)(start + 1 - near));
         cur = YH_TAG_SCENE | (unsigned)(start + near);
       } else {
         int num = meta & 0xffff;
-        for (int i = num - 1; i >= 1; i--) stk.push(YH_TAG_ENTER | (unsigned)sc.scene_prims[start + i]);
+        for (int i = num - 1; i >= 1; i--) push(YH_TAG_ENTER | (unsigned)sc.scene_prims[start + i]);
         if (num > 0) cur = YH_TAG_ENTER | (unsigned)sc.scene_prims[start];
       }
       continue;
     }
     // shape node
-    int        idx = (int)cur;
-    yhd_float4 n0, n1;
-    int        rel = idx - sc.lds_node_base;
-    if (tc.lds_nodes && rel >= 0 && rel < sc.lds_node_count) {
+    int idx = (int)cur;
+    v4f n0, n1;
+    int rel = idx - sc.lds_node_base;
+    if (LDS && rel >= 0 && rel < sc.lds_node_count) {
       n0 = tc.lds_nodes[2 * rel], n1 = tc.lds_nodes[2 * rel + 1];
     } else {
-      n0 = sc.nodes[2 * (size_t)idx], n1 = sc.nodes[2 * (size_t)idx + 1];
+      n0 = ldg4(sc.nodes + 2 * (size_t)idx), n1 = ldg4(sc.nodes + 2 * (size_t)idx + 1);
     }
     n_nodes++;
     cur = YH_NONE;
@@ -246,14 +250,14 @@ YH_DEV hit_t trace_ray(const trace_ctx& tc, const ray_t& ray, int first_object) 
       int axis = (meta >> 24) & 3;
       int near = (lsign >> axis) & 1;
       int a    = node_base + start;
-      stk.push((unsigned)(a + 1 - near));
+      push((unsigned)(a + 1 - near));
       cur = (unsigned)(a + near);
     } else {
       int num = meta & 0xffff;
       if (kind == YH_KIND_LINES) {
         for (int i = 0; i < num; i++) {
-          size_t     r = (size_t)prim_base + (size_t)(start + i) * 2;
-          yhd_float4 a = sc.prims[r], b = sc.prims[r + 1];
+          size_t r = (size_t)prim_base + (size_t)(start + i) * 2;
+          v4f    a = ldg4(sc.prims + r), b = ldg4(sc.prims + r + 1);
           n_seg++;
           float uu, vv, dist;
           if (intersect_line(lo, ld, ray.tmin, tmax, xyz(a), xyz(b), a.w, b.w, uu, vv, dist)) {
@@ -264,8 +268,8 @@ YH_DEV hit_t trace_ray(const trace_ctx& tc, const ray_t& ray, int first_object) 
         }
       } else {
         for (int i = 0; i < num; i++) {
-          size_t     r = (size_t)prim_base + (size_t)(start + i) * 3;
-          yhd_float4 a = sc.prims[r], b = sc.prims[r + 1], c = sc.prims[r + 2];
+          size_t r = (size_t)prim_base + (size_t)(start + i) * 3;
+          v4f    a = ldg4(sc.prims + r), b = ldg4(sc.prims + r + 1), c = ldg4(sc.prims + r + 2);
           n_tri++;
           float uu, vv, dist;
           if (intersect_triangle(lo, ld, ray.tmin, tmax, xyz(a), xyz(b), xyz(c), uu, vv, dist)) {

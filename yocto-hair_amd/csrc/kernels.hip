@@ -40,22 +40,21 @@ using namespace yhd;
 template <bool COUNT>
 __global__ __launch_bounds__(YH_BLOCK, YH_MIN_WAVES) void k_trace(const yhd_scene sc, const yhd_state st,
     int nsamples, yhd_counters* counters) {
-  extern __shared__ yhd_float4 lds_dyn[];
-  // LDS carve-out: [nodelets: 2 * lds_node_count float4][stack: YH_LDS_STACK x blockDim uint]
-  yhd_float4*   lds_nodes = lds_dyn;
-  unsigned int* lds_stack = (unsigned int*)(lds_dyn + 2 * sc.lds_node_count);
+  extern __shared__ v4f lds_dyn[];
+  // LDS carve-out: [nodelets: 2 * lds_node_count float4][stack: YH_LDS_STACK x YH_BLOCK uint]
+  YH_LDS v4f*          lds_nodes = (YH_LDS v4f*)lds_dyn;
+  YH_LDS unsigned int* lds_stack = (YH_LDS unsigned int*)(lds_nodes + 2 * sc.lds_node_count);
   // stage the nodelets: the first lds_node_count nodes (breadth-first = top
   // levels) of the dominant hair shape, 32 B each, coalesced dwordx4 loads
   for (int i = threadIdx.x; i < 2 * sc.lds_node_count; i += blockDim.x)
-    lds_nodes[i] = sc.nodes[2 * (size_t)sc.lds_node_base + i];
+    lds_nodes[i] = ldg4(sc.nodes + 2 * (size_t)sc.lds_node_base + i);
   __syncthreads();
 
   trace_ctx tc;
   tc.sc         = &sc;
-  tc.lds_nodes  = sc.lds_node_count ? lds_nodes : nullptr;
-  tc.lds_stack  = lds_stack + threadIdx.x;
-  tc.lds_stride = blockDim.x;
-  tc.counters   = counters;
+  tc.lds_nodes = lds_nodes;
+  tc.lds_stack = lds_stack + threadIdx.x;
+  tc.counters  = counters;
 
   const int lane = threadIdx.x & 63;
   while (true) {
@@ -86,8 +85,8 @@ __global__ __launch_bounds__(YH_BLOCK, YH_MIN_WAVES) void k_trace(const yhd_scen
       if (!__any(alive)) break;
       if (alive) {
         if (COUNT) count_add<COUNT>(&counters->rays, 1);
-        hit_t isec = trace_ray<COUNT>(tc, ps.ray, -1);
-        alive      = path_step<COUNT>(tc, ps, isec, rng, st.bounces);
+        hit_t isec = trace_ray<COUNT, true, YH_BLOCK>(tc, ps.ray, -1);
+        alive      = path_step<COUNT, true, YH_BLOCK>(tc, ps, isec, rng, st.bounces);
         if (!alive) {
           path_end(ps, st.clamp, acc);
           if (COUNT) count_add<COUNT>(&counters->samples, 1);
@@ -250,10 +249,10 @@ __global__ void k_intersect(const yhd_scene sc, int n, const float* rays, int* o
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   trace_ctx tc;
-  tc.sc = &sc, tc.lds_nodes = nullptr, tc.lds_stack = nullptr, tc.lds_stride = 0, tc.counters = nullptr;
+  tc.sc = &sc, tc.lds_nodes = nullptr, tc.lds_stack = nullptr, tc.counters = nullptr;
   const float* r = rays + 8 * (size_t)i;
   ray_t ray      = ray_t{ld3(r), ld3(r + 3), r[6], r[7]};
-  hit_t h        = trace_ray<false>(tc, ray, -1);
+  hit_t h        = trace_ray<false, false, 1>(tc, ray, -1);
   object[i] = h.object, element[i] = h.object < 0 ? -1 : h.element;
   uv[2 * i] = h.u, uv[2 * i + 1] = h.v, dist[i] = h.distance;
 }
