@@ -184,8 +184,9 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "kernel": "k_trace",
                          "avg_launch_ms": round(launch_s * 1e3, 3),
                          "algorithmic_bytes_per_sample": round(bytes_per_sample, 1),
-                         "work_counts_per_sample": {k: round(v / max(1, counts["samples"]), 3) for k, v in counts.items()
-                                                    if k != "samples"}},
+                         "work_counts_per_sample": {k: round(counts[k] / max(1, counts["samples"]), 3) for k in
+                                                    ("rays", "nodes", "seg_tests", "tri_tests", "hair_shades",
+                                                     "surf_shades", "env_lookups", "env_samples")}},
         }
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(scene_json, a.resolution)

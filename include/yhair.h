@@ -127,6 +127,11 @@ typedef struct yh_workcounts {
   uint64_t surf_shades;
   uint64_t env_lookups;
   uint64_t env_samples;
+  /* wave-level profile of the instrumented launch (diagnostics): shader-clock
+   * cycles in traversal / shading summed over waves, 100 MHz ticks spent on
+   * tiles, regeneration-loop iterations, traversal trip counts per wave (max
+   * over lanes) and per lane (sum), live lanes per iteration                 */
+  uint64_t cyc_trace, cyc_shade, ticks_tile, wave_iters, wave_steps, lane_steps, lane_iters;
 } yh_workcounts;
 
 typedef struct yh_context yh_context;

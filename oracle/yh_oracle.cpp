@@ -1492,6 +1492,7 @@ int yo_render(const yo_scene* scene, const yh_trace_params* params, int samples,
     for (size_t i = 0; i < pixels.size(); i++)
       rng_out[2 * i] = pixels[i].rng.state, rng_out[2 * i + 1] = pixels[i].rng.inc;
   if (counts) {
+    std::memset(counts, 0, sizeof(*counts));
     counts->samples = total.samples, counts->rays = total.rays;
     counts->nodes = total.nodes, counts->seg_tests = total.seg;
     counts->tri_tests = total.tri, counts->hair_shades = total.hair;

@@ -4,6 +4,7 @@ import sys
 
 import numpy as np
 import pytest
+import torch  # noqa: F401  (first: torch's bundled HIP runtime must be the one libyhair.so binds to)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))

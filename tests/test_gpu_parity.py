@@ -249,7 +249,8 @@ def test_work_counters_match_oracle_on_identical_paths(ctx, oracle, yh):
     wc = ctx.trace_samples_counted(2)
     osc = oracle.scene(sf.desc)
     _, owc = osc.render(p, 2, want_counts=True)
-    assert wc.as_dict() == owc.as_dict()
+    algo = ("samples", "rays", "nodes", "seg_tests", "tri_tests", "hair_shades", "surf_shades", "env_lookups", "env_samples")
+    assert {k: wc.as_dict()[k] for k in algo} == {k: owc.as_dict()[k] for k in algo}
     osc.close(), sf.close()
 
 

@@ -159,7 +159,7 @@ YH_DEV void count_add(unsigned long long* slot, unsigned long long n) {
 // the near child becomes `cur` directly and only the far child is pushed —
 // the same visiting order as the reference's push(far), push(near), pop().
 template <bool COUNT, bool LDS, int STRIDE>
-YH_DEV hit_t trace_ray(const trace_ctx& tc, const ray_t& ray, int first_object) {
+YH_DEV hit_t trace_ray(const trace_ctx& tc, const ray_t& ray, int first_object, unsigned int* steps_out = nullptr) {
   const yhd_scene& sc = *tc.sc;
   // stack: `sp` and the LDS column pointer stay in registers; only the
   // overflow array is addressable memory
@@ -187,6 +187,7 @@ YH_DEV hit_t trace_ray(const trace_ctx& tc, const ray_t& ray, int first_object) 
   f3  lo = ray.o, ld = ray.d, ldinv = wdinv;
   int lsign = wsign, cur_obj = -1, kind = 0, node_base = 0, prim_base = 0;
   unsigned long long n_nodes = 0, n_seg = 0, n_tri = 0;
+  unsigned int       n_steps = 0;
 
   unsigned int cur;
   if (first_object >= 0) {
@@ -196,6 +197,7 @@ YH_DEV hit_t trace_ray(const trace_ctx& tc, const ray_t& ray, int first_object) 
     cur = YH_TAG_SCENE | 0u;
   }
   while (true) {
+    if (COUNT) n_steps++;
     if (cur == YH_NONE) {
       if (sp == 0) break;
       cur = pop();
@@ -292,6 +294,7 @@ YH_DEV hit_t trace_ray(const trace_ctx& tc, const ray_t& ray, int first_object) 
     }
   }
   if (COUNT) {
+    if (steps_out) *steps_out = n_steps;
     count_add<COUNT>(&tc.counters->nodes, n_nodes);
     count_add<COUNT>(&tc.counters->seg, n_seg);
     count_add<COUNT>(&tc.counters->tri, n_tri);

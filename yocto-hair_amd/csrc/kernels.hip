@@ -83,13 +83,38 @@ __global__ __launch_bounds__(YH_BLOCK, YH_MIN_WAVES) void k_trace(const yhd_scen
         alive = true;
       }
       if (!__any(alive)) break;
+      unsigned long long c0 = 0, c1 = 0, c2 = 0;
+      unsigned int       steps = 0;
+      bool               was_alive = alive;
+      if (COUNT) c0 = clock64();
+      hit_t isec;
       if (alive) {
         if (COUNT) count_add<COUNT>(&counters->rays, 1);
-        hit_t isec = trace_ray<COUNT, true, YH_BLOCK>(tc, ps.ray, -1);
-        alive      = path_step<COUNT, true, YH_BLOCK>(tc, ps, isec, rng, st.bounces);
+        isec = trace_ray<COUNT, true, YH_BLOCK>(tc, ps.ray, -1, &steps);
+      }
+      if (COUNT) c1 = clock64();
+      if (alive) {
+        alive = path_step<COUNT, true, YH_BLOCK>(tc, ps, isec, rng, st.bounces);
         if (!alive) {
           path_end(ps, st.clamp, acc);
           if (COUNT) count_add<COUNT>(&counters->samples, 1);
+        }
+      }
+      if (COUNT) {
+        c2 = clock64();
+        unsigned int smax = steps, ssum = steps, nl = was_alive ? 1 : 0;
+        for (int off = 32; off > 0; off >>= 1) {
+          smax = max(smax, (unsigned int)__shfl_xor((int)smax, off, 64));
+          ssum += (unsigned int)__shfl_xor((int)ssum, off, 64);
+          nl += (unsigned int)__shfl_xor((int)nl, off, 64);
+        }
+        if (lane == 0) {
+          atomicAdd(&counters->cyc_trace, c1 - c0);
+          atomicAdd(&counters->cyc_shade, c2 - c1);
+          atomicAdd(&counters->wave_iters, 1ull);
+          atomicAdd(&counters->wave_steps, (unsigned long long)smax);
+          atomicAdd(&counters->lane_steps, (unsigned long long)ssum);
+          atomicAdd(&counters->lane_iters, (unsigned long long)nl);
         }
       }
     }
@@ -98,6 +123,7 @@ __global__ __launch_bounds__(YH_BLOCK, YH_MIN_WAVES) void k_trace(const yhd_scen
       st.accum[pix]     = acc;
     }
     if (lane == 0) st.tile_cost[tile] = (unsigned int)(wall_clock64() - t0);
+    if (COUNT && lane == 0) atomicAdd(&counters->cyc_tile, wall_clock64() - t0);
   }
 }
 

@@ -135,6 +135,11 @@ typedef struct yhd_state {
 // instrumented kernel variant only.
 typedef struct yhd_counters {
   unsigned long long samples, rays, nodes, seg, tri, hair, surf, envl, envs;
+  // wave-level profile of the instrumented build (developer diagnostics):
+  // shader-clock cycles inside trace_ray / path_step, wave-level iterations of
+  // the regeneration loop, and traversal-loop trip counts (per wave = max over
+  // lanes; per lane = sum over lanes) of the main rays
+  unsigned long long cyc_trace, cyc_shade, cyc_tile, wave_iters, wave_steps, lane_steps, lane_iters;
 } yhd_counters;
 
 #endif

@@ -664,6 +664,8 @@ int yh_trace_samples_counted(yh_context* ctx, int nsamples, yh_workcounts* out) 
   HIPCHK(ctx, hipMemcpy(&c, ctx->d_counters.p, sizeof(c), hipMemcpyDeviceToHost));
   out->samples = c.samples, out->rays = c.rays, out->nodes = c.nodes, out->seg_tests = c.seg, out->tri_tests = c.tri;
   out->hair_shades = c.hair, out->surf_shades = c.surf, out->env_lookups = c.envl, out->env_samples = c.envs;
+  out->cyc_trace = c.cyc_trace, out->cyc_shade = c.cyc_shade, out->ticks_tile = c.cyc_tile, out->wave_iters = c.wave_iters;
+  out->wave_steps = c.wave_steps, out->lane_steps = c.lane_steps, out->lane_iters = c.lane_iters;
   return YH_OK;
 }
 
