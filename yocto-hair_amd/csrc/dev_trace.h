@@ -196,27 +196,59 @@ YH_DEV hit_t trace_ray(const trace_ctx& tc, const ray_t& ray, int first_object, 
     if (sc.num_scene_nodes == 0) return hit;
     cur = YH_TAG_SCENE | 0u;
   }
+  // "while-while" traversal: every lane first walks nodes until it owns a leaf
+  // (or has nothing left), then all lanes of the wave test their leaf's
+  // primitives together. A lane that reaches a leaf early waits for the others
+  // instead of dragging the whole wave through the (long) primitive tests on
+  // every node step.
   while (true) {
-    if (COUNT) n_steps++;
-    if (cur == YH_NONE) {
-      if (sp == 0) break;
-      cur = pop();
-    }
-    unsigned int tag = cur & YH_TAG_MASK;
-    if (tag == YH_TAG_ENTER) {
-      // transform_ray(inverse(object.frame, true), ray) (pt.cpp:1012-1013)
-      cur_obj             = (int)(cur & ~YH_TAG_MASK);
-      const yhd_object& o = sc.objects[cur_obj];
-      frame inv           = ldframe(o.inv_frame);
-      lo                  = transform_point(inv, ray.o);
-      ld                  = transform_vector(inv, ray.d);
-      ldinv               = {1 / ld.x, 1 / ld.y, 1 / ld.z};
-      lsign = (ldinv.x < 0 ? 1 : 0) | (ldinv.y < 0 ? 2 : 0) | (ldinv.z < 0 ? 4 : 0);
-      kind = o.kind, node_base = o.node_base, prim_base = o.prim_base;
-      cur = YH_TAG_SHAPE | (unsigned)node_base;  // shape root
-      continue;
-    }
-    if (tag == YH_TAG_SCENE) {
+    int leaf_start = 0, leaf_num = 0;
+    // ---- phase 1: nodes -----------------------------------------------------
+    while (true) {
+      if (COUNT) n_steps++;
+      if (cur == YH_NONE) {
+        if (sp == 0) break;
+        cur = pop();
+      }
+      unsigned int tag = cur & YH_TAG_MASK;
+      if (tag == YH_TAG_SHAPE) {
+        int idx = (int)cur;
+        v4f n0, n1;
+        int rel = idx - sc.lds_node_base;
+        if (LDS && rel >= 0 && rel < sc.lds_node_count) {
+          n0 = tc.lds_nodes[2 * rel], n1 = tc.lds_nodes[2 * rel + 1];
+        } else {
+          n0 = ldg4(sc.nodes + 2 * (size_t)idx), n1 = ldg4(sc.nodes + 2 * (size_t)idx + 1);
+        }
+        n_nodes++;
+        cur = YH_NONE;
+        if (!intersect_bbox(lo, ldinv, ray.tmin, tmax, xyz(n0), xyz(n1))) continue;
+        int start = __float_as_int(n0.w), meta = __float_as_int(n1.w);
+        if (meta & 0x10000) {
+          int axis = (meta >> 24) & 3;
+          int near = (lsign >> axis) & 1;  // dsign set: visit start+1 first (pt.cpp:887-893)
+          int a    = node_base + start;
+          push((unsigned)(a + 1 - near));
+          cur = (unsigned)(a + near);
+          continue;
+        }
+        leaf_start = start, leaf_num = meta & 0xffff;
+        break;
+      }
+      if (tag == YH_TAG_ENTER) {
+        // transform_ray(inverse(object.frame, true), ray) (pt.cpp:1012-1013)
+        cur_obj             = (int)(cur & ~YH_TAG_MASK);
+        const yhd_object& o = sc.objects[cur_obj];
+        frame inv           = ldframe(o.inv_frame);
+        lo                  = transform_point(inv, ray.o);
+        ld                  = transform_vector(inv, ray.d);
+        ldinv               = {1 / ld.x, 1 / ld.y, 1 / ld.z};
+        lsign = (ldinv.x < 0 ? 1 : 0) | (ldinv.y < 0 ? 2 : 0) | (ldinv.z < 0 ? 4 : 0);
+        kind = o.kind, node_base = o.node_base, prim_base = o.prim_base;
+        cur = YH_TAG_SHAPE | (unsigned)node_base;  // shape root
+        continue;
+      }
+      // scene-level node
       int idx = (int)(cur & ~YH_TAG_MASK);
       v4f n0 = ldg4(sc.scene_nodes + 2 * idx), n1 = ldg4(sc.scene_nodes + 2 * idx + 1);
       n_nodes++;
@@ -225,7 +257,7 @@ YH_DEV hit_t trace_ray(const trace_ctx& tc, const ray_t& ray, int first_object, 
       int start = __float_as_int(n0.w), meta = __float_as_int(n1.w);
       if (meta & 0x10000) {  // internal
         int axis = (meta >> 24) & 3;
-        int near = (wsign >> axis) & 1;  // dsign set: visit start+1 first
+        int near = (wsign >> axis) & 1;
         push(YH_TAG_SCENE | (unsigned)(start + 1 - near));
         cur = YH_TAG_SCENE | (unsigned)(start + near);
       } else {
@@ -233,52 +265,34 @@ YH_DEV hit_t trace_ray(const trace_ctx& tc, const ray_t& ray, int first_object, 
         for (int i = num - 1; i >= 1; i--) push(YH_TAG_ENTER | (unsigned)sc.scene_prims[start + i]);
         if (num > 0) cur = YH_TAG_ENTER | (unsigned)sc.scene_prims[start];
       }
-      continue;
     }
-    // shape node
-    int idx = (int)cur;
-    v4f n0, n1;
-    int rel = idx - sc.lds_node_base;
-    if (LDS && rel >= 0 && rel < sc.lds_node_count) {
-      n0 = tc.lds_nodes[2 * rel], n1 = tc.lds_nodes[2 * rel + 1];
-    } else {
-      n0 = ldg4(sc.nodes + 2 * (size_t)idx), n1 = ldg4(sc.nodes + 2 * (size_t)idx + 1);
+    if (leaf_num == 0) {
+      if (cur == YH_NONE && sp == 0) break;  // traversal finished
+      continue;                              // empty leaf
     }
-    n_nodes++;
-    cur = YH_NONE;
-    if (!intersect_bbox(lo, ldinv, ray.tmin, tmax, xyz(n0), xyz(n1))) continue;
-    int start = __float_as_int(n0.w), meta = __float_as_int(n1.w);
-    if (meta & 0x10000) {
-      int axis = (meta >> 24) & 3;
-      int near = (lsign >> axis) & 1;
-      int a    = node_base + start;
-      push((unsigned)(a + 1 - near));
-      cur = (unsigned)(a + near);
-    } else {
-      int num = meta & 0xffff;
-      if (kind == YH_KIND_LINES) {
-        for (int i = 0; i < num; i++) {
-          size_t r = (size_t)prim_base + (size_t)(start + i) * 2;
-          v4f    a = ldg4(sc.prims + r), b = ldg4(sc.prims + r + 1);
-          n_seg++;
-          float uu, vv, dist;
-          if (intersect_line(lo, ld, ray.tmin, tmax, xyz(a), xyz(b), a.w, b.w, uu, vv, dist)) {
-            hit.object = cur_obj, hit.element = start + i;  // leaf slot; resolved below
-            hit.u = uu, hit.v = vv, hit.distance = dist;
-            tmax = dist;
-          }
+    // ---- phase 2: the leaf's primitives, in leaf order (pt.cpp:905-923) -------
+    if (kind == YH_KIND_LINES) {
+      for (int i = 0; i < leaf_num; i++) {
+        size_t r = (size_t)prim_base + (size_t)(leaf_start + i) * 2;
+        v4f    a = ldg4(sc.prims + r), b = ldg4(sc.prims + r + 1);
+        n_seg++;
+        float uu, vv, dist;
+        if (intersect_line(lo, ld, ray.tmin, tmax, xyz(a), xyz(b), a.w, b.w, uu, vv, dist)) {
+          hit.object = cur_obj, hit.element = leaf_start + i;  // leaf slot; resolved below
+          hit.u = uu, hit.v = vv, hit.distance = dist;
+          tmax = dist;
         }
-      } else {
-        for (int i = 0; i < num; i++) {
-          size_t r = (size_t)prim_base + (size_t)(start + i) * 3;
-          v4f    a = ldg4(sc.prims + r), b = ldg4(sc.prims + r + 1), c = ldg4(sc.prims + r + 2);
-          n_tri++;
-          float uu, vv, dist;
-          if (intersect_triangle(lo, ld, ray.tmin, tmax, xyz(a), xyz(b), xyz(c), uu, vv, dist)) {
-            hit.object = cur_obj, hit.element = ~__float_as_int(a.w);  // already an element id
-            hit.u = uu, hit.v = vv, hit.distance = dist;
-            tmax = dist;
-          }
+      }
+    } else {
+      for (int i = 0; i < leaf_num; i++) {
+        size_t r = (size_t)prim_base + (size_t)(leaf_start + i) * 3;
+        v4f    a = ldg4(sc.prims + r), b = ldg4(sc.prims + r + 1), c = ldg4(sc.prims + r + 2);
+        n_tri++;
+        float uu, vv, dist;
+        if (intersect_triangle(lo, ld, ray.tmin, tmax, xyz(a), xyz(b), xyz(c), uu, vv, dist)) {
+          hit.object = cur_obj, hit.element = ~__float_as_int(a.w);  // already an element id
+          hit.u = uu, hit.v = vv, hit.distance = dist;
+          tmax = dist;
         }
       }
     }
