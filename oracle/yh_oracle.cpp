@@ -1430,6 +1430,18 @@ void yo_scene_intersect(const yo_scene* scene, int n, const float* rays, int* ob
   }
 }
 
+// per-ray traversal work of the reference algorithm: nodes visited and segment
+// / triangle tests, for load-balance and kernel-efficiency analysis
+void yo_scene_intersect_counted(const yo_scene* scene, int n, const float* rays, int* nodes, int* prims) {
+  for (int i = 0; i < n; i++) {
+    tls_counters = Counters{};
+    int   o = -1, e = -1;
+    float u[2] = {0, 0}, d = 0;
+    intersect_scene_bvh(*scene, mkray(rays + 8 * i), o, e, u, d);
+    nodes[i] = (int)tls_counters.nodes, prims[i] = (int)(tls_counters.seg + tls_counters.tri);
+  }
+}
+
 int yo_scene_bvh(const yo_scene* scene, int shape, float* nodes, int* prims) {
   auto& t = shape < 0 ? scene->bvh : scene->shapes[shape].bvh;
   if (nodes) {

@@ -60,6 +60,7 @@ int       yo_scene_num_lights(const yo_scene* scene);
 /* pt.cpp:1039-1046; element/object -1 on miss */
 void yo_scene_intersect(const yo_scene* scene, int n, const float* rays,
     int* object, int* element, float* uv, float* dist);
+void yo_scene_intersect_counted(const yo_scene* scene, int n, const float* rays, int* nodes, int* prims);
 /* BVH export for structural checks: returns node count of shape `shape`
  * (-1 = scene-level BVH); fills nodes (8 floats: bbox min/max, then start,
  * num|internal<<16|axis<<24 as int bits) and primitives when non-NULL.       */

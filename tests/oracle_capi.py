@@ -109,6 +109,7 @@ class Oracle(_UnitApi):
         lib.yo_scene_free.argtypes = [C.c_void_p]
         lib.yo_scene_num_lights.argtypes = [C.c_void_p]
         lib.yo_scene_intersect.argtypes = [C.c_void_p, C.c_int, fp, ip, ip, fp, fp]
+        lib.yo_scene_intersect_counted.argtypes = [C.c_void_p, C.c_int, fp, ip, ip]
         lib.yo_scene_bvh.argtypes = [C.c_void_p, C.c_int, fp, ip]
         lib.yo_render.argtypes = [C.c_void_p, C.POINTER(yh.TraceParams), C.c_int, C.c_int, ip, ip, fp, u64p,
                                   C.POINTER(yh.WorkCounts)]
@@ -145,6 +146,12 @@ class OracleScene:
         uv, dist = np.zeros((n, 2), np.float32), np.zeros(n, np.float32)
         self.o.lib.yo_scene_intersect(self.h, n, yh.fptr(rays), yh.iptr(obj), yh.iptr(elem), yh.fptr(uv), yh.fptr(dist))
         return obj, elem, uv, dist
+
+    def intersect_counted(self, rays):
+        rays = _f(rays).reshape(-1, 8)
+        nodes, prims = np.zeros(len(rays), np.int32), np.zeros(len(rays), np.int32)
+        self.o.lib.yo_scene_intersect_counted(self.h, len(rays), yh.fptr(rays), yh.iptr(nodes), yh.iptr(prims))
+        return nodes, prims
 
     def bvh(self, shape):
         n = self.o.lib.yo_scene_bvh(self.h, shape, None, None)

@@ -32,13 +32,10 @@ YH_DEV ray_t sample_camera(const yhd_camera& cam, int i, int j, int w, int h, fl
   return mkray(transform_point(f, e), transform_direction(f, d));
 }
 
-// Geometry of a hit: position, shading normal and (for hair) tangent.
-struct shade_pt {
-  f3 position, normal, tangent;
-};
 YH_DEV f3 transform_normal(const frame& a, f3 b) { return normalize(transform_vector(a, b)); }
 
-// eval_position (pt.cpp:232-250)
+// eval_position (pt.cpp:232-250) of a point on ELEMENT `element` (used to
+// sample area lights by triangle index): goes through elems / vpos.
 YH_DEV f3 eval_position(const yhd_scene& sc, const yhd_object& o, int element, float u, float v) {
   frame    fr = ldframe(o.frame);
   yhd_int4 e  = sc.elems[o.elem_base + element];
@@ -51,30 +48,40 @@ YH_DEV f3 eval_position(const yhd_scene& sc, const yhd_object& o, int element, f
     return transform_point(fr, p0 * (1 - u) + p1 * u);
   }
 }
-// eval_element_normal (pt.cpp:253-269)
-YH_DEV f3 eval_element_normal(const yhd_scene& sc, const yhd_object& o, int element) {
+
+// Geometry of a HIT, from its leaf record (one fetch, no index chasing):
+// eval_position (pt.cpp:232-250), eval_normal (272-292) with its
+// eval_element_normal fallback (253-269).
+struct hit_geom {
+  f3 position, normal, element_normal;
+};
+YH_DEV hit_geom eval_hit(const yhd_scene& sc, const yhd_object& o, int slot, float u, float v) {
   frame    fr = ldframe(o.frame);
-  yhd_int4 e  = sc.elems[o.elem_base + element];
-  f3       p0 = xyz(sc.vpos[o.vert_base + e.x]), p1 = xyz(sc.vpos[o.vert_base + e.y]);
+  hit_geom g;
   if (o.kind == YH_KIND_TRIANGLES) {
-    f3 p2 = xyz(sc.vpos[o.vert_base + e.z]);
-    return transform_normal(fr, normalize(cross(p1 - p0, p2 - p0)));
+    const yhd_float4* rec = sc.prims + (size_t)o.prim_base + (size_t)slot * 6;
+    f3 p0 = xyz(ldg4(rec)), p1 = xyz(ldg4(rec + 1)), p2 = xyz(ldg4(rec + 2));
+    g.position       = transform_point(fr, p0 * (1 - u - v) + p1 * u + p2 * v);
+    g.element_normal = transform_normal(fr, normalize(cross(p1 - p0, p2 - p0)));
+    if (o.has_normals) {
+      f3 n0 = xyz(ldg4(rec + 3)), n1 = xyz(ldg4(rec + 4)), n2 = xyz(ldg4(rec + 5));
+      g.normal = transform_normal(fr, normalize(n0 * (1 - u - v) + n1 * u + n2 * v));
+    } else {
+      g.normal = g.element_normal;
+    }
   } else {
-    return transform_normal(fr, normalize(p1 - p0));
+    const yhd_float4* rec = sc.prims + (size_t)o.prim_base + (size_t)slot * 4;
+    f3 p0 = xyz(ldg4(rec)), p1 = xyz(ldg4(rec + 1));
+    g.position       = transform_point(fr, p0 * (1 - u) + p1 * u);
+    g.element_normal = transform_normal(fr, normalize(p1 - p0));
+    if (o.has_normals) {
+      f3 n0 = xyz(ldg4(rec + 2)), n1 = xyz(ldg4(rec + 3));
+      g.normal = transform_normal(fr, normalize(n0 * (1 - u) + n1 * u));
+    } else {
+      g.normal = g.element_normal;
+    }
   }
-}
-// eval_normal (pt.cpp:272-292)
-YH_DEV f3 eval_normal(const yhd_scene& sc, const yhd_object& o, int element, float u, float v) {
-  if (!o.has_normals) return eval_element_normal(sc, o, element);
-  frame    fr = ldframe(o.frame);
-  yhd_int4 e  = sc.elems[o.elem_base + element];
-  f3       n0 = xyz(sc.vnrm[o.vert_base + e.x]), n1 = xyz(sc.vnrm[o.vert_base + e.y]);
-  if (o.kind == YH_KIND_TRIANGLES) {
-    f3 n2 = xyz(sc.vnrm[o.vert_base + e.z]);
-    return transform_normal(fr, normalize(n0 * (1 - u - v) + n1 * u + n2 * v));
-  } else {
-    return transform_normal(fr, normalize(n0 * (1 - u) + n1 * u));
-  }
+  return g;
 }
 
 // texture lookup of an environment (pt.cpp:167-200), wrap + bilinear
@@ -175,8 +182,9 @@ YH_DEV float sample_lights_pdf(const trace_ctx& tc, f3 position, f3 direction) {
       for (int bounce = 0; bounce < 100; bounce++) {
         hit_t isec = trace_ray<COUNT, LDS, STRIDE>(tc, mkray(next_position, direction), light.object);
         if (isec.object < 0) break;
-        f3    lposition = eval_position(sc, o, isec.element, isec.u, isec.v);
-        f3    lnormal   = eval_element_normal(sc, o, isec.element);
+        hit_geom lg        = eval_hit(sc, o, isec.slot, isec.u, isec.v);
+        f3       lposition = lg.position;
+        f3       lnormal   = lg.element_normal;
         float area      = sc.light_cdf[light.cdf_base + light.cdf_count - 1];
         f3    dp        = lposition - position;
         lpdf += dot(dp, dp) / (fabs_(dot(lnormal, direction)) * area);
@@ -243,8 +251,9 @@ YH_DEV bool path_step(const trace_ctx& tc, path_t& ps, const hit_t& isec, rng_t&
   const yhd_object&   o   = sc.objects[isec.object];
   const yhd_material& mat = sc.materials[o.material];
   f3 outgoing = -ps.ray.d;
-  f3 position = eval_position(sc, o, isec.element, isec.u, isec.v);
-  f3 nrm      = eval_normal(sc, o, isec.element, isec.u, isec.v);
+  hit_geom hg = eval_hit(sc, o, isec.slot, isec.u, isec.v);
+  f3 position = hg.position;
+  f3 nrm      = hg.normal;
   f3 normal;  // eval_shading_normal (pt.cpp:350-369)
   bool is_hair = o.kind == YH_KIND_LINES;
   if (is_hair) {

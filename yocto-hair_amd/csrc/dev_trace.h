@@ -59,7 +59,7 @@ struct ray_t {
 YH_DEV ray_t mkray(f3 o, f3 d) { return ray_t{o, d, ray_eps, flt_max}; }
 
 struct hit_t {
-  int   object, element;  // -1 on miss
+  int   object, slot;  // object -1 on miss; slot = leaf-order index of the primitive in its shape
   float u, v, distance;
 };
 
@@ -119,9 +119,10 @@ YH_DEV bool intersect_bbox(f3 ro, f3 dinv, float tmin_, float tmax_, f3 bmin, f3
 // ---------------------------------------------------------------------------
 // Traversal
 // ---------------------------------------------------------------------------
-#define YH_TAG_SHAPE 0u          /* entry = global shape-node index          */
+#define YH_TAG_SHAPE 0u          /* entry = global wide-node index            */
 #define YH_TAG_SCENE 0x40000000u /* entry = scene-node index                 */
 #define YH_TAG_ENTER 0x80000000u /* entry = object id to enter               */
+#define YH_TAG_LEAF 0xC0000000u  /* entry = count << 27 | first leaf slot    */
 #define YH_TAG_MASK 0xC0000000u
 #define YH_NONE 0xFFFFFFFFu
 
@@ -155,9 +156,13 @@ YH_DEV void count_add(unsigned long long* slot, unsigned long long n) {
 // Closest hit against the whole scene (first_object < 0) or against a single
 // instance (intersect_instance_bvh, pt.cpp:1031-1037).
 //
-// The node being visited is kept in a register (`cur`): at an internal node
-// the near child becomes `cur` directly and only the far child is pushed —
-// the same visiting order as the reference's push(far), push(near), pop().
+// "while-while" traversal over the 4-wide tree: every lane first walks nodes
+// until it owns a leaf (or has nothing left), then the lanes of the wave test
+// their leaf's primitives together. One node step = one 128-byte fetch + four
+// of the reference's slab tests; the hit children are visited in exactly the
+// order the reference's binary traversal visits them (near side first by the
+// sign of the ray direction on each split axis, pt.cpp:887-893), so `tmax`
+// shrinks identically and exact-t ties resolve identically.
 template <bool COUNT, bool LDS, int STRIDE>
 YH_DEV hit_t trace_ray(const trace_ctx& tc, const ray_t& ray, int first_object, unsigned int* steps_out = nullptr) {
   const yhd_scene& sc = *tc.sc;
@@ -178,7 +183,7 @@ YH_DEV hit_t trace_ray(const trace_ctx& tc, const ray_t& ray, int first_object, 
     return ovf[sp - kLds];
   };
   hit_t hit;
-  hit.object = -1, hit.element = -1, hit.u = 0, hit.v = 0, hit.distance = 0;
+  hit.object = -1, hit.slot = -1, hit.u = 0, hit.v = 0, hit.distance = 0;
   float tmax = ray.tmax;
   // world-space ray data for the scene level
   f3  wdinv = {1 / ray.d.x, 1 / ray.d.y, 1 / ray.d.z};
@@ -196,14 +201,8 @@ YH_DEV hit_t trace_ray(const trace_ctx& tc, const ray_t& ray, int first_object, 
     if (sc.num_scene_nodes == 0) return hit;
     cur = YH_TAG_SCENE | 0u;
   }
-  // "while-while" traversal: every lane first walks nodes until it owns a leaf
-  // (or has nothing left), then all lanes of the wave test their leaf's
-  // primitives together. A lane that reaches a leaf early waits for the others
-  // instead of dragging the whole wave through the (long) primitive tests on
-  // every node step.
   while (true) {
-    int leaf_start = 0, leaf_num = 0;
-    // ---- phase 1: nodes -----------------------------------------------------
+    // ---- phase 1: nodes, until this lane holds a leaf -------------------------
     while (true) {
       if (COUNT) n_steps++;
       if (cur == YH_NONE) {
@@ -211,29 +210,49 @@ YH_DEV hit_t trace_ray(const trace_ctx& tc, const ray_t& ray, int first_object, 
         cur = pop();
       }
       unsigned int tag = cur & YH_TAG_MASK;
+      if (tag == YH_TAG_LEAF) break;
       if (tag == YH_TAG_SHAPE) {
         int idx = (int)cur;
-        v4f n0, n1;
+        v4f bx0, by0, bz0, bx1, by1, bz1, rf, mt;
         int rel = idx - sc.lds_node_base;
         if (LDS && rel >= 0 && rel < sc.lds_node_count) {
-          n0 = tc.lds_nodes[2 * rel], n1 = tc.lds_nodes[2 * rel + 1];
+          const YH_LDS v4f* n = tc.lds_nodes + 8 * rel;
+          bx0 = n[0], by0 = n[1], bz0 = n[2], bx1 = n[3], by1 = n[4], bz1 = n[5], rf = n[6], mt = n[7];
         } else {
-          n0 = ldg4(sc.nodes + 2 * (size_t)idx), n1 = ldg4(sc.nodes + 2 * (size_t)idx + 1);
+          const yhd_float4* n = sc.nodes + 8 * (size_t)idx;
+          bx0 = ldg4(n), by0 = ldg4(n + 1), bz0 = ldg4(n + 2), bx1 = ldg4(n + 3), by1 = ldg4(n + 4);
+          bz1 = ldg4(n + 5), rf = ldg4(n + 6), mt = ldg4(n + 7);
         }
         n_nodes++;
-        cur = YH_NONE;
-        if (!intersect_bbox(lo, ldinv, ray.tmin, tmax, xyz(n0), xyz(n1))) continue;
-        int start = __float_as_int(n0.w), meta = __float_as_int(n1.w);
-        if (meta & 0x10000) {
-          int axis = (meta >> 24) & 3;
-          int near = (lsign >> axis) & 1;  // dsign set: visit start+1 first (pt.cpp:887-893)
-          int a    = node_base + start;
-          push((unsigned)(a + 1 - near));
-          cur = (unsigned)(a + near);
-          continue;
-        }
-        leaf_start = start, leaf_num = meta & 0xffff;
-        break;
+        bool h0 = intersect_bbox(lo, ldinv, ray.tmin, tmax, f3{bx0.x, by0.x, bz0.x}, f3{bx1.x, by1.x, bz1.x});
+        bool h1 = intersect_bbox(lo, ldinv, ray.tmin, tmax, f3{bx0.y, by0.y, bz0.y}, f3{bx1.y, by1.y, bz1.y});
+        bool h2 = intersect_bbox(lo, ldinv, ray.tmin, tmax, f3{bx0.z, by0.z, bz0.z}, f3{bx1.z, by1.z, bz1.z});
+        bool h3 = intersect_bbox(lo, ldinv, ray.tmin, tmax, f3{bx0.w, by0.w, bz0.w}, f3{bx1.w, by1.w, bz1.w});
+        unsigned int r0 = __float_as_uint(rf.x), r1 = __float_as_uint(rf.y), r2 = __float_as_uint(rf.z),
+                     r3 = __float_as_uint(rf.w);
+        // child wide nodes are shape-local indices
+        if ((r0 & YH_TAG_MASK) == 0) r0 += (unsigned)node_base;
+        if ((r1 & YH_TAG_MASK) == 0) r1 += (unsigned)node_base;
+        if ((r2 & YH_TAG_MASK) == 0) r2 += (unsigned)node_base;
+        if ((r3 & YH_TAG_MASK) == 0) r3 += (unsigned)node_base;
+        unsigned int axes = __float_as_uint(mt.x);
+        bool s0 = (lsign >> (axes & 3)) & 1, sl = (lsign >> ((axes >> 2) & 3)) & 1, sr = (lsign >> ((axes >> 4) & 3)) & 1;
+        // visiting order: (left pair, right pair) or reversed by s0; inside a
+        // pair (first, second) or reversed by that child's own axis sign
+        unsigned int la = sl ? r1 : r0, lb = sl ? r0 : r1;  // left pair in visiting order
+        bool         ha = sl ? h1 : h0, hb = sl ? h0 : h1;
+        unsigned int ra = sr ? r3 : r2, rb = sr ? r2 : r3;
+        bool         hc = sr ? h3 : h2, hd = sr ? h2 : h3;
+        unsigned int o0 = s0 ? ra : la, o1 = s0 ? rb : lb, o2 = s0 ? la : ra, o3 = s0 ? lb : rb;
+        bool         g0 = s0 ? hc : ha, g1 = s0 ? hd : hb, g2 = s0 ? ha : hc, g3 = s0 ? hb : hd;
+        // push the hit children in reverse visiting order; the first one stays in `cur`
+        unsigned int next = YH_NONE;
+        if (g3) next = o3;
+        if (g2) { if (next != YH_NONE) push(next); next = o2; }
+        if (g1) { if (next != YH_NONE) push(next); next = o1; }
+        if (g0) { if (next != YH_NONE) push(next); next = o0; }
+        cur = next;
+        continue;
       }
       if (tag == YH_TAG_ENTER) {
         // transform_ray(inverse(object.frame, true), ray) (pt.cpp:1012-1013)
@@ -248,7 +267,7 @@ YH_DEV hit_t trace_ray(const trace_ctx& tc, const ray_t& ray, int first_object, 
         cur = YH_TAG_SHAPE | (unsigned)node_base;  // shape root
         continue;
       }
-      // scene-level node
+      // scene-level node (binary, reference layout)
       int idx = (int)(cur & ~YH_TAG_MASK);
       v4f n0 = ldg4(sc.scene_nodes + 2 * idx), n1 = ldg4(sc.scene_nodes + 2 * idx + 1);
       n_nodes++;
@@ -257,7 +276,7 @@ YH_DEV hit_t trace_ray(const trace_ctx& tc, const ray_t& ray, int first_object, 
       int start = __float_as_int(n0.w), meta = __float_as_int(n1.w);
       if (meta & 0x10000) {  // internal
         int axis = (meta >> 24) & 3;
-        int near = (wsign >> axis) & 1;
+        int near = (wsign >> axis) & 1;  // dsign set: visit start+1 first
         push(YH_TAG_SCENE | (unsigned)(start + 1 - near));
         cur = YH_TAG_SCENE | (unsigned)(start + near);
       } else {
@@ -266,45 +285,40 @@ YH_DEV hit_t trace_ray(const trace_ctx& tc, const ray_t& ray, int first_object, 
         if (num > 0) cur = YH_TAG_ENTER | (unsigned)sc.scene_prims[start];
       }
     }
-    if (leaf_num == 0) {
-      if (cur == YH_NONE && sp == 0) break;  // traversal finished
-      continue;                              // empty leaf
-    }
+    if (cur == YH_NONE) break;  // stack exhausted: traversal finished
     // ---- phase 2: the leaf's primitives, in leaf order (pt.cpp:905-923) -------
+    int leaf_start = (int)(cur & 0x07FFFFFFu), leaf_num = (int)((cur >> 27) & 7u);
+    cur = YH_NONE;
     if (kind == YH_KIND_LINES) {
+      // all of the leaf's records are requested before the first test
+      const yhd_float4* rec = sc.prims + (size_t)prim_base + (size_t)leaf_start * 4;
+      v4f a0 = ldg4(rec), b0 = ldg4(rec + 1), a1 = a0, b1 = b0, a2 = a0, b2 = b0, a3 = a0, b3 = b0;
+      if (leaf_num > 1) a1 = ldg4(rec + 4), b1 = ldg4(rec + 5);
+      if (leaf_num > 2) a2 = ldg4(rec + 8), b2 = ldg4(rec + 9);
+      if (leaf_num > 3) a3 = ldg4(rec + 12), b3 = ldg4(rec + 13);
       for (int i = 0; i < leaf_num; i++) {
-        size_t r = (size_t)prim_base + (size_t)(leaf_start + i) * 2;
-        v4f    a = ldg4(sc.prims + r), b = ldg4(sc.prims + r + 1);
+        v4f a = i == 0 ? a0 : i == 1 ? a1 : i == 2 ? a2 : a3;
+        v4f b = i == 0 ? b0 : i == 1 ? b1 : i == 2 ? b2 : b3;
         n_seg++;
         float uu, vv, dist;
         if (intersect_line(lo, ld, ray.tmin, tmax, xyz(a), xyz(b), a.w, b.w, uu, vv, dist)) {
-          hit.object = cur_obj, hit.element = leaf_start + i;  // leaf slot; resolved below
+          hit.object = cur_obj, hit.slot = leaf_start + i;
           hit.u = uu, hit.v = vv, hit.distance = dist;
           tmax = dist;
         }
       }
     } else {
       for (int i = 0; i < leaf_num; i++) {
-        size_t r = (size_t)prim_base + (size_t)(leaf_start + i) * 3;
-        v4f    a = ldg4(sc.prims + r), b = ldg4(sc.prims + r + 1), c = ldg4(sc.prims + r + 2);
+        const yhd_float4* rec = sc.prims + (size_t)prim_base + (size_t)(leaf_start + i) * 6;
+        v4f a = ldg4(rec), b = ldg4(rec + 1), c = ldg4(rec + 2);
         n_tri++;
         float uu, vv, dist;
         if (intersect_triangle(lo, ld, ray.tmin, tmax, xyz(a), xyz(b), xyz(c), uu, vv, dist)) {
-          hit.object = cur_obj, hit.element = ~__float_as_int(a.w);  // already an element id
+          hit.object = cur_obj, hit.slot = leaf_start + i;
           hit.u = uu, hit.v = vv, hit.distance = dist;
           tmax = dist;
         }
       }
-    }
-  }
-  // hair hits carry the leaf slot: one dependent load of the element id, only
-  // for the final closest hit (triangle hits were stored complemented)
-  if (hit.object >= 0) {
-    if (hit.element >= 0) {
-      const yhd_object& o = sc.objects[hit.object];
-      hit.element         = sc.prim_elem[o.slot_base + hit.element];
-    } else {
-      hit.element = ~hit.element;
     }
   }
   if (COUNT) {
@@ -314,6 +328,14 @@ YH_DEV hit_t trace_ray(const trace_ctx& tc, const ray_t& ray, int first_object, 
     count_add<COUNT>(&tc.counters->tri, n_tri);
   }
   return hit;
+}
+
+// Element id (the reference's `element`) of a hit, read from its leaf record.
+YH_DEV int hit_element(const yhd_scene& sc, const hit_t& hit) {
+  if (hit.object < 0) return -1;
+  const yhd_object& o = sc.objects[hit.object];
+  if (o.kind == YH_KIND_LINES) return __float_as_int(sc.prims[(size_t)o.prim_base + (size_t)hit.slot * 4 + 2].w);
+  return __float_as_int(sc.prims[(size_t)o.prim_base + (size_t)hit.slot * 6].w);
 }
 
 }  // namespace yhd

@@ -41,13 +41,13 @@ template <bool COUNT>
 __global__ __launch_bounds__(YH_BLOCK, YH_MIN_WAVES) void k_trace(const yhd_scene sc, const yhd_state st,
     int nsamples, yhd_counters* counters) {
   extern __shared__ v4f lds_dyn[];
-  // LDS carve-out: [nodelets: 2 * lds_node_count float4][stack: YH_LDS_STACK x YH_BLOCK uint]
+  // LDS carve-out: [nodelets: 8 * lds_node_count float4][stack: YH_LDS_STACK x YH_BLOCK uint]
   YH_LDS v4f*          lds_nodes = (YH_LDS v4f*)lds_dyn;
-  YH_LDS unsigned int* lds_stack = (YH_LDS unsigned int*)(lds_nodes + 2 * sc.lds_node_count);
+  YH_LDS unsigned int* lds_stack = (YH_LDS unsigned int*)(lds_nodes + 8 * sc.lds_node_count);
   // stage the nodelets: the first lds_node_count nodes (breadth-first = top
   // levels) of the dominant hair shape, 32 B each, coalesced dwordx4 loads
-  for (int i = threadIdx.x; i < 2 * sc.lds_node_count; i += blockDim.x)
-    lds_nodes[i] = ldg4(sc.nodes + 2 * (size_t)sc.lds_node_base + i);
+  for (int i = threadIdx.x; i < 8 * sc.lds_node_count; i += blockDim.x)
+    lds_nodes[i] = ldg4(sc.nodes + 8 * (size_t)sc.lds_node_base + i);
   __syncthreads();
 
   trace_ctx tc;
@@ -279,7 +279,7 @@ __global__ void k_intersect(const yhd_scene sc, int n, const float* rays, int* o
   const float* r = rays + 8 * (size_t)i;
   ray_t ray      = ray_t{ld3(r), ld3(r + 3), r[6], r[7]};
   hit_t h        = trace_ray<false, false, 1>(tc, ray, -1);
-  object[i] = h.object, element[i] = h.object < 0 ? -1 : h.element;
+  object[i] = h.object, element[i] = hit_element(sc, h);
   uv[2 * i] = h.u, uv[2 * i + 1] = h.v, dist[i] = h.distance;
 }
 
@@ -395,7 +395,7 @@ extern "C" {
 
 int yhk_trace(const yhd_scene* sc, const yhd_state* st, int nsamples, yhd_counters* counters,
     int grid_blocks, hipStream_t stream) {
-  size_t lds = (size_t)sc->lds_node_count * 32 + (size_t)YH_LDS_STACK * YH_BLOCK * 4;
+  size_t lds = (size_t)sc->lds_node_count * 128 + (size_t)YH_LDS_STACK * YH_BLOCK * 4;
   static size_t lds_set[2] = {0, 0};
   if (lds > lds_set[counters ? 1 : 0]) {  // above 64 KB the dynamic-LDS limit must be raised explicitly
     hipError_t e = counters ? hipFuncSetAttribute((const void*)k_trace<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
@@ -410,7 +410,7 @@ int yhk_trace(const yhd_scene* sc, const yhd_state* st, int nsamples, yhd_counte
   return (int)hipGetLastError();
 }
 int yhk_block_threads(void) { return YH_BLOCK; }
-int yhk_trace_lds_bytes(int lds_node_count) { return lds_node_count * 32 + YH_LDS_STACK * YH_BLOCK * 4; }
+int yhk_trace_lds_bytes(int lds_node_count) { return lds_node_count * 128 + YH_LDS_STACK * YH_BLOCK * 4; }
 int yhk_trace_occupancy(int lds_bytes) {
   int blocks = 0;
   (void)hipFuncSetAttribute((const void*)k_trace<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);

@@ -1,19 +1,24 @@
 // yh_device.h — layout of the scene and render state in HBM, shared by the
 // host upload code (g++) and the HIP kernels (hipcc). Plain C structs only.
 //
-// Everything a ray touches is stored in 16-byte records so that every fetch
-// is one or two `global_load_dwordx4`:
-//   * BVH node (32 B): {min.xyz, start} {max.xyz, meta}; meta = num |
+// Everything a ray touches is a 16-byte-aligned record fetched with dwordx4
+// loads, laid out so that one traversal step is ONE dependent fetch:
+//   * shape BVH node (128 B, one cache line): the reference's binary tree
+//     (pt.cpp:557-650) with two levels collapsed into a 4-wide node, SoA over
+//     the four slots: minx[4] miny[4] minz[4] maxx[4] maxy[4] maxz[4] ref[4]
+//     {axes,0,0,0} (host/bvh_build.h: WideNode). Wide nodes are numbered
+//     breadth-first, so the first K nodes are the top of the tree (the
+//     "nodelets" staged in LDS).
+//   * scene-level node (32 B): {min.xyz, start} {max.xyz, meta}; meta = num |
 //     internal << 16 | axis << 24 — the reference's bvh_node (pt.h:243-249).
-//     Nodes keep the reference's breadth-first order, so the first N nodes are
-//     the top of the tree (the "nodelets" staged in LDS).
-//   * hair segment (32 B), stored in BVH LEAF ORDER (no primitives[] / lines[]
-//     / positions[] / radius[] indirection in the inner loop):
-//     {p0.xyz, r0} {p1.xyz, r1}; the element id is in a parallel int array
-//     read only on a hit.
-//   * triangle (48 B) in leaf order: {p0.xyz, elem} {p1.xyz, 0} {p2.xyz, 0}.
-//   * shading data per vertex: float4 {pos.xyz, radius}, float4 {normal.xyz,0}
-//     (normal = hair tangent for line shapes), and int4 element indices.
+//   * hair segment (64 B), stored in BVH LEAF ORDER (no primitives[] / lines[]
+//     / positions[] / radius[] indirection): {p0.xyz, r0} {p1.xyz, r1} used by
+//     the ray test, then {t0.xyz, element} {t1.xyz, 0} (vertex tangents) used
+//     only when the hit is shaded — no index chasing after a hit either.
+//   * triangle (96 B) in leaf order: {p0.xyz, element} {p1.xyz,0} {p2.xyz,0}
+//     {n0.xyz,0} {n1.xyz,0} {n2.xyz,0}.
+//   * per-vertex / per-element arrays (vpos, elems) are kept only for sampling
+//     a point on an area light by triangle index (pt.cpp:1288-1290).
 #ifndef YH_DEVICE_H_
 #define YH_DEVICE_H_
 #include <stdint.h>
@@ -34,12 +39,12 @@ typedef struct yhd_object {
   float inv_frame[12];  // inverse(frame, non_rigid = true), pt.cpp:1012-1013
   int   kind;           // YH_KIND_*
   int   node_base;      // first BVH node of the shape in `nodes`
-  int   prim_base;      // first leaf-ordered primitive record of the shape
+  int   prim_base;      // first leaf-ordered record of the shape (float4 units)
   int   vert_base;      // first vertex in vpos / vnrm
   int   elem_base;      // first element in elems
   int   has_normals;
   int   material;
-  int   slot_base;      // first leaf slot of the shape in prim_elem
+  int   pad;
 } yhd_object;
 
 // ptr::material + everything of hair_brdf that depends on the material only
@@ -88,9 +93,8 @@ typedef struct yhd_camera {
 
 typedef struct yhd_scene {
   // geometry
-  const yhd_float4* nodes;      // 2 float4 per node
-  const yhd_float4* prims;      // leaf-ordered records (2 or 3 float4 each)
-  const int*        prim_elem;  // element id of each leaf-ordered hair segment
+  const yhd_float4* nodes;      // 8 float4 per 4-wide node
+  const yhd_float4* prims;      // leaf-ordered records (4 or 6 float4 each)
   const yhd_float4* vpos;       // per vertex {pos, radius}
   const yhd_float4* vnrm;       // per vertex {normal/tangent, 0}
   const yhd_int4*   elems;      // per element vertex indices (shape-local)

@@ -93,4 +93,57 @@ void build_bvh(Tree& tree, const std::vector<Box>& boxes) {
   for (size_t i = 0; i < prims.size(); i++) tree.primitives[i] = prims[i].primitive;
 }
 
+
+int collapse_wide(const Tree& tree, std::vector<WideNode>& out) {
+  out.clear();
+  const float inf = std::numeric_limits<float>::infinity();
+  auto leaf_ref = [](const Node& n) { return 0xC0000000u | ((unsigned)n.num << 27) | (unsigned)n.start; };
+  struct Item {
+    int binary, wide, depth;
+  };
+  std::deque<Item> queue;
+  auto new_wide = [&](int binary, int depth) {
+    out.emplace_back();
+    queue.push_back({binary, (int)out.size() - 1, depth});
+    return (unsigned)out.size() - 1;
+  };
+  int max_depth = 1;
+  new_wide(0, 1);
+  while (!queue.empty()) {
+    Item it = queue.front();
+    queue.pop_front();
+    max_depth = std::max(max_depth, it.depth);
+    WideNode w;
+    for (int s = 0; s < 4; s++) {
+      for (int k = 0; k < 3; k++) w.bmin[k][s] = inf, w.bmax[k][s] = -inf;
+      w.ref[s] = 0xFFFFFFFFu;
+    }
+    w.axes = 0, w.pad[0] = w.pad[1] = w.pad[2] = 0;
+    auto set_slot = [&](int s, int binary) {
+      const Node& n = tree.nodes[binary];
+      for (int k = 0; k < 3; k++) w.bmin[k][s] = n.bbox.min[k], w.bmax[k][s] = n.bbox.max[k];
+      w.ref[s] = n.internal ? new_wide(binary, it.depth + 1) : leaf_ref(n);
+    };
+    const Node& b = tree.nodes[it.binary];
+    if (!b.internal) {  // a shape whose binary root is a leaf
+      set_slot(0, it.binary);
+    } else {
+      w.axes = b.axis;
+      for (int side = 0; side < 2; side++) {
+        int         child = b.start + side;
+        const Node& c     = tree.nodes[child];
+        if (c.internal) {
+          w.axes |= (unsigned)c.axis << (2 + 2 * side);
+          set_slot(2 * side + 0, c.start + 0);
+          set_slot(2 * side + 1, c.start + 1);
+        } else {
+          set_slot(2 * side, child);
+        }
+      }
+    }
+    out[it.wide] = w;
+  }
+  return max_depth;
+}
+
 }  // namespace yhh

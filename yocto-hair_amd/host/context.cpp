@@ -202,7 +202,7 @@ struct yh_context {
   // scene
   bool      have_scene = false;
   yhd_scene scene{};
-  DevBuf    d_nodes, d_prims, d_prim_elem, d_vpos, d_vnrm, d_elems, d_objects, d_materials, d_scene_nodes,
+  DevBuf    d_nodes, d_prims, d_vpos, d_vnrm, d_elems, d_objects, d_materials, d_scene_nodes,
       d_scene_prims, d_light_cdf, d_env_texels;
   int       stack_need = 0;
   // state
@@ -327,13 +327,12 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
   }
   // ---- per-shape BVHs and flattened arrays --------------------------------
   struct ShapeInfo {
-    int kind, node_base, prim_base, vert_base, elem_base, slot_base, has_normals, depth;
+    int kind, node_base, prim_base, vert_base, elem_base, has_normals, depth;
     yhh::Box root;
     int num_nodes;
   };
   std::vector<ShapeInfo>  info(sd->num_shapes);
   std::vector<yhd_float4> nodes, prims, vpos, vnrm;
-  std::vector<int>        prim_elem;
   std::vector<yhd_int4>   elems;
   int                     best_lines = -1, best_shape = -1;
   for (int si = 0; si < sd->num_shapes; si++) {
@@ -347,11 +346,10 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
       if (idx[k] < 0 || idx[k] >= s.num_vertices) return fail(ctx, YH_E_INVALID, "shape %d: vertex index out of range", si);
     auto& I       = info[si];
     I.kind        = lines ? YH_KIND_LINES : YH_KIND_TRIANGLES;
-    I.node_base   = (int)nodes.size() / 2;
+    I.node_base   = (int)nodes.size() / 8;
     I.prim_base   = (int)prims.size();
     I.vert_base   = (int)vpos.size();
     I.elem_base   = (int)elems.size();
-    I.slot_base   = (int)prim_elem.size();
     I.has_normals = s.normals != nullptr;
     auto pos = [&](int v) { return ld3(s.positions + 3 * (size_t)v); };
     auto rad = [&](int v) { return s.radius ? s.radius[v] : 0.001f; };  // add_radius, sceneio.cpp:390
@@ -376,23 +374,35 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
     }
     yhh::Tree tree;
     yhh::build_bvh(tree, boxes);
-    I.depth = tree.max_depth, I.root = tree.nodes[0].bbox, I.num_nodes = (int)tree.nodes.size();
-    for (auto& n : tree.nodes) nodes.push_back(node_lo(n)), nodes.push_back(node_hi(n));
-    for (int slot = 0; slot < nel; slot++) {  // leaf-ordered records
-      int e = tree.primitives[slot];
+    std::vector<yhh::WideNode> wide;
+    I.depth = yhh::collapse_wide(tree, wide);
+    I.root = tree.nodes[0].bbox, I.num_nodes = (int)wide.size();
+    {
+      size_t at = nodes.size();
+      nodes.resize(at + wide.size() * 8);
+      memcpy(&nodes[at], wide.data(), wide.size() * sizeof(yhh::WideNode));
+    }
+    auto nrm = [&](int v) { return s.normals ? ld3(s.normals + 3 * (size_t)v) : F3{0, 0, 0}; };
+    for (int slot = 0; slot < nel; slot++) {  // leaf-ordered records (yh_device.h)
+      int   e = tree.primitives[slot];
+      float ew;
+      memcpy(&ew, &e, 4);
       if (lines) {
         int a = idx[2 * e], b = idx[2 * e + 1];
-        F3  p0 = pos(a), p1 = pos(b);
+        F3  p0 = pos(a), p1 = pos(b), t0 = nrm(a), t1 = nrm(b);
         prims.push_back({p0.x, p0.y, p0.z, rad(a)});
         prims.push_back({p1.x, p1.y, p1.z, rad(b)});
-        prim_elem.push_back(e);
+        prims.push_back({t0.x, t0.y, t0.z, ew});
+        prims.push_back({t1.x, t1.y, t1.z, 0});
       } else {
-        F3    p0 = pos(idx[3 * e]), p1 = pos(idx[3 * e + 1]), p2 = pos(idx[3 * e + 2]);
-        float ew;
-        memcpy(&ew, &e, 4);
+        int a = idx[3 * e], b = idx[3 * e + 1], cc = idx[3 * e + 2];
+        F3  p0 = pos(a), p1 = pos(b), p2 = pos(cc), n0 = nrm(a), n1 = nrm(b), n2 = nrm(cc);
         prims.push_back({p0.x, p0.y, p0.z, ew});
         prims.push_back({p1.x, p1.y, p1.z, 0});
         prims.push_back({p2.x, p2.y, p2.z, 0});
+        prims.push_back({n0.x, n0.y, n0.z, 0});
+        prims.push_back({n1.x, n1.y, n1.z, 0});
+        prims.push_back({n2.x, n2.y, n2.z, 0});
       }
     }
     for (int v = 0; v < s.num_vertices; v++) {
@@ -418,7 +428,7 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
     memcpy(d.frame, o.frame, 48);
     inverse_frame(o.frame, true, d.inv_frame);
     d.kind = I.kind, d.node_base = I.node_base, d.prim_base = I.prim_base, d.vert_base = I.vert_base;
-    d.elem_base = I.elem_base, d.has_normals = I.has_normals, d.material = o.material, d.slot_base = I.slot_base;
+    d.elem_base = I.elem_base, d.has_normals = I.has_normals, d.material = o.material, d.pad = 0;
     // transform_bbox (math.h:3174-3185)
     const yhh::Box& b = I.root;
     float lo[3] = {std::numeric_limits<float>::max(), std::numeric_limits<float>::max(), std::numeric_limits<float>::max()};
@@ -438,7 +448,8 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
   for (auto& n : scene_tree.nodes) scene_nodes.push_back(node_lo(n)), scene_nodes.push_back(node_hi(n));
   int max_shape_depth = 0;
   for (auto& I : info) max_shape_depth = std::max(max_shape_depth, I.depth);
-  ctx->stack_need = scene_tree.max_depth + 4 + max_shape_depth + 2;
+  // a wide node pushes at most three entries and keeps the fourth in a register
+  ctx->stack_need = scene_tree.max_depth + 4 + 3 * max_shape_depth + 2;
   if (ctx->stack_need > YH_STACK_MAX)
     return fail(ctx, YH_E_INVALID, "BVH too deep for the traversal stack (%d > %d)", ctx->stack_need, YH_STACK_MAX);
   // ---- materials ---------------------------------------------------------
@@ -500,7 +511,6 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
   int rc;
   if ((rc = upload(ctx, ctx->d_nodes, nodes.data(), nodes.size() * 16))) return rc;
   if ((rc = upload(ctx, ctx->d_prims, prims.data(), prims.size() * 16))) return rc;
-  if ((rc = upload(ctx, ctx->d_prim_elem, prim_elem.data(), prim_elem.size() * 4))) return rc;
   if ((rc = upload(ctx, ctx->d_vpos, vpos.data(), vpos.size() * 16))) return rc;
   if ((rc = upload(ctx, ctx->d_vnrm, vnrm.data(), vnrm.size() * 16))) return rc;
   if ((rc = upload(ctx, ctx->d_elems, elems.data(), elems.size() * 16))) return rc;
@@ -511,7 +521,7 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
   if ((rc = upload(ctx, ctx->d_light_cdf, light_cdf.data(), light_cdf.size() * 4))) return rc;
   if ((rc = upload(ctx, ctx->d_env_texels, env_texels.data(), env_texels.size() * 16))) return rc;
   sc.nodes = (const yhd_float4*)ctx->d_nodes.p, sc.prims = (const yhd_float4*)ctx->d_prims.p;
-  sc.prim_elem = (const int*)ctx->d_prim_elem.p, sc.vpos = (const yhd_float4*)ctx->d_vpos.p;
+  sc.vpos = (const yhd_float4*)ctx->d_vpos.p;
   sc.vnrm = (const yhd_float4*)ctx->d_vnrm.p, sc.elems = (const yhd_int4*)ctx->d_elems.p;
   sc.objects = (const yhd_object*)ctx->d_objects.p, sc.materials = (const yhd_material*)ctx->d_materials.p;
   sc.scene_nodes = (const yhd_float4*)ctx->d_scene_nodes.p, sc.scene_prims = (const int*)ctx->d_scene_prims.p;
@@ -524,7 +534,7 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
   sc.lds_node_base = 0, sc.lds_node_count = 0;
   if (best_shape >= 0) {
     sc.lds_node_base  = info[best_shape].node_base;
-    int want = 1023;  // 32 KB of nodelets + 48 KB of stacks = 80 KB: two 512-thread blocks per CU
+    int want = 255;  // 255 wide nodes = 32 KB of nodelets + 48 KB of stacks = 80 KB: two 512-thread blocks per CU
     if (const char* env = getenv("YHAIR_LDS_NODES")) want = std::max(0, std::min(atoi(env), 3000));
     sc.lds_node_count = std::min(info[best_shape].num_nodes, want);
   }
