@@ -241,16 +241,23 @@ def test_pack_unpack_tiles_on_device(ctx, yh):
 
 
 def test_work_counters_match_oracle_on_identical_paths(ctx, oracle, yh):
-    """Scene-level rays are counted identically where no path can diverge (1 bounce)."""
+    """Where no path can diverge (1 bounce) the instrumented kernel counts the same rays and
+    shading events as the reference algorithm. Node visits are fewer (4-wide nodes: one visit
+    tests four reference boxes); primitive tests can only be equal or slightly more (a child box
+    is accepted with the ray extent current at its parent, before nearer hits shrink it)."""
     sf = yh.SceneFile(scene_path("sphere-hairblock", scale=0.02))
     ctx.upload_scene(sf.desc)
     p = yh.TraceParams.default(resolution=64, bounces=1)
     ctx.init_state(p)
-    wc = ctx.trace_samples_counted(2)
+    wc = ctx.trace_samples_counted(2).as_dict()
     osc = oracle.scene(sf.desc)
     _, owc = osc.render(p, 2, want_counts=True)
-    algo = ("samples", "rays", "nodes", "seg_tests", "tri_tests", "hair_shades", "surf_shades", "env_lookups", "env_samples")
-    assert {k: wc.as_dict()[k] for k in algo} == {k: owc.as_dict()[k] for k in algo}
+    owc = owc.as_dict()
+    for k in ("samples", "rays", "hair_shades", "surf_shades", "env_lookups", "env_samples"):
+        assert wc[k] == owc[k], k
+    assert 0 < wc["nodes"] < owc["nodes"]
+    assert owc["seg_tests"] <= wc["seg_tests"] <= 1.05 * owc["seg_tests"]
+    assert owc["tri_tests"] <= wc["tri_tests"] <= 1.05 * owc["tri_tests"]
     osc.close(), sf.close()
 
 

@@ -63,10 +63,21 @@ __global__ __launch_bounds__(YH_BLOCK, YH_MIN_WAVES) void k_trace(const yhd_scen
     t = __builtin_amdgcn_readfirstlane(t);
     if (t >= st.num_tiles) break;
     unsigned long long t0 = wall_clock64();
-    int  tile  = st.tiles[t];
-    int  i     = (tile % st.tiles_x) * YH_TILE + (lane & 7);
-    int  j     = (tile / st.tiles_x) * YH_TILE + (lane >> 3);
-    bool owner = i < st.width && j < st.height;
+    int  item  = st.tiles[t];
+    int  tile  = item & 0xFFFFF, part = (item >> 20) & 15, mode = (item >> 24) & 3;
+    // lane -> pixel inside the tile for the item's split mode
+    int  px, py;
+    bool active;
+    if (mode == 0) {
+      px = lane & 7, py = lane >> 3, active = true;
+    } else if (mode == 1) {
+      px = (part & 1) * 4 + (lane & 3), py = (part >> 1) * 4 + ((lane >> 2) & 3), active = lane < 16;
+    } else {
+      px = (part & 3) * 2 + (lane & 1), py = (part >> 2) * 2 + ((lane >> 1) & 1), active = lane < 4;
+    }
+    int  i     = (tile % st.tiles_x) * YH_TILE + px;
+    int  j     = (tile / st.tiles_x) * YH_TILE + py;
+    bool owner = active && i < st.width && j < st.height;
     size_t pix = owner ? (size_t)j * st.width + i : 0;
     rng_t  rng;
     rng.state      = st.rng_state[pix];
@@ -122,16 +133,20 @@ __global__ __launch_bounds__(YH_BLOCK, YH_MIN_WAVES) void k_trace(const yhd_scen
       st.rng_state[pix] = rng.state;
       st.accum[pix]     = acc;
     }
-    if (lane == 0) st.tile_cost[tile] = (unsigned int)(wall_clock64() - t0);
-    if (COUNT && lane == 0) atomicAdd(&counters->cyc_tile, wall_clock64() - t0);
+    if (lane == 0) {
+      unsigned int dt = (unsigned int)(wall_clock64() - t0);
+      atomicMax(&st.tile_cost[tile], dt);
+      atomicAdd(&st.tile_work[tile], dt);
+      if (COUNT) atomicAdd(&counters->cyc_tile, (unsigned long long)dt);
+    }
   }
 }
 
 // render[ij] = accumulated / samples (pt.cpp:1688) into a full W*H image
 __global__ void k_resolve(const yhd_state st, int samples, yhd_float4* image) {
-  int t = blockIdx.x, lane = threadIdx.x;
-  if (t >= st.num_tiles) return;
-  int tile = st.tiles[t];
+  // block k handles the k-th tile owned by this shard: tile id rank + k * world
+  int lane = threadIdx.x;
+  int tile = st.shard_rank + blockIdx.x * st.shard_world;
   int i    = (tile % st.tiles_x) * YH_TILE + (lane & 7);
   int j    = (tile / st.tiles_x) * YH_TILE + (lane >> 3);
   if (i >= st.width || j >= st.height) return;
@@ -142,9 +157,8 @@ __global__ void k_resolve(const yhd_state st, int samples, yhd_float4* image) {
 }
 // tile-packed variant: 64 float4 per owned tile, tiles in increasing id order
 __global__ void k_pack(const yhd_state st, int samples, yhd_float4* packed) {
-  int t = blockIdx.x, lane = threadIdx.x;
-  if (t >= st.num_tiles) return;
-  int tile = st.tiles[t];
+  int lane = threadIdx.x;
+  int tile = st.shard_rank + blockIdx.x * st.shard_world;
   int i    = (tile % st.tiles_x) * YH_TILE + (lane & 7);
   int j    = (tile / st.tiles_x) * YH_TILE + (lane >> 3);
   yhd_float4 out = {0, 0, 0, 0};
@@ -153,9 +167,7 @@ __global__ void k_pack(const yhd_state st, int samples, yhd_float4* packed) {
     float      n = (float)samples;
     out          = yhd_float4{a.x / n, a.y / n, a.z / n, a.w / n};
   }
-  // position in the packed buffer = rank of the tile id within this shard (the
-  // hand-out order of `tiles` changes from launch to launch)
-  packed[(size_t)((tile - st.shard_rank) / st.shard_world) * 64 + lane] = out;
+  packed[(size_t)blockIdx.x * 64 + lane] = out;
 }
 __global__ void k_unpack(const yhd_float4* packed, int src_rank, int world, int num_tiles_total,
     int tiles_x, int width, int height, yhd_float4* image) {
@@ -417,12 +429,12 @@ int yhk_trace_occupancy(int lds_bytes) {
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_trace<false>, YH_BLOCK, lds_bytes) != hipSuccess) return 1;
   return blocks < 1 ? 1 : blocks;
 }
-int yhk_resolve(const yhd_state* st, int samples, void* image, hipStream_t stream) {
-  if (st->num_tiles) hipLaunchKernelGGL(k_resolve, dim3(st->num_tiles), dim3(64), 0, stream, *st, samples, (yhd_float4*)image);
+int yhk_resolve(const yhd_state* st, int owned_tiles, int samples, void* image, hipStream_t stream) {
+  if (owned_tiles) hipLaunchKernelGGL(k_resolve, dim3(owned_tiles), dim3(64), 0, stream, *st, samples, (yhd_float4*)image);
   return (int)hipGetLastError();
 }
-int yhk_pack(const yhd_state* st, int samples, void* packed, hipStream_t stream) {
-  if (st->num_tiles) hipLaunchKernelGGL(k_pack, dim3(st->num_tiles), dim3(64), 0, stream, *st, samples, (yhd_float4*)packed);
+int yhk_pack(const yhd_state* st, int owned_tiles, int samples, void* packed, hipStream_t stream) {
+  if (owned_tiles) hipLaunchKernelGGL(k_pack, dim3(owned_tiles), dim3(64), 0, stream, *st, samples, (yhd_float4*)packed);
   return (int)hipGetLastError();
 }
 int yhk_unpack(const void* packed, int src_rank, int world, int ntiles_src, int num_tiles_total, int tiles_x,

@@ -33,8 +33,8 @@ int yhk_trace(const yhd_scene*, const yhd_state*, int, yhd_counters*, int, hipSt
 int yhk_block_threads(void);
 int yhk_trace_occupancy(int lds_bytes);
 int yhk_trace_lds_bytes(int lds_node_count);
-int yhk_resolve(const yhd_state*, int, void*, hipStream_t);
-int yhk_pack(const yhd_state*, int, void*, hipStream_t);
+int yhk_resolve(const yhd_state*, int, int, void*, hipStream_t);
+int yhk_pack(const yhd_state*, int, int, void*, hipStream_t);
 int yhk_unpack(const void*, int, int, int, int, int, int, int, void*, hipStream_t);
 int yhk_hair_brdf(int, const void*, const float*, const float*, const float*, float*, hipStream_t);
 int yhk_hair_eval(int, const float*, const float*, const float*, float*, hipStream_t);
@@ -209,8 +209,11 @@ struct yh_context {
   bool             have_state = false;
   yhd_state        state{};
   yh_trace_params  params{};
-  DevBuf           d_rng_state, d_rng_inc, d_accum, d_tiles, d_image, d_counters, d_tile_cursor, d_tile_cost;
-  std::vector<int> tiles;  // owned tile ids in hand-out order (most expensive first)
+  DevBuf           d_rng_state, d_rng_inc, d_accum, d_tiles, d_image, d_counters, d_tile_cursor, d_tile_cost, d_tile_work;
+  std::vector<int> owned;      // owned tile ids, increasing
+  std::vector<unsigned char> tile_mode;  // per tile id: split mode 0 / 1 / 2 (scheduling hint, kept across init_state)
+  std::vector<unsigned int>  tile_cost;  // per tile id: last measured max-part cost
+  int              items_capacity = 0;
   int              rank = 0, world = 1;
   int              num_tiles_total = 0;
   float            last_ms = 0;
@@ -266,6 +269,27 @@ yhd_float4 node_hi(const yhh::Node& n) {
 
 int tiles_of(int n) { return (n + YH_TILE - 1) / YH_TILE; }
 
+// Work items (yh_device.h: yhd_state::tiles) for the owned tiles with their
+// current split modes, most expensive first.
+void build_work_items(const yh_context* ctx, std::vector<int>& items);
+
+}  // namespace
+
+namespace {
+void build_work_items(const yh_context* ctx, std::vector<int>& items) {
+  struct It {
+    int          item;
+    unsigned int cost;
+  };
+  std::vector<It> v;
+  for (int t : ctx->owned) {
+    int mode = ctx->tile_mode[t], parts = mode == 0 ? 1 : mode == 1 ? 4 : 16;
+    for (int p = 0; p < parts; p++) v.push_back({t | (p << 20) | (mode << 24), ctx->tile_cost[t]});
+  }
+  std::stable_sort(v.begin(), v.end(), [](const It& a, const It& b) { return a.cost > b.cost; });
+  items.resize(v.size());
+  for (size_t i = 0; i < v.size(); i++) items[i] = v[i].item;
+}
 }  // namespace
 
 extern "C" {
@@ -581,20 +605,30 @@ int yh_init_state(yh_context* ctx, const yh_trace_params* params) {
   }
   int tx = tiles_of(w), ty = tiles_of(h);
   ctx->num_tiles_total = tx * ty;
-  auto& tiles = ctx->tiles;
-  tiles.clear();
-  for (int t = ctx->rank; t < ctx->num_tiles_total; t += ctx->world) tiles.push_back(t);
+  auto& owned = ctx->owned;
+  owned.clear();
+  for (int t = ctx->rank; t < ctx->num_tiles_total; t += ctx->world) owned.push_back(t);
+  if ((int)ctx->tile_mode.size() != ctx->num_tiles_total) {  // scheduling hints survive a re-init of the same image
+    ctx->tile_mode.assign(ctx->num_tiles_total, 0);
+    ctx->tile_cost.assign(ctx->num_tiles_total, 0);
+  }
+  std::vector<int> tiles;
+  build_work_items(ctx, tiles);
+  ctx->items_capacity = (int)owned.size() * 16;
   int rc;
   if ((rc = upload(ctx, ctx->d_rng_state, st.data(), npix * 8))) return rc;
   if ((rc = upload(ctx, ctx->d_rng_inc, inc.data(), npix * 8))) return rc;
   if ((rc = alloc_zero(ctx, ctx->d_accum, npix * 16))) return rc;
   if ((rc = alloc_zero(ctx, ctx->d_image, npix * 16))) return rc;
-  if ((rc = upload(ctx, ctx->d_tiles, tiles.data(), tiles.size() * 4))) return rc;
+  if ((rc = alloc_zero(ctx, ctx->d_tiles, (size_t)ctx->items_capacity * 4 + 16))) return rc;
+  HIPCHK(ctx, hipMemcpy(ctx->d_tiles.p, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice));
   if ((rc = alloc_zero(ctx, ctx->d_counters, sizeof(yhd_counters)))) return rc;
   if ((rc = alloc_zero(ctx, ctx->d_tile_cursor, 4))) return rc;
   if ((rc = alloc_zero(ctx, ctx->d_tile_cost, (size_t)ctx->num_tiles_total * 4))) return rc;
+  if ((rc = alloc_zero(ctx, ctx->d_tile_work, (size_t)ctx->num_tiles_total * 4))) return rc;
   auto& s = ctx->state;
   s.tile_cursor = (int*)ctx->d_tile_cursor.p, s.tile_cost = (unsigned int*)ctx->d_tile_cost.p;
+  s.tile_work = (unsigned int*)ctx->d_tile_work.p;
   s.rng_state = (uint64_t*)ctx->d_rng_state.p, s.rng_inc = (uint64_t*)ctx->d_rng_inc.p;
   s.accum = (yhd_float4*)ctx->d_accum.p, s.tiles = (const int*)ctx->d_tiles.p;
   s.num_tiles = (int)tiles.size(), s.width = w, s.height = h, s.tiles_x = tx;
@@ -616,7 +650,7 @@ static int trace_impl(yh_context* ctx, int nsamples, bool counted, bool sync) {
   if (!ctx->have_state) return fail(ctx, YH_E_STATE, "yh_trace_samples before yh_init_state");
   if (nsamples < 0) return fail(ctx, YH_E_INVALID, "negative sample count");
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  if (nsamples == 0 || ctx->state.num_tiles == 0) {
+  if (nsamples == 0 || ctx->owned.empty()) {
     ctx->state.samples_done += nsamples;
     ctx->last_ms = 0, ctx->last_launches = 0;
     return YH_OK;
@@ -627,6 +661,8 @@ static int trace_impl(yh_context* ctx, int nsamples, bool counted, bool sync) {
   int want            = (ctx->state.num_tiles + waves_per_block - 1) / waves_per_block;
   int grid            = std::max(1, std::min(want, resident));
   HIPCHK(ctx, hipMemsetAsync(ctx->d_tile_cursor.p, 0, 4, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(ctx->d_tile_cost.p, 0, (size_t)ctx->num_tiles_total * 4, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(ctx->d_tile_work.p, 0, (size_t)ctx->num_tiles_total * 4, ctx->stream));
   HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   int e = yhk_trace(&ctx->scene, &ctx->state, nsamples, counted ? (yhd_counters*)ctx->d_counters.p : nullptr, grid,
       ctx->stream);
@@ -637,14 +673,28 @@ static int trace_impl(yh_context* ctx, int nsamples, bool counted, bool sync) {
   if (sync) {
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     HIPCHK(ctx, hipEventElapsedTime(&ctx->last_ms, ctx->ev0, ctx->ev1));
-    // Longest-processing-time-first: hand the tiles out in decreasing order of
-    // the cost they just reported (hair tiles cost 10-100x background tiles and
-    // a pixel's samples are sequential, so the last tile to start bounds the
-    // launch). Pixel results do not depend on the order.
-    std::vector<unsigned int> cost(ctx->num_tiles_total);
-    HIPCHK(ctx, hipMemcpy(cost.data(), ctx->d_tile_cost.p, cost.size() * 4, hipMemcpyDeviceToHost));
-    std::stable_sort(ctx->tiles.begin(), ctx->tiles.end(), [&](int a, int b) { return cost[a] > cost[b]; });
-    HIPCHK(ctx, hipMemcpy(ctx->d_tiles.p, ctx->tiles.data(), ctx->tiles.size() * 4, hipMemcpyHostToDevice));
+    // Re-plan the next launch from what this one measured (pixel results do not
+    // depend on the plan): split tiles whose slowest part exceeds the balanced
+    // share of a wave slot, merge cheap ones back, and hand items out
+    // longest-first. A pixel's samples are sequential (one PCG32 stream), so an
+    // expensive hair tile bounds the launch unless its pixels are spread over
+    // more wavefronts.
+    std::vector<unsigned int> work(ctx->num_tiles_total);
+    HIPCHK(ctx, hipMemcpy(ctx->tile_cost.data(), ctx->d_tile_cost.p, work.size() * 4, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(work.data(), ctx->d_tile_work.p, work.size() * 4, hipMemcpyDeviceToHost));
+    double total = 0;
+    for (int t : ctx->owned) total += work[t];
+    double slots = (double)ctx->num_cus * 16;  // 4 waves per SIMD
+    double goal  = 1.5 * total / slots;
+    for (int t : ctx->owned) {
+      auto& m = ctx->tile_mode[t];
+      if (ctx->tile_cost[t] > goal && m < 2) m++;
+      else if (m > 0 && 4.0 * ctx->tile_cost[t] < goal) m--;
+    }
+    std::vector<int> tiles;
+    build_work_items(ctx, tiles);
+    HIPCHK(ctx, hipMemcpy(ctx->d_tiles.p, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice));
+    ctx->state.num_tiles = (int)tiles.size();
   }
   return YH_OK;
 }
@@ -685,7 +735,7 @@ int yh_download(yh_context* ctx, float* rgba) {
   HIPCHK(ctx, hipSetDevice(ctx->device));
   size_t bytes = (size_t)ctx->state.width * ctx->state.height * 16;
   HIPCHK(ctx, hipMemsetAsync(ctx->d_image.p, 0, bytes, ctx->stream));
-  int e = yhk_resolve(&ctx->state, ctx->state.samples_done, ctx->d_image.p, ctx->stream);
+  int e = yhk_resolve(&ctx->state, (int)ctx->owned.size(), ctx->state.samples_done, ctx->d_image.p, ctx->stream);
   if (e) return fail(ctx, YH_E_DEVICE, "k_resolve launch: %s", hipGetErrorString((hipError_t)e));
   HIPCHK(ctx, hipMemcpyAsync(rgba, ctx->d_image.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -700,10 +750,10 @@ int64_t yh_shard_pixels(const yh_context* ctx, int rank, int world) {
 int yh_pack_tiles_device(yh_context* ctx, void* device_rgba, int64_t capacity, int64_t* count) {
   if (!ctx || !device_rgba) return YH_E_INVALID;
   if (!ctx->have_state) return fail(ctx, YH_E_STATE, "yh_pack_tiles_device before yh_init_state");
-  int64_t need = (int64_t)ctx->state.num_tiles * 64;
+  int64_t need = (int64_t)ctx->owned.size() * 64;
   if (capacity < need) return fail(ctx, YH_E_INVALID, "pack buffer too small (%lld < %lld pixels)", (long long)capacity, (long long)need);
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  int e = yhk_pack(&ctx->state, ctx->state.samples_done, device_rgba, ctx->stream);
+  int e = yhk_pack(&ctx->state, (int)ctx->owned.size(), ctx->state.samples_done, device_rgba, ctx->stream);
   if (e) return fail(ctx, YH_E_DEVICE, "k_pack launch: %s", hipGetErrorString((hipError_t)e));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   if (count) *count = need;
