@@ -197,6 +197,52 @@ YH_DEV void hair_eval_pdf(const yhd_material& m, const hair_hit& hh, f3 outgoing
   if (WANT_PDF) pdf += mpl * ap_pdf[p_max] * (1 / (2 * pif));
 }
 
+// The integrator's fused eval + pdf with the four lobes p = 0..3 spread over the
+// four lanes of a quad (dev_trace.h): lane p evaluates Mp and Np of lobe p
+// (the transcendental-heavy part: exp, log, the I0 series), everything else is
+// computed redundantly by the four lanes, and the lobe terms are summed in the
+// reference's order p = 0, 1, 2, 3 (ext.cpp:297-332, 516-549) in every lane.
+// Bit-identical to hair_eval_pdf<true, true>.
+YH_DEV void hair_eval_pdf_quad(const yhd_material& m, const hair_hit& hh, f3 outgoing_, f3 incoming_,
+    f3& f, float& pdf) {
+  const int p       = (int)(__lane_id() & 3u);
+  f3    outgoing    = transform_direction(hh.w2b, outgoing_);
+  f3    incoming    = transform_direction(hh.w2b, incoming_);
+  float sin_theta_o = outgoing.x;
+  float cos_theta_o = safe_sqrt(1 - sqr(sin_theta_o));
+  float phi_o       = atan2f(outgoing.z, outgoing.y);
+  float sin_theta_i = incoming.x;
+  float cos_theta_i = safe_sqrt(1 - sqr(sin_theta_i));
+  float phi_i       = atan2f(incoming.z, incoming.y);
+  float gamma_t;
+  f3    T   = transmittance(m, hh.h, sin_theta_o, cos_theta_o, gamma_t);
+  float phi = phi_i - phi_o;
+  f3    apv[p_max + 1];
+  float ap_pdf[p_max + 1];
+  ap(cos_theta_o, m.eta, hh.h, T, apv);
+  compute_ap_pdf(m, hh.h, cos_theta_o, ap_pdf);
+  // this lane's lobe
+  float sin_theta_op, cos_theta_op;
+  tilt(m, p, sin_theta_o, cos_theta_o, sin_theta_op, cos_theta_op);
+  if (p < p_max) cos_theta_op = fabs_(cos_theta_op);
+  float mpv   = mp(m, p, cos_theta_i, cos_theta_op, sin_theta_i, sin_theta_op);
+  float npv   = p < p_max ? np(m, phi, p, hh.gamma_o, gamma_t) : 0.0f;
+  f3    apq   = p == 0 ? apv[0] : p == 1 ? apv[1] : p == 2 ? apv[2] : apv[3];
+  float appq  = p == 0 ? ap_pdf[0] : p == 1 ? ap_pdf[1] : p == 2 ? ap_pdf[2] : ap_pdf[3];
+  f3    tf    = p < p_max ? mpv * apq * npv : mpv * apq / (2 * pif);
+  float tp    = p < p_max ? mpv * appq * npv : mpv * appq * (1 / (2 * pif));
+  f   = mk3(0.0f);
+  pdf = 0.0f;
+  f   = f + f3{quad_bcast_f<0>(tf.x), quad_bcast_f<0>(tf.y), quad_bcast_f<0>(tf.z)};
+  pdf += quad_bcast_f<0>(tp);
+  f   = f + f3{quad_bcast_f<1>(tf.x), quad_bcast_f<1>(tf.y), quad_bcast_f<1>(tf.z)};
+  pdf += quad_bcast_f<1>(tp);
+  f   = f + f3{quad_bcast_f<2>(tf.x), quad_bcast_f<2>(tf.y), quad_bcast_f<2>(tf.z)};
+  pdf += quad_bcast_f<2>(tp);
+  f   = f + f3{quad_bcast_f<3>(tf.x), quad_bcast_f<3>(tf.y), quad_bcast_f<3>(tf.z)};
+  pdf += quad_bcast_f<3>(tp);
+}
+
 // ext.cpp:339-357
 YH_DEV uint32_t compact1by1(uint32_t x) {
   x &= 0x55555555;

@@ -82,5 +82,26 @@ YH_DEV frame transpose_rot(const frame& a) {
   return r;
 }
 
+// ---------------------------------------------------------------------------
+// Quads: four adjacent lanes that own one ray / one pixel (dev_trace.h).
+// ---------------------------------------------------------------------------
+// DPP quad permutes: data exchange between the four lanes of a quad in one
+// VALU instruction (quad_perm control = sel0 | sel1 << 2 | sel2 << 4 | sel3 << 6)
+template <int CTRL>
+YH_DEV int dpp_i(int v) { return __builtin_amdgcn_mov_dpp(v, CTRL, 0xF, 0xF, true); }
+template <int CTRL>
+YH_DEV float dpp_f(float v) { return __int_as_float(dpp_i<CTRL>(__float_as_int(v))); }
+template <int K>
+YH_DEV unsigned int quad_bcast_u(unsigned int v) { return (unsigned int)dpp_i<K * 0x55>((int)v); }
+template <int K>
+YH_DEV float quad_bcast_f(float v) { return dpp_f<K * 0x55>(v); }
+#define YH_QUAD_XOR1 0xB1 /* quad_perm [1,0,3,2] */
+#define YH_QUAD_XOR2 0x4E /* quad_perm [2,3,0,1] */
+// 4-bit mask of `p` over the lanes of this lane's quad
+YH_DEV unsigned int quad_ballot(bool p) {
+  unsigned long long b = __ballot(p);
+  return (unsigned int)(b >> (__lane_id() & ~3u)) & 15u;
+}
+
 }  // namespace yhd
 #endif

@@ -111,7 +111,7 @@ YH_DEV f3 eval_environment(const trace_ctx& tc, f3 dir) {
     float tx = atan2f(wl.z, wl.x) / (2 * pif);
     float ty = acosf(fclamp(wl.y, -1.0f, 1.0f)) / pif;
     if (tx < 0) tx += 1;
-    if (COUNT) count_add<COUNT>(&tc.counters->envl, 1);
+    if (COUNT) count_quad<COUNT>(&tc.counters->envl);
     emission = emission + ld3(env.emission) * eval_env_texture(sc, env, tx, ty);
   }
   return emission;
@@ -151,7 +151,7 @@ YH_DEV f3 sample_lights(const trace_ctx& tc, f3 position, float rl, float rel, f
   } else if (light.environment >= 0) {
     const yhd_environment& env = sc.environments[light.environment];
     if (env.tex_w) {
-      if (COUNT) count_add<COUNT>(&tc.counters->envs, 1);
+      if (COUNT) count_quad<COUNT>(&tc.counters->envs);
       int   idx = sample_discrete_cdf(sc.light_cdf + light.cdf_base, light.cdf_count, rel);
       float ux  = (idx % env.tex_w + 0.5f) / env.tex_w;
       float uy  = (idx / env.tex_w + 0.5f) / env.tex_h;
@@ -169,7 +169,7 @@ YH_DEV f3 sample_lights(const trace_ctx& tc, f3 position, float rl, float rel, f
 }
 
 // sample_lights_pdf (pt.cpp:1311-1358)
-template <bool COUNT, bool LDS, int STRIDE>
+template <bool COUNT, int STRIDE>
 YH_DEV float sample_lights_pdf(const trace_ctx& tc, f3 position, f3 direction) {
   const yhd_scene& sc = *tc.sc;
   float pdf = 0.0f;
@@ -180,7 +180,7 @@ YH_DEV float sample_lights_pdf(const trace_ctx& tc, f3 position, f3 direction) {
       float lpdf = 0.0f;
       f3    next_position = position;
       for (int bounce = 0; bounce < 100; bounce++) {
-        hit_t isec = trace_ray<COUNT, LDS, STRIDE>(tc, mkray(next_position, direction), light.object);
+        hit_t isec = trace_ray<COUNT, STRIDE>(tc, mkray(next_position, direction), light.object);
         if (isec.object < 0) break;
         hit_geom lg        = eval_hit(sc, o, isec.slot, isec.u, isec.v);
         f3       lposition = lg.position;
@@ -241,7 +241,7 @@ struct path_t {
 // closest hit of ps.ray. Returns true when the path continues with the new
 // ps.ray, false when it ended (miss, zero / non-finite weight, Russian
 // roulette or the bounce limit).
-template <bool COUNT, bool LDS, int STRIDE>
+template <bool COUNT, int STRIDE>
 YH_DEV bool path_step(const trace_ctx& tc, path_t& ps, const hit_t& isec, rng_t& rng, int bounces) {
   const yhd_scene& sc = *tc.sc;
   if (isec.object < 0) {
@@ -261,7 +261,7 @@ YH_DEV bool path_step(const trace_ctx& tc, path_t& ps, const hit_t& isec, rng_t&
   } else {
     normal = (!mat.thin || dot(nrm, outgoing) >= 0) ? nrm : -nrm;
   }
-  if (COUNT) count_add<COUNT>(is_hair ? &tc.counters->hair : &tc.counters->surf, 1);
+  if (COUNT) count_quad<COUNT>(is_hair ? &tc.counters->hair : &tc.counters->surf);
   ps.hit      = true;
   ps.radiance = ps.radiance + ps.weight * (ld3(mat.emission) * mk3(1.0f));
   hair_hit hh;
@@ -288,7 +288,7 @@ YH_DEV bool path_step(const trace_ctx& tc, path_t& ps, const hit_t& isec, rng_t&
   f3    brdfcos;
   float brdf_pdf;
   if (is_hair) {
-    hair_eval_pdf<true, true>(mat, hh, outgoing, incoming, brdfcos, brdf_pdf);
+    hair_eval_pdf_quad(mat, hh, outgoing, incoming, brdfcos, brdf_pdf);
   } else {  // eval_brdfcos / sample_brdfcos_pdf, diffuse lobe (math.h:4427,4572)
     brdfcos  = mk3(0.0f);
     brdf_pdf = 0.0f;
@@ -307,7 +307,7 @@ YH_DEV bool path_step(const trace_ctx& tc, path_t& ps, const hit_t& isec, rng_t&
       brdf_pdf += mat.diffuse_pdf * lobe;
     }
   }
-  float light_pdf = sample_lights_pdf<COUNT, LDS, STRIDE>(tc, position, incoming);
+  float light_pdf = sample_lights_pdf<COUNT, STRIDE>(tc, position, incoming);
   ps.weight = ps.weight * (brdfcos / (0.5f * brdf_pdf + 0.5f * light_pdf));
   ps.ray    = mkray(position, incoming);
   if (is_zero(ps.weight) || !finite3(ps.weight)) return false;

@@ -6,17 +6,26 @@
 //
 // MI355X-first differences from the reference's nested, pointer-chasing
 // loops (results are unchanged):
-//   * ONE flattened traversal loop with one stack for both levels: stack
-//     entries are tagged {scene node, enter-instance, shape node}; the
-//     instance's leaf loop `for idx in start..start+num` of the scene level
-//     becomes enter-instance entries pushed in reverse order, so instances
-//     are visited in the reference's order and `tmax` shrinks identically.
-//   * inverse object frames are precomputed at upload instead of per ray per
-//     object (pt.cpp:1012-1013 recomputes a 3x3 adjugate inverse each time);
-//   * leaf primitives are 16-byte-aligned records in leaf order (yh_device.h)
-//     so a segment test costs two dwordx4 loads and no index indirection;
-//   * BVH nodes whose index falls in the LDS-resident window (the top of the
-//     hair tree) are read from LDS.
+//   * QUADS: four adjacent lanes own ONE ray. A hair path is a long serial
+//     chain (its pixel's PCG32 stream is sequential) and a lone wavefront
+//     issues at most one vector instruction every ~4 cycles, so the cost of a
+//     ray is the number of instructions on its chain. With a quad per ray a
+//     node step is one box test per lane (not four per lane) and a leaf step
+//     is one primitive test per lane (not up to four), exchanged with DPP
+//     quad permutes — no LDS, no memory.
+//   * the shape BVH is 4-wide: two levels of the reference's binary tree per
+//     128-byte node (host/bvh_build.h), one dependent fetch per step; children
+//     are visited in the order the binary traversal would visit them.
+//   * ONE flattened loop with one stack for both levels: entries are tagged
+//     {wide node, leaf, scene node, enter-instance}; the scene level's leaf
+//     loop `for idx in start..start+num` becomes enter-instance entries pushed
+//     in reverse order, so instances are visited in the reference's order and
+//     `tmax` shrinks identically.
+//   * the stack lives in LDS, one column per quad; inverse object frames are
+//     precomputed at upload (pt.cpp:1012-1013 recomputes a 3x3 adjugate
+//     inverse per ray per object); leaf primitives are 16-byte-aligned records
+//     in leaf order (yh_device.h); the top of the dominant hair tree is read
+//     from LDS ("nodelets").
 #ifndef YH_DEV_TRACE_H_
 #define YH_DEV_TRACE_H_
 #include "dev_math.h"
@@ -126,22 +135,19 @@ YH_DEV bool intersect_bbox(f3 ro, f3 dinv, float tmin_, float tmax_, f3 bmin, f3
 #define YH_TAG_MASK 0xC0000000u
 #define YH_NONE 0xFFFFFFFFu
 
-// Traversal stack. In k_trace the first YH_LDS_STACK entries of every lane
-// live in LDS (column `tid` of a [depth][block] array: conflict-free, one
-// ds_write_b32 / ds_read_b32 per push / pop) and only deeper entries overflow
-// to scratch; kernels without an LDS carve-out (unit-level batches) use
-// scratch only. Pointers into LDS carry the LDS address space so that the
-// compiler emits ds_* instructions instead of flat ones.
-#ifndef YH_LDS_STACK
-#define YH_LDS_STACK 24
+// Traversal stack: YH_QSTACK entries per quad in LDS, column `quad` of a
+// [depth][quads] array (conflict-free; the four lanes of a quad read / write
+// the same word). yh_upload_scene refuses scenes whose trees could need more.
+#ifndef YH_QSTACK
+#define YH_QSTACK 96
 #endif
 #define YH_LDS __attribute__((address_space(3)))
 typedef float v4f __attribute__((ext_vector_type(4)));
 
 struct trace_ctx {
   const yhd_scene*      sc;
-  const YH_LDS v4f*     lds_nodes;  // LDS copy of nodes[lds_node_base ..+count)
-  YH_LDS unsigned int*  lds_stack;  // this lane's LDS stack column
+  const YH_LDS v4f*     lds_nodes;  // LDS copy of nodes[lds_node_base ..+count), or nullptr
+  YH_LDS unsigned int*  lds_stack;  // this quad's LDS stack column
   yhd_counters*         counters;   // NULL in the production kernel
 };
 // one 16-byte load (never split into dwordx3 + dword)
@@ -150,38 +156,36 @@ YH_DEV f3  xyz(v4f a) { return f3{a.x, a.y, a.z}; }
 
 template <bool COUNT>
 YH_DEV void count_add(unsigned long long* slot, unsigned long long n) {
-  if (COUNT) atomicAdd(slot, n);
+  if (COUNT && n) atomicAdd(slot, n);
+}
+// one count per quad (the four lanes of a quad run the same path)
+template <bool COUNT>
+YH_DEV void count_quad(unsigned long long* slot) {
+  if (COUNT && (__lane_id() & 3u) == 0) atomicAdd(slot, 1ull);
 }
 
 // Closest hit against the whole scene (first_object < 0) or against a single
-// instance (intersect_instance_bvh, pt.cpp:1031-1037).
+// instance (intersect_instance_bvh, pt.cpp:1031-1037). Called by all four
+// lanes of a quad with identical arguments; all four return the same hit.
 //
-// "while-while" traversal over the 4-wide tree: every lane first walks nodes
-// until it owns a leaf (or has nothing left), then the lanes of the wave test
-// their leaf's primitives together. One node step = one 128-byte fetch + four
-// of the reference's slab tests; the hit children are visited in exactly the
-// order the reference's binary traversal visits them (near side first by the
-// sign of the ray direction on each split axis, pt.cpp:887-893), so `tmax`
-// shrinks identically and exact-t ties resolve identically.
-template <bool COUNT, bool LDS, int STRIDE>
+// "while-while" traversal over the 4-wide tree: a quad first walks nodes until
+// it holds a leaf (or has nothing left), then the quads of the wave test their
+// leaves' primitives together. One node step = one 128-byte fetch (32 bytes
+// per lane) + one of the reference's slab tests per lane; the hit children are
+// visited in exactly the order the reference's binary traversal visits them
+// (near side first by the sign of the ray direction on each split axis,
+// pt.cpp:887-893), so `tmax` shrinks identically and exact-t ties resolve
+// identically. One leaf step = one primitive test per lane, then the
+// reference's sequential accept rule (math.h:3450: reject only t > tmax, so
+// among equal t the LATER primitive wins) applied as a quad reduction.
+template <bool COUNT, int STRIDE>
 YH_DEV hit_t trace_ray(const trace_ctx& tc, const ray_t& ray, int first_object, unsigned int* steps_out = nullptr) {
-  const yhd_scene& sc = *tc.sc;
-  // stack: `sp` and the LDS column pointer stay in registers; only the
-  // overflow array is addressable memory
-  constexpr int         kLds = LDS ? YH_LDS_STACK : 0;
-  unsigned int          ovf[YH_STACK_MAX - kLds];
-  int                   sp   = 0;
-  YH_LDS unsigned int*  lstk = tc.lds_stack;
-  auto push = [&](unsigned int v) {
-    if (LDS && sp < kLds) lstk[sp * STRIDE] = v;
-    else ovf[sp - kLds] = v;
-    sp++;
-  };
-  auto pop = [&]() -> unsigned int {
-    sp--;
-    if (LDS && sp < kLds) return lstk[sp * STRIDE];
-    return ovf[sp - kLds];
-  };
+  const yhd_scene&     sc   = *tc.sc;
+  const unsigned int   q    = __lane_id() & 3u;
+  int                  sp   = 0;
+  YH_LDS unsigned int* lstk = tc.lds_stack;
+  auto push = [&](unsigned int v) { lstk[sp * STRIDE] = v, sp++; };
+  auto pop  = [&]() -> unsigned int { sp--; return lstk[sp * STRIDE]; };
   hit_t hit;
   hit.object = -1, hit.slot = -1, hit.u = 0, hit.v = 0, hit.distance = 0;
   float tmax = ray.tmax;
@@ -202,7 +206,7 @@ YH_DEV hit_t trace_ray(const trace_ctx& tc, const ray_t& ray, int first_object, 
     cur = YH_TAG_SCENE | 0u;
   }
   while (true) {
-    // ---- phase 1: nodes, until this lane holds a leaf -------------------------
+    // ---- phase 1: nodes, until this quad holds a leaf --------------------------
     while (true) {
       if (COUNT) n_steps++;
       if (cur == YH_NONE) {
@@ -212,40 +216,36 @@ YH_DEV hit_t trace_ray(const trace_ctx& tc, const ray_t& ray, int first_object, 
       unsigned int tag = cur & YH_TAG_MASK;
       if (tag == YH_TAG_LEAF) break;
       if (tag == YH_TAG_SHAPE) {
+        // lane q fetches and tests slot q: {min.xyz, max.x} {max.yz, ref, axes}
         int idx = (int)cur;
-        v4f bx0, by0, bz0, bx1, by1, bz1, rf, mt;
+        v4f s0, s1;
         int rel = idx - sc.lds_node_base;
-        if (LDS && rel >= 0 && rel < sc.lds_node_count) {
-          const YH_LDS v4f* n = tc.lds_nodes + 8 * rel;
-          bx0 = n[0], by0 = n[1], bz0 = n[2], bx1 = n[3], by1 = n[4], bz1 = n[5], rf = n[6], mt = n[7];
+        if (tc.lds_nodes && rel >= 0 && rel < sc.lds_node_count) {
+          const YH_LDS v4f* n = tc.lds_nodes + 8 * rel + 2 * q;
+          s0 = n[0], s1 = n[1];
         } else {
-          const yhd_float4* n = sc.nodes + 8 * (size_t)idx;
-          bx0 = ldg4(n), by0 = ldg4(n + 1), bz0 = ldg4(n + 2), bx1 = ldg4(n + 3), by1 = ldg4(n + 4);
-          bz1 = ldg4(n + 5), rf = ldg4(n + 6), mt = ldg4(n + 7);
+          const yhd_float4* n = sc.nodes + 8 * (size_t)idx + 2 * q;
+          s0 = ldg4(n), s1 = ldg4(n + 1);
         }
-        n_nodes++;
-        bool h0 = intersect_bbox(lo, ldinv, ray.tmin, tmax, f3{bx0.x, by0.x, bz0.x}, f3{bx1.x, by1.x, bz1.x});
-        bool h1 = intersect_bbox(lo, ldinv, ray.tmin, tmax, f3{bx0.y, by0.y, bz0.y}, f3{bx1.y, by1.y, bz1.y});
-        bool h2 = intersect_bbox(lo, ldinv, ray.tmin, tmax, f3{bx0.z, by0.z, bz0.z}, f3{bx1.z, by1.z, bz1.z});
-        bool h3 = intersect_bbox(lo, ldinv, ray.tmin, tmax, f3{bx0.w, by0.w, bz0.w}, f3{bx1.w, by1.w, bz1.w});
-        unsigned int r0 = __float_as_uint(rf.x), r1 = __float_as_uint(rf.y), r2 = __float_as_uint(rf.z),
-                     r3 = __float_as_uint(rf.w);
-        // child wide nodes are shape-local indices
-        if ((r0 & YH_TAG_MASK) == 0) r0 += (unsigned)node_base;
-        if ((r1 & YH_TAG_MASK) == 0) r1 += (unsigned)node_base;
-        if ((r2 & YH_TAG_MASK) == 0) r2 += (unsigned)node_base;
-        if ((r3 & YH_TAG_MASK) == 0) r3 += (unsigned)node_base;
-        unsigned int axes = __float_as_uint(mt.x);
-        bool s0 = (lsign >> (axes & 3)) & 1, sl = (lsign >> ((axes >> 2) & 3)) & 1, sr = (lsign >> ((axes >> 4) & 3)) & 1;
-        // visiting order: (left pair, right pair) or reversed by s0; inside a
-        // pair (first, second) or reversed by that child's own axis sign
-        unsigned int la = sl ? r1 : r0, lb = sl ? r0 : r1;  // left pair in visiting order
+        if (q == 0) n_nodes++;
+        bool         h    = intersect_bbox(lo, ldinv, ray.tmin, tmax, f3{s0.x, s0.y, s0.z}, f3{s0.w, s1.x, s1.y});
+        unsigned int ref  = __float_as_uint(s1.z);
+        unsigned int axes = __float_as_uint(s1.w);
+        if ((ref & YH_TAG_MASK) == 0) ref += (unsigned)node_base;  // child wide nodes are shape-local indices
+        unsigned int m  = quad_ballot(h);
+        unsigned int r0 = quad_bcast_u<0>(ref), r1 = quad_bcast_u<1>(ref), r2 = quad_bcast_u<2>(ref),
+                     r3 = quad_bcast_u<3>(ref);
+        bool h0 = m & 1, h1 = m & 2, h2 = m & 4, h3 = m & 8;
+        bool s0_ = (lsign >> (axes & 3)) & 1, sl = (lsign >> ((axes >> 2) & 3)) & 1, sr = (lsign >> ((axes >> 4) & 3)) & 1;
+        // visiting order: (left pair, right pair) or reversed by the node's own
+        // axis sign; inside a pair (first, second) or reversed by that child's
+        unsigned int la = sl ? r1 : r0, lb = sl ? r0 : r1;
         bool         ha = sl ? h1 : h0, hb = sl ? h0 : h1;
         unsigned int ra = sr ? r3 : r2, rb = sr ? r2 : r3;
         bool         hc = sr ? h3 : h2, hd = sr ? h2 : h3;
-        unsigned int o0 = s0 ? ra : la, o1 = s0 ? rb : lb, o2 = s0 ? la : ra, o3 = s0 ? lb : rb;
-        bool         g0 = s0 ? hc : ha, g1 = s0 ? hd : hb, g2 = s0 ? ha : hc, g3 = s0 ? hb : hd;
-        // push the hit children in reverse visiting order; the first one stays in `cur`
+        unsigned int o0 = s0_ ? ra : la, o1 = s0_ ? rb : lb, o2 = s0_ ? la : ra, o3 = s0_ ? lb : rb;
+        bool         g0 = s0_ ? hc : ha, g1 = s0_ ? hd : hb, g2 = s0_ ? ha : hc, g3 = s0_ ? hb : hd;
+        // push the hit children in reverse visiting order; the first stays in `cur`
         unsigned int next = YH_NONE;
         if (g3) next = o3;
         if (g2) { if (next != YH_NONE) push(next); next = o2; }
@@ -267,10 +267,10 @@ YH_DEV hit_t trace_ray(const trace_ctx& tc, const ray_t& ray, int first_object, 
         cur = YH_TAG_SHAPE | (unsigned)node_base;  // shape root
         continue;
       }
-      // scene-level node (binary, reference layout)
+      // scene-level node (binary, reference layout; every lane of the quad does it)
       int idx = (int)(cur & ~YH_TAG_MASK);
       v4f n0 = ldg4(sc.scene_nodes + 2 * idx), n1 = ldg4(sc.scene_nodes + 2 * idx + 1);
-      n_nodes++;
+      if (q == 0) n_nodes++;
       cur = YH_NONE;
       if (!intersect_bbox(ray.o, wdinv, ray.tmin, tmax, xyz(n0), xyz(n1))) continue;
       int start = __float_as_int(n0.w), meta = __float_as_int(n1.w);
@@ -286,39 +286,43 @@ YH_DEV hit_t trace_ray(const trace_ctx& tc, const ray_t& ray, int first_object, 
       }
     }
     if (cur == YH_NONE) break;  // stack exhausted: traversal finished
-    // ---- phase 2: the leaf's primitives, in leaf order (pt.cpp:905-923) -------
+    // ---- phase 2: the leaf's primitives, one per lane (pt.cpp:905-923) ----------
     int leaf_start = (int)(cur & 0x07FFFFFFu), leaf_num = (int)((cur >> 27) & 7u);
     cur = YH_NONE;
-    if (kind == YH_KIND_LINES) {
-      // all of the leaf's records are requested before the first test
-      const yhd_float4* rec = sc.prims + (size_t)prim_base + (size_t)leaf_start * 4;
-      v4f a0 = ldg4(rec), b0 = ldg4(rec + 1), a1 = a0, b1 = b0, a2 = a0, b2 = b0, a3 = a0, b3 = b0;
-      if (leaf_num > 1) a1 = ldg4(rec + 4), b1 = ldg4(rec + 5);
-      if (leaf_num > 2) a2 = ldg4(rec + 8), b2 = ldg4(rec + 9);
-      if (leaf_num > 3) a3 = ldg4(rec + 12), b3 = ldg4(rec + 13);
-      for (int i = 0; i < leaf_num; i++) {
-        v4f a = i == 0 ? a0 : i == 1 ? a1 : i == 2 ? a2 : a3;
-        v4f b = i == 0 ? b0 : i == 1 ? b1 : i == 2 ? b2 : b3;
+    bool  ok = false;
+    float uu = 0, vv = 0, dist = 0;
+    if ((int)q < leaf_num) {
+      if (kind == YH_KIND_LINES) {
+        const yhd_float4* rec = sc.prims + (size_t)prim_base + (size_t)(leaf_start + (int)q) * 4;
+        v4f a = ldg4(rec), b = ldg4(rec + 1);
         n_seg++;
-        float uu, vv, dist;
-        if (intersect_line(lo, ld, ray.tmin, tmax, xyz(a), xyz(b), a.w, b.w, uu, vv, dist)) {
-          hit.object = cur_obj, hit.slot = leaf_start + i;
-          hit.u = uu, hit.v = vv, hit.distance = dist;
-          tmax = dist;
-        }
-      }
-    } else {
-      for (int i = 0; i < leaf_num; i++) {
-        const yhd_float4* rec = sc.prims + (size_t)prim_base + (size_t)(leaf_start + i) * 6;
+        ok = intersect_line(lo, ld, ray.tmin, tmax, xyz(a), xyz(b), a.w, b.w, uu, vv, dist);
+      } else {
+        const yhd_float4* rec = sc.prims + (size_t)prim_base + (size_t)(leaf_start + (int)q) * 6;
         v4f a = ldg4(rec), b = ldg4(rec + 1), c = ldg4(rec + 2);
         n_tri++;
-        float uu, vv, dist;
-        if (intersect_triangle(lo, ld, ray.tmin, tmax, xyz(a), xyz(b), xyz(c), uu, vv, dist)) {
-          hit.object = cur_obj, hit.slot = leaf_start + i;
-          hit.u = uu, hit.v = vv, hit.distance = dist;
-          tmax = dist;
-        }
+        ok = intersect_triangle(lo, ld, ray.tmin, tmax, xyz(a), xyz(b), xyz(c), uu, vv, dist);
       }
+    }
+    // The reference tests the leaf's primitives in order, shrinking tmax after
+    // each accepted hit: the survivor is the accepted primitive of minimum t,
+    // the LATER one among equal t. Same result as a quad min-reduction.
+    int   key_i = ok ? (int)q : -1;
+    float key_t = dist;
+#define YH_QUAD_MERGE(CTRL)                                                                \
+  {                                                                                        \
+    int   oi = dpp_i<CTRL>(key_i);                                                         \
+    float ot = dpp_f<CTRL>(key_t), ou = dpp_f<CTRL>(uu), ov = dpp_f<CTRL>(vv);             \
+    bool  take = oi >= 0 && (key_i < 0 || ot < key_t || (ot == key_t && oi > key_i));      \
+    if (take) key_i = oi, key_t = ot, uu = ou, vv = ov;                                    \
+  }
+    YH_QUAD_MERGE(YH_QUAD_XOR1)
+    YH_QUAD_MERGE(YH_QUAD_XOR2)
+#undef YH_QUAD_MERGE
+    if (key_i >= 0) {
+      hit.object = cur_obj, hit.slot = leaf_start + key_i;
+      hit.u = uu, hit.v = vv, hit.distance = key_t;
+      tmax = key_t;
     }
   }
   if (COUNT) {

@@ -29,31 +29,35 @@ using namespace yhd;
 // ---------------------------------------------------------------------------
 // The sample loop
 // ---------------------------------------------------------------------------
-// Persistent wavefronts with path regeneration. A wave pulls an 8x8 tile from
-// the launch's tile queue (tiles are queued most-expensive-first using the
-// cost each tile reported in the previous launch); each lane owns one pixel
-// and keeps ONE path in flight. Every iteration traces the current segment of
-// all live lanes, shades it, and a lane whose path ended starts its pixel's
-// next sample in the same iteration (its PCG32 stream is sequential per pixel,
-// pt.cpp:1942-1945, so samples of one pixel cannot run side by side) — lanes
-// never wait for the longest path of a sample, only for the tile's last lane.
+// Persistent wavefronts, quads and path regeneration. A wave pulls a work item
+// — one 4x4-pixel quadrant of an 8x8 tile — from the launch's queue (items are
+// queued most-expensive-first using the cost each reported in the previous
+// launch). Each QUAD (four adjacent lanes) owns one pixel and keeps ONE path in
+// flight: the four lanes run the same path redundantly and split the work
+// inside BVH steps (one box / one primitive per lane) and inside the hair BSDF
+// (one lobe per lane). Every iteration traces the current segment of all live
+// quads and shades it; a quad whose path ended starts its pixel's next sample
+// in the same iteration (a pixel's PCG32 stream is sequential, pt.cpp:1942-1945,
+// so its samples cannot run side by side) — quads never wait for the longest
+// path of a sample, only for the item's last quad.
+#define YH_QUADS (YH_BLOCK / 4)
 template <bool COUNT>
 __global__ __launch_bounds__(YH_BLOCK, YH_MIN_WAVES) void k_trace(const yhd_scene sc, const yhd_state st,
     int nsamples, yhd_counters* counters) {
   extern __shared__ v4f lds_dyn[];
-  // LDS carve-out: [nodelets: 8 * lds_node_count float4][stack: YH_LDS_STACK x YH_BLOCK uint]
+  // LDS carve-out: [nodelets: 8 * lds_node_count float4][stacks: YH_QSTACK x YH_QUADS uint]
   YH_LDS v4f*          lds_nodes = (YH_LDS v4f*)lds_dyn;
   YH_LDS unsigned int* lds_stack = (YH_LDS unsigned int*)(lds_nodes + 8 * sc.lds_node_count);
-  // stage the nodelets: the first lds_node_count nodes (breadth-first = top
-  // levels) of the dominant hair shape, 32 B each, coalesced dwordx4 loads
+  // stage the nodelets: the first lds_node_count wide nodes (breadth-first =
+  // top levels) of the dominant hair shape, 128 B each, coalesced dwordx4 loads
   for (int i = threadIdx.x; i < 8 * sc.lds_node_count; i += blockDim.x)
     lds_nodes[i] = ldg4(sc.nodes + 8 * (size_t)sc.lds_node_base + i);
   __syncthreads();
 
   trace_ctx tc;
-  tc.sc         = &sc;
-  tc.lds_nodes = lds_nodes;
-  tc.lds_stack = lds_stack + threadIdx.x;
+  tc.sc        = &sc;
+  tc.lds_nodes = sc.lds_node_count ? lds_nodes : nullptr;
+  tc.lds_stack = lds_stack + (threadIdx.x >> 2);
   tc.counters  = counters;
 
   const int lane = threadIdx.x & 63;
@@ -64,26 +68,17 @@ __global__ __launch_bounds__(YH_BLOCK, YH_MIN_WAVES) void k_trace(const yhd_scen
     if (t >= st.num_tiles) break;
     unsigned long long t0 = wall_clock64();
     int  item  = st.tiles[t];
-    int  tile  = item & 0xFFFFF, part = (item >> 20) & 15, mode = (item >> 24) & 3;
-    // lane -> pixel inside the tile for the item's split mode
-    int  px, py;
-    bool active;
-    if (mode == 0) {
-      px = lane & 7, py = lane >> 3, active = true;
-    } else if (mode == 1) {
-      px = (part & 1) * 4 + (lane & 3), py = (part >> 1) * 4 + ((lane >> 2) & 3), active = lane < 16;
-    } else {
-      px = (part & 3) * 2 + (lane & 1), py = (part >> 2) * 2 + ((lane >> 1) & 1), active = lane < 4;
-    }
-    int  i     = (tile % st.tiles_x) * YH_TILE + px;
-    int  j     = (tile / st.tiles_x) * YH_TILE + py;
-    bool owner = active && i < st.width && j < st.height;
+    int  tile  = item >> 2, part = item & 3;
+    int  pq    = lane >> 2;  // pixel of the 4x4 quadrant owned by this lane's quad
+    int  i     = (tile % st.tiles_x) * YH_TILE + (part & 1) * 4 + (pq & 3);
+    int  j     = (tile / st.tiles_x) * YH_TILE + (part >> 1) * 4 + (pq >> 2);
+    bool owner = i < st.width && j < st.height;
     size_t pix = owner ? (size_t)j * st.width + i : 0;
     rng_t  rng;
     rng.state      = st.rng_state[pix];
     rng.inc        = st.rng_inc[pix];
     yhd_float4 acc = st.accum[pix];
-    int    left    = owner ? nsamples : 0;  // samples this lane still has to start
+    int    left    = owner ? nsamples : 0;  // samples this quad still has to start
     bool   alive   = false;
     path_t ps;
     ps.bounce = 0, ps.hit = false;
@@ -100,20 +95,20 @@ __global__ __launch_bounds__(YH_BLOCK, YH_MIN_WAVES) void k_trace(const yhd_scen
       if (COUNT) c0 = clock64();
       hit_t isec;
       if (alive) {
-        if (COUNT) count_add<COUNT>(&counters->rays, 1);
-        isec = trace_ray<COUNT, true, YH_BLOCK>(tc, ps.ray, -1, &steps);
+        if (COUNT) count_quad<COUNT>(&counters->rays);
+        isec = trace_ray<COUNT, YH_QUADS>(tc, ps.ray, -1, &steps);
       }
       if (COUNT) c1 = clock64();
       if (alive) {
-        alive = path_step<COUNT, true, YH_BLOCK>(tc, ps, isec, rng, st.bounces);
+        alive = path_step<COUNT, YH_QUADS>(tc, ps, isec, rng, st.bounces);
         if (!alive) {
           path_end(ps, st.clamp, acc);
-          if (COUNT) count_add<COUNT>(&counters->samples, 1);
+          if (COUNT) count_quad<COUNT>(&counters->samples);
         }
       }
       if (COUNT) {
         c2 = clock64();
-        unsigned int smax = steps, ssum = steps, nl = was_alive ? 1 : 0;
+        unsigned int smax = steps, ssum = (lane & 3) == 0 ? steps : 0, nl = (was_alive && (lane & 3) == 0) ? 1 : 0;
         for (int off = 32; off > 0; off >>= 1) {
           smax = max(smax, (unsigned int)__shfl_xor((int)smax, off, 64));
           ssum += (unsigned int)__shfl_xor((int)ssum, off, 64);
@@ -129,14 +124,13 @@ __global__ __launch_bounds__(YH_BLOCK, YH_MIN_WAVES) void k_trace(const yhd_scen
         }
       }
     }
-    if (owner) {
+    if (owner && (lane & 3) == 0) {
       st.rng_state[pix] = rng.state;
       st.accum[pix]     = acc;
     }
     if (lane == 0) {
       unsigned int dt = (unsigned int)(wall_clock64() - t0);
-      atomicMax(&st.tile_cost[tile], dt);
-      atomicAdd(&st.tile_work[tile], dt);
+      st.tile_cost[item] = dt;
       if (COUNT) atomicAdd(&counters->cyc_tile, (unsigned long long)dt);
     }
   }
@@ -282,17 +276,23 @@ __global__ void k_hair_sample(int n, const float* brdf, const float* wo, const f
   f3 w = hair_sample(m, hh, ld3(wo + 3 * i), rn[2 * i], rn[2 * i + 1]);
   out[3 * i] = w.x, out[3 * i + 1] = w.y, out[3 * i + 2] = w.z;
 }
-__global__ void k_intersect(const yhd_scene sc, int n, const float* rays, int* object, int* element,
-    float* uv, float* dist) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+// four threads (one quad) per ray; block of 256 threads = 64 quads
+__global__ __launch_bounds__(256) void k_intersect(const yhd_scene sc, int n, const float* rays, int* object,
+    int* element, float* uv, float* dist) {
+  __shared__ unsigned int stacks[YH_QSTACK * 64];
+  int  i     = (blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+  bool valid = i < n;
+  if (!valid) i = n - 1;  // whole quads stay converged; surplus quads redo the last ray
   trace_ctx tc;
-  tc.sc = &sc, tc.lds_nodes = nullptr, tc.lds_stack = nullptr, tc.counters = nullptr;
+  tc.sc = &sc, tc.lds_nodes = nullptr, tc.counters = nullptr;
+  tc.lds_stack   = (YH_LDS unsigned int*)stacks + (threadIdx.x >> 2);
   const float* r = rays + 8 * (size_t)i;
   ray_t ray      = ray_t{ld3(r), ld3(r + 3), r[6], r[7]};
-  hit_t h        = trace_ray<false, false, 1>(tc, ray, -1);
-  object[i] = h.object, element[i] = hit_element(sc, h);
-  uv[2 * i] = h.u, uv[2 * i + 1] = h.v, dist[i] = h.distance;
+  hit_t h        = trace_ray<false, 64>(tc, ray, -1);
+  if (valid && (threadIdx.x & 3) == 0) {
+    object[i] = h.object, element[i] = hit_element(sc, h);
+    uv[2 * i] = h.u, uv[2 * i + 1] = h.v, dist[i] = h.distance;
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -407,7 +407,7 @@ extern "C" {
 
 int yhk_trace(const yhd_scene* sc, const yhd_state* st, int nsamples, yhd_counters* counters,
     int grid_blocks, hipStream_t stream) {
-  size_t lds = (size_t)sc->lds_node_count * 128 + (size_t)YH_LDS_STACK * YH_BLOCK * 4;
+  size_t lds = (size_t)sc->lds_node_count * 128 + (size_t)YH_QSTACK * YH_QUADS * 4;
   static size_t lds_set[2] = {0, 0};
   if (lds > lds_set[counters ? 1 : 0]) {  // above 64 KB the dynamic-LDS limit must be raised explicitly
     hipError_t e = counters ? hipFuncSetAttribute((const void*)k_trace<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
@@ -422,7 +422,8 @@ int yhk_trace(const yhd_scene* sc, const yhd_state* st, int nsamples, yhd_counte
   return (int)hipGetLastError();
 }
 int yhk_block_threads(void) { return YH_BLOCK; }
-int yhk_trace_lds_bytes(int lds_node_count) { return lds_node_count * 128 + YH_LDS_STACK * YH_BLOCK * 4; }
+int yhk_stack_entries(void) { return YH_QSTACK; }
+int yhk_trace_lds_bytes(int lds_node_count) { return lds_node_count * 128 + YH_QSTACK * YH_QUADS * 4; }
 int yhk_trace_occupancy(int lds_bytes) {
   int blocks = 0;
   (void)hipFuncSetAttribute((const void*)k_trace<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
@@ -462,7 +463,7 @@ int yhk_hair_sample(int n, const float* brdf, const float* wo, const float* rn, 
 }
 int yhk_intersect(const yhd_scene* sc, int n, const float* rays, int* object, int* element, float* uv, float* dist,
     hipStream_t s) {
-  hipLaunchKernelGGL(k_intersect, dim3((n + 255) / 256), dim3(256), 0, s, *sc, n, rays, object, element, uv, dist);
+  hipLaunchKernelGGL(k_intersect, dim3((n + 63) / 64), dim3(256), 0, s, *sc, n, rays, object, element, uv, dist);
   return (int)hipGetLastError();
 }
 int yhk_selftest(int which, float beta_m, float beta_n, uint64_t state, uint64_t inc, int count, const float* wo,

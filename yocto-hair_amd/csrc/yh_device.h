@@ -26,7 +26,6 @@
 #define YH_KIND_LINES 1
 #define YH_KIND_TRIANGLES 2
 #define YH_TILE 8          /* tiles are 8x8 pixels = one 64-lane wavefront  */
-#define YH_STACK_MAX 96    /* traversal stack entries per lane               */
 #define YH_MAX_LIGHTS 16
 #define YH_MAX_ENVS 4
 
@@ -123,16 +122,11 @@ typedef struct yhd_state {
   uint64_t*   rng_state;  // per pixel
   uint64_t*   rng_inc;    // per pixel
   yhd_float4* accum;      // per pixel: sum of clamped radiance, w = hit count
-  // Work items of a launch, in hand-out order. An item is a tile or a part of
-  // one: bits 0-19 tile id, bits 20-23 part index, bits 24-25 split mode
-  // (0 = whole 8x8 tile on 64 lanes, 1 = one of four 4x4 quadrants on 16
-  // lanes, 2 = one of sixteen 2x2 blocks on 4 lanes). Expensive (hair) tiles
-  // are split so that their pixels' sequential sample chains run on several
-  // SIMDs instead of waiting for each other inside one wavefront.
+  // Work items of a launch, in hand-out order: item = tile id * 4 + quadrant
+  // (one 4x4-pixel quadrant of an 8x8 tile = 16 quads = one wavefront).
   const int*  tiles;
   int*        tile_cursor;  // next position in `tiles` (zeroed before every launch)
-  unsigned int* tile_cost;  // per tile id: max over its parts of the wall-clock ticks spent (zeroed per launch)
-  unsigned int* tile_work;  // per tile id: sum over its parts (zeroed per launch)
+  unsigned int* tile_cost;  // per item: wall-clock ticks (100 MHz) its last launch took
   int         num_tiles;  // number of work items in `tiles`
   int         width, height;
   int         tiles_x;

@@ -114,26 +114,26 @@ int collapse_wide(const Tree& tree, std::vector<WideNode>& out) {
     queue.pop_front();
     max_depth = std::max(max_depth, it.depth);
     WideNode w;
+    unsigned axes = 0;
     for (int s = 0; s < 4; s++) {
-      for (int k = 0; k < 3; k++) w.bmin[k][s] = inf, w.bmax[k][s] = -inf;
-      w.ref[s] = 0xFFFFFFFFu;
+      for (int k = 0; k < 3; k++) w.slot[s].bmin[k] = inf, w.slot[s].bmax[k] = -inf;
+      w.slot[s].ref = 0xFFFFFFFFu, w.slot[s].axes = 0;
     }
-    w.axes = 0, w.pad[0] = w.pad[1] = w.pad[2] = 0;
     auto set_slot = [&](int s, int binary) {
       const Node& n = tree.nodes[binary];
-      for (int k = 0; k < 3; k++) w.bmin[k][s] = n.bbox.min[k], w.bmax[k][s] = n.bbox.max[k];
-      w.ref[s] = n.internal ? new_wide(binary, it.depth + 1) : leaf_ref(n);
+      for (int k = 0; k < 3; k++) w.slot[s].bmin[k] = n.bbox.min[k], w.slot[s].bmax[k] = n.bbox.max[k];
+      w.slot[s].ref = n.internal ? new_wide(binary, it.depth + 1) : leaf_ref(n);
     };
     const Node& b = tree.nodes[it.binary];
     if (!b.internal) {  // a shape whose binary root is a leaf
       set_slot(0, it.binary);
     } else {
-      w.axes = b.axis;
+      axes = b.axis;
       for (int side = 0; side < 2; side++) {
         int         child = b.start + side;
         const Node& c     = tree.nodes[child];
         if (c.internal) {
-          w.axes |= (unsigned)c.axis << (2 + 2 * side);
+          axes |= (unsigned)c.axis << (2 + 2 * side);
           set_slot(2 * side + 0, c.start + 0);
           set_slot(2 * side + 1, c.start + 1);
         } else {
@@ -141,6 +141,7 @@ int collapse_wide(const Tree& tree, std::vector<WideNode>& out) {
         }
       }
     }
+    for (int s = 0; s < 4; s++) w.slot[s].axes = axes;
     out[it.wide] = w;
   }
   return max_depth;

@@ -31,21 +31,24 @@ struct Tree {
 void build_bvh(Tree& tree, const std::vector<Box>& boxes);
 
 // 4-wide node for the device: two levels of the binary tree collapsed into one
-// 128-byte record (SoA over the four slots) so that a traversal step is ONE
-// dependent fetch that tests four of the reference's node boxes.
+// 128-byte record of four 32-byte slots, so that a traversal step is ONE
+// dependent fetch in which the four lanes of a "quad" each test one of the
+// reference's node boxes.
 //   slots 0,1 = children of the binary node's left child (or the left child
 //   itself in slot 0 when it is a leaf); slots 2,3 likewise for the right child.
 //   ref: bits 31,30 set = leaf, bits 27..29 = primitive count, bits 0..26 =
-//        first leaf slot; otherwise the index of the child wide node. 0xFFFFFFFF =
-//        empty slot (its box is inverted and can never be hit).
-//   axes = split axis of the binary node | left child's << 2 | right child's
-//        << 4: the three comparisons that reproduce the reference's near-first
-//        visiting order (pt.cpp:887-893), so leaves are visited in the same
-//        order as in the binary tree.
+//        first leaf slot; otherwise the index of the child wide node.
+//        0xFFFFFFFF = empty slot (its box is inverted and can never be hit).
+//   axes (same in the four slots) = split axis of the binary node | left
+//        child's << 2 | right child's << 4: the three comparisons that
+//        reproduce the reference's near-first visiting order (pt.cpp:887-893),
+//        so leaves are visited in the same order as in the binary tree.
+struct WideSlot {
+  float    bmin[3], bmax[3];
+  unsigned ref, axes;
+};
 struct WideNode {
-  float    bmin[3][4], bmax[3][4];
-  unsigned ref[4];
-  unsigned axes, pad[3];
+  WideSlot slot[4];
 };
 static_assert(sizeof(WideNode) == 128, "wide node is 128 bytes");
 // Wide nodes come out in breadth-first order (the first K nodes are the top of

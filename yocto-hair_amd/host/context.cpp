@@ -33,6 +33,7 @@ int yhk_trace(const yhd_scene*, const yhd_state*, int, yhd_counters*, int, hipSt
 int yhk_block_threads(void);
 int yhk_trace_occupancy(int lds_bytes);
 int yhk_trace_lds_bytes(int lds_node_count);
+int yhk_stack_entries(void);
 int yhk_resolve(const yhd_state*, int, int, void*, hipStream_t);
 int yhk_pack(const yhd_state*, int, int, void*, hipStream_t);
 int yhk_unpack(const void*, int, int, int, int, int, int, int, void*, hipStream_t);
@@ -209,11 +210,9 @@ struct yh_context {
   bool             have_state = false;
   yhd_state        state{};
   yh_trace_params  params{};
-  DevBuf           d_rng_state, d_rng_inc, d_accum, d_tiles, d_image, d_counters, d_tile_cursor, d_tile_cost, d_tile_work;
+  DevBuf           d_rng_state, d_rng_inc, d_accum, d_tiles, d_image, d_counters, d_tile_cursor, d_tile_cost;
   std::vector<int> owned;      // owned tile ids, increasing
-  std::vector<unsigned char> tile_mode;  // per tile id: split mode 0 / 1 / 2 (scheduling hint, kept across init_state)
-  std::vector<unsigned int>  tile_cost;  // per tile id: last measured max-part cost
-  int              items_capacity = 0;
+  std::vector<unsigned int>  item_cost;  // per work item (tile * 4 + quadrant): last measured cost (scheduling hint, kept across init_state)
   int              rank = 0, world = 1;
   int              num_tiles_total = 0;
   float            last_ms = 0;
@@ -277,18 +276,10 @@ void build_work_items(const yh_context* ctx, std::vector<int>& items);
 
 namespace {
 void build_work_items(const yh_context* ctx, std::vector<int>& items) {
-  struct It {
-    int          item;
-    unsigned int cost;
-  };
-  std::vector<It> v;
-  for (int t : ctx->owned) {
-    int mode = ctx->tile_mode[t], parts = mode == 0 ? 1 : mode == 1 ? 4 : 16;
-    for (int p = 0; p < parts; p++) v.push_back({t | (p << 20) | (mode << 24), ctx->tile_cost[t]});
-  }
-  std::stable_sort(v.begin(), v.end(), [](const It& a, const It& b) { return a.cost > b.cost; });
-  items.resize(v.size());
-  for (size_t i = 0; i < v.size(); i++) items[i] = v[i].item;
+  items.clear();
+  for (int t : ctx->owned)
+    for (int p = 0; p < 4; p++) items.push_back(t * 4 + p);
+  std::stable_sort(items.begin(), items.end(), [&](int a, int b) { return ctx->item_cost[a] > ctx->item_cost[b]; });
 }
 }  // namespace
 
@@ -474,8 +465,8 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
   for (auto& I : info) max_shape_depth = std::max(max_shape_depth, I.depth);
   // a wide node pushes at most three entries and keeps the fourth in a register
   ctx->stack_need = scene_tree.max_depth + 4 + 3 * max_shape_depth + 2;
-  if (ctx->stack_need > YH_STACK_MAX)
-    return fail(ctx, YH_E_INVALID, "BVH too deep for the traversal stack (%d > %d)", ctx->stack_need, YH_STACK_MAX);
+  if (ctx->stack_need > yhk_stack_entries())
+    return fail(ctx, YH_E_INVALID, "BVH too deep for the traversal stack (%d > %d)", ctx->stack_need, yhk_stack_entries());
   // ---- materials ---------------------------------------------------------
   std::vector<yhd_material> materials(sd->num_materials);
   for (int i = 0; i < sd->num_materials; i++) make_material(sd->materials[i], materials[i]);
@@ -608,27 +599,21 @@ int yh_init_state(yh_context* ctx, const yh_trace_params* params) {
   auto& owned = ctx->owned;
   owned.clear();
   for (int t = ctx->rank; t < ctx->num_tiles_total; t += ctx->world) owned.push_back(t);
-  if ((int)ctx->tile_mode.size() != ctx->num_tiles_total) {  // scheduling hints survive a re-init of the same image
-    ctx->tile_mode.assign(ctx->num_tiles_total, 0);
-    ctx->tile_cost.assign(ctx->num_tiles_total, 0);
-  }
+  if ((int)ctx->item_cost.size() != ctx->num_tiles_total * 4)  // scheduling hints survive a re-init of the same image
+    ctx->item_cost.assign((size_t)ctx->num_tiles_total * 4, 0);
   std::vector<int> tiles;
   build_work_items(ctx, tiles);
-  ctx->items_capacity = (int)owned.size() * 16;
   int rc;
   if ((rc = upload(ctx, ctx->d_rng_state, st.data(), npix * 8))) return rc;
   if ((rc = upload(ctx, ctx->d_rng_inc, inc.data(), npix * 8))) return rc;
   if ((rc = alloc_zero(ctx, ctx->d_accum, npix * 16))) return rc;
   if ((rc = alloc_zero(ctx, ctx->d_image, npix * 16))) return rc;
-  if ((rc = alloc_zero(ctx, ctx->d_tiles, (size_t)ctx->items_capacity * 4 + 16))) return rc;
-  HIPCHK(ctx, hipMemcpy(ctx->d_tiles.p, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice));
+  if ((rc = upload(ctx, ctx->d_tiles, tiles.data(), tiles.size() * 4))) return rc;
   if ((rc = alloc_zero(ctx, ctx->d_counters, sizeof(yhd_counters)))) return rc;
   if ((rc = alloc_zero(ctx, ctx->d_tile_cursor, 4))) return rc;
-  if ((rc = alloc_zero(ctx, ctx->d_tile_cost, (size_t)ctx->num_tiles_total * 4))) return rc;
-  if ((rc = alloc_zero(ctx, ctx->d_tile_work, (size_t)ctx->num_tiles_total * 4))) return rc;
+  if ((rc = alloc_zero(ctx, ctx->d_tile_cost, (size_t)ctx->num_tiles_total * 16))) return rc;
   auto& s = ctx->state;
   s.tile_cursor = (int*)ctx->d_tile_cursor.p, s.tile_cost = (unsigned int*)ctx->d_tile_cost.p;
-  s.tile_work = (unsigned int*)ctx->d_tile_work.p;
   s.rng_state = (uint64_t*)ctx->d_rng_state.p, s.rng_inc = (uint64_t*)ctx->d_rng_inc.p;
   s.accum = (yhd_float4*)ctx->d_accum.p, s.tiles = (const int*)ctx->d_tiles.p;
   s.num_tiles = (int)tiles.size(), s.width = w, s.height = h, s.tiles_x = tx;
@@ -655,14 +640,13 @@ static int trace_impl(yh_context* ctx, int nsamples, bool counted, bool sync) {
     ctx->last_ms = 0, ctx->last_launches = 0;
     return YH_OK;
   }
-  int waves_per_block = yhk_block_threads() / 64;
+  int waves_per_block = yhk_block_threads() / 64;  // one work item per wave at a time
   int lds_bytes       = yhk_trace_lds_bytes(ctx->scene.lds_node_count);
   int resident        = ctx->num_cus * yhk_trace_occupancy(lds_bytes);
   int want            = (ctx->state.num_tiles + waves_per_block - 1) / waves_per_block;
   int grid            = std::max(1, std::min(want, resident));
   HIPCHK(ctx, hipMemsetAsync(ctx->d_tile_cursor.p, 0, 4, ctx->stream));
-  HIPCHK(ctx, hipMemsetAsync(ctx->d_tile_cost.p, 0, (size_t)ctx->num_tiles_total * 4, ctx->stream));
-  HIPCHK(ctx, hipMemsetAsync(ctx->d_tile_work.p, 0, (size_t)ctx->num_tiles_total * 4, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(ctx->d_tile_cost.p, 0, (size_t)ctx->num_tiles_total * 16, ctx->stream));
   HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   int e = yhk_trace(&ctx->scene, &ctx->state, nsamples, counted ? (yhd_counters*)ctx->d_counters.p : nullptr, grid,
       ctx->stream);
@@ -673,28 +657,13 @@ static int trace_impl(yh_context* ctx, int nsamples, bool counted, bool sync) {
   if (sync) {
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     HIPCHK(ctx, hipEventElapsedTime(&ctx->last_ms, ctx->ev0, ctx->ev1));
-    // Re-plan the next launch from what this one measured (pixel results do not
-    // depend on the plan): split tiles whose slowest part exceeds the balanced
-    // share of a wave slot, merge cheap ones back, and hand items out
-    // longest-first. A pixel's samples are sequential (one PCG32 stream), so an
-    // expensive hair tile bounds the launch unless its pixels are spread over
-    // more wavefronts.
-    std::vector<unsigned int> work(ctx->num_tiles_total);
-    HIPCHK(ctx, hipMemcpy(ctx->tile_cost.data(), ctx->d_tile_cost.p, work.size() * 4, hipMemcpyDeviceToHost));
-    HIPCHK(ctx, hipMemcpy(work.data(), ctx->d_tile_work.p, work.size() * 4, hipMemcpyDeviceToHost));
-    double total = 0;
-    for (int t : ctx->owned) total += work[t];
-    double slots = (double)ctx->num_cus * 16;  // 4 waves per SIMD
-    double goal  = 1.5 * total / slots;
-    for (int t : ctx->owned) {
-      auto& m = ctx->tile_mode[t];
-      if (ctx->tile_cost[t] > goal && m < 2) m++;
-      else if (m > 0 && 4.0 * ctx->tile_cost[t] < goal) m--;
-    }
+    // Longest-processing-time-first for the next launch (pixel results do not
+    // depend on the order): a pixel's samples are sequential, so the items that
+    // start last bound the launch; hair quadrants cost 10-100x background ones.
+    HIPCHK(ctx, hipMemcpy(ctx->item_cost.data(), ctx->d_tile_cost.p, ctx->item_cost.size() * 4, hipMemcpyDeviceToHost));
     std::vector<int> tiles;
     build_work_items(ctx, tiles);
     HIPCHK(ctx, hipMemcpy(ctx->d_tiles.p, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice));
-    ctx->state.num_tiles = (int)tiles.size();
   }
   return YH_OK;
 }
@@ -791,7 +760,10 @@ int yh_tile_costs(yh_context* ctx, uint32_t* ticks, int count) {
   if (count < ctx->num_tiles_total) return fail(ctx, YH_E_INVALID, "buffer holds %d tiles, image has %d", count, ctx->num_tiles_total);
   HIPCHK(ctx, hipSetDevice(ctx->device));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  HIPCHK(ctx, hipMemcpy(ticks, ctx->d_tile_cost.p, (size_t)ctx->num_tiles_total * 4, hipMemcpyDeviceToHost));
+  std::vector<unsigned int> cost((size_t)ctx->num_tiles_total * 4);
+  HIPCHK(ctx, hipMemcpy(cost.data(), ctx->d_tile_cost.p, cost.size() * 4, hipMemcpyDeviceToHost));
+  for (int t = 0; t < ctx->num_tiles_total; t++)  // a tile is four work items (4x4 quadrants): report their sum
+    ticks[t] = cost[4 * t] + cost[4 * t + 1] + cost[4 * t + 2] + cost[4 * t + 3];
   return YH_OK;
 }
 
