@@ -60,11 +60,14 @@ def cpu_baseline(scene_json, resolution, budget_s=15.0):
     img = sc.render(p, spp, nthreads=threads)
     dt = time.time() - t0
     n = img.shape[0] * img.shape[1] * spp
+    # work counts of the REFERENCE algorithm (binary BVH, <= 4 primitives per leaf) on this scene:
+    # the N_* of SURVEY.md 8(d)'s algorithmic-bytes formula
+    _, wc = sc.render(p, 2, nthreads=threads, want_counts=True)
     sc.close()
     sf.close()
     return {"value": round(n / dt / 1e6, 3), "unit": "Msamples/s", "cores": threads, "kind": "port",
             "sample": f"{img.shape[1]}x{img.shape[0]} x {spp} spp of the same scene, {dt:.1f} s, "
-                      f"oracle/libyh_oracle.so with {threads} threads (BVH build {build_s:.1f} s not counted)"}
+                      f"oracle/libyh_oracle.so with {threads} threads (BVH build {build_s:.1f} s not counted)"}, wc
 
 
 def main():
@@ -121,16 +124,18 @@ def main():
     ctx.set_shard(rank, world)
     width, height = ctx.init_state(p)
 
-    # ---- work counts for the roofline (instrumented kernel, outside the timed region) ------------
-    wc = ctx.trace_samples_counted(2)
-    counts = wc.as_dict()
-    if world > 1:
-        t = torch.tensor([counts[k] for k in sorted(counts)], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t)
-        counts = {k: int(v) for k, v in zip(sorted(counts), t.tolist())}
-        wc = yh.WorkCounts(**counts)
-    bytes_per_sample = wc.bytes_per_sample(a.spp_per_step)
+    # ---- work counts (outside the timed region) ---------------------------------------------------
+    # The roofline's algorithmic bytes use the work counts of the REFERENCE algorithm, measured by
+    # the CPU oracle on this scene (rank 0; 2 spp). The instrumented kernel's own counts are
+    # reported next to them: its 4-wide BVH visits fewer, fatter nodes.
+    ALGO = ("samples", "rays", "nodes", "seg_tests", "tri_tests", "hair_shades", "surf_shades", "env_lookups", "env_samples")
+    gpu_counts = ctx.trace_samples_counted(2).as_dict()
     ctx.init_state(p)  # start the measured render from a fresh state
+    cpu = None
+    if rank == 0 and not a.no_cpu_baseline:
+        cpu, ref_wc = cpu_baseline(scene_json, a.resolution)
+    elif rank == 0:
+        ref_wc = None
 
     # ---- warmup + timed steps ------------------------------------------------------------------
     for _ in range(a.warmup):
@@ -167,6 +172,14 @@ def main():
         samples = width * height * spp_total
         value = samples / elapsed / 1e6
         launch_s = kernel_ms / 1e3 / max(1, a.steps)               # average k_trace duration (per rank)
+        if ref_wc is not None:
+            counts, counts_from = ref_wc.as_dict(), "reference algorithm (CPU oracle, 2 spp)"
+            bytes_per_sample = ref_wc.bytes_per_sample(a.spp_per_step)
+        else:  # --no-cpu-baseline: fall back to the kernel's own counters (4-wide nodes counted as 128 B)
+            counts, counts_from = gpu_counts, "instrumented kernel (4-wide BVH; --no-cpu-baseline)"
+            g = gpu_counts
+            bytes_per_sample = (128 * g["nodes"] + 44 * g["seg_tests"] + 52 * g["tri_tests"] + 104 * g["hair_shades"] +
+                                48 * g["env_lookups"] + 88 * g["env_samples"]) / max(1, g["samples"]) + 32.0 / a.spp_per_step
         bytes_per_launch = bytes_per_sample * width * height * a.spp_per_step / world
         achieved = bytes_per_launch / launch_s / 1e9
         out = {
@@ -184,12 +197,13 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "kernel": "k_trace",
                          "avg_launch_ms": round(launch_s * 1e3, 3),
                          "algorithmic_bytes_per_sample": round(bytes_per_sample, 1),
-                         "work_counts_per_sample": {k: round(counts[k] / max(1, counts["samples"]), 3) for k in
-                                                    ("rays", "nodes", "seg_tests", "tri_tests", "hair_shades",
-                                                     "surf_shades", "env_lookups", "env_samples")}},
+                         "work_counts_from": counts_from,
+                         "work_counts_per_sample": {k: round(counts[k] / max(1, counts["samples"]), 3) for k in ALGO[1:]},
+                         "kernel_counts_per_sample": {k: round(gpu_counts[k] * world / max(1, gpu_counts["samples"] * world), 3)
+                                                      for k in ALGO[1:]}},
         }
-        if not a.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(scene_json, a.resolution)
+        if cpu is not None and world == 1:
+            out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
