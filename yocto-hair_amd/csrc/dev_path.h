@@ -20,12 +20,15 @@ namespace yhd {
 YH_DEV ray_t sample_camera(const yhd_camera& cam, int i, int j, int w, int h, float pu, float pv,
     float lu, float lv) {
   float uvx = ((float)i + pu) / (float)w, uvy = ((float)j + pv) / (float)h;
-  float r   = sqrtf(lv);
-  float phi = 2 * pif * lu;
-  float lx = cosf(phi) * r, ly = sinf(phi) * r;
   f3    q  = {cam.film_x * (0.5f - uvx), cam.film_y * (uvy - 0.5f), cam.lens};
   f3    dc = -normalize(q);
-  f3    e  = {lx * cam.aperture / 2, ly * cam.aperture / 2, 0};
+  f3    e  = mk3(0.0f);
+  if (cam.aperture != 0) {  // pinhole: lens point = finite * 0 / 2 = 0 whatever sample_disk returns
+    float r   = sqrtf(lv);
+    float phi = 2 * pif * lu;
+    float lx = cosf(phi) * r, ly = sinf(phi) * r;
+    e = f3{lx * cam.aperture / 2, ly * cam.aperture / 2, 0};
+  }
   f3    p  = dc * cam.focus / fabs_(dc.z);
   f3    d  = normalize(p - e);
   frame f  = ldframe(cam.frame);
@@ -107,11 +110,15 @@ YH_DEV f3 eval_environment(const trace_ctx& tc, f3 dir) {
   f3 emission = mk3(0.0f);
   for (int k = 0; k < sc.num_environments; k++) {
     const yhd_environment& env = sc.environments[k];
+    if (COUNT) count_quad<COUNT>(&tc.counters->envl);
+    if (env.tex_w == 0) {  // no texture: eval_texture returns {1,1,1} whatever the coordinates are
+      emission = emission + ld3(env.emission) * mk3(1.0f);
+      continue;
+    }
     f3    wl = transform_direction(ldframe(env.inv_frame), dir);
     float tx = atan2f(wl.z, wl.x) / (2 * pif);
     float ty = acosf(fclamp(wl.y, -1.0f, 1.0f)) / pif;
     if (tx < 0) tx += 1;
-    if (COUNT) count_quad<COUNT>(&tc.counters->envl);
     emission = emission + ld3(env.emission) * eval_env_texture(sc, env, tx, ty);
   }
   return emission;

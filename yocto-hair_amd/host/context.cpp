@@ -276,10 +276,17 @@ void build_work_items(const yh_context* ctx, std::vector<int>& items);
 
 namespace {
 void build_work_items(const yh_context* ctx, std::vector<int>& items) {
-  items.clear();
+  // sort (cost descending, item ascending) as packed 64-bit keys
+  std::vector<uint64_t> keys;
+  keys.reserve(ctx->owned.size() * 4);
   for (int t : ctx->owned)
-    for (int p = 0; p < 4; p++) items.push_back(t * 4 + p);
-  std::stable_sort(items.begin(), items.end(), [&](int a, int b) { return ctx->item_cost[a] > ctx->item_cost[b]; });
+    for (int p = 0; p < 4; p++) {
+      unsigned item = (unsigned)(t * 4 + p);
+      keys.push_back(((uint64_t)(0xFFFFFFFFu - ctx->item_cost[item]) << 32) | item);
+    }
+  std::sort(keys.begin(), keys.end());
+  items.resize(keys.size());
+  for (size_t i = 0; i < keys.size(); i++) items[i] = (int)(keys[i] & 0xFFFFFFFFu);
 }
 }  // namespace
 

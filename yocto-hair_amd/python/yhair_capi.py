@@ -178,12 +178,15 @@ class SceneFile:
         self.desc = lib.yh_scene_get(self.handle)
 
     def close(self):
-        if self.handle:
+        if self.handle and load is not None:
             load().yh_scene_free(self.handle)
             self.handle = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown
+            pass
 
 
 class Context:
