@@ -168,10 +168,8 @@ YH_DEV void count_quad(unsigned long long* slot) {
 // instance (intersect_instance_bvh, pt.cpp:1031-1037). Called by all four
 // lanes of a quad with identical arguments; all four return the same hit.
 //
-// "while-while" traversal over the 4-wide tree: a quad first walks nodes until
-// it holds a leaf (or has nothing left), then the quads of the wave test their
-// leaves' primitives together. One node step = one 128-byte fetch (32 bytes
-// per lane) + one of the reference's slab tests per lane; the hit children are
+// One node step = one 128-byte fetch (32 bytes per lane) + one of the
+// reference's slab tests per lane; the hit children are
 // visited in exactly the order the reference's binary traversal visits them
 // (near side first by the sign of the ray direction on each split axis,
 // pt.cpp:887-893), so `tmax` shrinks identically and exact-t ties resolve
@@ -205,28 +203,29 @@ YH_DEV hit_t trace_ray(const trace_ctx& tc, const ray_t& ray, int first_object, 
     if (sc.num_scene_nodes == 0) return hit;
     cur = YH_TAG_SCENE | 0u;
   }
+  // One loop, one dependent fetch per iteration: whatever a quad holds — a wide
+  // node or a leaf — every lane fetches "its" 32 bytes (slot q of the node, or
+  // the test half of primitive q of the leaf) with the same two load
+  // instructions, and only the arithmetic diverges. The wave therefore pays one
+  // memory round trip per step of its slowest quad, not one per kind of step.
   while (true) {
-    // ---- phase 1: nodes, until this quad holds a leaf --------------------------
-    while (true) {
-      if (COUNT) n_steps++;
-      if (cur == YH_NONE) {
-        if (sp == 0) break;
-        cur = pop();
-      }
-      unsigned int tag = cur & YH_TAG_MASK;
-      if (tag == YH_TAG_LEAF) break;
-      if (tag == YH_TAG_SHAPE) {
-        // lane q fetches and tests slot q: {min.xyz, max.x} {max.yz, ref, axes}
-        int idx = (int)cur;
-        v4f s0, s1;
-        int rel = idx - sc.lds_node_base;
-        if (tc.lds_nodes && rel >= 0 && rel < sc.lds_node_count) {
-          const YH_LDS v4f* n = tc.lds_nodes + 8 * rel + 2 * q;
-          s0 = n[0], s1 = n[1];
-        } else {
-          const yhd_float4* n = sc.nodes + 8 * (size_t)idx + 2 * q;
-          s0 = ldg4(n), s1 = ldg4(n + 1);
-        }
+    if (COUNT) n_steps++;
+    if (cur == YH_NONE) {
+      if (sp == 0) break;
+      cur = pop();
+    }
+    unsigned int tag = cur & YH_TAG_MASK;
+    if (tag == YH_TAG_SHAPE || tag == YH_TAG_LEAF) {
+      bool is_leaf    = tag == YH_TAG_LEAF;
+      int  leaf_start = (int)(cur & 0x07FFFFFFu), leaf_num = (int)((cur >> 27) & 7u);
+      int  rec        = kind == YH_KIND_LINES ? 4 : 6;  // float4 per leaf record
+      bool mine       = !is_leaf || (int)q < leaf_num;  // lanes beyond the leaf's count re-read its last record
+      int  pq         = mine ? (int)q : leaf_num - 1;
+      const yhd_float4* addr = is_leaf ? sc.prims + (size_t)prim_base + (size_t)(leaf_start + pq) * rec
+                                       : sc.nodes + 8 * (size_t)cur + 2 * q;
+      v4f s0 = ldg4(addr), s1 = ldg4(addr + 1);
+      if (!is_leaf) {
+        // ---- wide node: lane q tests slot q {min.xyz, max.x} {max.yz, ref, axes} ----
         if (q == 0) n_nodes++;
         bool         h    = intersect_bbox(lo, ldinv, ray.tmin, tmax, f3{s0.x, s0.y, s0.z}, f3{s0.w, s1.x, s1.y});
         unsigned int ref  = __float_as_uint(s1.z);
@@ -252,63 +251,28 @@ YH_DEV hit_t trace_ray(const trace_ctx& tc, const ray_t& ray, int first_object, 
         if (g1) { if (next != YH_NONE) push(next); next = o1; }
         if (g0) { if (next != YH_NONE) push(next); next = o0; }
         cur = next;
-        continue;
-      }
-      if (tag == YH_TAG_ENTER) {
-        // transform_ray(inverse(object.frame, true), ray) (pt.cpp:1012-1013)
-        cur_obj             = (int)(cur & ~YH_TAG_MASK);
-        const yhd_object& o = sc.objects[cur_obj];
-        frame inv           = ldframe(o.inv_frame);
-        lo                  = transform_point(inv, ray.o);
-        ld                  = transform_vector(inv, ray.d);
-        ldinv               = {1 / ld.x, 1 / ld.y, 1 / ld.z};
-        lsign = (ldinv.x < 0 ? 1 : 0) | (ldinv.y < 0 ? 2 : 0) | (ldinv.z < 0 ? 4 : 0);
-        kind = o.kind, node_base = o.node_base, prim_base = o.prim_base;
-        cur = YH_TAG_SHAPE | (unsigned)node_base;  // shape root
-        continue;
-      }
-      // scene-level node (binary, reference layout; every lane of the quad does it)
-      int idx = (int)(cur & ~YH_TAG_MASK);
-      v4f n0 = ldg4(sc.scene_nodes + 2 * idx), n1 = ldg4(sc.scene_nodes + 2 * idx + 1);
-      if (q == 0) n_nodes++;
-      cur = YH_NONE;
-      if (!intersect_bbox(ray.o, wdinv, ray.tmin, tmax, xyz(n0), xyz(n1))) continue;
-      int start = __float_as_int(n0.w), meta = __float_as_int(n1.w);
-      if (meta & 0x10000) {  // internal
-        int axis = (meta >> 24) & 3;
-        int near = (wsign >> axis) & 1;  // dsign set: visit start+1 first
-        push(YH_TAG_SCENE | (unsigned)(start + 1 - near));
-        cur = YH_TAG_SCENE | (unsigned)(start + near);
       } else {
-        int num = meta & 0xffff;
-        for (int i = num - 1; i >= 1; i--) push(YH_TAG_ENTER | (unsigned)sc.scene_prims[start + i]);
-        if (num > 0) cur = YH_TAG_ENTER | (unsigned)sc.scene_prims[start];
-      }
-    }
-    if (cur == YH_NONE) break;  // stack exhausted: traversal finished
-    // ---- phase 2: the leaf's primitives, one per lane (pt.cpp:905-923) ----------
-    int leaf_start = (int)(cur & 0x07FFFFFFu), leaf_num = (int)((cur >> 27) & 7u);
-    cur = YH_NONE;
-    bool  ok = false;
-    float uu = 0, vv = 0, dist = 0;
-    if ((int)q < leaf_num) {
-      if (kind == YH_KIND_LINES) {
-        const yhd_float4* rec = sc.prims + (size_t)prim_base + (size_t)(leaf_start + (int)q) * 4;
-        v4f a = ldg4(rec), b = ldg4(rec + 1);
-        n_seg++;
-        ok = intersect_line(lo, ld, ray.tmin, tmax, xyz(a), xyz(b), a.w, b.w, uu, vv, dist);
-      } else {
-        const yhd_float4* rec = sc.prims + (size_t)prim_base + (size_t)(leaf_start + (int)q) * 6;
-        v4f a = ldg4(rec), b = ldg4(rec + 1), c = ldg4(rec + 2);
-        n_tri++;
-        ok = intersect_triangle(lo, ld, ray.tmin, tmax, xyz(a), xyz(b), xyz(c), uu, vv, dist);
-      }
-    }
-    // The reference tests the leaf's primitives in order, shrinking tmax after
-    // each accepted hit: the survivor is the accepted primitive of minimum t,
-    // the LATER one among equal t. Same result as a quad min-reduction.
-    int   key_i = ok ? (int)q : -1;
-    float key_t = dist;
+        // ---- leaf: lane q tests primitive q, in leaf order (pt.cpp:905-923) ---------
+        cur = YH_NONE;
+        bool  ok = false;
+        float uu = 0, vv = 0, dist = 0;
+        if (kind == YH_KIND_LINES) {
+          if (mine) {
+            n_seg++;
+            ok = intersect_line(lo, ld, ray.tmin, tmax, xyz(s0), xyz(s1), s0.w, s1.w, uu, vv, dist);
+          }
+        } else {
+          v4f s2 = ldg4(addr + 2);
+          if (mine) {
+            n_tri++;
+            ok = intersect_triangle(lo, ld, ray.tmin, tmax, xyz(s0), xyz(s1), xyz(s2), uu, vv, dist);
+          }
+        }
+        // The reference tests the leaf's primitives in order, shrinking tmax after
+        // each accepted hit: the survivor is the accepted primitive of minimum t,
+        // the LATER one among equal t. Same result as a quad min-reduction.
+        int   key_i = ok ? (int)q : -1;
+        float key_t = dist;
 #define YH_QUAD_MERGE(CTRL)                                                                \
   {                                                                                        \
     int   oi = dpp_i<CTRL>(key_i);                                                         \
@@ -316,13 +280,46 @@ YH_DEV hit_t trace_ray(const trace_ctx& tc, const ray_t& ray, int first_object, 
     bool  take = oi >= 0 && (key_i < 0 || ot < key_t || (ot == key_t && oi > key_i));      \
     if (take) key_i = oi, key_t = ot, uu = ou, vv = ov;                                    \
   }
-    YH_QUAD_MERGE(YH_QUAD_XOR1)
-    YH_QUAD_MERGE(YH_QUAD_XOR2)
+        YH_QUAD_MERGE(YH_QUAD_XOR1)
+        YH_QUAD_MERGE(YH_QUAD_XOR2)
 #undef YH_QUAD_MERGE
-    if (key_i >= 0) {
-      hit.object = cur_obj, hit.slot = leaf_start + key_i;
-      hit.u = uu, hit.v = vv, hit.distance = key_t;
-      tmax = key_t;
+        if (key_i >= 0) {
+          hit.object = cur_obj, hit.slot = leaf_start + key_i;
+          hit.u = uu, hit.v = vv, hit.distance = key_t;
+          tmax = key_t;
+        }
+      }
+      continue;
+    }
+    if (tag == YH_TAG_ENTER) {
+      // transform_ray(inverse(object.frame, true), ray) (pt.cpp:1012-1013)
+      cur_obj             = (int)(cur & ~YH_TAG_MASK);
+      const yhd_object& o = sc.objects[cur_obj];
+      frame inv           = ldframe(o.inv_frame);
+      lo                  = transform_point(inv, ray.o);
+      ld                  = transform_vector(inv, ray.d);
+      ldinv               = {1 / ld.x, 1 / ld.y, 1 / ld.z};
+      lsign = (ldinv.x < 0 ? 1 : 0) | (ldinv.y < 0 ? 2 : 0) | (ldinv.z < 0 ? 4 : 0);
+      kind = o.kind, node_base = o.node_base, prim_base = o.prim_base;
+      cur = YH_TAG_SHAPE | (unsigned)node_base;  // shape root
+      continue;
+    }
+    // scene-level node (binary, reference layout; every lane of the quad does it)
+    int idx = (int)(cur & ~YH_TAG_MASK);
+    v4f n0 = ldg4(sc.scene_nodes + 2 * idx), n1 = ldg4(sc.scene_nodes + 2 * idx + 1);
+    if (q == 0) n_nodes++;
+    cur = YH_NONE;
+    if (!intersect_bbox(ray.o, wdinv, ray.tmin, tmax, xyz(n0), xyz(n1))) continue;
+    int start = __float_as_int(n0.w), meta = __float_as_int(n1.w);
+    if (meta & 0x10000) {  // internal
+      int axis = (meta >> 24) & 3;
+      int near = (wsign >> axis) & 1;  // dsign set: visit start+1 first
+      push(YH_TAG_SCENE | (unsigned)(start + 1 - near));
+      cur = YH_TAG_SCENE | (unsigned)(start + near);
+    } else {
+      int num = meta & 0xffff;
+      for (int i = num - 1; i >= 1; i--) push(YH_TAG_ENTER | (unsigned)sc.scene_prims[start + i]);
+      if (num > 0) cur = YH_TAG_ENTER | (unsigned)sc.scene_prims[start];
     }
   }
   if (COUNT) {

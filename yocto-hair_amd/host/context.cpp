@@ -556,7 +556,7 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
   sc.lds_node_base = 0, sc.lds_node_count = 0;
   if (best_shape >= 0) {
     sc.lds_node_base  = info[best_shape].node_base;
-    int want = 255;  // 255 wide nodes = 32 KB of nodelets + 48 KB of stacks = 80 KB: two 512-thread blocks per CU
+    int want = 0;  // LDS nodelets are optional (YHAIR_LDS_NODES): measured no gain once a step is a single fetch, see DESIGN.md
     if (const char* env = getenv("YHAIR_LDS_NODES")) want = std::max(0, std::min(atoi(env), 3000));
     sc.lds_node_count = std::min(info[best_shape].num_nodes, want);
   }
