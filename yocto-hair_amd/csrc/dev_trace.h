@@ -180,15 +180,10 @@ template <bool COUNT, int STRIDE>
 YH_DEV hit_t trace_ray(const trace_ctx& tc, const ray_t& ray, int first_object, unsigned int* steps_out = nullptr) {
   const yhd_scene&     sc   = *tc.sc;
   const unsigned int   q    = __lane_id() & 3u;
-  // Stack: the newest entry lives in a register (`top`) together with the 32
-  // bytes this lane will need from it (`t0`, `t1`, requested the moment the
-  // entry becomes the top); older entries are in this quad's LDS column. A pop
-  // therefore costs no memory round trip: the data was requested while the
-  // current subtree was being walked.
-  int                  sp   = 0;  // entries in LDS (below `top`)
+  int                  sp   = 0;
   YH_LDS unsigned int* lstk = tc.lds_stack;
-  unsigned int         top  = YH_NONE;
-  v4f                  t0 = {0, 0, 0, 0}, t1 = {0, 0, 0, 0};
+  auto push = [&](unsigned int v) { lstk[sp * STRIDE] = v, sp++; };
+  auto pop  = [&]() -> unsigned int { sp--; return lstk[sp * STRIDE]; };
   hit_t hit;
   hit.object = -1, hit.slot = -1, hit.u = 0, hit.v = 0, hit.distance = 0;
   float tmax = ray.tmax;
@@ -213,45 +208,22 @@ YH_DEV hit_t trace_ray(const trace_ctx& tc, const ray_t& ray, int first_object, 
   // the test half of primitive q of the leaf) with the same two load
   // instructions, and only the arithmetic diverges. The wave therefore pays one
   // memory round trip per step of its slowest quad, not one per kind of step.
-  // address of the 32 bytes lane q needs from a wide-node / leaf entry of the
-  // CURRENT instance (lanes beyond a leaf's count re-read its last record)
-  auto entry_addr = [&](unsigned int e) -> const yhd_float4* {
-    if ((e & YH_TAG_MASK) == YH_TAG_LEAF) {
-      int start = (int)(e & 0x07FFFFFFu), num = (int)((e >> 27) & 7u);
-      int pq    = (int)q < num ? (int)q : num - 1;
-      return sc.prims + (size_t)prim_base + (size_t)(start + pq) * (kind == YH_KIND_LINES ? 4 : 6);
-    }
-    return sc.nodes + 8 * (size_t)e + 2 * q;
-  };
-  auto is_geom = [](unsigned int e) { unsigned int g = e & YH_TAG_MASK; return g == YH_TAG_SHAPE || g == YH_TAG_LEAF; };
-  auto push = [&](unsigned int v) {
-    if (top != YH_NONE) lstk[sp * STRIDE] = top, sp++;
-    top = v;
-  };
   while (true) {
     if (COUNT) n_steps++;
-    v4f  s0, s1;
-    bool have = false;
     if (cur == YH_NONE) {
-      if (top == YH_NONE) break;
-      cur = top, s0 = t0, s1 = t1, have = true;
-      top = YH_NONE;
-      if (sp > 0) {
-        sp--;
-        top = lstk[sp * STRIDE];
-        if (is_geom(top)) {
-          const yhd_float4* a = entry_addr(top);
-          t0 = ldg4(a), t1 = ldg4(a + 1);
-        }
-      }
+      if (sp == 0) break;
+      cur = pop();
     }
     unsigned int tag = cur & YH_TAG_MASK;
     if (tag == YH_TAG_SHAPE || tag == YH_TAG_LEAF) {
       bool is_leaf    = tag == YH_TAG_LEAF;
       int  leaf_start = (int)(cur & 0x07FFFFFFu), leaf_num = (int)((cur >> 27) & 7u);
-      bool mine       = !is_leaf || (int)q < leaf_num;
-      const yhd_float4* addr = entry_addr(cur);
-      if (!have) s0 = ldg4(addr), s1 = ldg4(addr + 1);
+      int  rec        = kind == YH_KIND_LINES ? 4 : 6;  // float4 per leaf record
+      bool mine       = !is_leaf || (int)q < leaf_num;  // lanes beyond the leaf's count re-read its last record
+      int  pq         = mine ? (int)q : leaf_num - 1;
+      const yhd_float4* addr = is_leaf ? sc.prims + (size_t)prim_base + (size_t)(leaf_start + pq) * rec
+                                       : sc.nodes + 8 * (size_t)cur + 2 * q;
+      v4f s0 = ldg4(addr), s1 = ldg4(addr + 1);
       if (!is_leaf) {
         // ---- wide node: lane q tests slot q {min.xyz, max.x} {max.yz, ref, axes} ----
         if (q == 0) n_nodes++;
@@ -273,16 +245,12 @@ YH_DEV hit_t trace_ray(const trace_ctx& tc, const ray_t& ray, int first_object, 
         unsigned int o0 = s0_ ? ra : la, o1 = s0_ ? rb : lb, o2 = s0_ ? la : ra, o3 = s0_ ? lb : rb;
         bool         g0 = s0_ ? hc : ha, g1 = s0_ ? hd : hb, g2 = s0_ ? ha : hc, g3 = s0_ ? hb : hd;
         // push the hit children in reverse visiting order; the first stays in `cur`
-        unsigned int next = YH_NONE, old_top = top;
+        unsigned int next = YH_NONE;
         if (g3) next = o3;
         if (g2) { if (next != YH_NONE) push(next); next = o2; }
         if (g1) { if (next != YH_NONE) push(next); next = o1; }
         if (g0) { if (next != YH_NONE) push(next); next = o0; }
         cur = next;
-        if (top != old_top) {  // a new top: request its bytes now, they are used when it is popped
-          const yhd_float4* a = entry_addr(top);
-          t0 = ldg4(a), t1 = ldg4(a + 1);
-        }
       } else {
         // ---- leaf: lane q tests primitive q, in leaf order (pt.cpp:905-923) ---------
         cur = YH_NONE;
