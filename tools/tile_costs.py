@@ -18,8 +18,8 @@ for n in (1, 4, 16, spp, spp):
     s = np.sort(c.ravel())[::-1]
     print(f"{n:3d} spp: kernel {ms:8.2f} ms | tile cost ms: max {s[0]:.2f} p99 {s[len(s)//100]:.2f} median {np.median(s):.3f} sum {s.sum():.1f} "
           f"| sum/2048 waves {s.sum()/2048:.2f} | top5 {np.round(s[:5],2)} | tiles>1ms {np.sum(s>1)}")
-wc = ctx.trace_samples_counted(8).as_dict()
-print("profile (8 spp, instrumented):", wc)
+t0 = time.time(); wc = ctx.trace_samples_counted(64).as_dict(); print("instrumented 64 spp launch: %.1f ms" % ctx.last_trace_ms()[0])
+print("profile (64 spp, instrumented):", wc)
 wi = max(1, wc["wave_iters"])
 print(f"  per wave-iteration: trace {wc['cyc_trace']/wi:.0f} cyc, shade {wc['cyc_shade']/wi:.0f} cyc, traversal trips {wc['wave_steps']/wi:.1f} (lane avg {wc['lane_steps']/max(1,wc['lane_iters']):.1f}), live lanes {wc['lane_iters']/wi:.1f}; cycles per trip {wc['cyc_trace']/max(1,wc['wave_steps']):.0f}")
 top = np.argsort(c.ravel())[::-1][:8]

@@ -110,7 +110,7 @@ YH_DEV f3 eval_environment(const trace_ctx& tc, f3 dir) {
   f3 emission = mk3(0.0f);
   for (int k = 0; k < sc.num_environments; k++) {
     const yhd_environment& env = sc.environments[k];
-    if (COUNT) count_quad<COUNT>(&tc.counters->envl);
+    if (COUNT) count_quad<COUNT>(tc.stats->envl);
     if (env.tex_w == 0) {  // no texture: eval_texture returns {1,1,1} whatever the coordinates are
       emission = emission + ld3(env.emission) * mk3(1.0f);
       continue;
@@ -158,7 +158,7 @@ YH_DEV f3 sample_lights(const trace_ctx& tc, f3 position, float rl, float rel, f
   } else if (light.environment >= 0) {
     const yhd_environment& env = sc.environments[light.environment];
     if (env.tex_w) {
-      if (COUNT) count_quad<COUNT>(&tc.counters->envs);
+      if (COUNT) count_quad<COUNT>(tc.stats->envs);
       int   idx = sample_discrete_cdf(sc.light_cdf + light.cdf_base, light.cdf_count, rel);
       float ux  = (idx % env.tex_w + 0.5f) / env.tex_w;
       float uy  = (idx / env.tex_w + 0.5f) / env.tex_h;
@@ -268,7 +268,7 @@ YH_DEV bool path_step(const trace_ctx& tc, path_t& ps, const hit_t& isec, rng_t&
   } else {
     normal = (!mat.thin || dot(nrm, outgoing) >= 0) ? nrm : -nrm;
   }
-  if (COUNT) count_quad<COUNT>(is_hair ? &tc.counters->hair : &tc.counters->surf);
+  if (COUNT) count_quad<COUNT>(is_hair ? tc.stats->hair : tc.stats->surf);
   ps.hit      = true;
   ps.radiance = ps.radiance + ps.weight * (ld3(mat.emission) * mk3(1.0f));
   hair_hit hh;

@@ -148,20 +148,22 @@ struct trace_ctx {
   const yhd_scene*      sc;
   const YH_LDS v4f*     lds_nodes;  // LDS copy of nodes[lds_node_base ..+count), or nullptr
   YH_LDS unsigned int*  lds_stack;  // this quad's LDS stack column
-  yhd_counters*         counters;   // NULL in the production kernel
+  struct stats_t*       stats;      // per-lane work counters of the instrumented build, else NULL
+};
+// Per-lane counters of the instrumented build (COUNT = true): kept in registers
+// for a whole work item and flushed once, so that the instrumented kernel runs
+// at nearly the speed of the production one and its cycle stamps mean something.
+struct stats_t {
+  unsigned int samples, rays, nodes, seg, tri, hair, surf, envl, envs;
 };
 // one 16-byte load (never split into dwordx3 + dword)
 YH_DEV v4f ldg4(const yhd_float4* p) { return *(const v4f*)p; }
 YH_DEV f3  xyz(v4f a) { return f3{a.x, a.y, a.z}; }
 
-template <bool COUNT>
-YH_DEV void count_add(unsigned long long* slot, unsigned long long n) {
-  if (COUNT && n) atomicAdd(slot, n);
-}
 // one count per quad (the four lanes of a quad run the same path)
 template <bool COUNT>
-YH_DEV void count_quad(unsigned long long* slot) {
-  if (COUNT && (__lane_id() & 3u) == 0) atomicAdd(slot, 1ull);
+YH_DEV void count_quad(unsigned int& slot) {
+  if (COUNT && (__lane_id() & 3u) == 0) slot++;
 }
 
 // Closest hit against the whole scene (first_object < 0) or against a single
@@ -324,9 +326,7 @@ YH_DEV hit_t trace_ray(const trace_ctx& tc, const ray_t& ray, int first_object, 
   }
   if (COUNT) {
     if (steps_out) *steps_out = n_steps;
-    count_add<COUNT>(&tc.counters->nodes, n_nodes);
-    count_add<COUNT>(&tc.counters->seg, n_seg);
-    count_add<COUNT>(&tc.counters->tri, n_tri);
+    tc.stats->nodes += (unsigned int)n_nodes, tc.stats->seg += (unsigned int)n_seg, tc.stats->tri += (unsigned int)n_tri;
   }
   return hit;
 }

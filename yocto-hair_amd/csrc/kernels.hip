@@ -58,7 +58,8 @@ __global__ __launch_bounds__(YH_BLOCK, YH_MIN_WAVES) void k_trace(const yhd_scen
   tc.sc        = &sc;
   tc.lds_nodes = sc.lds_node_count ? lds_nodes : nullptr;
   tc.lds_stack = lds_stack + (threadIdx.x >> 2);
-  tc.counters  = counters;
+  stats_t stats = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  tc.stats = COUNT ? &stats : nullptr;
 
   const int lane = threadIdx.x & 63;
   while (true) {
@@ -82,6 +83,8 @@ __global__ __launch_bounds__(YH_BLOCK, YH_MIN_WAVES) void k_trace(const yhd_scen
     bool   alive   = false;
     path_t ps;
     ps.bounce = 0, ps.hit = false;
+    unsigned long long cyc_trace = 0, cyc_shade = 0;
+    unsigned int       w_iters = 0, w_steps = 0, l_steps = 0, l_iters = 0;
     while (true) {
       if (!alive && left > 0) {
         path_begin(sc.camera, ps, rng, i, j, st.width, st.height);
@@ -89,40 +92,45 @@ __global__ __launch_bounds__(YH_BLOCK, YH_MIN_WAVES) void k_trace(const yhd_scen
         alive = true;
       }
       if (!__any(alive)) break;
-      unsigned long long c0 = 0, c1 = 0, c2 = 0;
+      unsigned long long c0 = 0, c1 = 0;
       unsigned int       steps = 0;
-      bool               was_alive = alive;
-      if (COUNT) c0 = clock64();
+      if (COUNT) c0 = clock64(), l_iters += (alive && (lane & 3) == 0) ? 1 : 0, w_iters++;
       hit_t isec;
       if (alive) {
-        if (COUNT) count_quad<COUNT>(&counters->rays);
+        if (COUNT) count_quad<COUNT>(stats.rays);
         isec = trace_ray<COUNT, YH_QUADS>(tc, ps.ray, -1, &steps);
       }
-      if (COUNT) c1 = clock64();
+      if (COUNT) {
+        c1 = clock64(), cyc_trace += c1 - c0;
+        unsigned int smax = steps;
+        for (int off = 32; off > 0; off >>= 1) smax = max(smax, (unsigned int)__shfl_xor((int)smax, off, 64));
+        w_steps += smax, l_steps += (lane & 3) == 0 ? steps : 0;
+      }
       if (alive) {
         alive = path_step<COUNT, YH_QUADS>(tc, ps, isec, rng, st.bounces);
         if (!alive) {
           path_end(ps, st.clamp, acc);
-          if (COUNT) count_quad<COUNT>(&counters->samples);
+          if (COUNT) count_quad<COUNT>(stats.samples);
         }
       }
-      if (COUNT) {
-        c2 = clock64();
-        unsigned int smax = steps, ssum = (lane & 3) == 0 ? steps : 0, nl = (was_alive && (lane & 3) == 0) ? 1 : 0;
-        for (int off = 32; off > 0; off >>= 1) {
-          smax = max(smax, (unsigned int)__shfl_xor((int)smax, off, 64));
-          ssum += (unsigned int)__shfl_xor((int)ssum, off, 64);
-          nl += (unsigned int)__shfl_xor((int)nl, off, 64);
-        }
-        if (lane == 0) {
-          atomicAdd(&counters->cyc_trace, c1 - c0);
-          atomicAdd(&counters->cyc_shade, c2 - c1);
-          atomicAdd(&counters->wave_iters, 1ull);
-          atomicAdd(&counters->wave_steps, (unsigned long long)smax);
-          atomicAdd(&counters->lane_steps, (unsigned long long)ssum);
-          atomicAdd(&counters->lane_iters, (unsigned long long)nl);
-        }
+      if (COUNT) cyc_shade += clock64() - c1;
+    }
+    if (COUNT) {  // flush this item's counters: one wave reduction, one atomic per counter
+      unsigned int v[11] = {stats.samples, stats.rays, stats.nodes, stats.seg, stats.tri, stats.hair, stats.surf,
+          stats.envl, stats.envs, l_steps, l_iters};
+      for (int k = 0; k < 11; k++)
+        for (int off = 32; off > 0; off >>= 1) v[k] += (unsigned int)__shfl_xor((int)v[k], off, 64);
+      if (lane == 0) {
+        atomicAdd(&counters->samples, (unsigned long long)v[0]), atomicAdd(&counters->rays, (unsigned long long)v[1]);
+        atomicAdd(&counters->nodes, (unsigned long long)v[2]), atomicAdd(&counters->seg, (unsigned long long)v[3]);
+        atomicAdd(&counters->tri, (unsigned long long)v[4]), atomicAdd(&counters->hair, (unsigned long long)v[5]);
+        atomicAdd(&counters->surf, (unsigned long long)v[6]), atomicAdd(&counters->envl, (unsigned long long)v[7]);
+        atomicAdd(&counters->envs, (unsigned long long)v[8]);
+        atomicAdd(&counters->lane_steps, (unsigned long long)v[9]), atomicAdd(&counters->lane_iters, (unsigned long long)v[10]);
+        atomicAdd(&counters->cyc_trace, cyc_trace), atomicAdd(&counters->cyc_shade, cyc_shade);
+        atomicAdd(&counters->wave_iters, (unsigned long long)w_iters), atomicAdd(&counters->wave_steps, (unsigned long long)w_steps);
       }
+      stats = stats_t{0, 0, 0, 0, 0, 0, 0, 0, 0};
     }
     if (owner && (lane & 3) == 0) {
       st.rng_state[pix] = rng.state;
@@ -284,7 +292,7 @@ __global__ __launch_bounds__(256) void k_intersect(const yhd_scene sc, int n, co
   bool valid = i < n;
   if (!valid) i = n - 1;  // whole quads stay converged; surplus quads redo the last ray
   trace_ctx tc;
-  tc.sc = &sc, tc.lds_nodes = nullptr, tc.counters = nullptr;
+  tc.sc = &sc, tc.lds_nodes = nullptr, tc.stats = nullptr;
   tc.lds_stack   = (YH_LDS unsigned int*)stacks + (threadIdx.x >> 2);
   const float* r = rays + 8 * (size_t)i;
   ray_t ray      = ray_t{ld3(r), ld3(r + 3), r[6], r[7]};
