@@ -132,6 +132,7 @@ typedef struct yh_workcounts {
    * tiles, regeneration-loop iterations, traversal trip counts per wave (max
    * over lanes) and per lane (sum), live lanes per iteration                 */
   uint64_t cyc_trace, cyc_shade, ticks_tile, wave_iters, wave_steps, lane_steps, lane_iters;
+  uint64_t cyc_geom, cyc_sample, cyc_eval, cyc_rest; /* split of cyc_shade */
 } yh_workcounts;
 
 typedef struct yh_context yh_context;

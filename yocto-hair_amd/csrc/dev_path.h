@@ -251,8 +251,11 @@ struct path_t {
 template <bool COUNT, int STRIDE>
 YH_DEV bool path_step(const trace_ctx& tc, path_t& ps, const hit_t& isec, rng_t& rng, int bounces) {
   const yhd_scene& sc = *tc.sc;
+  unsigned long long k0 = 0, k1 = 0, k2 = 0, k3 = 0;
+  if (COUNT) k0 = clock64();
   if (isec.object < 0) {
     ps.radiance = ps.radiance + ps.weight * eval_environment<COUNT>(tc, ps.ray.d);
+    if (COUNT) tc.stats->c_rest += clock64() - k0;
     return false;
   }
   const yhd_object&   o   = sc.objects[isec.object];
@@ -274,6 +277,7 @@ YH_DEV bool path_step(const trace_ctx& tc, path_t& ps, const hit_t& isec, rng_t&
   hair_hit hh;
   if (is_hair) hh = hair_setup(isec.v, normal, nrm);  // tangent = eval_normal (pt.cpp:487)
 
+  if (COUNT) k1 = clock64(), tc.stats->c_geom += k1 - k0;
   f3 incoming;
   if (rand1f(rng) < 0.5f) {
     float rnx = rand1f(rng), rny = rand1f(rng);
@@ -292,6 +296,7 @@ YH_DEV bool path_step(const trace_ctx& tc, path_t& ps, const hit_t& isec, rng_t&
     float rl  = rand1f(rng);
     incoming  = sample_lights<COUNT>(tc, position, rl, rel, ruvx, ruvy);
   }
+  if (COUNT) k2 = clock64(), tc.stats->c_sample += k2 - k1;
   f3    brdfcos;
   float brdf_pdf;
   if (is_hair) {
@@ -314,9 +319,11 @@ YH_DEV bool path_step(const trace_ctx& tc, path_t& ps, const hit_t& isec, rng_t&
       brdf_pdf += mat.diffuse_pdf * lobe;
     }
   }
+  if (COUNT) k3 = clock64(), tc.stats->c_eval += k3 - k2;
   float light_pdf = sample_lights_pdf<COUNT, STRIDE>(tc, position, incoming);
   ps.weight = ps.weight * (brdfcos / (0.5f * brdf_pdf + 0.5f * light_pdf));
   ps.ray    = mkray(position, incoming);
+  if (COUNT) tc.stats->c_rest += clock64() - k3;
   if (is_zero(ps.weight) || !finite3(ps.weight)) return false;
   if (ps.bounce > 3) {
     float rr_prob = fmin_(0.99f, hmax(ps.weight));

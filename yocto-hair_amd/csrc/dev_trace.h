@@ -155,6 +155,7 @@ struct trace_ctx {
 // at nearly the speed of the production one and its cycle stamps mean something.
 struct stats_t {
   unsigned int samples, rays, nodes, seg, tri, hair, surf, envl, envs;
+  unsigned long long c_geom, c_sample, c_eval, c_rest;  // shader-clock stamps inside path_step
 };
 // one 16-byte load (never split into dwordx3 + dword)
 YH_DEV v4f ldg4(const yhd_float4* p) { return *(const v4f*)p; }

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(YH_BLOCK, YH_MIN_WAVES) void k_trace(const yhd_scen
   tc.sc        = &sc;
   tc.lds_nodes = sc.lds_node_count ? lds_nodes : nullptr;
   tc.lds_stack = lds_stack + (threadIdx.x >> 2);
-  stats_t stats = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  stats_t stats = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   tc.stats = COUNT ? &stats : nullptr;
 
   const int lane = threadIdx.x & 63;
@@ -130,7 +130,11 @@ __global__ __launch_bounds__(YH_BLOCK, YH_MIN_WAVES) void k_trace(const yhd_scen
         atomicAdd(&counters->cyc_trace, cyc_trace), atomicAdd(&counters->cyc_shade, cyc_shade);
         atomicAdd(&counters->wave_iters, (unsigned long long)w_iters), atomicAdd(&counters->wave_steps, (unsigned long long)w_steps);
       }
-      stats = stats_t{0, 0, 0, 0, 0, 0, 0, 0, 0};
+      if (lane == 0) {
+        atomicAdd(&counters->c_geom, stats.c_geom), atomicAdd(&counters->c_sample, stats.c_sample);
+        atomicAdd(&counters->c_eval, stats.c_eval), atomicAdd(&counters->c_rest, stats.c_rest);
+      }
+      stats = stats_t{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     }
     if (owner && (lane & 3) == 0) {
       st.rng_state[pix] = rng.state;

@@ -145,6 +145,7 @@ typedef struct yhd_counters {
   // the regeneration loop, and traversal-loop trip counts (per wave = max over
   // lanes; per lane = sum over lanes) of the main rays
   unsigned long long cyc_trace, cyc_shade, cyc_tile, wave_iters, wave_steps, lane_steps, lane_iters;
+  unsigned long long c_geom, c_sample, c_eval, c_rest;  // lane-0 cycles inside path_step: hit geometry, direction sampling, BSDF eval+pdf, the rest
 } yhd_counters;
 
 #endif

@@ -70,7 +70,8 @@ class WorkCounts(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("samples", "rays", "nodes", "seg_tests", "tri_tests",
                                           "hair_shades", "surf_shades", "env_lookups",
                                           "env_samples", "cyc_trace", "cyc_shade", "ticks_tile",
-                                          "wave_iters", "wave_steps", "lane_steps", "lane_iters")]
+                                          "wave_iters", "wave_steps", "lane_steps", "lane_iters", "cyc_geom", "cyc_sample",
+                                          "cyc_eval", "cyc_rest")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
