@@ -182,6 +182,15 @@ def main():
                                 48 * g["env_lookups"] + 88 * g["env_samples"]) / max(1, g["samples"]) + 32.0 / a.spp_per_step
         bytes_per_launch = bytes_per_sample * width * height * a.spp_per_step / world
         achieved = bytes_per_launch / launch_s / 1e9
+        # HBM traffic of k_trace from the committed PMC passes (profiles/), valid for the default config only
+        traffic, traffic_src, pmc = None, None, {}
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "k_trace_traffic.json")))
+            if (pmc["scene"], pmc["resolution"], pmc["spp_per_launch"], pmc["scale"]) == (a.scene, a.resolution, a.spp_per_step, a.scale) and world == 1:
+                traffic = round((pmc["hbm_fetch_bytes_per_launch"] + pmc["hbm_write_bytes_per_launch"]) / 1e9, 3)
+                traffic_src = pmc["source"]
+        except Exception:
+            pass
         out = {
             "metric": "Msamples/sec (whole node), 720x720x1536spp sphere-hairblock; per-pixel L2 vs CPU ref",
             "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -194,7 +203,10 @@ def main():
                        "upload_s": round(upload_s, 2), "gather_ms": round(gather_ms, 2),
                        "image_mean_rgb": [round(float(x), 5) for x in img[..., :3].mean(axis=(0, 1))]},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "kernel": "k_trace",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_unit": "GB per launch",
+                         "traffic_source": traffic_src, "algorithmic_gb_per_launch": round(bytes_per_launch / 1e9, 3),
+                         "valu_issue_fraction": pmc.get("valu_issue_fraction") if traffic is not None else None,
+                         "wait_fraction": pmc.get("wait_any_fraction") if traffic is not None else None, "kernel": "k_trace",
                          "avg_launch_ms": round(launch_s * 1e3, 3),
                          "algorithmic_bytes_per_sample": round(bytes_per_sample, 1),
                          "work_counts_from": counts_from,
