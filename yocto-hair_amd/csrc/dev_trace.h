@@ -226,7 +226,14 @@ YH_DEV hit_t trace_ray(const trace_ctx& tc, const ray_t& ray, int first_object, 
       int  pq         = mine ? (int)q : leaf_num - 1;
       const yhd_float4* addr = is_leaf ? sc.prims + (size_t)prim_base + (size_t)(leaf_start + pq) * rec
                                        : sc.nodes + 8 * (size_t)cur + 2 * q;
-      v4f s0 = ldg4(addr), s1 = ldg4(addr + 1);
+      v4f s0, s1;
+      int rel = (int)cur - sc.lds_node_base;
+      if (tc.lds_nodes && !is_leaf && rel >= 0 && rel < sc.lds_node_count) {
+        const YH_LDS v4f* n = tc.lds_nodes + 8 * rel + 2 * q;  // optional nodelets (YHAIR_LDS_NODES), off by default
+        s0 = n[0], s1 = n[1];
+      } else {
+        s0 = ldg4(addr), s1 = ldg4(addr + 1);
+      }
       if (!is_leaf) {
         // ---- wide node: lane q tests slot q {min.xyz, max.x} {max.yz, ref, axes} ----
         if (q == 0) n_nodes++;
