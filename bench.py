@@ -14,8 +14,14 @@ one k_trace launch adding `spp_per_step` samples to every pixel. The defaults (2
 spp) are exactly the 1536 spp the metric is quoted on. For N > 1 the image's 8x8 tiles are dealt
 round-robin to the ranks (one process per GPU, launched by torch.distributed.run), every rank
 renders all samples of its own tiles with no data-path collective, and ONE RCCL gather of the
-packed float4 tiles follows the timed loop (reported as gather_ms). The total work is fixed as N
-grows, so scaling is "strong".
+packed float4 tiles follows the timed loop (reported as gather_ms).
+
+Scaling is WEAK by default: the units that shard are pixel tiles, and N GPUs render the same scene
+with N times the tiles (image side 720 * sqrt(N), rounded to a multiple of 8; 518 400 pixels per
+GPU as at N = 1), the way BASELINE.json pairs its 8-GPU configs with larger images. `--strong`
+keeps the 720x720 image instead; because a pixel's samples are sequential (one PCG32 stream per
+pixel, pt.cpp:1942-1945) the 1536-sample chain of the most expensive pixel bounds that run at any
+N.
 
 The JSON line also carries
   roofline:     the dominant kernel (k_trace) against the HBM roofline. achieved = algorithmic
@@ -81,6 +87,7 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0, help="hair strand-count multiplier (1.0 = the metric's scene)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--save", default="", help="write the final image (.pfm/.hdr) on rank 0")
+    ap.add_argument("--strong", action="store_true", help="N > 1: keep the --resolution image (strong scaling)")
     a = ap.parse_args()
 
     import torch
@@ -120,7 +127,10 @@ def main():
     ctx.upload_scene(sf.desc)
     upload_s = time.time() - t0
     segments = sum(sf.desc.contents.shapes[i].num_lines for i in range(sf.desc.contents.num_shapes))
-    p = yh.TraceParams.default(resolution=a.resolution)
+    resolution = a.resolution
+    if world > 1 and not a.strong:  # weak scaling: pixels per GPU fixed
+        resolution = int(round(a.resolution * world ** 0.5 / 8.0)) * 8
+    p = yh.TraceParams.default(resolution=resolution)
     ctx.set_shard(rank, world)
     width, height = ctx.init_state(p)
 
@@ -132,8 +142,8 @@ def main():
     gpu_counts = ctx.trace_samples_counted(2).as_dict()
     ctx.init_state(p)  # start the measured render from a fresh state
     cpu = None
-    if rank == 0 and not a.no_cpu_baseline:
-        cpu, ref_wc = cpu_baseline(scene_json, a.resolution)
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:  # the CPU leg runs at N = 1 only
+        cpu, ref_wc = cpu_baseline(scene_json, resolution)
     elif rank == 0:
         ref_wc = None
 
@@ -186,7 +196,7 @@ def main():
         traffic, traffic_src, pmc = None, None, {}
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "k_trace_traffic.json")))
-            if (pmc["scene"], pmc["resolution"], pmc["spp_per_launch"], pmc["scale"]) == (a.scene, a.resolution, a.spp_per_step, a.scale) and world == 1:
+            if (pmc["scene"], pmc["resolution"], pmc["spp_per_launch"], pmc["scale"]) == (a.scene, resolution, a.spp_per_step, a.scale) and world == 1:
                 traffic = round((pmc["hbm_fetch_bytes_per_launch"] + pmc["hbm_write_bytes_per_launch"]) / 1e9, 3)
                 traffic_src = pmc["source"]
         except Exception:
@@ -195,11 +205,13 @@ def main():
             "metric": "Msamples/sec (whole node), 720x720x1536spp sphere-hairblock; per-pixel L2 vs CPU ref",
             "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed * 1e3 / max(1, a.steps), 3), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong" if (a.strong and world > 1) else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{a.scene} {width}x{height} x {spp_total} spp (C1: eumelanin 1.3, aspect 1.0), "
                                    f"synthetic hair block {segments} segments x scale {a.scale:g}",
                        "spp_per_step": a.spp_per_step, "bounces": 8, "seed": 961748941,
-                       "sharding": f"8x8 tiles round-robin over {world} GPU(s), one RCCL gather after the loop",
+                       "sharding": f"8x8 tiles round-robin over {world} GPU(s), one RCCL gather after the loop"
+                                   + ("" if world == 1 else (" (strong: fixed image)" if a.strong else
+                                      f" (weak: image side {a.resolution} * sqrt({world}) -> {width}, {width * height // world} pixels per GPU)")),
                        "upload_s": round(upload_s, 2), "gather_ms": round(gather_ms, 2),
                        "image_mean_rgb": [round(float(x), 5) for x in img[..., :3].mean(axis=(0, 1))]},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
