@@ -88,6 +88,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--save", default="", help="write the final image (.pfm/.hdr) on rank 0")
     ap.add_argument("--strong", action="store_true", help="N > 1: keep the --resolution image (strong scaling)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend; gloo (CPU staging) lets the N > 1 flow be exercised on a one-GPU box")
     a = ap.parse_args()
 
     import torch
@@ -104,10 +106,16 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if a.gpus > 1 and world == 1:
         raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    if a.backend == "gloo":  # functional test of the N > 1 flow: ranks may share a GPU
+        local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
+    cdev = "cuda" if a.backend == "nccl" else "cpu"  # where collective payloads live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     def barrier():
         if world > 1:
@@ -160,7 +168,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms = t.tolist()
 
@@ -169,6 +177,8 @@ def main():
     n = ctx.shard_pixels(rank, world)
     packed = torch.zeros((n, 4), dtype=torch.float32, device="cuda")
     ctx.pack_tiles_device(packed.data_ptr(), n)
+    if cdev == "cpu":
+        packed = packed.cpu()
     image = yhair_dist.gather_framebuffer(packed, width, height, rank, world, ctx=ctx)
     torch.cuda.synchronize()
     gather_ms = (time.perf_counter() - t0) * 1e3
