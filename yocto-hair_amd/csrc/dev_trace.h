@@ -223,6 +223,17 @@ YH_DEV hit_t trace_ray(const trace_ctx& tc, const ray_t& ray, int first_object, 
       int  leaf_start = (int)(cur & 0x07FFFFFFu), leaf_num = (int)((cur >> 27) & 7u);
       int  rec        = kind == YH_KIND_LINES ? 4 : 6;  // float4 per leaf record
       bool mine       = !is_leaf || (int)q < leaf_num;  // lanes beyond the leaf's count re-read its last record
+#ifdef YH_DEBUG_BOUNDS
+      {
+        bool bad = is_leaf ? (leaf_num < 1 || leaf_num > 4 || (size_t)prim_base + (size_t)(leaf_start + leaf_num) * rec > (size_t)sc.num_prim_f4)
+                           : (cur >= (unsigned)sc.num_nodes_total);
+        if (bad) {
+          printf("BAD entry %08x leaf %d sp %d obj %d lane %d steps %u\n", cur, (int)is_leaf, sp, cur_obj, (int)__lane_id(), n_steps);
+          break;
+        }
+        if (sp < 0 || sp > YH_QSTACK - 4) { printf("BAD sp %d\n", sp); break; }
+      }
+#endif
       int  pq         = mine ? (int)q : leaf_num - 1;
       const yhd_float4* addr = is_leaf ? sc.prims + (size_t)prim_base + (size_t)(leaf_start + pq) * rec
                                        : sc.nodes + 8 * (size_t)cur + 2 * q;
@@ -240,27 +251,30 @@ YH_DEV hit_t trace_ray(const trace_ctx& tc, const ray_t& ray, int first_object, 
         bool         h    = intersect_bbox(lo, ldinv, ray.tmin, tmax, f3{s0.x, s0.y, s0.z}, f3{s0.w, s1.x, s1.y});
         unsigned int ref  = __float_as_uint(s1.z);
         unsigned int axes = __float_as_uint(s1.w);
+        h = h && ref != YH_NONE;  // an empty slot's inverted box still passes the min/max slab test
         if ((ref & YH_TAG_MASK) == 0) ref += (unsigned)node_base;  // child wide nodes are shape-local indices
-        unsigned int m  = quad_ballot(h);
-        unsigned int r0 = quad_bcast_u<0>(ref), r1 = quad_bcast_u<1>(ref), r2 = quad_bcast_u<2>(ref),
-                     r3 = quad_bcast_u<3>(ref);
-        bool h0 = m & 1, h1 = m & 2, h2 = m & 4, h3 = m & 8;
-        bool s0_ = (lsign >> (axes & 3)) & 1, sl = (lsign >> ((axes >> 2) & 3)) & 1, sr = (lsign >> ((axes >> 4) & 3)) & 1;
-        // visiting order: (left pair, right pair) or reversed by the node's own
-        // axis sign; inside a pair (first, second) or reversed by that child's
-        unsigned int la = sl ? r1 : r0, lb = sl ? r0 : r1;
-        bool         ha = sl ? h1 : h0, hb = sl ? h0 : h1;
-        unsigned int ra = sr ? r3 : r2, rb = sr ? r2 : r3;
-        bool         hc = sr ? h3 : h2, hd = sr ? h2 : h3;
-        unsigned int o0 = s0_ ? ra : la, o1 = s0_ ? rb : lb, o2 = s0_ ? la : ra, o3 = s0_ ? lb : rb;
-        bool         g0 = s0_ ? hc : ha, g1 = s0_ ? hd : hb, g2 = s0_ ? ha : hc, g3 = s0_ ? hb : hd;
-        // push the hit children in reverse visiting order; the first stays in `cur`
-        unsigned int next = YH_NONE;
-        if (g3) next = o3;
-        if (g2) { if (next != YH_NONE) push(next); next = o2; }
-        if (g1) { if (next != YH_NONE) push(next); next = o1; }
-        if (g0) { if (next != YH_NONE) push(next); next = o0; }
-        cur = next;
+        // Visiting order of the four slots (pt.cpp:887-893 applied at both collapsed
+        // levels): the pair on the near side of the node's own axis first, and
+        // inside each pair the slot on the near side of that child's axis first.
+        // Each lane computes the RANK of its own slot in that order; the hit lanes
+        // then push themselves in one parallel step: the first hit in visiting order
+        // becomes `cur`, the others go on the stack so that they pop in visiting order.
+        unsigned int pair = q >> 1;
+        unsigned int sgn  = (lsign >> ((axes >> (2 + 2 * pair)) & 3)) & 1;   // near side of this pair's own axis
+        unsigned int s0_  = (lsign >> (axes & 3)) & 1;                      // near side of the node's axis
+        unsigned int rank = ((pair ^ s0_) << 1) | ((q & 1) ^ sgn);
+        unsigned int bit  = h ? (1u << rank) : 0u;
+        unsigned int M    = bit | (unsigned int)dpp_i<YH_QUAD_XOR1>((int)bit);
+        M |= (unsigned int)dpp_i<YH_QUAD_XOR2>((int)M);                     // hits in visiting order, bit k = k-th visited
+        bool         first = h && (M & (bit - 1)) == 0;
+        unsigned int after = (unsigned int)__popc(M >> (rank + 1));         // hit slots visited after this one
+        if (h && !first) lstk[(sp + (int)after) * STRIDE] = ref;
+        unsigned int mine = first ? ref : 0u;                                // child refs are never 0 (node 0 is a root)
+        mine |= (unsigned int)dpp_i<YH_QUAD_XOR1>((int)mine);
+        mine |= (unsigned int)dpp_i<YH_QUAD_XOR2>((int)mine);
+        int nh = __popc(M);
+        sp += nh > 0 ? nh - 1 : 0;
+        cur = nh > 0 ? mine : YH_NONE;
       } else {
         // ---- leaf: lane q tests primitive q, in leaf order (pt.cpp:905-923) ---------
         cur = YH_NONE;

@@ -113,6 +113,8 @@ typedef struct yhd_scene {
   const yhd_float4* env_texels;
   yhd_camera        camera;
   // number of leading nodes of the largest line shape staged in LDS
+  int               num_nodes_total; // wide nodes in `nodes` (bounds checks of the debug build)
+  int               num_prim_f4;     // float4 in `prims`
   int               lds_node_base;   // global index of that shape's root
   int               lds_node_count;
 } yhd_scene;

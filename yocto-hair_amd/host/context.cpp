@@ -552,6 +552,7 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
   memcpy(sc.camera.frame, sd->camera.frame, 48);
   sc.camera.lens = sd->camera.lens, sc.camera.film_x = sd->camera.film[0], sc.camera.film_y = sd->camera.film[1];
   sc.camera.focus = sd->camera.focus, sc.camera.aperture = sd->camera.aperture;
+  sc.num_nodes_total = (int)(nodes.size() / 8), sc.num_prim_f4 = (int)prims.size();
   // nodelets: the top (breadth-first prefix) of the largest hair shape's BVH
   sc.lds_node_base = 0, sc.lds_node_count = 0;
   if (best_shape >= 0) {
