@@ -261,6 +261,35 @@ def test_work_counters_match_oracle_on_identical_paths(ctx, oracle, yh):
     osc.close(), sf.close()
 
 
+def test_cli_matches_the_library(ctx, yh, tmp_path):
+    """yscenetrace (the reference's command line on the C++ mirror of its API) writes the same
+    pixels yh_download returns, in the reference's .pfm layout (top row first, rgb)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "yocto-hair_amd", "yscenetrace")
+    scene = scene_path("hair-curls", scale=0.05)
+    out = str(tmp_path / "cli.pfm")
+    r = subprocess.run([exe, scene, "-r", "48", "-s", "6", "-o", out, "--spp-per-launch", "4"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    raw = open(out, "rb").read()
+    head = b"PF\n48 48\n-1\n"
+    assert raw.startswith(head)
+    cli = np.frombuffer(raw[len(head):], np.float32).reshape(48, 48, 3)
+    sf = yh.SceneFile(scene)
+    ctx.upload_scene(sf.desc)
+    ctx.set_shard(0, 1)
+    ctx.init_state(yh.TraceParams.default(resolution=48))
+    ctx.trace_samples(6)
+    assert np.array_equal(cli, ctx.download()[..., :3])
+    # reference CLI behaviour: debug shaders are refused loudly, bad scenes exit(1) with the message
+    r = subprocess.run([exe, scene, "-t", "eyelight"], capture_output=True, text=True)
+    assert r.returncode == 1 and "only 'path'" in r.stdout
+    r = subprocess.run([exe, str(tmp_path / "missing.json")], capture_output=True, text=True)
+    assert r.returncode == 1 and "file not found" in r.stdout
+    sf.close()
+
+
 def test_full_size_properties(ctx, yh):
     """BASELINE.json's full C1 size (720x720, 1.6 M segments): properties that do not need the
     oracle — determinism, finiteness, energy bounds, background pixels = environment."""

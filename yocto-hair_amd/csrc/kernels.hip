@@ -257,27 +257,32 @@ __global__ void k_hair_brdf(int n, const yh_material_in* mats, const float* v, c
   o[18] = w.x.x, o[19] = w.x.y, o[20] = w.x.z, o[21] = w.y.x, o[22] = w.y.y, o[23] = w.y.z;
   o[24] = w.z.x, o[25] = w.z.y, o[26] = w.z.z, o[27] = w.o.x, o[28] = w.o.y, o[29] = w.o.z;
 }
+// eval and pdf run the INTEGRATOR's code path: one quad (four threads) per item,
+// lobe p on lane p (hair_eval_pdf_quad). The scalar hair_eval_pdf<> is what the
+// self-test kernel uses, so both formulations are checked against the reference.
 __global__ void k_hair_eval(int n, const float* brdf, const float* wo, const float* wi, float* out) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  int  i     = (blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+  bool valid = i < n;
+  if (!valid) i = n - 1;  // keep whole quads converged
   yhd_material m;
   hair_hit     hh;
   unpack_brdf(brdf + 30 * (size_t)i, m, hh);
   f3    f;
   float pdf;
-  hair_eval_pdf<true, false>(m, hh, ld3(wo + 3 * i), ld3(wi + 3 * i), f, pdf);
-  out[3 * i] = f.x, out[3 * i + 1] = f.y, out[3 * i + 2] = f.z;
+  hair_eval_pdf_quad(m, hh, ld3(wo + 3 * i), ld3(wi + 3 * i), f, pdf);
+  if (valid && (threadIdx.x & 3) == 0) out[3 * i] = f.x, out[3 * i + 1] = f.y, out[3 * i + 2] = f.z;
 }
 __global__ void k_hair_pdf(int n, const float* brdf, const float* wo, const float* wi, float* out) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  int  i     = (blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+  bool valid = i < n;
+  if (!valid) i = n - 1;
   yhd_material m;
   hair_hit     hh;
   unpack_brdf(brdf + 30 * (size_t)i, m, hh);
   f3    f;
   float pdf;
-  hair_eval_pdf<false, true>(m, hh, ld3(wo + 3 * i), ld3(wi + 3 * i), f, pdf);
-  out[i] = pdf;
+  hair_eval_pdf_quad(m, hh, ld3(wo + 3 * i), ld3(wi + 3 * i), f, pdf);
+  if (valid && (threadIdx.x & 3) == 0) out[i] = pdf;
 }
 __global__ void k_hair_sample(int n, const float* brdf, const float* wo, const float* rn, float* out) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -462,11 +467,11 @@ int yhk_hair_brdf(int n, const void* mats, const float* v, const float* nrm, con
   return (int)hipGetLastError();
 }
 int yhk_hair_eval(int n, const float* brdf, const float* wo, const float* wi, float* out, hipStream_t s) {
-  hipLaunchKernelGGL(k_hair_eval, dim3((n + 255) / 256), dim3(256), 0, s, n, brdf, wo, wi, out);
+  hipLaunchKernelGGL(k_hair_eval, dim3((n + 63) / 64), dim3(256), 0, s, n, brdf, wo, wi, out);
   return (int)hipGetLastError();
 }
 int yhk_hair_pdf(int n, const float* brdf, const float* wo, const float* wi, float* out, hipStream_t s) {
-  hipLaunchKernelGGL(k_hair_pdf, dim3((n + 255) / 256), dim3(256), 0, s, n, brdf, wo, wi, out);
+  hipLaunchKernelGGL(k_hair_pdf, dim3((n + 63) / 64), dim3(256), 0, s, n, brdf, wo, wi, out);
   return (int)hipGetLastError();
 }
 int yhk_hair_sample(int n, const float* brdf, const float* wo, const float* rn, float* out, hipStream_t s) {
