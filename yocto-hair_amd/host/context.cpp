@@ -276,7 +276,9 @@ void build_work_items(const yh_context* ctx, std::vector<int>& items);
 
 namespace {
 void build_work_items(const yh_context* ctx, std::vector<int>& items) {
-  // sort (cost descending, item ascending) as packed 64-bit keys
+  // Expensive items first, in decreasing cost (they bound the launch); the cheap
+  // majority (background quadrants, within 8x of the median) follows unsorted:
+  // its order does not matter and sorting it would cost more than it saves.
   std::vector<uint64_t> keys;
   keys.reserve(ctx->owned.size() * 4);
   for (int t : ctx->owned)
@@ -284,7 +286,15 @@ void build_work_items(const yh_context* ctx, std::vector<int>& items) {
       unsigned item = (unsigned)(t * 4 + p);
       keys.push_back(((uint64_t)(0xFFFFFFFFu - ctx->item_cost[item]) << 32) | item);
     }
-  std::sort(keys.begin(), keys.end());
+  if (!keys.empty()) {
+    auto mid = keys.begin() + keys.size() / 2;
+    std::nth_element(keys.begin(), mid, keys.end());
+    uint64_t median_cost = 0xFFFFFFFFu - (uint32_t)(*mid >> 32);
+    uint64_t cut_cost    = std::min<uint64_t>(0xFFFFFFFFu, median_cost * 8 + 1);
+    uint64_t cut_key     = (uint64_t)(0xFFFFFFFFu - (uint32_t)cut_cost) << 32;  // keys below it cost more than cut_cost
+    auto heavy_end = std::partition(keys.begin(), keys.end(), [&](uint64_t k) { return k < cut_key; });
+    std::sort(keys.begin(), heavy_end);
+  }
   items.resize(keys.size());
   for (size_t i = 0; i < keys.size(); i++) items[i] = (int)(keys[i] & 0xFFFFFFFFu);
 }
