@@ -197,40 +197,52 @@ YH_DEV void hair_eval_pdf(const yhd_material& m, const hair_hit& hh, f3 outgoing
   if (WANT_PDF) pdf += mpl * ap_pdf[p_max] * (1 / (2 * pif));
 }
 
+// Everything of eval / sample / pdf that depends on the OUTGOING direction only
+// (ext.cpp:267-273,281-295,365-397,410-421): computed once per shaded hit and
+// shared by sample_hair_scattering and the fused eval + pdf — the reference
+// recomputes the same expressions in each of the three functions, so sharing
+// them changes no bit.
+struct hair_out {
+  float sin_theta_o, cos_theta_o, phi_o, gamma_t;
+  f3    apv[p_max + 1];       // Ap for f: T from sin_theta_o = outgoing.x (ext.cpp:281-295)
+  float ap_pdf[p_max + 1];    // lobe pdfs: T from sin_theta_o = sqrt(1 - cos^2) (ext.cpp:372)
+};
+YH_DEV hair_out hair_prepare(const yhd_material& m, const hair_hit& hh, f3 outgoing_) {
+  hair_out o;
+  f3 outgoing   = transform_direction(hh.w2b, outgoing_);
+  o.sin_theta_o = outgoing.x;
+  o.cos_theta_o = safe_sqrt(1 - sqr(o.sin_theta_o));
+  o.phi_o       = atan2f(outgoing.z, outgoing.y);
+  f3 T          = transmittance(m, hh.h, o.sin_theta_o, o.cos_theta_o, o.gamma_t);
+  ap(o.cos_theta_o, m.eta, hh.h, T, o.apv);
+  compute_ap_pdf(m, hh.h, o.cos_theta_o, o.ap_pdf);
+  return o;
+}
+
 // The integrator's fused eval + pdf with the four lobes p = 0..3 spread over the
-// four lanes of a quad (dev_trace.h): lane p evaluates Mp and Np of lobe p
-// (the transcendental-heavy part: exp, log, the I0 series), everything else is
-// computed redundantly by the four lanes, and the lobe terms are summed in the
-// reference's order p = 0, 1, 2, 3 (ext.cpp:297-332, 516-549) in every lane.
-// Bit-identical to hair_eval_pdf<true, true>.
-YH_DEV void hair_eval_pdf_quad(const yhd_material& m, const hair_hit& hh, f3 outgoing_, f3 incoming_,
+// four lanes of a quad (dev_math.h): lane p evaluates Mp and Np of lobe p (the
+// transcendental-heavy part: exp, log, the I0 series) and the lobe terms are
+// summed in the reference's order p = 0, 1, 2, 3 (ext.cpp:297-332, 516-549) in
+// every lane. Bit-identical to hair_eval_pdf<true, true>.
+YH_DEV void hair_eval_pdf_quad(const yhd_material& m, const hair_hit& hh, const hair_out& ho, f3 incoming_,
     f3& f, float& pdf) {
   const int p       = (int)(__lane_id() & 3u);
-  f3    outgoing    = transform_direction(hh.w2b, outgoing_);
   f3    incoming    = transform_direction(hh.w2b, incoming_);
-  float sin_theta_o = outgoing.x;
-  float cos_theta_o = safe_sqrt(1 - sqr(sin_theta_o));
-  float phi_o       = atan2f(outgoing.z, outgoing.y);
+  float sin_theta_o = ho.sin_theta_o, cos_theta_o = ho.cos_theta_o;
   float sin_theta_i = incoming.x;
   float cos_theta_i = safe_sqrt(1 - sqr(sin_theta_i));
   float phi_i       = atan2f(incoming.z, incoming.y);
-  float gamma_t;
-  f3    T   = transmittance(m, hh.h, sin_theta_o, cos_theta_o, gamma_t);
-  float phi = phi_i - phi_o;
-  f3    apv[p_max + 1];
-  float ap_pdf[p_max + 1];
-  ap(cos_theta_o, m.eta, hh.h, T, apv);
-  compute_ap_pdf(m, hh.h, cos_theta_o, ap_pdf);
+  float phi         = phi_i - ho.phi_o;
   // this lane's lobe
   float sin_theta_op, cos_theta_op;
   tilt(m, p, sin_theta_o, cos_theta_o, sin_theta_op, cos_theta_op);
   if (p < p_max) cos_theta_op = fabs_(cos_theta_op);
-  float mpv   = mp(m, p, cos_theta_i, cos_theta_op, sin_theta_i, sin_theta_op);
-  float npv   = p < p_max ? np(m, phi, p, hh.gamma_o, gamma_t) : 0.0f;
-  f3    apq   = p == 0 ? apv[0] : p == 1 ? apv[1] : p == 2 ? apv[2] : apv[3];
-  float appq  = p == 0 ? ap_pdf[0] : p == 1 ? ap_pdf[1] : p == 2 ? ap_pdf[2] : ap_pdf[3];
-  f3    tf    = p < p_max ? mpv * apq * npv : mpv * apq / (2 * pif);
-  float tp    = p < p_max ? mpv * appq * npv : mpv * appq * (1 / (2 * pif));
+  float mpv  = mp(m, p, cos_theta_i, cos_theta_op, sin_theta_i, sin_theta_op);
+  float npv  = p < p_max ? np(m, phi, p, hh.gamma_o, ho.gamma_t) : 0.0f;
+  f3    apq  = p == 0 ? ho.apv[0] : p == 1 ? ho.apv[1] : p == 2 ? ho.apv[2] : ho.apv[3];
+  float appq = p == 0 ? ho.ap_pdf[0] : p == 1 ? ho.ap_pdf[1] : p == 2 ? ho.ap_pdf[2] : ho.ap_pdf[3];
+  f3    tf   = p < p_max ? mpv * apq * npv : mpv * apq / (2 * pif);
+  float tp   = p < p_max ? mpv * appq * npv : mpv * appq * (1 / (2 * pif));
   f   = mk3(0.0f);
   pdf = 0.0f;
   f   = f + f3{quad_bcast_f<0>(tf.x), quad_bcast_f<0>(tf.y), quad_bcast_f<0>(tf.z)};
@@ -241,6 +253,11 @@ YH_DEV void hair_eval_pdf_quad(const yhd_material& m, const hair_hit& hh, f3 out
   pdf += quad_bcast_f<2>(tp);
   f   = f + f3{quad_bcast_f<3>(tf.x), quad_bcast_f<3>(tf.y), quad_bcast_f<3>(tf.z)};
   pdf += quad_bcast_f<3>(tp);
+}
+YH_DEV void hair_eval_pdf_quad(const yhd_material& m, const hair_hit& hh, f3 outgoing_, f3 incoming_,
+    f3& f, float& pdf) {
+  hair_out ho = hair_prepare(m, hh, outgoing_);
+  hair_eval_pdf_quad(m, hh, ho, incoming_, f, pdf);
 }
 
 // ext.cpp:339-357
@@ -258,21 +275,16 @@ YH_DEV void demux_float(float f, float& a, float& b) {
   b          = (float)compact1by1((uint32_t)(v >> 1)) / 65536.0f;
 }
 
-// sample_hair_scattering (ext.cpp:399-479)
-YH_DEV f3 hair_sample(const yhd_material& m, const hair_hit& hh, f3 outgoing_, float rnx, float rny) {
-  f3    outgoing    = transform_direction(hh.w2b, outgoing_);
-  float sin_theta_o = outgoing.x;
-  float cos_theta_o = safe_sqrt(1 - sqr(sin_theta_o));
-  float phi_o       = atan2f(outgoing.z, outgoing.y);
+// sample_hair_scattering (ext.cpp:399-479) given the outgoing-only terms
+YH_DEV f3 hair_sample(const yhd_material& m, const hair_hit& hh, const hair_out& ho, float rnx, float rny) {
+  float sin_theta_o = ho.sin_theta_o, cos_theta_o = ho.cos_theta_o, phi_o = ho.phi_o;
   float u00, u01, u10, u11;
   demux_float(rnx, u00, u01);
   demux_float(rny, u10, u11);
-  float ap_pdf[p_max + 1];
-  compute_ap_pdf(m, hh.h, cos_theta_o, ap_pdf);
   int p = 0;
   for (p = 0; p < p_max; p++) {
-    if (u00 < ap_pdf[p]) break;
-    u00 -= ap_pdf[p];
+    if (u00 < ho.ap_pdf[p]) break;
+    u00 -= ho.ap_pdf[p];
   }
   float sin_theta_op, cos_theta_op;
   tilt(m, p, sin_theta_o, cos_theta_o, sin_theta_op, cos_theta_op);
@@ -286,20 +298,22 @@ YH_DEV f3 hair_sample(const yhd_material& m, const hair_hit& hh, f3 outgoing_, f
   float cos_phi     = cosf(2 * pif * u11);
   float sin_theta_i = -cos_theta * sin_theta_op + sin_theta * cos_phi * cos_theta_op;
   float cos_theta_i = safe_sqrt(1 - sqr(sin_theta_i));
-  float etap        = sqrtf(m.eta * m.eta - sqr(sin_theta_o)) / cos_theta_o;
-  float sin_gamma_t = hh.h / etap;
-  float gamma_t     = safe_asin(sin_gamma_t);
+  // gamma_t (ext.cpp:463-465) is the same expression as in eval: ho.gamma_t
   float dphi;
   if (p < p_max) {
     // sample_trimmed_logistic (ext.cpp:359-363)
     float x = -m.s * logf(1 / (u01 * m.tl_norm + m.tl_cdf_a) - 1);
-    dphi    = phi_fn(p, hh.gamma_o, gamma_t) + fclamp(x, -pif, pif);
+    dphi    = phi_fn(p, hh.gamma_o, ho.gamma_t) + fclamp(x, -pif, pif);
   } else {
     dphi = 2 * pif * u01;
   }
   float phi_i    = phi_o + dphi;
   f3    incoming = f3{sin_theta_i, cos_theta_i * cosf(phi_i), cos_theta_i * sinf(phi_i)};
   return transform_direction(transpose_rot(hh.w2b), incoming);
+}
+YH_DEV f3 hair_sample(const yhd_material& m, const hair_hit& hh, f3 outgoing_, float rnx, float rny) {
+  hair_out ho = hair_prepare(m, hh, outgoing_);
+  return hair_sample(m, hh, ho, rnx, rny);
 }
 
 // Fills the per-material constants from (beta-derived) v[], s on the DEVICE;

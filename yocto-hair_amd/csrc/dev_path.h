@@ -275,7 +275,11 @@ YH_DEV bool path_step(const trace_ctx& tc, path_t& ps, const hit_t& isec, rng_t&
   ps.hit      = true;
   ps.radiance = ps.radiance + ps.weight * (ld3(mat.emission) * mk3(1.0f));
   hair_hit hh;
-  if (is_hair) hh = hair_setup(isec.v, normal, nrm);  // tangent = eval_normal (pt.cpp:487)
+  hair_out ho;
+  if (is_hair) {
+    hh = hair_setup(isec.v, normal, nrm);  // tangent = eval_normal (pt.cpp:487)
+    ho = hair_prepare(mat, hh, outgoing);  // shared by sample / eval / pdf
+  }
 
   if (COUNT) k1 = clock64(), tc.stats->c_geom += k1 - k0;
   f3 incoming;
@@ -283,7 +287,7 @@ YH_DEV bool path_step(const trace_ctx& tc, path_t& ps, const hit_t& isec, rng_t&
     float rnx = rand1f(rng), rny = rand1f(rng);
     float rnl = rand1f(rng);
     if (is_hair) {
-      incoming = hair_sample(mat, hh, outgoing, rnx, rny);
+      incoming = hair_sample(mat, hh, ho, rnx, rny);
     } else {  // sample_brdfcos (pt.cpp:1139-1174): only the diffuse lobe
       incoming = mk3(0.0f);
       if (mat.diffuse_pdf != 0 && rnl < 0.0f + mat.diffuse_pdf) {
@@ -300,7 +304,7 @@ YH_DEV bool path_step(const trace_ctx& tc, path_t& ps, const hit_t& isec, rng_t&
   f3    brdfcos;
   float brdf_pdf;
   if (is_hair) {
-    hair_eval_pdf_quad(mat, hh, outgoing, incoming, brdfcos, brdf_pdf);
+    hair_eval_pdf_quad(mat, hh, ho, incoming, brdfcos, brdf_pdf);
   } else {  // eval_brdfcos / sample_brdfcos_pdf, diffuse lobe (math.h:4427,4572)
     brdfcos  = mk3(0.0f);
     brdf_pdf = 0.0f;
