@@ -223,6 +223,25 @@ int yh_tile_costs(yh_context* ctx, uint32_t* ticks, int count);
  * cos_2k_alpha[3] gamma_o world_to_brdf[12]  (yocto_extension.h:97-113)      */
 #define YH_HAIR_BRDF_FLOATS 30
 
+/* The surface lobes of yocto_math.h:1513-1620 (implementation 4307-4755).    */
+enum {
+  YH_LOBE_DIFFUSE            = 0, /* eval/sample/_pdf  diffuse_reflection         */
+  YH_LOBE_SPECULAR           = 1, /* microfacet_reflection(ior, ...)              */
+  YH_LOBE_METAL              = 2, /* microfacet_reflection(eta, etak, ...)        */
+  YH_LOBE_TRANSMISSION       = 3, /* microfacet_transmission                      */
+  YH_LOBE_REFRACTION         = 4, /* microfacet_refraction                        */
+  YH_LOBE_DELTA_SPECULAR     = 5, /* delta_reflection(ior, ...)                   */
+  YH_LOBE_DELTA_METAL        = 6, /* delta_reflection(eta, etak, ...)             */
+  YH_LOBE_DELTA_TRANSMISSION = 7, /* delta_transmission                           */
+  YH_LOBE_DELTA_REFRACTION   = 8, /* delta_refraction                             */
+  YH_LOBE_COUNT              = 9
+};
+/* yh_surface_bsdf_batch output per item: diffuse[3] specular[3] metal[3]
+ * transmission[3] refraction[3] roughness opacity, the five lobe pdfs, then
+ * f*|cos| [3], pdf and the sampled incoming [3] (delta forms when roughness
+ * is 0, pt.cpp:495).                                                        */
+#define YH_SURFACE_BSDF_FLOATS 29
+
 /* eval_hair_brdf (yocto_extension.cpp:127-177). materials: n x yh_material
  * (only hair fields read); v: n; normal, tangent: 3n; out: 30n.              */
 int yh_hair_brdf_batch(yh_context* ctx, int n, const yh_material* materials,

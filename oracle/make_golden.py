@@ -28,6 +28,7 @@ GOLDEN_SCENES = [
     ("straight-hair", dict(scale=0.05, beta_m=0.1), 64),
     ("curly-hair", dict(scale=0.05), 64),
     ("hair-curls", dict(scale=0.05), 64),
+    ("lobes", dict(scale=0.05), 96),      # specular / metal / delta / transmission / opacity
 ]
 
 
@@ -71,10 +72,41 @@ def hair_inputs(rng, n):
     return mats, v, nrm.astype(np.float32), tng, wo, wi, rn
 
 
+def lobe_inputs(rng, n):
+    """Inputs of the surface lobes (yocto_math.h:4427-4755): params = ior, roughness, eta[3], etak[3]."""
+    nn, wo, wi = unit_dirs(rng, n), unit_dirs(rng, n), unit_dirs(rng, n)
+    k = n // 4  # a quarter of the rows: incoming = what the lobe itself would reflect / transmit (the peak)
+    wi[:k] = (-wo[:k] + 2 * np.sum(nn[:k] * wo[:k], 1, keepdims=True) * nn[:k] + rng.normal(0, 0.05, (k, 3))).astype(np.float32)
+    wi[k:2 * k] = (-wo[k:2 * k] + rng.normal(0, 0.05, (k, 3))).astype(np.float32)
+    wi /= np.linalg.norm(wi, axis=1, keepdims=True)
+    p = np.zeros((n, 8), np.float32)
+    p[:, 0] = rng.choice([1.0, 1.0005, 1.33, 1.5, 2.4], n)
+    p[:, 1] = rng.choice([0.0009, 0.01, 0.04, 0.25, 1.0], n)      # brdf.roughness (already squared, pt.cpp:441)
+    p[:, 2:5] = rng.uniform(0.1, 3.5, (n, 3))
+    p[:, 5:8] = rng.choice([0, 1], n)[:, None] * rng.uniform(0, 4, (n, 3))
+    rn = rng.uniform(0, 1, (n, 3)).astype(np.float32)
+    rn[:4] = [[0, 0, 0], [0.999999, 0.999999, 0.999999], [0.5, 0.37, 0.81], [0.5, 0.5, 0.5]]
+    return p, nn, wo, wi.astype(np.float32), rn
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     ref = oc.Ref()
+    only = sys.argv[1:]  # e.g. `make_golden.py lobes` regenerates just the fixtures whose name contains "lobes"
+    want = lambda tag: not only or any(o in tag for o in only)  # noqa: E731
+
+    # ---- surface lobes (math.h:4215-4755), its own generator so older fixtures never move ------
+    if want("lobes.npz"):
+        lrng = np.random.default_rng(20240608)
+        p, nn, wo, wi, rn = lobe_inputs(lrng, 4096)
+        out = dict(params=p, normal=nn, wo=wo, wi=wi, rn=rn, fresnel=ref.fresnel(p, nn, wo))
+        for kind in range(yh.LOBE_COUNT):
+            out[f"lobe_{kind}"] = ref.surface_lobe(kind, p, nn, wo, wi, rn)
+        np.savez_compressed(os.path.join(GOLD, "lobes.npz"), **out)
     rng = np.random.default_rng(20240607)
+    if only:
+        scenes_only(ref, rng, want)
+        return
 
     # ---- rng (math.h:1405-1442, pt.cpp:1942-1945) -------------------------------------------
     streams = {}
@@ -120,13 +152,24 @@ def main():
                         bbox=np.concatenate([bmin, bmax], 1).astype(np.float32), line_hit=lh, line_uv=luv,
                         line_dist=ld, tri_hit=th, tri_uv=tuv, tri_dist=td, bbox_hit=bh)
 
+    scenes_only(ref, rng, want)
+
+
+def scenes_only(ref, rng, want):
     # ---- scenes: closest hits and images (pt.cpp:934-1046, 1380-1511, 1676-1689) -------------
     for name, kw, res in GOLDEN_SCENES:
         path = make_scenes.ensure_scene(name, "/tmp/yhair_golden_scenes", **kw)
         tag = os.path.basename(os.path.dirname(path))
+        if not want("scene_" + tag):
+            continue
+        if name == "lobes":
+            rng = np.random.default_rng(20240609)
         sc = ref.scene(path)
         m = 4096
-        if name == "sphere-hairblock":
+        if name == "lobes":
+            org = rng.uniform(-1, 1, (m, 3)) * [3, 1.2, 1] + [0.2, 2.0, 4.5]
+            tgt = rng.uniform(-1, 1, (m, 3)) * [2.4, 0.6, 1.2] + [0.3, 0.4, 0]
+        elif name == "sphere-hairblock":
             org = rng.uniform(-1, 1, (m, 3)) * 2 + [0, 1.0, 4]
             tgt = rng.uniform(-1, 1, (m, 3)) * [1.2, 0.7, 0.6] + [0.25, 0.5, -0.25]
         else:

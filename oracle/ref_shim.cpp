@@ -58,6 +58,81 @@ void ref_pixel_seqs(int n, int* out) {
   for (int i = 0; i < n; i++) out[i] = ym::rand1i(rng, 1 << 31) / 2 + 1;
 }
 
+// The public lobe functions of yocto_math.h:1513-1620, one kind per call
+// (numbering = YH_LOBE_* in include/yhair.h). params 8n: ior, roughness,
+// eta[3], etak[3]; rn 3n: rnl, rn.x, rn.y; out 7n: f*|cos| [3], pdf, sampled [3].
+void ref_surface_lobe(int kind, int n, const float* params, const float* normal,
+    const float* outgoing, const float* incoming, const float* rn, float* out) {
+  for (int i = 0; i < n; i++) {
+    auto q   = params + 8 * i;
+    auto ior = q[0], rough = q[1];
+    auto eta = v3(q + 2), etak = v3(q + 5);
+    auto nn = v3(normal + 3 * i), wo = v3(outgoing + 3 * i), wi = v3(incoming + 3 * i);
+    auto rnl = rn[3 * i];
+    auto r2  = ym::vec2f{rn[3 * i + 1], rn[3 * i + 2]};
+    auto f = ym::zero3f, w = ym::zero3f;
+    auto pdf = 0.0f;
+    switch (kind) {
+      case 0:
+        f = ym::eval_diffuse_reflection(nn, wo, wi), pdf = ym::sample_diffuse_reflection_pdf(nn, wo, wi);
+        w = ym::sample_diffuse_reflection(nn, wo, r2);
+        break;
+      case 1:
+        f   = ym::eval_microfacet_reflection(ior, rough, nn, wo, wi);
+        pdf = ym::sample_microfacet_reflection_pdf(ior, rough, nn, wo, wi);
+        w   = ym::sample_microfacet_reflection(ior, rough, nn, wo, r2);
+        break;
+      case 2:
+        f   = ym::eval_microfacet_reflection(eta, etak, rough, nn, wo, wi);
+        pdf = ym::sample_microfacet_reflection_pdf(eta, etak, rough, nn, wo, wi);
+        w   = ym::sample_microfacet_reflection(eta, etak, rough, nn, wo, r2);
+        break;
+      case 3:
+        f   = ym::eval_microfacet_transmission(ior, rough, nn, wo, wi);
+        pdf = ym::sample_microfacet_transmission_pdf(ior, rough, nn, wo, wi);
+        w   = ym::sample_microfacet_transmission(ior, rough, nn, wo, r2);
+        break;
+      case 4:
+        f   = ym::eval_microfacet_refraction(ior, rough, nn, wo, wi);
+        pdf = ym::sample_microfacet_refraction_pdf(ior, rough, nn, wo, wi);
+        w   = ym::sample_microfacet_refraction(ior, rough, nn, wo, rnl, r2);
+        break;
+      case 5:
+        f = ym::eval_delta_reflection(ior, nn, wo, wi), pdf = ym::sample_delta_reflection_pdf(ior, nn, wo, wi);
+        w = ym::sample_delta_reflection(ior, nn, wo);
+        break;
+      case 6:
+        f   = ym::eval_delta_reflection(eta, etak, nn, wo, wi);
+        pdf = ym::sample_delta_reflection_pdf(eta, etak, nn, wo, wi);
+        w   = ym::sample_delta_reflection(eta, etak, nn, wo);
+        break;
+      case 7:
+        f = ym::eval_delta_transmission(ior, nn, wo, wi), pdf = ym::sample_delta_transmission_pdf(ior, nn, wo, wi);
+        w = ym::sample_delta_transmission(ior, nn, wo);
+        break;
+      case 8:
+        f = ym::eval_delta_refraction(ior, nn, wo, wi), pdf = ym::sample_delta_refraction_pdf(ior, nn, wo, wi);
+        w = ym::sample_delta_refraction(ior, nn, wo, rnl);
+        break;
+      default: break;
+    }
+    auto o = out + 7 * i;
+    o[0] = f.x, o[1] = f.y, o[2] = f.z, o[3] = pdf, o[4] = w.x, o[5] = w.y, o[6] = w.z;
+  }
+}
+// fresnel_dielectric / fresnel_conductor / reflectivity_to_eta (yocto_math.h:1490-1503)
+void ref_fresnel(int n, const float* params, const float* normal, const float* outgoing, float* out) {
+  for (int i = 0; i < n; i++) {
+    auto q  = params + 8 * i;
+    auto nn = v3(normal + 3 * i), wo = v3(outgoing + 3 * i);
+    auto fd = ym::fresnel_dielectric(q[0], nn, wo);
+    auto fc = ym::fresnel_conductor(v3(q + 2), v3(q + 5), nn, wo);
+    auto e  = ym::reflectivity_to_eta(v3(q + 2));
+    auto o  = out + 7 * i;
+    o[0] = fd, o[1] = fc.x, o[2] = fc.y, o[3] = fc.z, o[4] = e.x, o[5] = e.y, o[6] = e.z;
+  }
+}
+
 // mats: 12 floats per item = sigma_a[3] beta_m beta_n alpha eta color[3]
 // eumelanin pheomelanin (yocto_extension.h:86-95 field order)
 void ref_hair_brdf(int n, const float* mats, const float* v, const float* nrm,

@@ -576,6 +576,7 @@ struct Shape {
 };
 struct Material {
   V3           emission, color;
+  float        specular = 0, metallic = 0, roughness = 0, ior = 1.5f, transmission = 0, opacity = 1;
   HairMaterial hair;
   bool         thin;
 };
@@ -869,83 +870,474 @@ V3 eval_shading_normal(const yo_scene& scene, int object, int element,
   return {0, 0, 0};
 }
 
-// The lobes reachable in scope (pt.cpp:405-492): diffuse weight and the hair
-// lobe. specular = metallic = transmission = 0 and opacity = 1 are enforced at
-// scene creation, which makes brdf.diffuse = color, diffuse_pdf = 1 when any
-// colour channel is non-zero (else 0) and roughness = 1 (never delta).
+// ---------------------------------------------------------------------------
+// Surface lobes (math.h:4215-4755, 2059-2067). Only the GGX forms the
+// reference's defaults select are restated. Operation order is the
+// reference's: with F held as a vector the dielectric ({1,1,1} * F * ...) and
+// conductor (F * ...) expressions are the same per-channel arithmetic.
+// ---------------------------------------------------------------------------
+inline V3 reflect(V3 w, V3 n) { return -w + 2 * dot(n, w) * n; }  // math.h:2059
+inline V3 refract(V3 w, V3 n, float inv_eta) {                    // math.h:2062
+  auto cosine = dot(n, w);
+  auto k      = 1 + inv_eta * inv_eta * (cosine * cosine - 1);
+  if (k < 0) return {0, 0, 0};
+  return -w * inv_eta + (inv_eta * cosine - std::sqrt(k)) * n;
+}
+inline float fresnel_dielectric(float eta, V3 normal, V3 outgoing) {  // math.h:4212
+  return fresnel_dielectric_cos(eta, dot(normal, outgoing));
+}
+float conductor_channel(float eta, float etak, float cosw, float cos2, float sin2) {
+  auto eta2 = eta * eta, etak2 = etak * etak;  // math.h:4246-4260, one channel
+  auto t0       = eta2 - etak2 - sin2;
+  auto a2plusb2 = std::sqrt(t0 * t0 + 4 * eta2 * etak2);
+  auto t1       = a2plusb2 + cos2;
+  auto a        = std::sqrt((a2plusb2 + t0) / 2);
+  auto t2       = 2 * a * cosw;
+  auto rs       = (t1 - t2) / (t1 + t2);
+  auto t3       = cos2 * a2plusb2 + sin2 * sin2;
+  auto t4       = t2 * sin2;
+  auto rp       = rs * (t3 - t4) / (t3 + t4);
+  return (rp + rs) / 2;
+}
+V3 fresnel_conductor(V3 eta, V3 etak, V3 normal, V3 outgoing) {  // math.h:4238-4262
+  auto cosw = dot(normal, outgoing);
+  if (cosw <= 0) return {0, 0, 0};
+  cosw      = fclamp(cosw, (float)-1, (float)1);
+  auto cos2 = cosw * cosw;
+  auto sin2 = fclamp(1 - cos2, (float)0, (float)1);
+  return {conductor_channel(eta.x, etak.x, cosw, cos2, sin2),
+      conductor_channel(eta.y, etak.y, cosw, cos2, sin2),
+      conductor_channel(eta.z, etak.z, cosw, cos2, sin2)};
+}
+V3 reflectivity_to_eta(V3 reflectivity) {  // math.h:4270-4273
+  auto one = [](float r_) {
+    auto r = fclamp(r_, 0.0f, 0.99f);
+    return (1 + std::sqrt(r)) / (1 - std::sqrt(r));
+  };
+  return {one(reflectivity.x), one(reflectivity.y), one(reflectivity.z)};
+}
+float microfacet_distribution(float roughness, V3 normal, V3 halfway) {  // math.h:4307-4322
+  auto cosine = dot(normal, halfway);
+  if (cosine <= 0) return 0;
+  auto roughness2 = roughness * roughness;
+  auto cosine2    = cosine * cosine;
+  return roughness2 / (pif * (cosine2 * roughness2 + 1 - cosine2) *
+                          (cosine2 * roughness2 + 1 - cosine2));
+}
+float microfacet_shadowing1(float roughness, V3 normal, V3 halfway, V3 direction) {
+  auto cosine  = dot(normal, direction);  // math.h:4325-4343
+  auto cosineh = dot(halfway, direction);
+  if (cosine * cosineh <= 0) return 0;
+  auto roughness2 = roughness * roughness;
+  auto cosine2    = cosine * cosine;
+  return 2 * fabs_(cosine) /
+         (fabs_(cosine) + std::sqrt(cosine2 - roughness2 * cosine2 + roughness2));
+}
+float microfacet_shadowing(float roughness, V3 normal, V3 halfway, V3 outgoing, V3 incoming) {
+  return microfacet_shadowing1(roughness, normal, halfway, outgoing) *  // math.h:4346-4351
+         microfacet_shadowing1(roughness, normal, halfway, incoming);
+}
+// basis_fromz + transform_direction(mat3f, v) (math.h:2743-2752)
+V3 from_local_z(V3 normal, V3 local) {
+  auto zz   = normalize(normal);
+  auto sign = copysignf(1.0f, zz.z);
+  auto a    = -1.0f / (sign + zz.z);
+  auto b    = zz.x * zz.y * a;
+  auto x    = V3{1.0f + sign * zz.x * zz.x * a, sign * b, -sign * zz.x};
+  auto y    = V3{b, sign + zz.y * zz.y * a, -zz.y};
+  return normalize(x * local.x + y * local.y + zz * local.z);
+}
+V3 sample_microfacet(float roughness, V3 normal, float rx, float ry) {  // math.h:4354-4367
+  auto phi   = 2 * pif * rx;
+  auto theta = std::atan(roughness * std::sqrt(ry / (1 - ry)));
+  return from_local_z(normal, {std::cos(phi) * std::sin(theta),
+                                  std::sin(phi) * std::sin(theta), std::cos(theta)});
+}
+float sample_microfacet_pdf(float roughness, V3 normal, V3 halfway) {  // math.h:4370-4375
+  auto cosine = dot(normal, halfway);
+  if (cosine < 0) return 0;
+  return microfacet_distribution(roughness, normal, halfway) * cosine;
+}
+V3 sample_hemisphere_cos(V3 normal, float rx, float ry) {  // math.h:4856-4878
+  auto z   = std::sqrt(ry);
+  auto r   = std::sqrt(1 - z * z);
+  auto phi = 2 * pif * rx;
+  return from_local_z(normal, {r * std::cos(phi), r * std::sin(phi), z});
+}
+inline bool same_side_up(V3 normal, V3 outgoing, V3 incoming) {
+  return !(dot(normal, incoming) <= 0 || dot(normal, outgoing) <= 0);
+}
+
+// --- rough lobes: value * |cos| --------------------------------------------
+V3 eval_diffuse_reflection(V3 normal, V3 outgoing, V3 incoming) {  // math.h:4427-4431
+  if (!same_side_up(normal, outgoing, incoming)) return {0, 0, 0};
+  return V3{1, 1, 1} / pif * dot(normal, incoming);
+}
+// math.h:4441-4466 with F = {f,f,f} (dielectric) or the conductor Fresnel
+V3 microfacet_reflection_with(V3 F, float roughness, V3 normal, V3 halfway, V3 outgoing,
+    V3 incoming) {
+  auto D = microfacet_distribution(roughness, normal, halfway);
+  auto G = microfacet_shadowing(roughness, normal, halfway, outgoing, incoming);
+  return F * D * G / (4 * dot(normal, outgoing) * dot(normal, incoming)) *
+         dot(normal, incoming);
+}
+V3 eval_microfacet_reflection(float ior, float roughness, V3 normal, V3 outgoing, V3 incoming) {
+  if (!same_side_up(normal, outgoing, incoming)) return {0, 0, 0};
+  auto halfway = normalize(incoming + outgoing);
+  auto f       = fresnel_dielectric(ior, halfway, incoming);
+  return microfacet_reflection_with(V3{1, 1, 1} * f, roughness, normal, halfway, outgoing, incoming);
+}
+V3 eval_microfacet_reflection(V3 eta, V3 etak, float roughness, V3 normal, V3 outgoing,
+    V3 incoming) {
+  if (!same_side_up(normal, outgoing, incoming)) return {0, 0, 0};
+  auto halfway = normalize(incoming + outgoing);
+  return microfacet_reflection_with(fresnel_conductor(eta, etak, halfway, incoming), roughness,
+      normal, halfway, outgoing, incoming);
+}
+V3 eval_microfacet_transmission(float ior, float roughness, V3 normal, V3 outgoing,
+    V3 incoming) {  // math.h:4469-4483: reflection lobe mirrored through the surface, no Fresnel
+  if (dot(normal, incoming) >= 0 || dot(normal, outgoing) <= 0) return {0, 0, 0};
+  auto reflected = reflect(-incoming, normal);
+  auto halfway   = normalize(reflected + outgoing);
+  auto D         = microfacet_distribution(roughness, normal, halfway);
+  auto G         = microfacet_shadowing(roughness, normal, halfway, outgoing, reflected);
+  return V3{1, 1, 1} * D * G / (4 * dot(normal, outgoing) * dot(normal, reflected)) *
+         (dot(normal, reflected));
+}
+struct RefractionSetup {  // the shared head of math.h:4486-4513 / 4610-4631
+  bool  entering;
+  V3    up_normal;
+  float rel_ior;
+};
+RefractionSetup refraction_setup(float ior, V3 normal, V3 outgoing) {
+  RefractionSetup s;
+  s.entering  = dot(normal, outgoing) >= 0;
+  s.up_normal = s.entering ? normal : -normal;
+  s.rel_ior   = s.entering ? ior : (1 / ior);
+  return s;
+}
+V3 eval_microfacet_refraction(float ior, float roughness, V3 normal, V3 outgoing, V3 incoming) {
+  auto s = refraction_setup(ior, normal, outgoing);
+  if (dot(normal, incoming) * dot(normal, outgoing) >= 0) {
+    auto halfway = normalize(incoming + outgoing);
+    auto F       = fresnel_dielectric(s.rel_ior, halfway, outgoing);
+    auto D       = microfacet_distribution(roughness, s.up_normal, halfway);
+    auto G       = microfacet_shadowing(roughness, s.up_normal, halfway, outgoing, incoming);
+    return V3{1, 1, 1} * F * D * G / fabs_(4 * dot(normal, outgoing) * dot(normal, incoming)) *
+           fabs_(dot(normal, incoming));
+  } else {
+    auto halfway = -normalize(s.rel_ior * incoming + outgoing) * (float)(s.entering ? 1 : -1);
+    auto F       = fresnel_dielectric(s.rel_ior, halfway, outgoing);
+    auto D       = microfacet_distribution(roughness, s.up_normal, halfway);
+    auto G       = microfacet_shadowing(roughness, s.up_normal, halfway, outgoing, incoming);
+    return V3{1, 1, 1} *
+           fabs_((dot(outgoing, halfway) * dot(incoming, halfway)) /
+                 (dot(outgoing, normal) * dot(incoming, normal))) *
+           (1 - F) * D * G /
+           std::pow(s.rel_ior * dot(halfway, incoming) + dot(halfway, outgoing), 2.0f) *
+           fabs_(dot(normal, incoming));
+  }
+}
+V3 sample_diffuse_reflection(V3 normal, V3 outgoing, float rx, float ry) {  // math.h:4515
+  if (dot(normal, outgoing) <= 0) return {0, 0, 0};
+  return sample_hemisphere_cos(normal, rx, ry);
+}
+// math.h:4528-4546: dielectric and conductor variants are the same code
+V3 sample_microfacet_reflection(float roughness, V3 normal, V3 outgoing, float rx, float ry) {
+  if (dot(normal, outgoing) <= 0) return {0, 0, 0};
+  return reflect(outgoing, sample_microfacet(roughness, normal, rx, ry));
+}
+V3 sample_microfacet_transmission(float roughness, V3 normal, V3 outgoing, float rx, float ry) {
+  if (dot(normal, outgoing) <= 0) return {0, 0, 0};  // math.h:4549-4556
+  auto reflected = reflect(outgoing, sample_microfacet(roughness, normal, rx, ry));
+  return -reflect(reflected, normal);
+}
+V3 sample_microfacet_refraction(float ior, float roughness, V3 normal, V3 outgoing, float rnl,
+    float rx, float ry) {  // math.h:4559-4570
+  auto s       = refraction_setup(ior, normal, outgoing);
+  auto halfway = sample_microfacet(roughness, s.up_normal, rx, ry);
+  if (rnl < fresnel_dielectric(s.entering ? ior : (1 / ior), halfway, outgoing))
+    return reflect(outgoing, halfway);
+  return refract(outgoing, halfway, s.entering ? (1 / ior) : ior);
+}
+float sample_diffuse_reflection_pdf(V3 normal, V3 outgoing, V3 incoming) {  // math.h:4572
+  if (!same_side_up(normal, outgoing, incoming)) return 0;
+  auto cosw = dot(normal, incoming);  // sample_hemisphere_cos_pdf, math.h:4874-4878
+  return (cosw <= 0) ? 0 : cosw / pif;
+}
+float sample_microfacet_reflection_pdf(float roughness, V3 normal, V3 outgoing, V3 incoming) {
+  if (!same_side_up(normal, outgoing, incoming)) return 0;  // math.h:4587-4607
+  auto halfway = normalize(outgoing + incoming);
+  return sample_microfacet_pdf(roughness, normal, halfway) / (4 * fabs_(dot(outgoing, halfway)));
+}
+float sample_microfacet_transmission_pdf(float roughness, V3 normal, V3 outgoing, V3 incoming) {
+  if (dot(normal, incoming) >= 0 || dot(normal, outgoing) <= 0) return 0;  // math.h:4610-4619
+  auto reflected = reflect(-incoming, normal);
+  auto halfway   = normalize(reflected + outgoing);
+  auto d         = sample_microfacet_pdf(roughness, normal, halfway);
+  return d / (4 * fabs_(dot(outgoing, halfway)));
+}
+float sample_microfacet_refraction_pdf(float ior, float roughness, V3 normal, V3 outgoing,
+    V3 incoming) {  // math.h:4622-4643
+  auto s = refraction_setup(ior, normal, outgoing);
+  if (dot(normal, incoming) * dot(normal, outgoing) >= 0) {
+    auto halfway = normalize(incoming + outgoing);
+    return fresnel_dielectric(s.rel_ior, halfway, outgoing) *
+           sample_microfacet_pdf(roughness, s.up_normal, halfway) /
+           (4 * fabs_(dot(outgoing, halfway)));
+  } else {
+    auto halfway = -normalize(s.rel_ior * incoming + outgoing) * (float)(s.entering ? 1 : -1);
+    return (1 - fresnel_dielectric(s.rel_ior, halfway, outgoing)) *
+           sample_microfacet_pdf(roughness, s.up_normal, halfway) *
+           fabs_(dot(halfway, outgoing)) /
+           std::pow(s.rel_ior * dot(halfway, incoming) + dot(halfway, outgoing), 2.0f);
+  }
+}
+
+// --- delta lobes (math.h:4646-4755) -----------------------------------------
+inline bool ior_is_one(float ior) { return fabs_(ior - 1) < 1e-3; }  // float vs double literal
+V3 eval_delta_reflection(float ior, V3 normal, V3 outgoing, V3 incoming) {
+  if (!same_side_up(normal, outgoing, incoming)) return {0, 0, 0};
+  return V3{1, 1, 1} * fresnel_dielectric(ior, normal, outgoing);
+}
+V3 eval_delta_reflection(V3 eta, V3 etak, V3 normal, V3 outgoing, V3 incoming) {
+  if (!same_side_up(normal, outgoing, incoming)) return {0, 0, 0};
+  return fresnel_conductor(eta, etak, normal, outgoing);
+}
+V3 eval_delta_transmission(V3 normal, V3 outgoing, V3 incoming) {
+  if (dot(normal, incoming) >= 0 || dot(normal, outgoing) <= 0) return {0, 0, 0};
+  return {1, 1, 1};
+}
+V3 eval_delta_refraction(float ior, V3 normal, V3 outgoing, V3 incoming) {
+  if (ior_is_one(ior))
+    return dot(normal, incoming) * dot(normal, outgoing) <= 0 ? V3{1, 1, 1} : V3{0, 0, 0};
+  auto s = refraction_setup(ior, normal, outgoing);
+  if (dot(normal, incoming) * dot(normal, outgoing) >= 0)
+    return V3{1, 1, 1} * fresnel_dielectric(s.rel_ior, s.up_normal, outgoing);
+  return V3{1, 1, 1} * (1 / (s.rel_ior * s.rel_ior)) *
+         (1 - fresnel_dielectric(s.rel_ior, s.up_normal, outgoing));
+}
+V3 sample_delta_reflection(V3 normal, V3 outgoing) {
+  if (dot(normal, outgoing) <= 0) return {0, 0, 0};
+  return reflect(outgoing, normal);
+}
+V3 sample_delta_transmission(V3 normal, V3 outgoing) {
+  if (dot(normal, outgoing) <= 0) return {0, 0, 0};
+  return -outgoing;
+}
+V3 sample_delta_refraction(float ior, V3 normal, V3 outgoing, float rnl) {
+  if (ior_is_one(ior)) return -outgoing;
+  auto s = refraction_setup(ior, normal, outgoing);
+  if (rnl < fresnel_dielectric(s.rel_ior, s.up_normal, outgoing))
+    return reflect(outgoing, s.up_normal);
+  return refract(outgoing, s.up_normal, 1 / s.rel_ior);
+}
+float sample_delta_reflection_pdf(V3 normal, V3 outgoing, V3 incoming) {
+  return same_side_up(normal, outgoing, incoming) ? 1 : 0;
+}
+float sample_delta_transmission_pdf(V3 normal, V3 outgoing, V3 incoming) {
+  if (dot(normal, incoming) >= 0 || dot(normal, outgoing) <= 0) return 0;
+  return 1;
+}
+float sample_delta_refraction_pdf(float ior, V3 normal, V3 outgoing, V3 incoming) {
+  if (ior_is_one(ior)) return dot(normal, incoming) * dot(normal, outgoing) < 0 ? 1 : 0;
+  auto s = refraction_setup(ior, normal, outgoing);
+  if (dot(normal, incoming) * dot(normal, outgoing) >= 0)
+    return fresnel_dielectric(s.rel_ior, s.up_normal, outgoing);
+  return (1 - fresnel_dielectric(s.rel_ior, s.up_normal, outgoing));
+}
+
+// ---------------------------------------------------------------------------
+// eval_brdf and the lobe dispatch (pt.cpp:372-394, 405-495, 1069-1280).
+// Textures are out of scope: every eval_texture(nullptr) factor is 1.
+// ---------------------------------------------------------------------------
 struct Brdf {
-  V3       diffuse;
-  float    diffuse_pdf;
-  bool     hair;
+  V3       diffuse{0, 0, 0}, specular{0, 0, 0}, metal{0, 0, 0}, transmission{0, 0, 0},
+      refraction{0, 0, 0};
+  float    roughness = 0, opacity = 1, ior = 1;
+  V3       meta{0, 0, 0}, metak{0, 0, 0};
+  float    diffuse_pdf = 0, specular_pdf = 0, metal_pdf = 0, transmission_pdf = 0,
+        refraction_pdf = 0;
+  bool     hair = false;
   HairBrdf hair_brdf;
 };
+Brdf surface_brdf(const Material& mat, V3 normal, V3 outgoing) {  // pt.cpp:405-471
+  auto base         = mat.color * V3{1, 1, 1};
+  auto specular     = mat.specular * 1.0f;
+  auto metallic     = mat.metallic * 1.0f;
+  auto roughness    = mat.roughness * 1.0f;
+  auto ior          = mat.ior;
+  auto transmission = mat.transmission * 1.0f;
+  auto opacity      = mat.opacity * ((1.0f + 1.0f + 1.0f) / 3);
+  auto thin         = mat.thin || !mat.transmission;
+
+  Brdf brdf;
+  auto weight = V3{1, 1, 1};
+  brdf.metal  = weight * metallic;
+  weight      = weight * (1 - metallic);
+  brdf.refraction = thin ? V3{0, 0, 0} : (weight * transmission);
+  weight          = weight * (1 - (thin ? 0 : transmission));
+  brdf.specular   = weight * specular;
+  weight          = weight * (1 - specular * fresnel_dielectric(ior, outgoing, normal));
+  brdf.transmission = thin ? (weight * transmission * base) : V3{0, 0, 0};
+  weight            = weight * (1 - (thin ? transmission : 0));
+  brdf.diffuse   = weight * base;
+  brdf.meta      = reflectivity_to_eta(base);
+  brdf.metak     = {0, 0, 0};
+  brdf.roughness = roughness * roughness;
+  brdf.ior       = ior;
+  brdf.opacity   = opacity;
+  if (nonzero(brdf.diffuse) || brdf.roughness)  // `!=` on vectors is !(==), math.h:1999
+    brdf.roughness = fclamp(brdf.roughness, 0.03f * 0.03f, 1.0f);
+  if (!nonzero(brdf.specular) && !nonzero(brdf.metal) && !nonzero(brdf.transmission) &&
+      !nonzero(brdf.refraction))
+    brdf.roughness = 1;
+  if (brdf.opacity > 0.999f) brdf.opacity = 1;
+
+  brdf.diffuse_pdf  = hmax(brdf.diffuse);
+  brdf.specular_pdf = hmax(brdf.specular * fresnel_dielectric(brdf.ior, normal, outgoing));
+  brdf.metal_pdf    = hmax(brdf.metal * fresnel_conductor(brdf.meta, brdf.metak, normal, outgoing));
+  brdf.transmission_pdf = hmax(brdf.transmission);
+  brdf.refraction_pdf   = hmax(brdf.refraction);
+  auto pdf_sum = brdf.diffuse_pdf + brdf.specular_pdf + brdf.metal_pdf + brdf.transmission_pdf +
+                 brdf.refraction_pdf;
+  if (pdf_sum) {
+    brdf.diffuse_pdf /= pdf_sum, brdf.specular_pdf /= pdf_sum, brdf.metal_pdf /= pdf_sum;
+    brdf.transmission_pdf /= pdf_sum, brdf.refraction_pdf /= pdf_sum;
+  }
+  return brdf;
+}
 Brdf eval_brdf(const yo_scene& scene, int object, int element, const float uv[2],
     V3 normal, V3 outgoing) {
   auto& obj   = scene.objects[object];
   auto& mat   = scene.materials[obj.material];
   auto& shape = scene.shapes[obj.shape];
-  Brdf  brdf{};
-  brdf.diffuse     = mat.color;  // weight {1,1,1} * base, pt.cpp:429-438
-  brdf.diffuse_pdf = hmax(brdf.diffuse);
-  if (brdf.diffuse_pdf) brdf.diffuse_pdf /= brdf.diffuse_pdf;  // pt.cpp:463-471
-  brdf.hair = shape.nlines() > 0;  // pt.cpp:474
+  auto  brdf  = surface_brdf(mat, normal, outgoing);
+  brdf.hair   = shape.nlines() > 0;  // pt.cpp:474
   if (brdf.hair) {
     auto tangent   = eval_normal(scene, object, element, uv);
     brdf.hair_brdf = eval_hair_brdf(mat.hair, uv[1], normal, tangent);
   }
   return brdf;
 }
+inline bool is_delta(const Brdf& brdf) { return !brdf.roughness; }  // pt.cpp:495
 
-// math.h:4427-4431, 4515-4519, 4572-4576, 4867-4878, 2743-2752
-V3 sample_hemisphere_cos(V3 normal, float rx, float ry) {
-  auto z     = std::sqrt(ry);
-  auto r     = std::sqrt(1 - z * z);
-  auto phi   = 2 * pif * rx;
-  auto local = V3{r * std::cos(phi), r * std::sin(phi), z};
-  auto zz    = normalize(normal);  // basis_fromz
-  auto sign  = copysignf(1.0f, zz.z);
-  auto a     = -1.0f / (sign + zz.z);
-  auto b     = zz.x * zz.y * a;
-  auto x     = V3{1.0f + sign * zz.x * zz.x * a, sign * b, -sign * zz.x};
-  auto y     = V3{b, sign + zz.y * zz.y * a, -zz.y};
-  return normalize(x * local.x + y * local.y + zz * local.z);
-}
-V3 eval_brdfcos(const Brdf& brdf, V3 normal, V3 outgoing, V3 incoming) {
+V3 eval_brdfcos(const Brdf& brdf, V3 normal, V3 outgoing, V3 incoming) {  // pt.cpp:1069-1102
   if (brdf.hair) return eval_hair_scattering(brdf.hair_brdf, outgoing, incoming);
-  auto brdfcos = V3{0, 0, 0};  // pt.cpp:1069-1102
-  if (nonzero(brdf.diffuse)) {
-    auto lobe = V3{0, 0, 0};
-    if (!(dot(normal, incoming) <= 0 || dot(normal, outgoing) <= 0))
-      lobe = V3{1, 1, 1} / pif * dot(normal, incoming);
-    brdfcos = brdfcos + brdf.diffuse * lobe;
-  }
+  if (!brdf.roughness) return {0, 0, 0};
+  auto brdfcos = V3{0, 0, 0};
+  if (nonzero(brdf.diffuse))
+    brdfcos = brdfcos + brdf.diffuse * eval_diffuse_reflection(normal, outgoing, incoming);
+  if (nonzero(brdf.specular))
+    brdfcos = brdfcos + brdf.specular * eval_microfacet_reflection(brdf.ior, brdf.roughness,
+                                            normal, outgoing, incoming);
+  if (nonzero(brdf.metal))
+    brdfcos = brdfcos + brdf.metal * eval_microfacet_reflection(brdf.meta, brdf.metak,
+                                         brdf.roughness, normal, outgoing, incoming);
+  if (nonzero(brdf.transmission))
+    brdfcos = brdfcos + brdf.transmission * eval_microfacet_transmission(brdf.ior,
+                                                brdf.roughness, normal, outgoing, incoming);
+  if (nonzero(brdf.refraction))
+    brdfcos = brdfcos + brdf.refraction * eval_microfacet_refraction(brdf.ior, brdf.roughness,
+                                              normal, outgoing, incoming);
+  return brdfcos;
+}
+V3 eval_delta(const Brdf& brdf, V3 normal, V3 outgoing, V3 incoming) {  // pt.cpp:1104-1128
+  if (brdf.roughness) return {0, 0, 0};
+  auto brdfcos = V3{0, 0, 0};
+  if (nonzero(brdf.specular) && !nonzero(brdf.refraction))
+    brdfcos = brdfcos + brdf.specular * eval_delta_reflection(brdf.ior, normal, outgoing, incoming);
+  if (nonzero(brdf.metal))
+    brdfcos = brdfcos + brdf.metal * eval_delta_reflection(brdf.meta, brdf.metak, normal,
+                                         outgoing, incoming);
+  if (nonzero(brdf.transmission))
+    brdfcos = brdfcos + brdf.transmission * eval_delta_transmission(normal, outgoing, incoming);
+  if (nonzero(brdf.refraction))
+    brdfcos = brdfcos + brdf.refraction * eval_delta_refraction(brdf.ior, normal, outgoing, incoming);
   return brdfcos;
 }
 V3 sample_brdfcos(const Brdf& brdf, V3 normal, V3 outgoing, float rnl, float rnx,
     float rny) {  // pt.cpp:1131-1175
   if (brdf.hair) return sample_hair_scattering(brdf.hair_brdf, outgoing, rnx, rny);
+  if (!brdf.roughness) return {0, 0, 0};
   auto cdf = 0.0f;
   if (brdf.diffuse_pdf) {
     cdf += brdf.diffuse_pdf;
-    if (rnl < cdf) {
-      if (dot(normal, outgoing) <= 0) return {0, 0, 0};
-      return sample_hemisphere_cos(normal, rnx, rny);
-    }
+    if (rnl < cdf) return sample_diffuse_reflection(normal, outgoing, rnx, rny);
+  }
+  if (brdf.specular_pdf && !brdf.refraction_pdf) {
+    cdf += brdf.specular_pdf;
+    if (rnl < cdf) return sample_microfacet_reflection(brdf.roughness, normal, outgoing, rnx, rny);
+  }
+  if (brdf.metal_pdf) {
+    cdf += brdf.metal_pdf;
+    if (rnl < cdf) return sample_microfacet_reflection(brdf.roughness, normal, outgoing, rnx, rny);
+  }
+  if (brdf.transmission_pdf) {
+    cdf += brdf.transmission_pdf;
+    if (rnl < cdf) return sample_microfacet_transmission(brdf.roughness, normal, outgoing, rnx, rny);
+  }
+  if (brdf.refraction_pdf) {
+    cdf += brdf.refraction_pdf;
+    if (rnl < cdf)
+      return sample_microfacet_refraction(brdf.ior, brdf.roughness, normal, outgoing, rnl, rnx, rny);
+  }
+  return {0, 0, 0};
+}
+V3 sample_delta(const Brdf& brdf, V3 normal, V3 outgoing, float rnl) {  // pt.cpp:1177-1214
+  if (brdf.roughness) return {0, 0, 0};
+  auto cdf = 0.0f;
+  cdf += brdf.diffuse_pdf;
+  if (brdf.specular_pdf && !brdf.refraction_pdf) {
+    cdf += brdf.specular_pdf;
+    if (rnl < cdf) return sample_delta_reflection(normal, outgoing);
+  }
+  if (brdf.metal_pdf) {
+    cdf += brdf.metal_pdf;
+    if (rnl < cdf) return sample_delta_reflection(normal, outgoing);
+  }
+  if (brdf.transmission_pdf) {
+    cdf += brdf.transmission_pdf;
+    if (rnl < cdf) return sample_delta_transmission(normal, outgoing);
+  }
+  if (brdf.refraction_pdf) {
+    cdf += brdf.refraction_pdf;
+    if (rnl < cdf) return sample_delta_refraction(brdf.ior, normal, outgoing, rnl);
   }
   return {0, 0, 0};
 }
 float sample_brdfcos_pdf(const Brdf& brdf, V3 normal, V3 outgoing, V3 incoming) {
   if (brdf.hair)  // pt.cpp:1217-1256
     return sample_hair_scattering_pdf(brdf.hair_brdf, outgoing, incoming);
+  if (!brdf.roughness) return 0;
   auto pdf = 0.0f;
-  if (brdf.diffuse_pdf) {
-    auto lobe = 0.0f;
-    if (!(dot(normal, incoming) <= 0 || dot(normal, outgoing) <= 0)) {
-      auto cosw = dot(normal, incoming);
-      lobe      = (cosw <= 0) ? 0 : cosw / pif;
-    }
-    pdf += brdf.diffuse_pdf * lobe;
-  }
+  if (brdf.diffuse_pdf)
+    pdf += brdf.diffuse_pdf * sample_diffuse_reflection_pdf(normal, outgoing, incoming);
+  if (brdf.specular_pdf && !brdf.refraction_pdf)
+    pdf += brdf.specular_pdf *
+           sample_microfacet_reflection_pdf(brdf.roughness, normal, outgoing, incoming);
+  if (brdf.metal_pdf)
+    pdf += brdf.metal_pdf *
+           sample_microfacet_reflection_pdf(brdf.roughness, normal, outgoing, incoming);
+  if (brdf.transmission_pdf)
+    pdf += brdf.transmission_pdf *
+           sample_microfacet_transmission_pdf(brdf.roughness, normal, outgoing, incoming);
+  if (brdf.refraction_pdf)
+    pdf += brdf.refraction_pdf * sample_microfacet_refraction_pdf(brdf.ior, brdf.roughness,
+                                     normal, outgoing, incoming);
+  return pdf;
+}
+float sample_delta_pdf(const Brdf& brdf, V3 normal, V3 outgoing, V3 incoming) {
+  if (brdf.roughness) return 0;  // pt.cpp:1258-1280
+  auto pdf = 0.0f;
+  if (brdf.specular_pdf && !brdf.refraction_pdf)
+    pdf += brdf.specular_pdf * sample_delta_reflection_pdf(normal, outgoing, incoming);
+  if (brdf.metal_pdf)
+    pdf += brdf.metal_pdf * sample_delta_reflection_pdf(normal, outgoing, incoming);
+  if (brdf.transmission_pdf)
+    pdf += brdf.transmission_pdf * sample_delta_transmission_pdf(normal, outgoing, incoming);
+  if (brdf.refraction_pdf)
+    pdf += brdf.refraction_pdf * sample_delta_refraction_pdf(brdf.ior, normal, outgoing, incoming);
   return pdf;
 }
 
@@ -1122,24 +1514,35 @@ Vec4 trace_path(const yo_scene& scene, const Ray& ray_, Rng& rng, int bounces) {
     auto emission = scene.materials[scene.objects[object].material].emission * V3{1, 1, 1};
     auto brdf     = eval_brdf(scene, object, element, uv, normal, outgoing);
     if (brdf.hair) tls_counters.hair++; else tls_counters.surf++;
+    if (brdf.opacity < 1 && rand1f(rng) >= brdf.opacity) {  // pt.cpp:1429-1433
+      ray = Ray{position + ray.d * 1e-2f, ray.d};
+      bounce -= 1;
+      continue;
+    }
     hit      = true;
     radiance = radiance + weight * emission;
     auto incoming = V3{0, 0, 0};
-    if (rand1f(rng) < 0.5f) {
-      // g++ evaluates call arguments right to left: rn (x then y), then rnl
-      auto rnx = rand1f(rng), rny = rand1f(rng);
-      auto rnl = rand1f(rng);
-      incoming = sample_brdfcos(brdf, normal, outgoing, rnl, rnx, rny);
-    } else {
-      // ruv (x then y), then rel, then rl
-      auto ruvx = rand1f(rng), ruvy = rand1f(rng);
-      auto rel = rand1f(rng);
-      auto rl  = rand1f(rng);
-      incoming = sample_lights(scene, position, rl, rel, ruvx, ruvy);
+    if (!is_delta(brdf)) {
+      if (rand1f(rng) < 0.5f) {
+        // g++ evaluates call arguments right to left: rn (x then y), then rnl
+        auto rnx = rand1f(rng), rny = rand1f(rng);
+        auto rnl = rand1f(rng);
+        incoming = sample_brdfcos(brdf, normal, outgoing, rnl, rnx, rny);
+      } else {
+        // ruv (x then y), then rel, then rl
+        auto ruvx = rand1f(rng), ruvy = rand1f(rng);
+        auto rel = rand1f(rng);
+        auto rl  = rand1f(rng);
+        incoming = sample_lights(scene, position, rl, rel, ruvx, ruvy);
+      }
+      weight = weight * (eval_brdfcos(brdf, normal, outgoing, incoming) /
+                            (0.5f * sample_brdfcos_pdf(brdf, normal, outgoing, incoming) +
+                                0.5f * sample_lights_pdf(scene, position, incoming)));
+    } else {  // pt.cpp:1452-1456
+      incoming = sample_delta(brdf, normal, outgoing, rand1f(rng));
+      weight   = weight * (eval_delta(brdf, normal, outgoing, incoming) /
+                            sample_delta_pdf(brdf, normal, outgoing, incoming));
     }
-    weight = weight * (eval_brdfcos(brdf, normal, outgoing, incoming) /
-                          (0.5f * sample_brdfcos_pdf(brdf, normal, outgoing, incoming) +
-                              0.5f * sample_lights_pdf(scene, position, incoming)));
     ray = Ray{position, incoming};
     if (weight == V3{0, 0, 0} || !finite3(weight)) break;
     if (bounce > 3) {
@@ -1356,6 +1759,112 @@ void yo_intersect_bbox(int n, const float* rays, const float* bbox, int* hit) {
   }
 }
 
+// One lobe of yocto_math.h:4427-4755 per call. params: 8 floats per item (ior,
+// roughness, eta[3], etak[3]); rn: 3 per item (rnl, rn.x, rn.y); out: 7 per
+// item (value*|cos| [3], pdf, sampled incoming [3]).
+void yo_surface_lobe(int kind, int n, const float* params, const float* normal,
+    const float* outgoing, const float* incoming, const float* rn, float* out) {
+  for (int i = 0; i < n; i++) {
+    auto  q   = params + 8 * i;
+    auto  ior = q[0], rough = q[1];
+    auto  eta = v3(q + 2), etak = v3(q + 5);
+    auto  nn = v3(normal + 3 * i), wo = v3(outgoing + 3 * i), wi = v3(incoming + 3 * i);
+    auto  rnl = rn[3 * i], rx = rn[3 * i + 1], ry = rn[3 * i + 2];
+    V3    f{0, 0, 0}, w{0, 0, 0};
+    float pdf = 0;
+    switch (kind) {
+      case YH_LOBE_DIFFUSE:
+        f = eval_diffuse_reflection(nn, wo, wi), pdf = sample_diffuse_reflection_pdf(nn, wo, wi);
+        w = sample_diffuse_reflection(nn, wo, rx, ry);
+        break;
+      case YH_LOBE_SPECULAR:
+        f   = eval_microfacet_reflection(ior, rough, nn, wo, wi);
+        pdf = sample_microfacet_reflection_pdf(rough, nn, wo, wi);
+        w   = sample_microfacet_reflection(rough, nn, wo, rx, ry);
+        break;
+      case YH_LOBE_METAL:
+        f   = eval_microfacet_reflection(eta, etak, rough, nn, wo, wi);
+        pdf = sample_microfacet_reflection_pdf(rough, nn, wo, wi);
+        w   = sample_microfacet_reflection(rough, nn, wo, rx, ry);
+        break;
+      case YH_LOBE_TRANSMISSION:
+        f   = eval_microfacet_transmission(ior, rough, nn, wo, wi);
+        pdf = sample_microfacet_transmission_pdf(rough, nn, wo, wi);
+        w   = sample_microfacet_transmission(rough, nn, wo, rx, ry);
+        break;
+      case YH_LOBE_REFRACTION:
+        f   = eval_microfacet_refraction(ior, rough, nn, wo, wi);
+        pdf = sample_microfacet_refraction_pdf(ior, rough, nn, wo, wi);
+        w   = sample_microfacet_refraction(ior, rough, nn, wo, rnl, rx, ry);
+        break;
+      case YH_LOBE_DELTA_SPECULAR:
+        f = eval_delta_reflection(ior, nn, wo, wi), pdf = sample_delta_reflection_pdf(nn, wo, wi);
+        w = sample_delta_reflection(nn, wo);
+        break;
+      case YH_LOBE_DELTA_METAL:
+        f = eval_delta_reflection(eta, etak, nn, wo, wi), pdf = sample_delta_reflection_pdf(nn, wo, wi);
+        w = sample_delta_reflection(nn, wo);
+        break;
+      case YH_LOBE_DELTA_TRANSMISSION:
+        f = eval_delta_transmission(nn, wo, wi), pdf = sample_delta_transmission_pdf(nn, wo, wi);
+        w = sample_delta_transmission(nn, wo);
+        break;
+      case YH_LOBE_DELTA_REFRACTION:
+        f = eval_delta_refraction(ior, nn, wo, wi), pdf = sample_delta_refraction_pdf(ior, nn, wo, wi);
+        w = sample_delta_refraction(ior, nn, wo, rnl);
+        break;
+      default: break;
+    }
+    auto o = out + 7 * i;
+    o[0] = f.x, o[1] = f.y, o[2] = f.z, o[3] = pdf, o[4] = w.x, o[5] = w.y, o[6] = w.z;
+  }
+}
+
+// fresnel_dielectric, fresnel_conductor, reflectivity_to_eta(params.eta) — out 7n
+void yo_fresnel(int n, const float* params, const float* normal, const float* outgoing, float* out) {
+  for (int i = 0; i < n; i++) {
+    auto q  = params + 8 * i;
+    auto nn = v3(normal + 3 * i), wo = v3(outgoing + 3 * i);
+    auto fd = fresnel_dielectric(q[0], nn, wo);
+    auto fc = fresnel_conductor(v3(q + 2), v3(q + 5), nn, wo);
+    auto e  = reflectivity_to_eta(v3(q + 2));
+    auto o  = out + 7 * i;
+    o[0] = fd, o[1] = fc.x, o[2] = fc.y, o[3] = fc.z, o[4] = e.x, o[5] = e.y, o[6] = e.z;
+  }
+}
+
+// eval_brdf + the lobe dispatch of pt.cpp:405-471,1069-1280 for non-hair
+// materials. out: YH_SURFACE_BSDF_FLOATS per item (layout in yhair.h).
+void yo_surface_bsdf(int n, const yh_material* materials, const float* normal,
+    const float* outgoing, const float* incoming, const float* rn, float* out) {
+  for (int i = 0; i < n; i++) {
+    auto&    m = materials[i];
+    Material mt;
+    mt.emission = v3(m.emission), mt.color = v3(m.color), mt.thin = m.thin != 0;
+    mt.specular = m.specular, mt.metallic = m.metallic, mt.roughness = m.roughness;
+    mt.ior = m.ior, mt.transmission = m.transmission, mt.opacity = m.opacity;
+    auto nn = v3(normal + 3 * i), wo = v3(outgoing + 3 * i), wi = v3(incoming + 3 * i);
+    auto rnl = rn[3 * i], rx = rn[3 * i + 1], ry = rn[3 * i + 2];
+    auto b  = surface_brdf(mt, nn, wo);
+    auto o  = out + YH_SURFACE_BSDF_FLOATS * i;
+    V3   lobes[5] = {b.diffuse, b.specular, b.metal, b.transmission, b.refraction};
+    for (int k = 0; k < 5; k++) o[3 * k] = lobes[k].x, o[3 * k + 1] = lobes[k].y, o[3 * k + 2] = lobes[k].z;
+    o[15] = b.roughness, o[16] = b.opacity;
+    o[17] = b.diffuse_pdf, o[18] = b.specular_pdf, o[19] = b.metal_pdf, o[20] = b.transmission_pdf,
+    o[21] = b.refraction_pdf;
+    V3    f, w;
+    float pdf;
+    if (!is_delta(b)) {
+      f = eval_brdfcos(b, nn, wo, wi), pdf = sample_brdfcos_pdf(b, nn, wo, wi);
+      w = sample_brdfcos(b, nn, wo, rnl, rx, ry);
+    } else {
+      f = eval_delta(b, nn, wo, wi), pdf = sample_delta_pdf(b, nn, wo, wi);
+      w = sample_delta(b, nn, wo, rnl);
+    }
+    o[22] = f.x, o[23] = f.y, o[24] = f.z, o[25] = pdf, o[26] = w.x, o[27] = w.y, o[28] = w.z;
+  }
+}
+
 yo_scene* yo_scene_create(const yh_scene_desc* d) {
   auto sc = new yo_scene{};
   for (int i = 0; i < d->num_shapes; i++) {
@@ -1379,6 +1888,12 @@ yo_scene* yo_scene_create(const yh_scene_desc* d) {
     Material mt;
     mt.emission = v3(m.emission), mt.color = v3(m.color);
     mt.thin = m.thin != 0;
+    mt.specular = m.specular, mt.metallic = m.metallic, mt.roughness = m.roughness;
+    mt.ior = m.ior, mt.transmission = m.transmission, mt.opacity = m.opacity;
+    if (!mt.thin && mt.transmission) {  // has_volume (pt.cpp:531): volumes are not restated
+      delete sc;
+      return nullptr;
+    }
     mt.hair.sigma_a = v3(m.sigma_a);
     mt.hair.beta_m = m.beta_m, mt.hair.beta_n = m.beta_n;
     mt.hair.alpha = m.alpha, mt.hair.eta = m.eta;

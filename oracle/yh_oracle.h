@@ -45,6 +45,17 @@ void yo_hair_pdf(
 /* ext.cpp:555-693: returns 1 = "OK!", 0 = "TEST FAILED!" */
 int yo_selftest(int which, float* worst);
 
+/* yocto_math.h:4427-4755: one lobe (YH_LOBE_*); params 8n (ior, roughness,
+ * eta[3], etak[3]); rn 3n (rnl, rn.x, rn.y); out 7n (f*|cos| [3], pdf,
+ * sampled incoming [3])                                                     */
+void yo_surface_lobe(int kind, int n, const float* params, const float* normal,
+    const float* outgoing, const float* incoming, const float* rn, float* out);
+/* fresnel_dielectric(ior), fresnel_conductor(eta, etak), reflectivity_to_eta(eta): out 7n */
+void yo_fresnel(int n, const float* params, const float* normal, const float* outgoing, float* out);
+/* pt.cpp:405-471 (eval_brdf) + 1069-1280 (dispatch), non-hair materials      */
+void yo_surface_bsdf(int n, const yh_material* materials, const float* normal,
+    const float* outgoing, const float* incoming, const float* rn, float* out);
+
 /* math.h:3426-3505,3544-3554 */
 void yo_intersect_line(int n, const float* rays, const float* p0,
     const float* p1, const float* r0, const float* r1, int* hit, float* uv,

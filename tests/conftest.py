@@ -71,6 +71,7 @@ GOLDEN_SCENES = [
     ("straight-hair", dict(scale=0.05, beta_m=0.1)),
     ("curly-hair", dict(scale=0.05)),
     ("hair-curls", dict(scale=0.05)),
+    ("lobes", dict(scale=0.05)),
 ]
 
 

@@ -38,6 +38,8 @@ class _UnitApi:
         g("intersect_line").argtypes = [C.c_int, fp, fp, fp, fp, fp, ip, fp, fp]
         g("intersect_triangle").argtypes = [C.c_int, fp, fp, fp, fp, ip, fp, fp]
         g("intersect_bbox").argtypes = [C.c_int, fp, fp, ip]
+        g("surface_lobe").argtypes = [C.c_int, C.c_int, fp, fp, fp, fp, fp, fp]
+        g("fresnel").argtypes = [C.c_int, fp, fp, fp, fp]
 
     def _g(self, n):
         return getattr(self.lib, self.p + n)
@@ -74,6 +76,20 @@ class _UnitApi:
     def hair_pdf(self, brdf, wo, wi):
         return self._wowi("hair_pdf", brdf, wo, wi, 1)
 
+    def surface_lobe(self, kind, params8, normal, wo, wi, rn3):
+        """One YH_LOBE_* kind: returns (n, 7) = f*|cos| [3], pdf, sampled incoming [3]."""
+        params8, normal, wo, wi, rn3 = _f(params8), _f(normal), _f(wo), _f(wi), _f(rn3)
+        out = np.zeros((len(params8), 7), np.float32)
+        self._g("surface_lobe")(kind, len(params8), yh.fptr(params8), yh.fptr(normal), yh.fptr(wo), yh.fptr(wi),
+                                yh.fptr(rn3), yh.fptr(out))
+        return out
+
+    def fresnel(self, params8, normal, wo):
+        params8, normal, wo = _f(params8), _f(normal), _f(wo)
+        out = np.zeros((len(params8), 7), np.float32)
+        self._g("fresnel")(len(params8), yh.fptr(params8), yh.fptr(normal), yh.fptr(wo), yh.fptr(out))
+        return out
+
     def intersect_line(self, rays, p0, p1, r0, r1):
         rays, p0, p1, r0, r1 = _f(rays), _f(p0), _f(p1), _f(r0), _f(r1)
         n = len(r0)
@@ -104,6 +120,7 @@ class Oracle(_UnitApi):
         lib = C.CDLL(ORACLE_SO)
         super().__init__(lib, "yo_")
         lib.yo_selftest.argtypes = [C.c_int, fp]
+        lib.yo_surface_bsdf.argtypes = [C.c_int, C.POINTER(yh.Material), fp, fp, fp, fp, fp]
         lib.yo_scene_create.restype = C.c_void_p
         lib.yo_scene_create.argtypes = [C.POINTER(yh.SceneDesc)]
         lib.yo_scene_free.argtypes = [C.c_void_p]
@@ -118,6 +135,14 @@ class Oracle(_UnitApi):
         worst = C.c_float()
         ok = self.lib.yo_selftest(which, C.byref(worst))
         return bool(ok), worst.value
+
+    def surface_bsdf(self, materials, normal, wo, wi, rn3):
+        """eval_brdf + lobe dispatch (pt.cpp:405-471,1069-1280): (n, YH_SURFACE_BSDF_FLOATS)."""
+        normal, wo, wi, rn3 = _f(normal), _f(wo), _f(wi), _f(rn3)
+        out = np.zeros((len(normal), yh.SURFACE_BSDF_FLOATS), np.float32)
+        self.lib.yo_surface_bsdf(len(normal), materials, yh.fptr(normal), yh.fptr(wo), yh.fptr(wi), yh.fptr(rn3),
+                                 yh.fptr(out))
+        return out
 
     def scene(self, desc):
         return OracleScene(self, desc)

@@ -56,6 +56,21 @@ def test_hair_bsdf_survey_sanity_row(oracle):
     assert np.allclose(g["brdf"][-2][0:3], [0.00143605738, 0.0242141783, 0.258826762], rtol=1e-6)
 
 
+def test_surface_lobes_bit_exact(oracle, yh):
+    """Fresnel terms and the nine surface lobes (yocto_math.h:4215-4755)
+    — value * |cos|, pdf and sampled direction — against vectors made by the reference."""
+    g = golden("lobes.npz")
+    args = (g["params"], g["normal"], g["wo"], g["wi"], g["rn"])
+    assert np.array_equal(oracle.fresnel(g["params"], g["normal"], g["wo"]), g["fresnel"], equal_nan=True)
+    for kind in range(yh.LOBE_COUNT):
+        want = g[f"lobe_{kind}"]
+        assert np.array_equal(oracle.surface_lobe(kind, *args), want, equal_nan=True), kind
+        # the fixture really exercises the lobe: non-zero values, non-zero samples, finite
+        assert np.isfinite(want).all()
+        assert (want[:, :3] != 0).any(axis=1).mean() > 0.15, kind
+        assert (want[:, 4:] != 0).any(axis=1).mean() > 0.4, kind
+
+
 def test_primitive_tests_bit_exact(oracle):
     g = golden("intersect.npz")
     h, uv, d = oracle.intersect_line(g["rays"], g["p0"], g["p1"], g["r0"], g["r1"])

@@ -41,6 +41,22 @@ def test_bsdf_random_inputs(oracle, ref):
     assert np.array_equal(oracle.hair_sample(b, wo, rn), ref.hair_sample(b, wo, rn), equal_nan=True)
 
 
+def test_surface_lobes_random_inputs(oracle, ref, yh):
+    rng = np.random.default_rng(100)
+    n = 20000
+    nn, wo, wi = _dirs(rng, n), _dirs(rng, n), _dirs(rng, n)
+    p = np.zeros((n, 8), np.float32)
+    p[:, 0] = rng.choice([1.0, 1.0005, 1.33, 1.5, 2.4], n)
+    p[:, 1] = rng.choice([0.0009, 0.01, 0.04, 0.25, 1.0], n)
+    p[:, 2:5] = rng.uniform(0, 4, (n, 3))
+    p[:, 5:8] = rng.choice([0, 1], n)[:, None] * rng.uniform(0, 4, (n, 3))
+    rn = rng.uniform(0, 1, (n, 3)).astype(np.float32)
+    assert np.array_equal(oracle.fresnel(p, nn, wo), ref.fresnel(p, nn, wo), equal_nan=True)
+    for kind in range(yh.LOBE_COUNT):
+        assert np.array_equal(oracle.surface_lobe(kind, p, nn, wo, wi, rn), ref.surface_lobe(kind, p, nn, wo, wi, rn),
+                              equal_nan=True), kind
+
+
 def test_selftests_match_reference(oracle, ref):
     # the reference prints "OK!"; ours returns 1. Only the two cheap ones here (the 300k-sample
     # furnace tests take ~12 s on the reference and are covered by the GPU self-tests).
@@ -53,6 +69,7 @@ def test_selftests_match_reference(oracle, ref):
     ("sphere-hairblock", dict(scale=0.1, zoom=True), 80, 4),
     ("hair-curls", dict(scale=0.1), 80, 4),
     ("straight-hair", dict(scale=0.1, beta_m=0.6), 80, 4),
+    ("lobes", dict(scale=0.1), 160, 8),
 ])
 def test_images_bit_identical_to_reference(oracle, ref, yh, name, kw, res, spp):
     path = scene_path(name, **kw)

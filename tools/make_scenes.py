@@ -174,6 +174,50 @@ def make_sphere_hairblock(outdir, scale=1.0, name="sphere-hairblock", zoom=False
     return os.path.join(d, name + ".json"), nseg
 
 
+LOBE_MATERIALS = {
+    # one sphere per lobe combination of pt.cpp:405-471
+    "plastic": {"color": [0.8, 0.2, 0.2], "specular": 1.0, "roughness": 0.2},
+    "roughmetal": {"color": [0.9, 0.7, 0.3], "metallic": 1.0, "roughness": 0.3},
+    "mirror": {"color": [0.9, 0.9, 0.9], "metallic": 1.0, "roughness": 0.0},
+    "polish": {"color": [0.0, 0.0, 0.0], "specular": 1.0, "roughness": 0.0},
+    "frosted": {"color": [0.9, 1.0, 0.9], "specular": 1.0, "transmission": 1.0, "thin": True, "roughness": 0.1},
+    "pane": {"color": [1.0, 1.0, 1.0], "specular": 1.0, "transmission": 1.0, "thin": True, "roughness": 0.0, "ior": 1.33},
+    "veil": {"color": [0.2, 0.8, 0.3], "opacity": 0.5},
+    "mixed": {"color": [0.5, 0.6, 0.9], "specular": 0.5, "metallic": 0.3, "transmission": 0.4, "thin": True,
+              "roughness": 0.15, "opacity": 0.9},
+}
+
+
+def make_lobes(outdir, scale=1.0, name="lobes"):
+    """Rank-1 widening scene: eight spheres (specular / metal / delta / thin transmission /
+    opacity materials), the hair block, one area light and a constant environment."""
+    d = _prep(outdir, name)
+    shutil.copy(os.path.join(ASSETS, "sphere.ply"), os.path.join(d, "shapes", "sphere.ply"))
+    shutil.copy(os.path.join(ASSETS, "arealight.ply"), os.path.join(d, "shapes", "arealight.ply"))
+    nseg = write_hair_ply(os.path.join(d, "shapes", "hair-block.ply"),
+                          gen_hair_block(max(64, int(100_000 * scale))), 0.004, 0.001)
+    objects = {
+        "hairblock": {"frame": [1, 0, 0, 0, 0, 1, 0, -1, 0, 1.6, 1, -0.5], "shape": "hair-block", "material": "hair"},
+        "floor": {"frame": [2, 0, 0, 0, 0, -2, 0, 2, 0, 0.3, 0, 0], "shape": "arealight", "material": "floor"},
+        "light": {"lookat": [0.3, 5, 2, 0.3, 0.5, 0, 0, 1, 0], "shape": "arealight", "material": "arealight"},
+    }
+    materials = {"hair": {"eumelanin": 1.3}, "floor": {"color": [0.6, 0.6, 0.6]}, "arealight": {"emission": [12, 12, 12]}}
+    for k, (mname, mat) in enumerate(LOBE_MATERIALS.items()):
+        x, z = -1.5 + 0.85 * (k % 4), (0.45 if k < 4 else -0.55)
+        sz = 0.7
+        objects["ball%d" % k] = {"frame": [sz, 0, 0, 0, sz, 0, 0, 0, sz, x, 0.0, z], "shape": "sphere", "material": mname}
+        materials[mname] = mat
+    scene = {
+        "asset": {"copyright": "synthetic; sphere and quad from the reference's test assets"},
+        "cameras": {"default": {"lens": 0.05, "aperture": 0.0, "aspect": 1.0, "lookat": [0.2, 2.6, 5.2, 0.2, 0.35, 0, 0, 1, 0]}},
+        "environments": {"sky": {"emission": [0.5, 0.5, 0.5]}},
+        "objects": objects,
+        "materials": materials,
+    }
+    _dump(scene, os.path.join(d, name + ".json"))
+    return os.path.join(d, name + ".json"), nseg
+
+
 def _head_scene(outdir, name, shape, pos, emission, lights, hair_mat):
     d = _prep(outdir, name)
     shutil.copy(os.path.join(ASSETS, "sky.hdr"), os.path.join(d, "textures", "sky.hdr"))
@@ -246,6 +290,7 @@ MAKERS = {
     "straight-hair": make_straight_hair,
     "curly-hair": make_curly_hair,
     "hair-curls": make_hair_curls,
+    "lobes": make_lobes,
 }
 
 

@@ -15,6 +15,10 @@ LIB_PATH = os.environ.get("YHAIR_LIB", os.path.join(ROOT, "yocto-hair_amd", "lib
 
 YH_OK, YH_E_INVALID, YH_E_DEVICE, YH_E_STATE, YH_E_IO, YH_E_SELFTEST = 0, -1, -2, -3, -4, -5
 YH_HAIR_BRDF_FLOATS = 30
+SURFACE_BSDF_FLOATS = 29
+(LOBE_DIFFUSE, LOBE_SPECULAR, LOBE_METAL, LOBE_TRANSMISSION, LOBE_REFRACTION, LOBE_DELTA_SPECULAR,
+ LOBE_DELTA_METAL, LOBE_DELTA_TRANSMISSION, LOBE_DELTA_REFRACTION) = range(9)
+LOBE_COUNT = 9
 
 c_float_p = C.POINTER(C.c_float)
 c_int_p = C.POINTER(C.c_int)
