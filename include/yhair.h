@@ -59,8 +59,10 @@ typedef struct yh_shape {
 
 /* ptr::material (yocto_pathtrace.h:293-329), restricted to the lobes the hair
  * configs reach: emission, diffuse colour and the hair parameters
- * (yocto_extension.h:86-95). Any other lobe (specular, metallic, transmission,
- * opacity < 1, textures) is rejected by yh_upload_scene with YH_E_INVALID.  */
+ * (yocto_extension.h:86-95). Specular, metallic, thin transmission, delta
+ * (roughness 0) and opacity lobes follow yocto_pathtrace.cpp:405-471; textures
+ * and volumes (transmission with thin = 0) are rejected by yh_upload_scene
+ * with YH_E_INVALID.                                                        */
 typedef struct yh_material {
   float emission[3];
   float color[3];
@@ -259,6 +261,21 @@ int yh_hair_pdf_batch(yh_context* ctx, int n, const float* brdf,
 int yh_hair_eval_pdf_batch(yh_context* ctx, int n, const float* brdf,
     const float* outgoing, const float* incoming, float* pdf);
 
+/* One surface lobe (kind = YH_LOBE_*) of yocto_math.h:1513-1620 (implementation
+ * 4427-4755): eval_* (value times |cos|), sample_*_pdf and sample_* in one
+ * call. params: 8n (ior, roughness [= brdf.roughness, already squared], eta[3],
+ * etak[3]); normal, outgoing, incoming: 3n; rn: 3n (rnl, rn.x, rn.y);
+ * out: 7n (f[3], pdf, sampled incoming[3]).                                   */
+int yh_surface_lobe_batch(yh_context* ctx, int kind, int n, const float* params,
+    const float* normal, const float* outgoing, const float* incoming,
+    const float* rn, float* out);
+/* The lobe mixture of a non-hair material: eval_brdf (yocto_pathtrace.cpp:
+ * 405-471) followed by eval_brdfcos / sample_brdfcos / sample_brdfcos_pdf or,
+ * for a delta mixture, eval_delta / sample_delta / sample_delta_pdf
+ * (:1069-1280). out: YH_SURFACE_BSDF_FLOATS per item.                          */
+int yh_surface_bsdf_batch(yh_context* ctx, int n, const yh_material* materials,
+    const float* normal, const float* outgoing, const float* incoming,
+    const float* rn, float* out);
 /* intersect_scene_bvh (yocto_pathtrace.cpp:934-1046) on the uploaded scene.
  * rays: 8n floats (o[3] d[3] tmin tmax). Outputs per ray: object, element
  * (-1 on miss), uv[2], distance.                                             */

@@ -86,6 +86,68 @@ def test_hair_batches_match_oracle_on_fresh_inputs(ctx, oracle):
     assert np.max(_rel(ctx.hair_pdf(b, wo, wi), oracle.hair_pdf(b, wo, wi), 1e-7)) <= REL_BSDF
 
 
+def _lobe_close(got, want):
+    """Rows of (f[3], pdf, sampled[3]) within the stated tolerances; returns the failing fraction.
+    Non-finite values (0 * inf in a grazing microfacet term) must be non-finite on both sides."""
+    same = (got == want) | (np.isnan(got) & np.isnan(want))
+    with np.errstate(invalid="ignore"):
+        ok_f = (same[:, :4] | (_rel(got[:, :4], want[:, :4], 1e-7) <= REL_BSDF)).all(axis=1)
+        ok_w = (same[:, 4:] | (np.abs(got[:, 4:] - want[:, 4:]) <= ABS_DIR)).all(axis=1)
+    return 1.0 - float(np.mean(ok_f & ok_w)), ok_f, ok_w
+
+
+def test_surface_lobes_match_reference_vectors(ctx, yh):
+    """each lobe of yocto_math.h:4427-4755 on the device vs the reference's
+    own outputs. Values and pdfs are + - * / sqrt only: all within 1e-4 (most bit-exact);
+    sampled directions go through device atan/sin/cos: 5e-5 absolute. The refraction lobes pick
+    reflect-or-refract by `rnl < F(sampled halfway)`, so a last-ulp change flips a few rows."""
+    g = golden("lobes.npz")
+    args = (g["params"], g["normal"], g["wo"], g["wi"], g["rn"])
+    for kind in range(yh.LOBE_COUNT):
+        got, want = ctx.surface_lobe(kind, *args), g[f"lobe_{kind}"]
+        bad, ok_f, ok_w = _lobe_close(got, want)
+        assert ok_f.all(), (kind, np.flatnonzero(~ok_f)[:5])
+        assert bad <= (2e-3 if kind == yh.LOBE_REFRACTION else 0.0), (kind, bad)
+        assert np.mean(got[:, :4] == want[:, :4]) > 0.97, kind
+
+
+def _random_surface_materials(yh, rng, n):
+    arr = (yh.Material * n)()
+    for i in range(n):
+        m = arr[i]
+        m.color[:] = rng.choice([0.0, 0.3, 0.9], 3).tolist() if rng.uniform() < 0.3 else rng.uniform(0, 1, 3).tolist()
+        m.specular = float(rng.choice([0, 0.5, 1]))
+        m.metallic = float(rng.choice([0, 0, 0.4, 1]))
+        m.transmission = float(rng.choice([0, 0, 0.6, 1]))
+        m.roughness = float(rng.choice([0, 0, 0.05, 0.3, 1]))
+        m.opacity = float(rng.choice([1, 1, 0.9995, 0.5]))
+        m.ior = float(rng.choice([1.0, 1.33, 1.5]))
+        m.thin = int(rng.choice([1, 1, 0]))  # 0 + transmission: the refraction lobe (batch API only)
+    return arr
+
+
+def test_surface_bsdf_mixture_matches_oracle(ctx, oracle, yh):
+    """eval_brdf + the rough / delta dispatch (pt.cpp:405-471, 1069-1280): lobe weights, roughness,
+    opacity and lobe pdfs bit-exact; value, pdf and sampled direction within tolerance."""
+    rng = np.random.default_rng(21)
+    n = 20000
+    mats = _random_surface_materials(yh, rng, n)
+    d = lambda: (lambda x: (x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float32))(rng.normal(size=(n, 3)))  # noqa
+    nn, wo, wi = d(), d(), d()
+    k = n // 2  # half of the rows: incoming near the mirror / straight-through direction (delta lobes fire)
+    wi[:k:2] = -wo[:k:2] + 2 * np.sum(nn[:k:2] * wo[:k:2], 1, keepdims=True) * nn[:k:2]
+    wi[1:k:2] = -wo[1:k:2]
+    rn = rng.uniform(0, 1, (n, 3)).astype(np.float32)
+    got, want = ctx.surface_bsdf(mats, nn, wo, wi, rn), oracle.surface_bsdf(mats, nn, wo, wi, rn)
+    assert np.array_equal(got[:, :22], want[:, :22])
+    delta = want[:, 15] == 0
+    assert 0.05 < delta.mean() < 0.6
+    bad, ok_f, ok_w = _lobe_close(got[:, 22:], want[:, 22:])
+    worst = np.flatnonzero(~ok_f)[:3]
+    assert ok_f.all() and bad <= 1e-3, (bad, worst, got[worst], want[worst])
+    assert (want[:, 22:25] != 0).any(axis=1).mean() > 0.2
+
+
 def test_empty_and_invalid_batches(ctx, yh):
     z = np.zeros((0, 3), np.float32)
     assert ctx.hair_eval(np.zeros((0, 30), np.float32), z, z).shape == (0, 3)
@@ -122,7 +184,7 @@ def test_closest_hits_bit_exact(ctx, oracle, yh, name, kw):
     obj, elem, uv, dist = ctx.intersect(g["rays"])
     assert np.array_equal(obj, g["object"]) and np.array_equal(elem, g["element"])
     assert np.array_equal(uv, g["uv"]) and np.array_equal(dist, g["distance"])
-    assert 0.2 < np.mean(obj >= 0) < 0.9
+    assert 0.2 < np.mean(obj >= 0) < 0.95
     # many more rays against the oracle, including axis-aligned and zero directions
     rng = np.random.default_rng(5)
     m = 100000

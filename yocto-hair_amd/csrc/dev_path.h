@@ -12,6 +12,7 @@
 #ifndef YH_DEV_PATH_H_
 #define YH_DEV_PATH_H_
 #include "dev_hair.h"
+#include "dev_surface.h"
 #include "dev_trace.h"
 
 namespace yhd {
@@ -221,21 +222,6 @@ YH_DEV float sample_lights_pdf(const trace_ctx& tc, f3 position, f3 direction) {
   return pdf;
 }
 
-// sample_hemisphere_cos(normal, ruv) with basis_fromz (math.h:4867-4878,2743)
-YH_DEV f3 sample_hemisphere_cos(f3 normal, float rx, float ry) {
-  float z     = sqrtf(ry);
-  float r     = sqrtf(1 - z * z);
-  float phi   = 2 * pif * rx;
-  f3    local = {r * cosf(phi), r * sinf(phi), z};
-  f3    zz    = normalize(normal);
-  float sign  = copysignf(1.0f, zz.z);
-  float a     = -1.0f / (sign + zz.z);
-  float b     = zz.x * zz.y * a;
-  f3    x     = {1.0f + sign * zz.x * zz.x * a, sign * b, -sign * zz.x};
-  f3    y     = {b, sign + zz.y * zz.y * a, -zz.y};
-  return normalize(x * local.x + y * local.y + zz * local.z);
-}
-
 // State of one path in flight (the locals of trace_path, pt.cpp:1383-1387).
 struct path_t {
   ray_t ray;
@@ -244,11 +230,23 @@ struct path_t {
   bool  hit;
 };
 
+// End of one bounce (pt.cpp:1499-1507): weight check, Russian roulette, bounce count.
+YH_DEV bool path_continue(path_t& ps, rng_t& rng, int bounces) {
+  if (is_zero(ps.weight) || !finite3(ps.weight)) return false;
+  if (ps.bounce > 3) {
+    float rr_prob = fmin_(0.99f, hmax(ps.weight));
+    if (rand1f(rng) >= rr_prob) return false;
+    ps.weight = ps.weight * (1 / rr_prob);
+  }
+  ps.bounce++;
+  return ps.bounce < bounces;
+}
+
 // One iteration of trace_path's bounce loop (pt.cpp:1395-1508) given the
 // closest hit of ps.ray. Returns true when the path continues with the new
 // ps.ray, false when it ended (miss, zero / non-finite weight, Russian
 // roulette or the bounce limit).
-template <bool COUNT, int STRIDE>
+template <bool COUNT, int STRIDE, bool GENERAL>
 YH_DEV bool path_step(const trace_ctx& tc, path_t& ps, const hit_t& isec, rng_t& rng, int bounces) {
   const yhd_scene& sc = *tc.sc;
   unsigned long long k0 = 0, k1 = 0, k2 = 0, k3 = 0;
@@ -271,9 +269,31 @@ YH_DEV bool path_step(const trace_ctx& tc, path_t& ps, const hit_t& isec, rng_t&
   } else {
     normal = (!mat.thin || dot(nrm, outgoing) >= 0) ? nrm : -nrm;
   }
+  // Materials with lobes beyond diffuse / hair (dev_surface.h): the lobe mixture
+  // decides opacity pass-through and whether the hit is a delta surface.
   if (COUNT) count_quad<COUNT>(is_hair ? tc.stats->hair : tc.stats->surf);
+  const bool     general = GENERAL && !mat.plain;
+  surface_brdf_t sb;
+  if (general) {
+    sb = surface_brdf(mat, normal, outgoing);
+    if (sb.opacity < 1 && rand1f(rng) >= sb.opacity) {  // pt.cpp:1429-1433: pass through, same bounce
+      ps.ray = mkray(position + ps.ray.d * 1e-2f, ps.ray.d);
+      if (COUNT) tc.stats->c_rest += clock64() - k0;
+      return true;
+    }
+  }
   ps.hit      = true;
   ps.radiance = ps.radiance + ps.weight * (ld3(mat.emission) * mk3(1.0f));
+  if (general && is_delta(sb)) {  // pt.cpp:1452-1456 (also for a hair shape whose mixture is a delta)
+    f3    incoming = surface_sample_delta(sb, normal, outgoing, rand1f(rng));
+    f3    brdfcos;
+    float pdf;
+    surface_eval_pdf_delta(sb, normal, outgoing, incoming, brdfcos, pdf);
+    ps.weight = ps.weight * (brdfcos / pdf);
+    ps.ray    = mkray(position, incoming);
+    if (COUNT) tc.stats->c_rest += clock64() - k0;
+    return path_continue(ps, rng, bounces);
+  }
   hair_hit hh;
   hair_out ho;
   if (is_hair) {
@@ -288,6 +308,8 @@ YH_DEV bool path_step(const trace_ctx& tc, path_t& ps, const hit_t& isec, rng_t&
     float rnl = rand1f(rng);
     if (is_hair) {
       incoming = hair_sample(mat, hh, ho, rnx, rny);
+    } else if (general) {
+      incoming = surface_sample(sb, normal, outgoing, rnl, rnx, rny);
     } else {  // sample_brdfcos (pt.cpp:1139-1174): only the diffuse lobe
       incoming = mk3(0.0f);
       if (mat.diffuse_pdf != 0 && rnl < 0.0f + mat.diffuse_pdf) {
@@ -305,6 +327,8 @@ YH_DEV bool path_step(const trace_ctx& tc, path_t& ps, const hit_t& isec, rng_t&
   float brdf_pdf;
   if (is_hair) {
     hair_eval_pdf_quad(mat, hh, ho, incoming, brdfcos, brdf_pdf);
+  } else if (general) {
+    surface_eval_pdf(sb, normal, outgoing, incoming, brdfcos, brdf_pdf);
   } else {  // eval_brdfcos / sample_brdfcos_pdf, diffuse lobe (math.h:4427,4572)
     brdfcos  = mk3(0.0f);
     brdf_pdf = 0.0f;
@@ -328,14 +352,7 @@ YH_DEV bool path_step(const trace_ctx& tc, path_t& ps, const hit_t& isec, rng_t&
   ps.weight = ps.weight * (brdfcos / (0.5f * brdf_pdf + 0.5f * light_pdf));
   ps.ray    = mkray(position, incoming);
   if (COUNT) tc.stats->c_rest += clock64() - k3;
-  if (is_zero(ps.weight) || !finite3(ps.weight)) return false;
-  if (ps.bounce > 3) {
-    float rr_prob = fmin_(0.99f, hmax(ps.weight));
-    if (rand1f(rng) >= rr_prob) return false;
-    ps.weight = ps.weight * (1 / rr_prob);
-  }
-  ps.bounce++;
-  return ps.bounce < bounces;
+  return path_continue(ps, rng, bounces);
 }
 
 // Start of trace_sample (pt.cpp:1676-1682): the four draws and the camera ray.

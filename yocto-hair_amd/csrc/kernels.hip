@@ -41,7 +41,9 @@ using namespace yhd;
 // so its samples cannot run side by side) — quads never wait for the longest
 // path of a sample, only for the item's last quad.
 #define YH_QUADS (YH_BLOCK / 4)
-template <bool COUNT>
+// GENERAL = the scene has materials with lobes beyond diffuse / hair (dev_surface.h); scenes
+// without them (all BASELINE configs) run the variant that does not carry that code.
+template <bool COUNT, bool GENERAL>
 __global__ __launch_bounds__(YH_BLOCK, YH_MIN_WAVES) void k_trace(const yhd_scene sc, const yhd_state st,
     int nsamples, yhd_counters* counters) {
   extern __shared__ v4f lds_dyn[];
@@ -107,7 +109,7 @@ __global__ __launch_bounds__(YH_BLOCK, YH_MIN_WAVES) void k_trace(const yhd_scen
         w_steps += smax, l_steps += (lane & 3) == 0 ? steps : 0;
       }
       if (alive) {
-        alive = path_step<COUNT, YH_QUADS>(tc, ps, isec, rng, st.bounces);
+        alive = path_step<COUNT, YH_QUADS, GENERAL>(tc, ps, isec, rng, st.bounces);
         if (!alive) {
           path_end(ps, st.clamp, acc);
           if (COUNT) count_quad<COUNT>(stats.samples);
@@ -420,31 +422,119 @@ __global__ void k_selftest(selftest_args a, double* sums, unsigned int* worst_bi
 // ---------------------------------------------------------------------------
 // Launchers (called from the g++-compiled host code)
 // ---------------------------------------------------------------------------
+// One surface lobe per launch (include/yhair.h YH_LOBE_*): the unit-level
+// counterpart of yocto_math.h:4427-4755 for the parity tests.
+__global__ void k_surface_lobe(int kind, int n, const float* params, const float* normal, const float* wo_,
+    const float* wi_, const float* rn, float* out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* q = params + 8 * (size_t)i;
+  float ior = q[0], rough = q[1];
+  f3    eta = ld3(q + 2), etak = ld3(q + 5);
+  f3    nn = ld3(normal + 3 * (size_t)i), wo = ld3(wo_ + 3 * (size_t)i), wi = ld3(wi_ + 3 * (size_t)i);
+  float rnl = rn[3 * (size_t)i], rx = rn[3 * (size_t)i + 1], ry = rn[3 * (size_t)i + 2];
+  f3    f = mk3(0.0f), w = mk3(0.0f);
+  float pdf = 0;
+  switch (kind) {
+    case 0:
+      f = eval_diffuse_reflection(nn, wo, wi), pdf = sample_diffuse_reflection_pdf(nn, wo, wi);
+      w = sample_diffuse_reflection(nn, wo, rx, ry);
+      break;
+    case 1:
+      f = eval_microfacet_reflection(ior, rough, nn, wo, wi), pdf = sample_microfacet_reflection_pdf(rough, nn, wo, wi);
+      w = sample_microfacet_reflection(rough, nn, wo, rx, ry);
+      break;
+    case 2:
+      f   = eval_microfacet_reflection(eta, etak, rough, nn, wo, wi);
+      pdf = sample_microfacet_reflection_pdf(rough, nn, wo, wi);
+      w   = sample_microfacet_reflection(rough, nn, wo, rx, ry);
+      break;
+    case 3:
+      f = eval_microfacet_transmission(rough, nn, wo, wi), pdf = sample_microfacet_transmission_pdf(rough, nn, wo, wi);
+      w = sample_microfacet_transmission(rough, nn, wo, rx, ry);
+      break;
+    case 4:
+      f   = eval_microfacet_refraction(ior, rough, nn, wo, wi);
+      pdf = sample_microfacet_refraction_pdf(ior, rough, nn, wo, wi);
+      w   = sample_microfacet_refraction(ior, rough, nn, wo, rnl, rx, ry);
+      break;
+    case 5:
+      f = eval_delta_reflection(ior, nn, wo, wi), pdf = sample_delta_reflection_pdf(nn, wo, wi);
+      w = sample_delta_reflection(nn, wo);
+      break;
+    case 6:
+      f = eval_delta_reflection(eta, etak, nn, wo, wi), pdf = sample_delta_reflection_pdf(nn, wo, wi);
+      w = sample_delta_reflection(nn, wo);
+      break;
+    case 7:
+      f = eval_delta_transmission(nn, wo, wi), pdf = sample_delta_transmission_pdf(nn, wo, wi);
+      w = sample_delta_transmission(nn, wo);
+      break;
+    case 8:
+      f = eval_delta_refraction(ior, nn, wo, wi), pdf = sample_delta_refraction_pdf(ior, nn, wo, wi);
+      w = sample_delta_refraction(ior, nn, wo, rnl);
+      break;
+    default: break;
+  }
+  float* o = out + 7 * (size_t)i;
+  o[0] = f.x, o[1] = f.y, o[2] = f.z, o[3] = pdf, o[4] = w.x, o[5] = w.y, o[6] = w.z;
+}
+// eval_brdf + lobe dispatch (pt.cpp:405-471, 1069-1280) of non-hair materials;
+// 29 floats per item (YH_SURFACE_BSDF_FLOATS in include/yhair.h)
+__global__ void k_surface_bsdf(int n, const yhd_material* mats, const float* normal, const float* wo_,
+    const float* wi_, const float* rn, float* out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  f3    nn = ld3(normal + 3 * (size_t)i), wo = ld3(wo_ + 3 * (size_t)i), wi = ld3(wi_ + 3 * (size_t)i);
+  float rnl = rn[3 * (size_t)i], rx = rn[3 * (size_t)i + 1], ry = rn[3 * (size_t)i + 2];
+  surface_brdf_t b = surface_brdf(mats[i], nn, wo);
+  float* o = out + 29 * (size_t)i;
+  f3 lobes[5] = {b.diffuse, b.specular, b.metal, b.transmission, b.refraction};
+  for (int k = 0; k < 5; k++) o[3 * k] = lobes[k].x, o[3 * k + 1] = lobes[k].y, o[3 * k + 2] = lobes[k].z;
+  o[15] = b.roughness, o[16] = b.opacity;
+  o[17] = b.diffuse_pdf, o[18] = b.specular_pdf, o[19] = b.metal_pdf, o[20] = b.transmission_pdf;
+  o[21] = b.refraction_pdf;
+  f3    f, w;
+  float pdf;
+  if (!is_delta(b)) {
+    surface_eval_pdf(b, nn, wo, wi, f, pdf);
+    w = surface_sample(b, nn, wo, rnl, rx, ry);
+  } else {
+    surface_eval_pdf_delta(b, nn, wo, wi, f, pdf);
+    w = surface_sample_delta(b, nn, wo, rnl);
+  }
+  o[22] = f.x, o[23] = f.y, o[24] = f.z, o[25] = pdf, o[26] = w.x, o[27] = w.y, o[28] = w.z;
+}
+
 extern "C" {
 
+typedef void (*trace_kernel_t)(const yhd_scene, const yhd_state, int, yhd_counters*);
+static trace_kernel_t trace_kernel(bool counted, bool general) {
+  return counted ? (general ? k_trace<true, true> : k_trace<true, false>)
+                 : (general ? k_trace<false, true> : k_trace<false, false>);
+}
 int yhk_trace(const yhd_scene* sc, const yhd_state* st, int nsamples, yhd_counters* counters,
     int grid_blocks, hipStream_t stream) {
   size_t lds = (size_t)sc->lds_node_count * 128 + (size_t)YH_QSTACK * YH_QUADS * 4;
-  static size_t lds_set[2] = {0, 0};
-  if (lds > lds_set[counters ? 1 : 0]) {  // above 64 KB the dynamic-LDS limit must be raised explicitly
-    hipError_t e = counters ? hipFuncSetAttribute((const void*)k_trace<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
-                            : hipFuncSetAttribute((const void*)k_trace<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  static size_t lds_set[4] = {0, 0, 0, 0};
+  int            which = (counters ? 1 : 0) + (sc->general_materials ? 2 : 0);
+  trace_kernel_t k     = trace_kernel(counters != nullptr, sc->general_materials != 0);
+  if (lds > lds_set[which]) {  // above 64 KB the dynamic-LDS limit must be raised explicitly
+    hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    lds_set[counters ? 1 : 0] = lds;
+    lds_set[which] = lds;
   }
-  if (counters)
-    hipLaunchKernelGGL(k_trace<true>, dim3(grid_blocks), dim3(YH_BLOCK), lds, stream, *sc, *st, nsamples, counters);
-  else
-    hipLaunchKernelGGL(k_trace<false>, dim3(grid_blocks), dim3(YH_BLOCK), lds, stream, *sc, *st, nsamples, counters);
+  hipLaunchKernelGGL(k, dim3(grid_blocks), dim3(YH_BLOCK), lds, stream, *sc, *st, nsamples, counters);
   return (int)hipGetLastError();
 }
 int yhk_block_threads(void) { return YH_BLOCK; }
 int yhk_stack_entries(void) { return YH_QSTACK; }
 int yhk_trace_lds_bytes(int lds_node_count) { return lds_node_count * 128 + YH_QSTACK * YH_QUADS * 4; }
-int yhk_trace_occupancy(int lds_bytes) {
-  int blocks = 0;
-  (void)hipFuncSetAttribute((const void*)k_trace<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_trace<false>, YH_BLOCK, lds_bytes) != hipSuccess) return 1;
+int yhk_trace_occupancy(int lds_bytes, int general) {
+  int            blocks = 0;
+  trace_kernel_t k      = trace_kernel(false, general != 0);
+  (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k, YH_BLOCK, lds_bytes) != hipSuccess) return 1;
   return blocks < 1 ? 1 : blocks;
 }
 int yhk_resolve(const yhd_state* st, int owned_tiles, int samples, void* image, hipStream_t stream) {
@@ -460,6 +550,16 @@ int yhk_unpack(const void* packed, int src_rank, int world, int ntiles_src, int 
   if (ntiles_src)
     hipLaunchKernelGGL(k_unpack, dim3(ntiles_src), dim3(64), 0, stream, (const yhd_float4*)packed, src_rank, world,
         num_tiles_total, tiles_x, width, height, (yhd_float4*)image);
+  return (int)hipGetLastError();
+}
+int yhk_surface_lobe(int kind, int n, const float* params, const float* normal, const float* wo, const float* wi,
+    const float* rn, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_surface_lobe, dim3((n + 255) / 256), dim3(256), 0, s, kind, n, params, normal, wo, wi, rn, out);
+  return (int)hipGetLastError();
+}
+int yhk_surface_bsdf(int n, const void* mats, const float* normal, const float* wo, const float* wi, const float* rn,
+    float* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_surface_bsdf, dim3((n + 255) / 256), dim3(256), 0, s, n, (const yhd_material*)mats, normal, wo, wi, rn, out);
   return (int)hipGetLastError();
 }
 int yhk_hair_brdf(int n, const void* mats, const float* v, const float* nrm, const float* tng, float* out, hipStream_t s) {

@@ -66,7 +66,13 @@ typedef struct yhd_material {
   double mp_den[4];        // sinh(1 / v[p]) * 2 * v[p]   (double, ext.cpp:206)
   float  tl_cdf_a;         // logistic_cdf(-pi, s)
   float  tl_norm;          // logistic_cdf(pi, s) - logistic_cdf(-pi, s)
-  float  pad0, pad1;
+  // surface lobes other than diffuse (dev_surface.h). `plain` = none of them:
+  // specular = metallic = transmission = 0 and opacity = 1, the only kind of
+  // surface in the BASELINE configs, which keeps its short diffuse-only path.
+  int    plain;
+  float  specular, metallic, roughness, ior, transmission;
+  float  opacity;          // material opacity, snapped to 1 above 0.999 (pt.cpp:454)
+  float  meta[3];          // reflectivity_to_eta(color) (pt.cpp:439)
 } yhd_material;
 
 typedef struct yhd_light {
@@ -115,6 +121,7 @@ typedef struct yhd_scene {
   // number of leading nodes of the largest line shape staged in LDS
   int               num_nodes_total; // wide nodes in `nodes` (bounds checks of the debug build)
   int               num_prim_f4;     // float4 in `prims`
+  int               general_materials;  // some material has lobes beyond diffuse / hair: k_trace<.., true>
   int               lds_node_base;   // global index of that shape's root
   int               lds_node_count;
 } yhd_scene;

@@ -31,7 +31,7 @@
 extern "C" {
 int yhk_trace(const yhd_scene*, const yhd_state*, int, yhd_counters*, int, hipStream_t);
 int yhk_block_threads(void);
-int yhk_trace_occupancy(int lds_bytes);
+int yhk_trace_occupancy(int lds_bytes, int general);
 int yhk_trace_lds_bytes(int lds_node_count);
 int yhk_stack_entries(void);
 int yhk_resolve(const yhd_state*, int, int, void*, hipStream_t);
@@ -42,6 +42,8 @@ int yhk_hair_eval(int, const float*, const float*, const float*, float*, hipStre
 int yhk_hair_pdf(int, const float*, const float*, const float*, float*, hipStream_t);
 int yhk_hair_sample(int, const float*, const float*, const float*, float*, hipStream_t);
 int yhk_intersect(const yhd_scene*, int, const float*, int*, int*, float*, float*, hipStream_t);
+int yhk_surface_lobe(int, int, const float*, const float*, const float*, const float*, const float*, float*, hipStream_t);
+int yhk_surface_bsdf(int, const void*, const float*, const float*, const float*, const float*, float*, hipStream_t);
 int yhk_selftest(int, float, float, uint64_t, uint64_t, int, const float*, double*, unsigned int*, hipStream_t);
 }
 
@@ -152,6 +154,15 @@ void make_material(const yh_material& m, yhd_material& d) {
   float dmax    = fmax_(fmax_(m.color[0], m.color[1]), m.color[2]);
   d.diffuse_pdf = dmax ? dmax / dmax : 0.0f;  // pt.cpp:456-471 with one lobe
   d.thin        = m.thin;
+  d.specular = m.specular, d.metallic = m.metallic, d.roughness = m.roughness, d.ior = m.ior;
+  d.transmission = m.transmission;
+  d.opacity      = m.opacity * ((1.0f + 1.0f + 1.0f) / 3);  // mean of the {1,1,1} null texture (pt.cpp:425)
+  if (d.opacity > 0.999f) d.opacity = 1;
+  d.plain = m.specular == 0 && m.metallic == 0 && m.transmission == 0 && d.opacity == 1;
+  for (int c = 0; c < 3; c++) {  // reflectivity_to_eta (math.h:4270-4273)
+    float r   = fmin_(fmax_(m.color[c], 0.0f), 0.99f);
+    d.meta[c] = (1 + std::sqrt(r)) / (1 - std::sqrt(r));
+  }
   F3 sa{0, 0, 0};
   if (m.sigma_a[0] || m.sigma_a[1] || m.sigma_a[2]) {
     sa = ld3(m.sigma_a);
@@ -250,7 +261,11 @@ int alloc_zero(yh_context* ctx, DevBuf& buf, size_t bytes) {
   size_t alloc = std::max<size_t>(bytes, 16);
   HIPCHK(ctx, hipMalloc(&buf.p, alloc));
   buf.bytes = alloc;
-  HIPCHK(ctx, hipMemset(buf.p, 0, alloc));
+  // The context's stream is non-blocking: a memset on the null stream would not be
+  // ordered against kernels launched on it. Clear on that stream and wait, so the
+  // buffer is zero for whoever touches it next (stream kernel or blocking copy).
+  HIPCHK(ctx, hipMemsetAsync(buf.p, 0, alloc, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return YH_OK;
 }
 
@@ -351,10 +366,10 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
   // ---- validate the material scope (yhair.h: yh_material) ----------------
   for (int i = 0; i < sd->num_materials; i++) {
     auto& m = sd->materials[i];
-    if (m.specular != 0 || m.metallic != 0 || m.transmission != 0 || m.opacity < 1)
+    if (!m.thin && m.transmission != 0)  // has_volume (pt.cpp:531)
       return fail(ctx, YH_E_INVALID,
-          "material %d uses a lobe outside the hair path (specular/metallic/transmission/opacity): "
-          "only emission, diffuse colour and hair parameters are supported",
+          "material %d is a volume (transmission with thin = false): the volume stack / subsurface walk "
+          "(pt.cpp:1403-1414,1458-1497) is not supported",
           i);
   }
   // ---- per-shape BVHs and flattened arrays --------------------------------
@@ -486,7 +501,11 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
     return fail(ctx, YH_E_INVALID, "BVH too deep for the traversal stack (%d > %d)", ctx->stack_need, yhk_stack_entries());
   // ---- materials ---------------------------------------------------------
   std::vector<yhd_material> materials(sd->num_materials);
-  for (int i = 0; i < sd->num_materials; i++) make_material(sd->materials[i], materials[i]);
+  int general_materials = 0;
+  for (int i = 0; i < sd->num_materials; i++) {
+    make_material(sd->materials[i], materials[i]);
+    if (!materials[i].plain) general_materials = 1;
+  }
   // ---- lights (pt.cpp:1695-1740) -----------------------------------------
   yhd_scene sc{};
   std::vector<float>      light_cdf;
@@ -564,6 +583,7 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
   sc.camera.focus = sd->camera.focus, sc.camera.aperture = sd->camera.aperture;
   sc.num_nodes_total = (int)(nodes.size() / 8), sc.num_prim_f4 = (int)prims.size();
   // nodelets: the top (breadth-first prefix) of the largest hair shape's BVH
+  sc.general_materials = general_materials;
   sc.lds_node_base = 0, sc.lds_node_count = 0;
   if (best_shape >= 0) {
     sc.lds_node_base  = info[best_shape].node_base;
@@ -660,7 +680,7 @@ static int trace_impl(yh_context* ctx, int nsamples, bool counted, bool sync) {
   }
   int waves_per_block = yhk_block_threads() / 64;  // one work item per wave at a time
   int lds_bytes       = yhk_trace_lds_bytes(ctx->scene.lds_node_count);
-  int resident        = ctx->num_cus * yhk_trace_occupancy(lds_bytes);
+  int resident        = ctx->num_cus * yhk_trace_occupancy(lds_bytes, ctx->scene.general_materials);
   int want            = (ctx->state.num_tiles + waves_per_block - 1) / waves_per_block;
   int grid            = std::max(1, std::min(want, resident));
   HIPCHK(ctx, hipMemsetAsync(ctx->d_tile_cursor.p, 0, 4, ctx->stream));
@@ -853,6 +873,40 @@ int yh_hair_pdf_batch(yh_context* ctx, int n, const float* brdf, const float* wo
 }
 int yh_hair_eval_pdf_batch(yh_context* ctx, int n, const float* brdf, const float* wo, const float* wi, float* pdf) {
   return yh_hair_pdf_batch(ctx, n, brdf, wo, wi, pdf);
+}
+
+int yh_surface_lobe_batch(yh_context* ctx, int kind, int n, const float* params, const float* normal,
+    const float* outgoing, const float* incoming, const float* rn, float* out) {
+  if (!ctx || n < 0 || kind < 0 || kind >= YH_LOBE_COUNT || (n && (!params || !normal || !outgoing || !incoming || !rn || !out)))
+    return YH_E_INVALID;
+  if (n == 0) return YH_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  Staged s(ctx);
+  auto   dp = (float*)s.in(params, 32 * (size_t)n);
+  auto   dn = (float*)s.in(normal, 12 * (size_t)n);
+  auto   da = (float*)s.in(outgoing, 12 * (size_t)n);
+  auto   db = (float*)s.in(incoming, 12 * (size_t)n);
+  auto   dr = (float*)s.in(rn, 12 * (size_t)n);
+  auto   o  = (float*)s.out(28 * (size_t)n);
+  if (s.rc) return s.rc;
+  return finish(ctx, yhk_surface_lobe(kind, n, dp, dn, da, db, dr, o, ctx->stream), out, o, 28 * (size_t)n);
+}
+int yh_surface_bsdf_batch(yh_context* ctx, int n, const yh_material* materials, const float* normal,
+    const float* outgoing, const float* incoming, const float* rn, float* out) {
+  if (!ctx || n < 0 || (n && (!materials || !normal || !outgoing || !incoming || !rn || !out))) return YH_E_INVALID;
+  if (n == 0) return YH_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  std::vector<yhd_material> mats((size_t)n);
+  for (int i = 0; i < n; i++) make_material(materials[i], mats[(size_t)i]);
+  Staged s(ctx);
+  auto   dm = s.in(mats.data(), sizeof(yhd_material) * (size_t)n);
+  auto   dn = (float*)s.in(normal, 12 * (size_t)n);
+  auto   da = (float*)s.in(outgoing, 12 * (size_t)n);
+  auto   db = (float*)s.in(incoming, 12 * (size_t)n);
+  auto   dr = (float*)s.in(rn, 12 * (size_t)n);
+  auto   o  = (float*)s.out(4 * YH_SURFACE_BSDF_FLOATS * (size_t)n);
+  if (s.rc) return s.rc;
+  return finish(ctx, yhk_surface_bsdf(n, dm, dn, da, db, dr, o, ctx->stream), out, o, 4 * YH_SURFACE_BSDF_FLOATS * (size_t)n);
 }
 
 int yh_intersect_batch(yh_context* ctx, int n, const float* rays, int* object, int* element, float* uv,

@@ -133,6 +133,10 @@ _SIGS = {
     "yh_tile_costs": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_int]),
     "yh_hair_brdf_batch": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Material), c_float_p,
                                      c_float_p, c_float_p, c_float_p]),
+    "yh_surface_lobe_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_float_p, c_float_p, c_float_p, c_float_p,
+                                        c_float_p, c_float_p]),
+    "yh_surface_bsdf_batch": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Material), c_float_p, c_float_p, c_float_p,
+                                        c_float_p, c_float_p]),
     "yh_hair_eval_batch": (C.c_int, [C.c_void_p, C.c_int, c_float_p, c_float_p, c_float_p, c_float_p]),
     "yh_hair_sample_batch": (C.c_int, [C.c_void_p, C.c_int, c_float_p, c_float_p, c_float_p, c_float_p]),
     "yh_hair_pdf_batch": (C.c_int, [C.c_void_p, C.c_int, c_float_p, c_float_p, c_float_p, c_float_p]),
@@ -307,6 +311,20 @@ class Context:
 
     def hair_pdf(self, brdf, wo, wi):
         return self._wowi(self.lib.yh_hair_pdf_batch, brdf, wo, wi, 1)
+
+    def surface_lobe(self, kind, params8, normal, wo, wi, rn3):
+        """One YH_LOBE_* kind (yocto_math.h:4427-4755): (n, 7) = f*|cos| [3], pdf, sampled incoming [3]."""
+        a = [np.ascontiguousarray(x, np.float32) for x in (params8, normal, wo, wi, rn3)]
+        out = np.zeros((len(a[0]), 7), np.float32)
+        self._chk(self.lib.yh_surface_lobe_batch(self.h, kind, len(a[0]), *(fptr(x) for x in a), fptr(out)))
+        return out
+
+    def surface_bsdf(self, materials, normal, wo, wi, rn3):
+        """eval_brdf + lobe dispatch of non-hair materials: (n, SURFACE_BSDF_FLOATS)."""
+        a = [np.ascontiguousarray(x, np.float32) for x in (normal, wo, wi, rn3)]
+        out = np.zeros((len(a[0]), SURFACE_BSDF_FLOATS), np.float32)
+        self._chk(self.lib.yh_surface_bsdf_batch(self.h, len(a[0]), materials, *(fptr(x) for x in a), fptr(out)))
+        return out
 
     def intersect(self, rays):
         rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
