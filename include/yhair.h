@@ -59,10 +59,10 @@ typedef struct yh_shape {
 
 /* ptr::material (yocto_pathtrace.h:293-329), restricted to the lobes the hair
  * configs reach: emission, diffuse colour and the hair parameters
- * (yocto_extension.h:86-95). Specular, metallic, thin transmission, delta
- * (roughness 0) and opacity lobes follow yocto_pathtrace.cpp:405-471; textures
- * and volumes (transmission with thin = 0) are rejected by yh_upload_scene
- * with YH_E_INVALID.                                                        */
+ * (yocto_extension.h:86-95). Specular, metallic, transmission / refraction,
+ * delta (roughness 0) and opacity lobes follow yocto_pathtrace.cpp:405-471,
+ * homogeneous volumes :498-533,1403-1414,1458-1497. Textures other than the
+ * environment map are not represented.                                      */
 typedef struct yh_material {
   float emission[3];
   float color[3];
@@ -70,6 +70,11 @@ typedef struct yh_material {
   int   thin;
   float sigma_a[3];
   float beta_m, beta_n, alpha, eta, eumelanin, pheomelanin;
+  /* homogeneous volume inside a closed surface (thin = 0 and transmission > 0,
+   * yocto_pathtrace.cpp:498-533): density = -log(clamp(color, 1e-4, 1)) / trdepth */
+  float scattering[3];
+  float scanisotropy;
+  float trdepth;      /* 0.01 (yocto_pathtrace.h:305)                          */
 } yh_material;
 
 /* ptr::object (yocto_pathtrace.h:369-373) */

@@ -29,6 +29,7 @@ GOLDEN_SCENES = [
     ("curly-hair", dict(scale=0.05), 64),
     ("hair-curls", dict(scale=0.05), 64),
     ("lobes", dict(scale=0.05), 96),      # specular / metal / delta / transmission / opacity
+    ("volumes", dict(scale=0.05), 96),    # refraction into homogeneous media, subsurface walk
 ]
 
 
@@ -162,11 +163,11 @@ def scenes_only(ref, rng, want):
         tag = os.path.basename(os.path.dirname(path))
         if not want("scene_" + tag):
             continue
-        if name == "lobes":
+        if name in ("lobes", "volumes"):
             rng = np.random.default_rng(20240609)
         sc = ref.scene(path)
         m = 4096
-        if name == "lobes":
+        if name in ("lobes", "volumes"):
             org = rng.uniform(-1, 1, (m, 3)) * [3, 1.2, 1] + [0.2, 2.0, 4.5]
             tgt = rng.uniform(-1, 1, (m, 3)) * [2.4, 0.6, 1.2] + [0.3, 0.4, 0]
         elif name == "sphere-hairblock":

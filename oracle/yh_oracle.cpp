@@ -577,6 +577,8 @@ struct Shape {
 struct Material {
   V3           emission, color;
   float        specular = 0, metallic = 0, roughness = 0, ior = 1.5f, transmission = 0, opacity = 1;
+  V3           scattering{0, 0, 0};
+  float        scanisotropy = 0, trdepth = 0.01f;
   HairMaterial hair;
   bool         thin;
 };
@@ -1496,17 +1498,129 @@ Ray sample_camera(const Camera& cam, int i, int j, int w, int h, float pu, float
 struct Vec4 {
   float x, y, z, w;
 };
+// ---------------------------------------------------------------------------
+// Homogeneous volumes (pt.cpp:498-533, 1360-1377; math.h:4758-4822)
+// ---------------------------------------------------------------------------
+struct Vsdf {
+  V3    density{0, 0, 0}, scatter{0, 0, 0};
+  float anisotropy = 0;
+};
+inline bool has_volume(const Material& mat) { return !mat.thin && mat.transmission; }  // pt.cpp:531
+Vsdf eval_vsdf(const Material& mat) {  // pt.cpp:504-527, textures absent
+  auto base         = mat.color * V3{1, 1, 1};
+  auto transmission = mat.transmission * 1.0f;
+  auto thin         = mat.thin || !mat.transmission;
+  Vsdf v;
+  if (transmission && !thin) {
+    auto c    = V3{fclamp(base.x, 0.0001f, 1.0f), fclamp(base.y, 0.0001f, 1.0f), fclamp(base.z, 0.0001f, 1.0f)};
+    v.density = -vlog(c) / mat.trdepth;
+  }
+  v.scatter    = mat.scattering * V3{1, 1, 1};
+  v.anisotropy = mat.scanisotropy;
+  return v;
+}
+inline V3 eval_transmittance(V3 density, float distance) { return vexp(-density * distance); }
+float sample_transmittance(V3 density, float max_distance, float rl, float rd) {
+  auto channel  = iclamp((int)(rl * 3), 0, 2);
+  auto distance = (at(density, channel) == 0) ? flt_max : -std::log(1 - rd) / at(density, channel);
+  return fmin_(distance, max_distance);
+}
+float sample_transmittance_pdf(V3 density, float distance, float max_distance) {
+  auto sum3 = [](V3 a) { return a.x + a.y + a.z; };
+  if (distance < max_distance) return sum3(density * vexp(-density * distance)) / 3;
+  return sum3(vexp(-density * max_distance)) / 3;
+}
+float eval_phasefunction(float anisotropy, V3 outgoing, V3 incoming) {  // Henyey-Greenstein
+  auto cosine = -dot(outgoing, incoming);
+  auto denom  = 1 + anisotropy * anisotropy - 2 * anisotropy * cosine;
+  return (1 - anisotropy * anisotropy) / (4 * pif * denom * std::sqrt(denom));
+}
+V3 sample_phasefunction(float anisotropy, V3 outgoing, float rx, float ry) {
+  auto cos_theta = 0.0f;
+  if (fabs_(anisotropy) < 1e-3f) {
+    cos_theta = 1 - 2 * ry;
+  } else {
+    float square = (1 - anisotropy * anisotropy) / (1 + anisotropy - 2 * anisotropy * ry);
+    cos_theta    = (1 + anisotropy * anisotropy - square * square) / (2 * anisotropy);
+  }
+  auto sin_theta = std::sqrt(fmax_(0.0f, 1 - cos_theta * cos_theta));
+  auto phi       = 2 * pif * rx;
+  auto local     = V3{sin_theta * std::cos(phi), sin_theta * std::sin(phi), cos_theta};
+  // basis_fromz(-outgoing) * local: a matrix product, not normalised (math.h:4815)
+  auto zz   = normalize(-outgoing);
+  auto sign = copysignf(1.0f, zz.z);
+  auto a    = -1.0f / (sign + zz.z);
+  auto b    = zz.x * zz.y * a;
+  auto x    = V3{1.0f + sign * zz.x * zz.x * a, sign * b, -sign * zz.x};
+  auto y    = V3{b, sign + zz.y * zz.y * a, -zz.y};
+  return x * local.x + y * local.y + zz * local.z;
+}
+inline V3 eval_scattering(const Vsdf& v, V3 outgoing, V3 incoming) {  // pt.cpp:1360-1365
+  if (v.density == V3{0, 0, 0}) return {0, 0, 0};
+  return v.scatter * v.density * eval_phasefunction(v.anisotropy, outgoing, incoming);
+}
+inline V3 sample_scattering(const Vsdf& v, V3 outgoing, float rx, float ry) {
+  if (v.density == V3{0, 0, 0}) return {0, 0, 0};
+  return sample_phasefunction(v.anisotropy, outgoing, rx, ry);
+}
+inline float sample_scattering_pdf(const Vsdf& v, V3 outgoing, V3 incoming) {
+  if (v.density == V3{0, 0, 0}) return 0;
+  return eval_phasefunction(v.anisotropy, outgoing, incoming);
+}
+
 Vec4 trace_path(const yo_scene& scene, const Ray& ray_, Rng& rng, int bounces) {
   auto radiance = V3{0, 0, 0};
   auto weight   = V3{1, 1, 1};
   auto ray      = ray_;
   auto hit      = false;
+  std::vector<Vsdf> volume_stack;
   for (auto bounce = 0; bounce < bounces; bounce++) {
     int   object = -1, element = -1;
     float uv[2] = {0, 0}, distance = 0;
     if (!intersect_scene_bvh(scene, ray, object, element, uv, distance)) {
       radiance = radiance + weight * eval_environment(scene, ray.d);
       break;
+    }
+    // inside a volume: sample the free-flight distance (pt.cpp:1403-1414). g++ evaluates
+    // the two rand1f arguments right to left: rd is drawn before rl.
+    auto in_volume = false;
+    if (!volume_stack.empty()) {
+      auto& vsdf = volume_stack.back();
+      auto  rd = rand1f(rng), rl = rand1f(rng);
+      auto  dist = sample_transmittance(vsdf.density, distance, rl, rd);
+      weight     = weight * (eval_transmittance(vsdf.density, dist) /
+                            sample_transmittance_pdf(vsdf.density, dist, distance));
+      in_volume  = dist < distance;
+      distance   = dist;
+    }
+    if (in_volume) {  // pt.cpp:1472-1497: scatter inside the medium
+      auto  outgoing = -ray.d;
+      auto  position = ray.o + ray.d * distance;
+      auto& vsdf     = volume_stack.back();
+      hit           = true;
+      auto incoming = V3{0, 0, 0};
+      if (rand1f(rng) < 0.5f) {
+        auto rnx = rand1f(rng), rny = rand1f(rng);
+        auto rnl = rand1f(rng);
+        (void)rnl;
+        incoming = sample_scattering(vsdf, outgoing, rnx, rny);
+      } else {
+        auto ruvx = rand1f(rng), ruvy = rand1f(rng);
+        auto rel = rand1f(rng);
+        auto rl  = rand1f(rng);
+        incoming = sample_lights(scene, position, rl, rel, ruvx, ruvy);
+      }
+      weight = weight * (eval_scattering(vsdf, outgoing, incoming) /
+                            (0.5f * sample_scattering_pdf(vsdf, outgoing, incoming) +
+                                0.5f * sample_lights_pdf(scene, position, incoming)));
+      ray = Ray{position, incoming};
+      if (weight == V3{0, 0, 0} || !finite3(weight)) break;
+      if (bounce > 3) {
+        auto rr_prob = fmin_((float)0.99, hmax(weight));
+        if (rand1f(rng) >= rr_prob) break;
+        weight = weight * (1 / rr_prob);
+      }
+      continue;
     }
     auto outgoing = -ray.d;
     auto position = eval_position(scene, object, element, uv);
@@ -1542,6 +1656,12 @@ Vec4 trace_path(const yo_scene& scene, const Ray& ray_, Rng& rng, int bounces) {
       incoming = sample_delta(brdf, normal, outgoing, rand1f(rng));
       weight   = weight * (eval_delta(brdf, normal, outgoing, incoming) /
                             sample_delta_pdf(brdf, normal, outgoing, incoming));
+    }
+    // entering / leaving a closed transmissive object (pt.cpp:1458-1467)
+    if (has_volume(scene.materials[scene.objects[object].material]) &&
+        dot(normal, outgoing) * dot(normal, incoming) < 0) {
+      if (volume_stack.empty()) volume_stack.push_back(eval_vsdf(scene.materials[scene.objects[object].material]));
+      else volume_stack.pop_back();
     }
     ray = Ray{position, incoming};
     if (weight == V3{0, 0, 0} || !finite3(weight)) break;
@@ -1890,10 +2010,7 @@ yo_scene* yo_scene_create(const yh_scene_desc* d) {
     mt.thin = m.thin != 0;
     mt.specular = m.specular, mt.metallic = m.metallic, mt.roughness = m.roughness;
     mt.ior = m.ior, mt.transmission = m.transmission, mt.opacity = m.opacity;
-    if (!mt.thin && mt.transmission) {  // has_volume (pt.cpp:531): volumes are not restated
-      delete sc;
-      return nullptr;
-    }
+    mt.scattering = v3(m.scattering), mt.scanisotropy = m.scanisotropy, mt.trdepth = m.trdepth;
     mt.hair.sigma_a = v3(m.sigma_a);
     mt.hair.beta_m = m.beta_m, mt.hair.beta_n = m.beta_n;
     mt.hair.alpha = m.alpha, mt.hair.eta = m.eta;

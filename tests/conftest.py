@@ -72,6 +72,7 @@ GOLDEN_SCENES = [
     ("curly-hair", dict(scale=0.05)),
     ("hair-curls", dict(scale=0.05)),
     ("lobes", dict(scale=0.05)),
+    ("volumes", dict(scale=0.05)),
 ]
 
 

@@ -70,6 +70,7 @@ def test_selftests_match_reference(oracle, ref):
     ("hair-curls", dict(scale=0.1), 80, 4),
     ("straight-hair", dict(scale=0.1, beta_m=0.6), 80, 4),
     ("lobes", dict(scale=0.1), 160, 8),
+    ("volumes", dict(scale=0.1), 160, 8),
 ])
 def test_images_bit_identical_to_reference(oracle, ref, yh, name, kw, res, spp):
     path = scene_path(name, **kw)

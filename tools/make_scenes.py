@@ -218,6 +218,49 @@ def make_lobes(outdir, scale=1.0, name="lobes"):
     return os.path.join(d, name + ".json"), nseg
 
 
+VOLUME_MATERIALS = {
+    # closed transmissive objects = homogeneous volumes (pt.cpp:498-533)
+    "glass": {"color": [0.92, 0.97, 0.95], "specular": 1.0, "transmission": 1.0, "thin": False, "roughness": 0.0,
+              "trdepth": 0.5},
+    "roughglass": {"color": [0.95, 0.85, 0.7], "specular": 1.0, "transmission": 1.0, "thin": False, "roughness": 0.15,
+                   "trdepth": 0.3},
+    # the sloth body / bold-man skin recipe (tests/sloth/sloth.json:90-103), texture replaced by a colour
+    "skin": {"color": [0.823, 0.516, 0.257], "specular": 1.0, "transmission": 1.0, "thin": False, "roughness": 0.5,
+             "scattering": [0.823, 0.516, 0.257], "scanisotropy": -0.8, "trdepth": 0.001},
+    "jade": {"color": [0.3, 0.7, 0.4], "specular": 1.0, "transmission": 0.8, "thin": False, "roughness": 0.2,
+             "scattering": [0.5, 0.9, 0.6], "scanisotropy": 0.4, "trdepth": 0.05, "opacity": 0.95},
+}
+
+
+def make_volumes(outdir, scale=1.0, name="volumes"):
+    """Rank-2 widening scene: four closed spheres with a medium inside (clear and rough glass,
+    skin-like and jade-like subsurface scattering), the hair block, one area light."""
+    d = _prep(outdir, name)
+    shutil.copy(os.path.join(ASSETS, "sphere.ply"), os.path.join(d, "shapes", "sphere.ply"))
+    shutil.copy(os.path.join(ASSETS, "arealight.ply"), os.path.join(d, "shapes", "arealight.ply"))
+    nseg = write_hair_ply(os.path.join(d, "shapes", "hair-block.ply"),
+                          gen_hair_block(max(64, int(100_000 * scale))), 0.004, 0.001)
+    objects = {
+        "hairblock": {"frame": [1, 0, 0, 0, 0, 1, 0, -1, 0, 1.6, 1, -0.5], "shape": "hair-block", "material": "hair"},
+        "floor": {"frame": [2, 0, 0, 0, 0, -2, 0, 2, 0, 0.3, 0, 0], "shape": "arealight", "material": "floor"},
+        "light": {"lookat": [0.3, 5, 2, 0.3, 0.5, 0, 0, 1, 0], "shape": "arealight", "material": "arealight"},
+    }
+    materials = {"hair": {"eumelanin": 0.3}, "floor": {"color": [0.6, 0.6, 0.6]}, "arealight": {"emission": [12, 12, 12]}}
+    for k, (mname, mat) in enumerate(VOLUME_MATERIALS.items()):
+        objects["ball%d" % k] = {"frame": [0.8, 0, 0, 0, 0.8, 0, 0, 0, 0.8, -1.5 + 0.95 * k, 0.0, 0.3], "shape": "sphere",
+                                 "material": mname}
+        materials[mname] = mat
+    scene = {
+        "asset": {"copyright": "synthetic; sphere and quad from the reference's test assets"},
+        "cameras": {"default": {"lens": 0.05, "aperture": 0.0, "aspect": 1.0, "lookat": [0.2, 2.2, 5.0, 0.2, 0.4, 0, 0, 1, 0]}},
+        "environments": {"sky": {"emission": [0.5, 0.5, 0.5]}},
+        "objects": objects,
+        "materials": materials,
+    }
+    _dump(scene, os.path.join(d, name + ".json"))
+    return os.path.join(d, name + ".json"), nseg
+
+
 def _head_scene(outdir, name, shape, pos, emission, lights, hair_mat):
     d = _prep(outdir, name)
     shutil.copy(os.path.join(ASSETS, "sky.hdr"), os.path.join(d, "textures", "sky.hdr"))
@@ -291,6 +334,7 @@ MAKERS = {
     "curly-hair": make_curly_hair,
     "hair-curls": make_hair_curls,
     "lobes": make_lobes,
+    "volumes": make_volumes,
 }
 
 

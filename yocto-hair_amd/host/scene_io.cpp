@@ -489,7 +489,7 @@ static yh_scene_file* load_scene(const std::string& path, const std::string& cam
   if (js.has("materials"))
     for (auto& [name, e] : js.at("materials").obj) {
       yh_material m{};
-      m.opacity = 1, m.ior = 1.5f, m.thin = 1;
+      m.opacity = 1, m.ior = 1.5f, m.thin = 1, m.trdepth = 0.01f;
       m.beta_m = 0.3f, m.beta_n = 0.3f, m.alpha = 2, m.eta = 1.55f;
       get_floats(e, "eumelanin", &m.eumelanin, 1), get_floats(e, "pheomelanin", &m.pheomelanin, 1);
       get_floats(e, "sigma_a", m.sigma_a, 3);
@@ -499,6 +499,8 @@ static yh_scene_file* load_scene(const std::string& path, const std::string& cam
       get_floats(e, "metallic", &m.metallic, 1), get_floats(e, "specular", &m.specular, 1);
       get_floats(e, "roughness", &m.roughness, 1), get_floats(e, "transmission", &m.transmission, 1);
       get_floats(e, "ior", &m.ior, 1), get_floats(e, "opacity", &m.opacity, 1);
+      get_floats(e, "scattering", m.scattering, 3), get_floats(e, "scanisotropy", &m.scanisotropy, 1);
+      get_floats(e, "trdepth", &m.trdepth, 1);
       if (e.has("thin")) m.thin = e.at("thin").b ? 1 : 0;
       for (auto& [k, v] : e.obj)
         if (k.size() > 4 && k.substr(k.size() - 4) == "_tex" && !v.str.empty())
@@ -526,6 +528,7 @@ static yh_scene_file* load_scene(const std::string& path, const std::string& cam
         if (default_material < 0) {
           yh_material m{};
           m.opacity = 1, m.ior = 1.5f, m.thin = 1, m.beta_m = 0.3f, m.beta_n = 0.3f, m.alpha = 2, m.eta = 1.55f;
+          m.trdepth = 0.01f;
           m.color[0] = m.color[1] = m.color[2] = 0.8f;
           default_material = (int)sf->materials.size();
           sf->materials.push_back(m);

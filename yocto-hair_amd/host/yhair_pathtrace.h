@@ -94,7 +94,7 @@ static_assert(sizeof(hair_brdf) == sizeof(float) * YH_HAIR_BRDF_FLOATS, "hair_br
 
 inline yh_material to_material(const hair_material& m) {
   yh_material o{};
-  o.opacity = 1, o.ior = 1.5f, o.thin = 1;
+  o.opacity = 1, o.ior = 1.5f, o.thin = 1, o.trdepth = 0.01f;
   o.sigma_a[0] = m.sigma_a.x, o.sigma_a[1] = m.sigma_a.y, o.sigma_a[2] = m.sigma_a.z;
   o.beta_m = m.beta_m, o.beta_n = m.beta_n, o.alpha = m.alpha, o.eta = m.eta;
   o.color[0] = m.color.x, o.color[1] = m.color.y, o.color[2] = m.color.z;
@@ -159,10 +159,12 @@ struct camera {  // pt.h:272-278
   float   focus    = 10000;
   float   aperture = 0;
 };
-struct material {  // pt.h:293-329 (lobes outside the hair path are rejected at init_bvh)
+struct material {  // pt.h:293-329 (textures are not represented)
   vec3f emission = {0, 0, 0}, color = {0, 0, 0};
   float specular = 0, roughness = 0, metallic = 0, ior = 1.5f, transmission = 0, opacity = 1;
   bool  thin = false;
+  vec3f scattering = {0, 0, 0};
+  float scanisotropy = 0, trdepth = 0.01f;
   float eumelanin = 0, pheomelanin = 0;
   vec3f sigma_a = {0, 0, 0};
   float beta_m = 0.3f, beta_n = 0.3f, alpha = 2, eta = 1.55f;
@@ -244,7 +246,12 @@ inline void set_color(material* m, const vec3f& c) { m->color = c; }
 inline void set_specular(material* m, float v = 1) { m->specular = v; }
 inline void set_ior(material* m, float v) { m->ior = v; }
 inline void set_metallic(material* m, float v) { m->metallic = v; }
-inline void set_transmission(material* m, float t, bool thin, float) { m->transmission = t, m->thin = thin; }
+inline void set_transmission(material* m, float t, bool thin, float trdepth) {
+  m->transmission = t, m->thin = thin, m->trdepth = trdepth;
+}
+inline void set_scattering(material* m, const vec3f& scattering, float scanisotropy) {
+  m->scattering = scattering, m->scanisotropy = scanisotropy;
+}
 inline void set_roughness(material* m, float v) { m->roughness = v; }
 inline void set_opacity(material* m, float v) { m->opacity = v; }
 inline void set_thin(material* m, bool thin) { m->thin = thin; }
@@ -291,6 +298,8 @@ inline void upload_scene(const scene* sc, const camera* cam) {
     o.sigma_a[0] = m->sigma_a.x, o.sigma_a[1] = m->sigma_a.y, o.sigma_a[2] = m->sigma_a.z;
     o.beta_m = m->beta_m, o.beta_n = m->beta_n, o.alpha = m->alpha, o.eta = m->eta;
     o.eumelanin = m->eumelanin, o.pheomelanin = m->pheomelanin;
+    o.scattering[0] = m->scattering.x, o.scattering[1] = m->scattering.y, o.scattering[2] = m->scattering.z;
+    o.scanisotropy = m->scanisotropy, o.trdepth = m->trdepth;
     materials.push_back(o);
   }
   for (auto& ob : sc->objects) {

@@ -46,7 +46,8 @@ static ptr::camera* init_scene(ptr::scene* scene, const yh_scene_desc* d) {
     ptr::set_emission(o, vec3f{m.emission[0], m.emission[1], m.emission[2]});
     ptr::set_color(o, {m.color[0], m.color[1], m.color[2]});
     ptr::set_specular(o, m.specular), ptr::set_ior(o, m.ior), ptr::set_metallic(o, m.metallic);
-    ptr::set_transmission(o, m.transmission, m.thin != 0, 0.01f);
+    ptr::set_transmission(o, m.transmission, m.thin != 0, m.trdepth);
+    ptr::set_scattering(o, {m.scattering[0], m.scattering[1], m.scattering[2]}, m.scanisotropy);
     ptr::set_roughness(o, m.roughness), ptr::set_opacity(o, m.opacity), ptr::set_thin(o, m.thin != 0);
     materials.push_back(o);
   }

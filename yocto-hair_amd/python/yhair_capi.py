@@ -36,7 +36,8 @@ class Material(C.Structure):
                 ("opacity", C.c_float), ("ior", C.c_float), ("thin", C.c_int),
                 ("sigma_a", C.c_float * 3), ("beta_m", C.c_float), ("beta_n", C.c_float),
                 ("alpha", C.c_float), ("eta", C.c_float), ("eumelanin", C.c_float),
-                ("pheomelanin", C.c_float)]
+                ("pheomelanin", C.c_float), ("scattering", C.c_float * 3), ("scanisotropy", C.c_float),
+                ("trdepth", C.c_float)]
 
 
 class Object(C.Structure):
@@ -107,7 +108,7 @@ def hair_material_rows(mats12):
         m.beta_m, m.beta_n, m.alpha, m.eta = map(float, r[3:7])
         m.color[:] = r[7:10].tolist()
         m.eumelanin, m.pheomelanin = float(r[10]), float(r[11])
-        m.opacity, m.ior, m.thin = 1.0, 1.5, 1
+        m.opacity, m.ior, m.thin, m.trdepth = 1.0, 1.5, 1, 0.01
     return arr
 
 
