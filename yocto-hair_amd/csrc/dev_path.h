@@ -228,6 +228,10 @@ struct path_t {
   f3    radiance, weight;
   int   bounce;
   bool  hit;
+  // the reference's volume_stack (pt.cpp:1385): it only pushes when empty and pops
+  // otherwise, so it never holds more than one medium. Used by GENERAL kernels only.
+  bool   in_medium;
+  vsdf_t medium;
 };
 
 // End of one bounce (pt.cpp:1499-1507): weight check, Russian roulette, bounce count.
@@ -240,6 +244,17 @@ YH_DEV bool path_continue(path_t& ps, rng_t& rng, int bounces) {
   }
   ps.bounce++;
   return ps.bounce < bounces;
+}
+
+// Entering / leaving a closed transmissive object (pt.cpp:1458-1467).
+YH_DEV void medium_crossing(path_t& ps, const yhd_material& mat, f3 normal, f3 outgoing, f3 incoming) {
+  if (!mat.has_volume || !(dot(normal, outgoing) * dot(normal, incoming) < 0)) return;
+  if (!ps.in_medium) {
+    ps.medium.density    = ld3(mat.vol_density);
+    ps.medium.scatter    = ld3(mat.vol_scatter);
+    ps.medium.anisotropy = mat.vol_anisotropy;
+  }
+  ps.in_medium = !ps.in_medium;
 }
 
 // One iteration of trace_path's bounce loop (pt.cpp:1395-1508) given the
@@ -256,9 +271,39 @@ YH_DEV bool path_step(const trace_ctx& tc, path_t& ps, const hit_t& isec, rng_t&
     if (COUNT) tc.stats->c_rest += clock64() - k0;
     return false;
   }
+  f3 outgoing = -ps.ray.d;
+  if (GENERAL && ps.in_medium) {
+    // free flight inside the medium (pt.cpp:1403-1414); g++ draws rd before rl
+    float rd = rand1f(rng), rl = rand1f(rng);
+    float dist = sample_transmittance(ps.medium.density, isec.distance, rl, rd);
+    ps.weight  = ps.weight * (eval_transmittance(ps.medium.density, dist) /
+                                sample_transmittance_pdf(ps.medium.density, dist, isec.distance));
+    if (dist < isec.distance) {  // scatter before reaching the surface (pt.cpp:1472-1497)
+      f3 position = ps.ray.o + ps.ray.d * dist;
+      ps.hit      = true;
+      f3 incoming;
+      if (rand1f(rng) < 0.5f) {
+        float rnx = rand1f(rng), rny = rand1f(rng);
+        float rnl = rand1f(rng);
+        (void)rnl;
+        incoming = sample_scattering(ps.medium, outgoing, rnx, rny);
+      } else {
+        float ruvx = rand1f(rng), ruvy = rand1f(rng);
+        float rel = rand1f(rng);
+        float rl2 = rand1f(rng);
+        incoming  = sample_lights<COUNT>(tc, position, rl2, rel, ruvx, ruvy);
+      }
+      f3    f         = eval_scattering(ps.medium, outgoing, incoming);
+      float pdf       = sample_scattering_pdf(ps.medium, outgoing, incoming);
+      float light_pdf = sample_lights_pdf<COUNT, STRIDE>(tc, position, incoming);
+      ps.weight = ps.weight * (f / (0.5f * pdf + 0.5f * light_pdf));
+      ps.ray    = mkray(position, incoming);
+      if (COUNT) tc.stats->c_rest += clock64() - k0;
+      return path_continue(ps, rng, bounces);
+    }
+  }
   const yhd_object&   o   = sc.objects[isec.object];
   const yhd_material& mat = sc.materials[o.material];
-  f3 outgoing = -ps.ray.d;
   hit_geom hg = eval_hit(sc, o, isec.slot, isec.u, isec.v);
   f3 position = hg.position;
   f3 nrm      = hg.normal;
@@ -290,6 +335,7 @@ YH_DEV bool path_step(const trace_ctx& tc, path_t& ps, const hit_t& isec, rng_t&
     float pdf;
     surface_eval_pdf_delta(sb, normal, outgoing, incoming, brdfcos, pdf);
     ps.weight = ps.weight * (brdfcos / pdf);
+    medium_crossing(ps, mat, normal, outgoing, incoming);
     ps.ray    = mkray(position, incoming);
     if (COUNT) tc.stats->c_rest += clock64() - k0;
     return path_continue(ps, rng, bounces);
@@ -350,6 +396,7 @@ YH_DEV bool path_step(const trace_ctx& tc, path_t& ps, const hit_t& isec, rng_t&
   if (COUNT) k3 = clock64(), tc.stats->c_eval += k3 - k2;
   float light_pdf = sample_lights_pdf<COUNT, STRIDE>(tc, position, incoming);
   ps.weight = ps.weight * (brdfcos / (0.5f * brdf_pdf + 0.5f * light_pdf));
+  if (general) medium_crossing(ps, mat, normal, outgoing, incoming);
   ps.ray    = mkray(position, incoming);
   if (COUNT) tc.stats->c_rest += clock64() - k3;
   return path_continue(ps, rng, bounces);
@@ -363,6 +410,7 @@ YH_DEV void path_begin(const yhd_camera& cam, path_t& ps, rng_t& rng, int i, int
   ps.radiance = mk3(0.0f), ps.weight = mk3(1.0f);
   ps.bounce   = 0;
   ps.hit      = false;
+  ps.in_medium = false;
 }
 // End of trace_sample (pt.cpp:1683-1686): sanitize, clamp, accumulate.
 YH_DEV void path_end(const path_t& ps, float clamp, yhd_float4& acc) {

@@ -9,8 +9,9 @@
 // pdfs, D, G) is bit-identical to the CPU; only atan / sin / cos in
 // sample_microfacet can differ in the last ulp.
 //
-// Out of scope here, refused at upload: textures and non-thin transmission
-// (has_volume, pt.cpp:531 — the volume stack is rank 2).
+// The homogeneous medium inside a closed transmissive object (SURVEY.md 8(f)
+// rank 2) follows at the end: pt.cpp:498-533,1360-1377 and math.h:4758-4822.
+// Textures are not represented.
 #ifndef YH_DEV_SURFACE_H_
 #define YH_DEV_SURFACE_H_
 #include "dev_hair.h"
@@ -399,6 +400,65 @@ YH_DEV f3 surface_sample_delta(const surface_brdf_t& b, f3 normal, f3 outgoing, 
     if (rnl < cdf) return sample_delta_refraction(b.ior, normal, outgoing, rnl);
   }
   return mk3(0.0f);
+}
+
+// ---- homogeneous volumes (math.h:4758-4822, pt.cpp:1360-1377) ---------------------
+struct vsdf_t {
+  f3    density, scatter;
+  float anisotropy;
+};
+YH_DEV f3 exp3(f3 a) { return {expf(a.x), expf(a.y), expf(a.z)}; }
+YH_DEV f3 eval_transmittance(f3 density, float distance) { return exp3(-density * distance); }
+YH_DEV float sample_transmittance(f3 density, float max_distance, float rl, float rd) {
+  int   channel  = iclamp((int)(rl * 3), 0, 2);
+  float d        = channel == 0 ? density.x : (channel == 1 ? density.y : density.z);
+  float distance = (d == 0) ? flt_max : -logf(1 - rd) / d;
+  return fmin_(distance, max_distance);
+}
+YH_DEV float sample_transmittance_pdf(f3 density, float distance, float max_distance) {
+  if (distance < max_distance) {
+    f3 t = density * exp3(-density * distance);
+    return (t.x + t.y + t.z) / 3;
+  }
+  f3 t = exp3(-density * max_distance);
+  return (t.x + t.y + t.z) / 3;
+}
+YH_DEV float eval_phasefunction(float anisotropy, f3 outgoing, f3 incoming) {
+  float cosine = -dot(outgoing, incoming);
+  float denom  = 1 + anisotropy * anisotropy - 2 * anisotropy * cosine;
+  return (1 - anisotropy * anisotropy) / (4 * pif * denom * sqrtf(denom));
+}
+YH_DEV f3 sample_phasefunction(float anisotropy, f3 outgoing, float rx, float ry) {
+  float cos_theta;
+  if (fabs_(anisotropy) < 1e-3f) {
+    cos_theta = 1 - 2 * ry;
+  } else {
+    float square = (1 - anisotropy * anisotropy) / (1 + anisotropy - 2 * anisotropy * ry);
+    cos_theta    = (1 + anisotropy * anisotropy - square * square) / (2 * anisotropy);
+  }
+  float sin_theta = sqrtf(fmax_(0.0f, 1 - cos_theta * cos_theta));
+  float phi       = 2 * pif * rx;
+  f3    local     = {sin_theta * cosf(phi), sin_theta * sinf(phi), cos_theta};
+  // basis_fromz(-outgoing) * local: a plain matrix product, not normalised (math.h:4815)
+  f3    zz   = normalize(-outgoing);
+  float sign = copysignf(1.0f, zz.z);
+  float a    = -1.0f / (sign + zz.z);
+  float b    = zz.x * zz.y * a;
+  f3    x    = {1.0f + sign * zz.x * zz.x * a, sign * b, -sign * zz.x};
+  f3    y    = {b, sign + zz.y * zz.y * a, -zz.y};
+  return x * local.x + y * local.y + zz * local.z;
+}
+YH_DEV f3 eval_scattering(const vsdf_t& v, f3 outgoing, f3 incoming) {
+  if (is_zero(v.density)) return mk3(0.0f);
+  return v.scatter * v.density * eval_phasefunction(v.anisotropy, outgoing, incoming);
+}
+YH_DEV f3 sample_scattering(const vsdf_t& v, f3 outgoing, float rx, float ry) {
+  if (is_zero(v.density)) return mk3(0.0f);
+  return sample_phasefunction(v.anisotropy, outgoing, rx, ry);
+}
+YH_DEV float sample_scattering_pdf(const vsdf_t& v, f3 outgoing, f3 incoming) {
+  if (is_zero(v.density)) return 0;
+  return eval_phasefunction(v.anisotropy, outgoing, incoming);
 }
 
 }  // namespace yhd

@@ -206,13 +206,8 @@ YH_DEV void unpack_brdf(const float* b, yhd_material& m, hair_hit& hh) {
 }
 
 // eval_hair_brdf (ext.cpp:127-177) entirely on the device
-struct yh_material_in {  // mirrors yh_material of include/yhair.h
-  float emission[3], color[3];
-  float specular, metallic, roughness, transmission, opacity, ior;
-  int   thin;
-  float sigma_a[3];
-  float beta_m, beta_n, alpha, eta, eumelanin, pheomelanin;
-};
+#include "yhair.h"
+typedef yh_material yh_material_in;  // the public struct itself (include/yhair.h)
 template <int N>
 YH_DEV float powt(float v) {  // ext.cpp:95-109
   if constexpr (N == 0) return 1;

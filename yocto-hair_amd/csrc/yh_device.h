@@ -73,6 +73,11 @@ typedef struct yhd_material {
   float  specular, metallic, roughness, ior, transmission;
   float  opacity;          // material opacity, snapped to 1 above 0.999 (pt.cpp:454)
   float  meta[3];          // reflectivity_to_eta(color) (pt.cpp:439)
+  // the medium inside a closed transmissive object (eval_vsdf, pt.cpp:504-527)
+  int    has_volume;       // !thin && transmission (pt.cpp:531)
+  float  vol_density[3];   // -log(clamp(color, 1e-4, 1)) / trdepth
+  float  vol_scatter[3];
+  float  vol_anisotropy;
 } yhd_material;
 
 typedef struct yhd_light {

@@ -163,6 +163,12 @@ void make_material(const yh_material& m, yhd_material& d) {
     float r   = fmin_(fmax_(m.color[c], 0.0f), 0.99f);
     d.meta[c] = (1 + std::sqrt(r)) / (1 - std::sqrt(r));
   }
+  d.has_volume = !m.thin && m.transmission != 0;
+  for (int c = 0; c < 3; c++) {  // eval_vsdf (pt.cpp:520-524)
+    d.vol_density[c] = d.has_volume ? -std::log(fmin_(fmax_(m.color[c], 0.0001f), 1.0f)) / m.trdepth : 0.0f;
+    d.vol_scatter[c] = m.scattering[c];
+  }
+  d.vol_anisotropy = m.scanisotropy;
   F3 sa{0, 0, 0};
   if (m.sigma_a[0] || m.sigma_a[1] || m.sigma_a[2]) {
     sa = ld3(m.sigma_a);
@@ -363,15 +369,6 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
   HIPCHK(ctx, hipSetDevice(ctx->device));
   if (sd->num_objects <= 0) return fail(ctx, YH_E_INVALID, "scene has no objects");
   if (sd->num_environments > YH_MAX_ENVS) return fail(ctx, YH_E_INVALID, "more than %d environments", YH_MAX_ENVS);
-  // ---- validate the material scope (yhair.h: yh_material) ----------------
-  for (int i = 0; i < sd->num_materials; i++) {
-    auto& m = sd->materials[i];
-    if (!m.thin && m.transmission != 0)  // has_volume (pt.cpp:531)
-      return fail(ctx, YH_E_INVALID,
-          "material %d is a volume (transmission with thin = false): the volume stack / subsurface walk "
-          "(pt.cpp:1403-1414,1458-1497) is not supported",
-          i);
-  }
   // ---- per-shape BVHs and flattened arrays --------------------------------
   struct ShapeInfo {
     int kind, node_base, prim_base, vert_base, elem_base, has_normals, depth;
