@@ -266,6 +266,13 @@ int yh_hair_pdf_batch(yh_context* ctx, int n, const float* brdf,
 int yh_hair_eval_pdf_batch(yh_context* ctx, int n, const float* brdf,
     const float* outgoing, const float* incoming, float* pdf);
 
+/* build_bvh (yocto_pathtrace.cpp:598-650) on the host, exactly as
+ * yh_upload_scene builds it: boxes = n x (min[3], max[3]). Call with nodes =
+ * NULL to get the node count; nodes = 8 floats per node (bbox min, bbox max,
+ * then as int bits: start, num | internal << 16 | axis << 24), primitives = n
+ * ints (leaf order). Needs no GPU and no context. Returns the node count.     */
+int yh_bvh_build(int n, const float* boxes, float* nodes, int* primitives);
+
 /* One surface lobe (kind = YH_LOBE_*) of yocto_math.h:1513-1620 (implementation
  * 4427-4755): eval_* (value times |cos|), sample_*_pdf and sample_* in one
  * call. params: 8n (ior, roughness [= brdf.roughness, already squared], eta[3],

@@ -112,3 +112,44 @@ def test_save_image_pfm_layout(yh, tmp_path):
     data = np.frombuffer(raw[len(b"PF\n3 2\n-1\n"):], np.float32).reshape(2, 3, 3)
     assert np.array_equal(data, img[..., :3])  # top row first, rgb only (yocto_image.cpp:1527-1556)
     assert lib.yh_save_image(str(tmp_path / "x.png").encode(), 3, 2, yh.fptr(img), err, 256) == yh.YH_E_IO
+
+
+def _shape_boxes(shape):
+    """primitive bounds as yh_upload_scene computes them (line_bounds / triangle_bounds, math.h:3037-3044)"""
+    pos = np.ctypeslib.as_array(shape.positions, (shape.num_vertices, 3))
+    if shape.num_lines > 0:
+        idx = np.ctypeslib.as_array(shape.lines, (shape.num_lines, 2))
+        rad = np.ctypeslib.as_array(shape.radius, (shape.num_vertices,)) if shape.radius else np.full(shape.num_vertices, 0.001, np.float32)
+        p, r = pos[idx], rad[idx][..., None]
+        return np.concatenate([(p - r).min(axis=1), (p + r).max(axis=1)], axis=1).astype(np.float32)
+    idx = np.ctypeslib.as_array(shape.triangles, (shape.num_triangles, 3))
+    p = pos[idx]
+    return np.concatenate([p.min(axis=1), p.max(axis=1)], axis=1).astype(np.float32)
+
+
+@pytest.mark.parametrize("name,kw", [("sphere-hairblock", dict(scale=0.5)), ("hair-curls", dict(scale=0.05))])
+def test_host_bvh_is_the_reference_tree(yh, oracle, name, kw):
+    """The product host builder must produce the reference's tree node for node
+    (boxes, child index, count, split axis, breadth-first numbering) and the same leaf order; the
+    oracle's tree is itself pinned to the reference through bit-identical hits and images."""
+    from conftest import scene_path
+    sf = yh.SceneFile(scene_path(name, **kw))
+    d = sf.desc.contents
+    osc = oracle.scene(sf.desc)
+    lib = yh.load()
+    for si in range(d.num_shapes):
+        boxes = np.ascontiguousarray(_shape_boxes(d.shapes[si]))
+        n = lib.yh_bvh_build(len(boxes), yh.fptr(boxes), None, None)
+        nodes, prims = np.zeros((n, 8), np.float32), np.zeros(len(boxes), np.int32)
+        assert lib.yh_bvh_build(len(boxes), yh.fptr(boxes), yh.fptr(nodes), yh.iptr(prims)) == n
+        want = osc.bvh(si)
+        assert nodes.shape == want.shape
+        assert np.array_equal(nodes.view(np.uint32), want.view(np.uint32))
+        wp = np.zeros(len(boxes), np.int32)
+        oracle.lib.yo_scene_bvh(osc.h, si, None, yh.iptr(wp))
+        assert np.array_equal(prims, wp)
+        # and it is deterministic
+        nodes2 = np.zeros_like(nodes)
+        lib.yh_bvh_build(len(boxes), yh.fptr(boxes), yh.fptr(nodes2), None)
+        assert np.array_equal(nodes.view(np.uint32), nodes2.view(np.uint32))
+    osc.close(), sf.close()

@@ -14,6 +14,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -21,6 +22,7 @@
 #include <cstring>
 #include <limits>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../csrc/yh_device.h"
@@ -211,6 +213,23 @@ void make_material(const yh_material& m, yhd_material& d) {
 
 }  // namespace
 
+// Splits [0, n) over a few host threads (upload-time array fills; not a hot path).
+template <typename F>
+void parallel_for(int n, F&& fn) {
+  int nt = (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+  if (n < 65536 || nt == 1) {
+    for (int i = 0; i < n; i++) fn(i);
+    return;
+  }
+  std::vector<std::thread> pool;
+  for (int t = 0; t < nt; t++)
+    pool.emplace_back([=, &fn] {
+      int lo = (int)((int64_t)n * t / nt), hi = (int)((int64_t)n * (t + 1) / nt);
+      for (int i = lo; i < hi; i++) fn(i);
+    });
+  for (auto& th : pool) th.join();
+}
+
 struct yh_context {
   int         device = 0;
   hipStream_t stream = nullptr;
@@ -369,6 +388,15 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
   HIPCHK(ctx, hipSetDevice(ctx->device));
   if (sd->num_objects <= 0) return fail(ctx, YH_E_INVALID, "scene has no objects");
   if (sd->num_environments > YH_MAX_ENVS) return fail(ctx, YH_E_INVALID, "more than %d environments", YH_MAX_ENVS);
+  // YHAIR_TIMING=1: stage times of the upload on stderr
+  const bool timing = getenv("YHAIR_TIMING") && atoi(getenv("YHAIR_TIMING")) != 0;
+  auto       t_last = std::chrono::steady_clock::now();
+  auto       lap    = [&](const char* what) {
+    if (!timing) return;
+    auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[yhair] upload: %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+    t_last = now;
+  };
   // ---- per-shape BVHs and flattened arrays --------------------------------
   struct ShapeInfo {
     int kind, node_base, prim_base, vert_base, elem_base, has_normals, depth;
@@ -379,6 +407,16 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
   std::vector<yhd_float4> nodes, prims, vpos, vnrm;
   std::vector<yhd_int4>   elems;
   int                     best_lines = -1, best_shape = -1;
+  {  // one allocation per array: growing them shape by shape would re-copy the hair every time
+    size_t np = 0, nv = 0, ne = 0;
+    for (int si = 0; si < sd->num_shapes; si++) {
+      auto& s = sd->shapes[si];
+      bool  lines = s.num_lines > 0;
+      size_t nel = (size_t)std::max(0, lines ? s.num_lines : s.num_triangles);
+      np += nel * (lines ? 4 : 6), nv += (size_t)std::max(0, s.num_vertices), ne += nel;
+    }
+    prims.reserve(np), vpos.reserve(nv), vnrm.reserve(nv), elems.reserve(ne), nodes.reserve(ne * 6);
+  }
   for (int si = 0; si < sd->num_shapes; si++) {
     auto& s = sd->shapes[si];
     if (s.num_vertices <= 0 || !s.positions) return fail(ctx, YH_E_INVALID, "shape %d has no vertices", si);
@@ -398,7 +436,7 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
     auto pos = [&](int v) { return ld3(s.positions + 3 * (size_t)v); };
     auto rad = [&](int v) { return s.radius ? s.radius[v] : 0.001f; };  // add_radius, sceneio.cpp:390
     std::vector<yhh::Box> boxes(nel);
-    for (int e = 0; e < nel; e++) {
+    parallel_for(nel, [&](int e) {
       if (lines) {  // line_bounds (math.h:3037-3040)
         int a = idx[2 * e], b = idx[2 * e + 1];
         F3  p0 = pos(a), p1 = pos(b);
@@ -415,11 +453,14 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
           boxes[e].max[k] = fmax_(p0[k], fmax_(p1[k], p2[k]));
         }
       }
-    }
+    });
+    lap("primitive bounds");
     yhh::Tree tree;
     yhh::build_bvh(tree, boxes);
+    lap("build_bvh (reference tree)");
     std::vector<yhh::WideNode> wide;
     I.depth = yhh::collapse_wide(tree, wide);
+    lap("collapse to 4-wide");
     I.root = tree.nodes[0].bbox, I.num_nodes = (int)wide.size();
     {
       size_t at = nodes.size();
@@ -427,38 +468,45 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
       memcpy(&nodes[at], wide.data(), wide.size() * sizeof(yhh::WideNode));
     }
     auto nrm = [&](int v) { return s.normals ? ld3(s.normals + 3 * (size_t)v) : F3{0, 0, 0}; };
-    for (int slot = 0; slot < nel; slot++) {  // leaf-ordered records (yh_device.h)
-      int   e = tree.primitives[slot];
-      float ew;
-      memcpy(&ew, &e, 4);
-      if (lines) {
-        int a = idx[2 * e], b = idx[2 * e + 1];
-        F3  p0 = pos(a), p1 = pos(b), t0 = nrm(a), t1 = nrm(b);
-        prims.push_back({p0.x, p0.y, p0.z, rad(a)});
-        prims.push_back({p1.x, p1.y, p1.z, rad(b)});
-        prims.push_back({t0.x, t0.y, t0.z, ew});
-        prims.push_back({t1.x, t1.y, t1.z, 0});
-      } else {
-        int a = idx[3 * e], b = idx[3 * e + 1], cc = idx[3 * e + 2];
-        F3  p0 = pos(a), p1 = pos(b), p2 = pos(cc), n0 = nrm(a), n1 = nrm(b), n2 = nrm(cc);
-        prims.push_back({p0.x, p0.y, p0.z, ew});
-        prims.push_back({p1.x, p1.y, p1.z, 0});
-        prims.push_back({p2.x, p2.y, p2.z, 0});
-        prims.push_back({n0.x, n0.y, n0.z, 0});
-        prims.push_back({n1.x, n1.y, n1.z, 0});
-        prims.push_back({n2.x, n2.y, n2.z, 0});
-      }
+    {  // leaf-ordered records (yh_device.h), filled in parallel
+      const size_t per = lines ? 4 : 6, at = prims.size();
+      prims.resize(at + per * (size_t)nel);
+      yhd_float4* out = prims.data() + at;
+      parallel_for(nel, [&](int slot) {
+        int   e = tree.primitives[slot];
+        float ew;
+        memcpy(&ew, &e, 4);
+        yhd_float4* r = out + per * (size_t)slot;
+        if (lines) {
+          int a = idx[2 * e], b = idx[2 * e + 1];
+          F3  p0 = pos(a), p1 = pos(b), t0 = nrm(a), t1 = nrm(b);
+          r[0] = {p0.x, p0.y, p0.z, rad(a)}, r[1] = {p1.x, p1.y, p1.z, rad(b)};
+          r[2] = {t0.x, t0.y, t0.z, ew}, r[3] = {t1.x, t1.y, t1.z, 0};
+        } else {
+          int a = idx[3 * e], b = idx[3 * e + 1], cc = idx[3 * e + 2];
+          F3  p0 = pos(a), p1 = pos(b), p2 = pos(cc), n0 = nrm(a), n1 = nrm(b), n2 = nrm(cc);
+          r[0] = {p0.x, p0.y, p0.z, ew}, r[1] = {p1.x, p1.y, p1.z, 0}, r[2] = {p2.x, p2.y, p2.z, 0};
+          r[3] = {n0.x, n0.y, n0.z, 0}, r[4] = {n1.x, n1.y, n1.z, 0}, r[5] = {n2.x, n2.y, n2.z, 0};
+        }
+      });
     }
-    for (int v = 0; v < s.num_vertices; v++) {
-      F3 p = pos(v);
-      vpos.push_back({p.x, p.y, p.z, lines ? rad(v) : 0.0f});
-      if (s.normals) vnrm.push_back({s.normals[3 * v], s.normals[3 * v + 1], s.normals[3 * v + 2], 0});
-      else vnrm.push_back({0, 0, 0, 0});
+    {
+      const size_t at = vpos.size();
+      vpos.resize(at + (size_t)s.num_vertices), vnrm.resize(at + (size_t)s.num_vertices);
+      parallel_for(s.num_vertices, [&](int v) {
+        F3 p = pos(v), n = nrm(v);
+        vpos[at + (size_t)v] = {p.x, p.y, p.z, lines ? rad(v) : 0.0f};
+        vnrm[at + (size_t)v] = {n.x, n.y, n.z, 0};
+      });
+      const size_t ea = elems.size();
+      elems.resize(ea + (size_t)nel);
+      parallel_for(nel, [&](int e) {
+        elems[ea + (size_t)e] = lines ? yhd_int4{idx[2 * e], idx[2 * e + 1], 0, 0}
+                                      : yhd_int4{idx[3 * e], idx[3 * e + 1], idx[3 * e + 2], 0};
+      });
     }
-    for (int e = 0; e < nel; e++)
-      elems.push_back(lines ? yhd_int4{idx[2 * e], idx[2 * e + 1], 0, 0}
-                            : yhd_int4{idx[3 * e], idx[3 * e + 1], idx[3 * e + 2], 0});
     if (lines && s.num_lines > best_lines) best_lines = s.num_lines, best_shape = si;
+    lap("leaf records + vertex arrays");
   }
   // ---- objects and the scene-level BVH (pt.cpp:792-814) -------------------
   std::vector<yhd_object> objects(sd->num_objects);
@@ -555,6 +603,7 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
     }
   }
   if (sc.num_lights == 0) return fail(ctx, YH_E_INVALID, "scene has no lights (the path sampler needs at least one)");
+  lap("objects, materials, lights");
   // ---- upload ------------------------------------------------------------
   int rc;
   if ((rc = upload(ctx, ctx->d_nodes, nodes.data(), nodes.size() * 16))) return rc;
@@ -568,6 +617,7 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
   if ((rc = upload(ctx, ctx->d_scene_prims, scene_tree.primitives.data(), scene_tree.primitives.size() * 4))) return rc;
   if ((rc = upload(ctx, ctx->d_light_cdf, light_cdf.data(), light_cdf.size() * 4))) return rc;
   if ((rc = upload(ctx, ctx->d_env_texels, env_texels.data(), env_texels.size() * 16))) return rc;
+  lap("hipMalloc + H2D copies");
   sc.nodes = (const yhd_float4*)ctx->d_nodes.p, sc.prims = (const yhd_float4*)ctx->d_prims.p;
   sc.vpos = (const yhd_float4*)ctx->d_vpos.p;
   sc.vnrm = (const yhd_float4*)ctx->d_vnrm.p, sc.elems = (const yhd_int4*)ctx->d_elems.p;
@@ -870,6 +920,25 @@ int yh_hair_pdf_batch(yh_context* ctx, int n, const float* brdf, const float* wo
 }
 int yh_hair_eval_pdf_batch(yh_context* ctx, int n, const float* brdf, const float* wo, const float* wi, float* pdf) {
   return yh_hair_pdf_batch(ctx, n, brdf, wo, wi, pdf);
+}
+
+int yh_bvh_build(int n, const float* boxes, float* nodes, int* primitives) {
+  if (n < 0 || (n && !boxes)) return YH_E_INVALID;
+  std::vector<yhh::Box> b((size_t)n);
+  for (int i = 0; i < n; i++)
+    for (int k = 0; k < 3; k++) b[(size_t)i].min[k] = boxes[6 * (size_t)i + k], b[(size_t)i].max[k] = boxes[6 * (size_t)i + 3 + k];
+  yhh::Tree tree;
+  yhh::build_bvh(tree, b);
+  if (nodes)
+    for (size_t i = 0; i < tree.nodes.size(); i++) {
+      auto&  nd = tree.nodes[i];
+      float* o  = nodes + 8 * i;
+      memcpy(o, nd.bbox.min, 12), memcpy(o + 3, nd.bbox.max, 12);
+      int a = nd.start, c = (int)nd.num | ((int)nd.internal << 16) | ((int)nd.axis << 24);
+      memcpy(o + 6, &a, 4), memcpy(o + 7, &c, 4);
+    }
+  if (primitives && n) memcpy(primitives, tree.primitives.data(), sizeof(int) * (size_t)n);
+  return (int)tree.nodes.size();
 }
 
 int yh_surface_lobe_batch(yh_context* ctx, int kind, int n, const float* params, const float* normal,

@@ -181,25 +181,40 @@ struct ShapeData {
   std::vector<float> positions, normals, radius;
   std::vector<int>   lines, triangles;
 };
-struct PlyProp { std::string name, type, ltype; bool list = false; };
-struct PlyElem { std::string name; size_t count = 0; std::vector<PlyProp> props; };
-size_t ply_size(const std::string& t) {
-  if (t == "char" || t == "uchar" || t == "int8" || t == "uint8") return 1;
-  if (t == "short" || t == "ushort" || t == "int16" || t == "uint16") return 2;
-  if (t == "int" || t == "uint" || t == "float" || t == "int32" || t == "uint32" || t == "float32") return 4;
-  if (t == "double" || t == "float64" || t == "int64" || t == "uint64") return 8;
+enum PlyType { PLY_I8, PLY_U8, PLY_I16, PLY_U16, PLY_I32, PLY_U32, PLY_F32, PLY_F64, PLY_I64, PLY_U64 };
+PlyType ply_type(const std::string& t) {
+  if (t == "char" || t == "int8") return PLY_I8;
+  if (t == "uchar" || t == "uint8") return PLY_U8;
+  if (t == "short" || t == "int16") return PLY_I16;
+  if (t == "ushort" || t == "uint16") return PLY_U16;
+  if (t == "int" || t == "int32") return PLY_I32;
+  if (t == "uint" || t == "uint32") return PLY_U32;
+  if (t == "float" || t == "float32") return PLY_F32;
+  if (t == "double" || t == "float64") return PLY_F64;
+  if (t == "int64") return PLY_I64;
+  if (t == "uint64") return PLY_U64;
   throw std::runtime_error("ply: unknown type " + t);
 }
-double ply_read_bin(const unsigned char*& p, const std::string& t) {
+inline size_t ply_size(PlyType t) {
+  static const size_t sizes[] = {1, 1, 2, 2, 4, 4, 4, 8, 8, 8};
+  return sizes[t];
+}
+struct PlyProp { std::string name; PlyType type = PLY_F32, ltype = PLY_U8; bool list = false; };
+struct PlyElem { std::string name; size_t count = 0; std::vector<PlyProp> props; };
+inline double ply_read_bin(const unsigned char*& p, PlyType t) {
   double v = 0;
-  if (t == "char" || t == "int8") { v = *(const signed char*)p; }
-  else if (t == "uchar" || t == "uint8") { v = *p; }
-  else if (t == "short" || t == "int16") { int16_t x; memcpy(&x, p, 2); v = x; }
-  else if (t == "ushort" || t == "uint16") { uint16_t x; memcpy(&x, p, 2); v = x; }
-  else if (t == "int" || t == "int32") { int32_t x; memcpy(&x, p, 4); v = x; }
-  else if (t == "uint" || t == "uint32") { uint32_t x; memcpy(&x, p, 4); v = x; }
-  else if (t == "float" || t == "float32") { float x; memcpy(&x, p, 4); v = x; }
-  else if (t == "double" || t == "float64") { double x; memcpy(&x, p, 8); v = x; }
+  switch (t) {
+    case PLY_I8: v = *(const signed char*)p; break;
+    case PLY_U8: v = *p; break;
+    case PLY_I16: { int16_t x; memcpy(&x, p, 2); v = x; } break;
+    case PLY_U16: { uint16_t x; memcpy(&x, p, 2); v = x; } break;
+    case PLY_I32: { int32_t x; memcpy(&x, p, 4); v = x; } break;
+    case PLY_U32: { uint32_t x; memcpy(&x, p, 4); v = x; } break;
+    case PLY_F32: { float x; memcpy(&x, p, 4); v = x; } break;
+    case PLY_F64: { double x; memcpy(&x, p, 8); v = x; } break;
+    case PLY_I64: { int64_t x; memcpy(&x, p, 8); v = (double)x; } break;
+    case PLY_U64: { uint64_t x; memcpy(&x, p, 8); v = (double)x; } break;
+  }
   p += ply_size(t);
   return v;
 }
@@ -240,9 +255,9 @@ void load_ply(const std::string& path, ShapeData& shape) {
         char t1[64], t2[64], nm[64];
         if (sscanf(l.c_str(), "property list %63s %63s %63s", t1, t2, nm) != 3)
           throw std::runtime_error(path + ": bad list property");
-        p.list = true, p.ltype = t1, p.type = t2, p.name = nm;
+        p.list = true, p.ltype = ply_type(t1), p.type = ply_type(t2), p.name = nm;
       } else {
-        p.type = b, p.name = c;
+        p.type = ply_type(b), p.name = c;
       }
       elems.back().props.push_back(p);
     }
@@ -250,7 +265,7 @@ void load_ply(const std::string& path, ShapeData& shape) {
   auto bp   = (const unsigned char*)data.data() + pos;
   auto bend = (const unsigned char*)data.data() + data.size();
   auto ap   = data.c_str() + pos;
-  auto next = [&](const std::string& t) -> double {
+  auto next = [&](PlyType t) -> double {
     if (ascii) {
       char* e = nullptr;
       auto  v = strtod(ap, &e);
@@ -279,16 +294,35 @@ void load_ply(const std::string& path, ShapeData& shape) {
       if (has_radius) shape.radius.resize(e.count);
     }
     std::vector<double> row(e.props.size());
+    std::vector<int>    idx;
+    const bool is_vertex = e.name == "vertex", is_face = e.name == "face", is_line = e.name == "line";
+    // binary rows of plain floats (the hair models: x y z nx ny nz radius): one gather per vertex
+    bool all_f32 = !ascii && is_vertex && !e.props.empty();
+    for (auto& pr : e.props) all_f32 = all_f32 && !pr.list && pr.type == PLY_F32;
+    if (all_f32) {
+      if (ix < 0 || iy < 0 || iz < 0) throw std::runtime_error(path + ": vertex without x y z");
+      size_t stride = e.props.size() * 4;
+      if (bp + stride * e.count > bend) throw std::runtime_error(path + ": truncated ply");
+      for (size_t i = 0; i < e.count; i++, bp += stride) {
+        auto f = [&](int k) { float x; memcpy(&x, bp + 4 * (size_t)k, 4); return x; };
+        shape.positions[3 * i] = f(ix), shape.positions[3 * i + 1] = f(iy), shape.positions[3 * i + 2] = f(iz);
+        if (has_normals) shape.normals[3 * i] = f(inx), shape.normals[3 * i + 1] = f(iny), shape.normals[3 * i + 2] = f(inz);
+        if (has_radius) shape.radius[i] = f(ir);
+      }
+      continue;
+    }
+    if (is_line) shape.lines.reserve(shape.lines.size() + 2 * e.count);
     for (size_t i = 0; i < e.count; i++) {
       for (int k = 0; k < (int)e.props.size(); k++) {
         auto& pr = e.props[k];
         if (pr.list) {
           auto n = (int)next(pr.ltype);
-          std::vector<int> idx(n);
+          if (n < 0) throw std::runtime_error(path + ": negative list length");
+          idx.resize((size_t)n);
           for (int c = 0; c < n; c++) idx[c] = (int)next(pr.type);
           if (pr.name == "vertex_indices" || pr.name == "vertex_index") {
-            if (e.name == "face") faces.push_back(std::move(idx));
-            else if (e.name == "line")
+            if (is_face) faces.push_back(idx);
+            else if (is_line)
               for (int c = 1; c < n; c++) shape.lines.push_back(idx[c - 1]), shape.lines.push_back(idx[c]);
           }
         } else {

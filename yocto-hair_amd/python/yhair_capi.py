@@ -134,6 +134,7 @@ _SIGS = {
     "yh_tile_costs": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_int]),
     "yh_hair_brdf_batch": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Material), c_float_p,
                                      c_float_p, c_float_p, c_float_p]),
+    "yh_bvh_build": (C.c_int, [C.c_int, c_float_p, c_float_p, c_int_p]),
     "yh_surface_lobe_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_float_p, c_float_p, c_float_p, c_float_p,
                                         c_float_p, c_float_p]),
     "yh_surface_bsdf_batch": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Material), c_float_p, c_float_p, c_float_p,
