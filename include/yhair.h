@@ -266,6 +266,16 @@ int yh_hair_pdf_batch(yh_context* ctx, int n, const float* brdf,
 int yh_hair_eval_pdf_batch(yh_context* ctx, int n, const float* brdf,
     const float* outgoing, const float* incoming, float* pdf);
 
+/* The pbrt `curve` -> hair-line conversion of the reference's pbrt loader
+ * (libs/yocto/yocto_pbrt.h:1751-1797): each curve's first four control points
+ * become a strand of five vertices (Bezier at u = 0, 1/4, 1/2, 3/4, 1), with
+ * tangents as "normals" and radius = lerp(width0, width1, u), joined by four
+ * lines. P: 12n; width0, width1: n; out: positions 15n, normals 15n, radius
+ * 5n, lines 8n ints (vertex indices start at base_vertex + 5 * curve).       */
+int yh_curves_to_lines(yh_context* ctx, int n, const float* P, const float* width0,
+    const float* width1, int base_vertex, float* positions, float* normals,
+    float* radius, int* lines);
+
 /* build_bvh (yocto_pathtrace.cpp:598-650) on the host, exactly as
  * yh_upload_scene builds it: boxes = n x (min[3], max[3]). Call with nodes =
  * NULL to get the node count; nodes = 8 floats per node (bbox min, bbox max,

@@ -104,6 +104,19 @@ def main():
         for kind in range(yh.LOBE_COUNT):
             out[f"lobe_{kind}"] = ref.surface_lobe(kind, p, nn, wo, wi, rn)
         np.savez_compressed(os.path.join(GOLD, "lobes.npz"), **out)
+    # ---- pbrt curve -> line strands (yocto_pbrt.h:1751-1797) ------------------------------------
+    if want("curves.npz"):
+        crng = np.random.default_rng(20240610)
+        n = 2048
+        root = crng.uniform(-1, 1, (n, 1, 3))
+        P = (root + np.cumsum(crng.normal(0, 0.05, (n, 4, 3)), axis=1)).astype(np.float32).reshape(n, 12)
+        P[0] = [0, 0, 0, 0, 1, 0, 0, 2, 0, 0, 3, 0]                  # straight
+        P[1] = [0, 0, 0, 0, 0, 0, 1, 0, 0, 1, 0, 0]                  # p1 == p0, p3 == p2: zero end tangents
+        w0 = crng.uniform(0.001, 0.01, n).astype(np.float32)
+        w1 = (w0 * crng.uniform(0.1, 1.0, n)).astype(np.float32)
+        pos, nrm, rad, lines = ref.curves_to_lines(P, w0, w1, 100)
+        np.savez_compressed(os.path.join(GOLD, "curves.npz"), P=P, width0=w0, width1=w1, base_vertex=100,
+                            positions=pos, normals=nrm, radius=rad, lines=lines)
     rng = np.random.default_rng(20240607)
     if only:
         scenes_only(ref, rng, want)

@@ -20,6 +20,7 @@
 #include <memory>
 #include <string>
 #include <unordered_map>
+#include <vector>
 
 namespace ym  = yocto::math;
 namespace ye  = yocto::extension;
@@ -118,6 +119,34 @@ void ref_surface_lobe(int kind, int n, const float* params, const float* normal,
     }
     auto o = out + 7 * i;
     o[0] = f.x, o[1] = f.y, o[2] = f.z, o[3] = pdf, o[4] = w.x, o[5] = w.y, o[6] = w.z;
+  }
+}
+// The arithmetic of the pbrt curve conversion (yocto_pbrt.h:1751-1797) through the
+// reference's own public helpers: interpolate_bezier, interpolate_bezier_derivative,
+// lerp, normalize (yocto_math.h:1251-1257, 245, 2036).
+void ref_curves_to_lines(int n, const float* P, const float* width0, const float* width1,
+    int base_vertex, float* positions, float* normals, float* radius, int* lines) {
+  auto number_sub = 4;
+  for (int c = 0; c < n; c++) {
+    auto p0 = v3(P + 12 * c), p1 = v3(P + 12 * c + 3), p2 = v3(P + 12 * c + 6), p3 = v3(P + 12 * c + 9);
+    std::vector<ym::vec3f> pos, nrm;
+    std::vector<float>     rad;
+    pos.push_back(p0);
+    for (auto i = 1; i < number_sub; i++) pos.push_back(ym::interpolate_bezier(p0, p1, p2, p3, (float)i / number_sub));
+    pos.push_back(p3);
+    nrm.push_back(ym::normalize(p1 - p0));
+    for (auto i = 1; i < number_sub; i++)
+      nrm.push_back(ym::normalize(ym::interpolate_bezier_derivative(p0, p1, p2, p3, (float)i / number_sub)));
+    nrm.push_back(ym::normalize(p3 - p2));
+    rad.push_back(width0[c]);
+    for (auto i = 1; i < number_sub; i++) rad.push_back(ym::lerp(width0[c], width1[c], (float)i / number_sub));
+    rad.push_back(width1[c]);
+    for (int i = 0; i < 5; i++) {
+      positions[15 * c + 3 * i] = pos[i].x, positions[15 * c + 3 * i + 1] = pos[i].y, positions[15 * c + 3 * i + 2] = pos[i].z;
+      normals[15 * c + 3 * i] = nrm[i].x, normals[15 * c + 3 * i + 1] = nrm[i].y, normals[15 * c + 3 * i + 2] = nrm[i].z;
+      radius[5 * c + i] = rad[i];
+    }
+    for (int i = 0; i < 4; i++) lines[8 * c + 2 * i] = base_vertex + 5 * c + i, lines[8 * c + 2 * i + 1] = base_vertex + 5 * c + i + 1;
   }
 }
 // fresnel_dielectric / fresnel_conductor / reflectivity_to_eta (yocto_math.h:1490-1503)

@@ -1940,6 +1940,39 @@ void yo_surface_lobe(int kind, int n, const float* params, const float* normal,
   }
 }
 
+// pbrt "curve" -> five-vertex line strand (yocto_pbrt.h:1751-1797, number_sub = 4;
+// interpolate_bezier / _derivative math.h:3346-3357, lerp :1803). P: 12 floats per
+// curve (the first four control points); out: positions 15, normals (= tangents) 15,
+// radius 5 (= the pbrt width, as the reference stores it), lines 8 ints per curve with
+// vertex indices starting at 5 * curve + base_vertex.
+void yo_curves_to_lines(int n, const float* P, const float* width0, const float* width1,
+    int base_vertex, float* positions, float* normals, float* radius, int* lines) {
+  const int number_sub = 4;
+  for (int c = 0; c < n; c++) {
+    auto p0 = v3(P + 12 * c), p1 = v3(P + 12 * c + 3), p2 = v3(P + 12 * c + 6), p3 = v3(P + 12 * c + 9);
+    auto put = [](float* o, V3 a) { o[0] = a.x, o[1] = a.y, o[2] = a.z; };
+    for (int i = 0; i <= number_sub; i++) {
+      V3    pos, tan;
+      float rad;
+      if (i == 0) {
+        pos = p0, tan = normalize(p1 - p0), rad = width0[c];
+      } else if (i == number_sub) {
+        pos = p3, tan = normalize(p3 - p2), rad = width1[c];
+      } else {
+        auto u = (float)i / number_sub;
+        pos    = p0 * (1 - u) * (1 - u) * (1 - u) + p1 * 3 * u * (1 - u) * (1 - u) + p2 * 3 * u * u * (1 - u) +
+              p3 * u * u * u;
+        tan = normalize((p1 - p0) * 3 * (1 - u) * (1 - u) + (p2 - p1) * 6 * u * (1 - u) + (p3 - p2) * 3 * u * u);
+        rad = width0[c] * (1 - u) + width1[c] * u;
+      }
+      put(positions + 15 * c + 3 * i, pos), put(normals + 15 * c + 3 * i, tan);
+      radius[5 * c + i] = rad;
+    }
+    for (int i = 0; i < number_sub; i++)
+      lines[8 * c + 2 * i] = base_vertex + 5 * c + i, lines[8 * c + 2 * i + 1] = base_vertex + 5 * c + i + 1;
+  }
+}
+
 // fresnel_dielectric, fresnel_conductor, reflectivity_to_eta(params.eta) — out 7n
 void yo_fresnel(int n, const float* params, const float* normal, const float* outgoing, float* out) {
   for (int i = 0; i < n; i++) {

@@ -50,6 +50,10 @@ int yo_selftest(int which, float* worst);
  * sampled incoming [3])                                                     */
 void yo_surface_lobe(int kind, int n, const float* params, const float* normal,
     const float* outgoing, const float* incoming, const float* rn, float* out);
+/* pbrt curve -> 5-vertex strand (yocto_pbrt.h:1751-1797): P 12n; out positions 15n,
+ * normals 15n, radius 5n, lines 8n (indices from base_vertex + 5 * curve)       */
+void yo_curves_to_lines(int n, const float* P, const float* width0, const float* width1,
+    int base_vertex, float* positions, float* normals, float* radius, int* lines);
 /* fresnel_dielectric(ior), fresnel_conductor(eta, etak), reflectivity_to_eta(eta): out 7n */
 void yo_fresnel(int n, const float* params, const float* normal, const float* outgoing, float* out);
 /* pt.cpp:405-471 (eval_brdf) + 1069-1280 (dispatch), non-hair materials      */

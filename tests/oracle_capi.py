@@ -40,6 +40,7 @@ class _UnitApi:
         g("intersect_bbox").argtypes = [C.c_int, fp, fp, ip]
         g("surface_lobe").argtypes = [C.c_int, C.c_int, fp, fp, fp, fp, fp, fp]
         g("fresnel").argtypes = [C.c_int, fp, fp, fp, fp]
+        g("curves_to_lines").argtypes = [C.c_int, fp, fp, fp, C.c_int, fp, fp, fp, ip]
 
     def _g(self, n):
         return getattr(self.lib, self.p + n)
@@ -83,6 +84,16 @@ class _UnitApi:
         self._g("surface_lobe")(kind, len(params8), yh.fptr(params8), yh.fptr(normal), yh.fptr(wo), yh.fptr(wi),
                                 yh.fptr(rn3), yh.fptr(out))
         return out
+
+    def curves_to_lines(self, P, width0, width1, base_vertex=0):
+        """pbrt curves (n, 12) -> positions (5n, 3), tangents (5n, 3), radius (5n), lines (4n, 2)."""
+        P, width0, width1 = _f(P).reshape(-1, 12), _f(width0), _f(width1)
+        n = len(P)
+        pos, nrm = np.zeros((5 * n, 3), np.float32), np.zeros((5 * n, 3), np.float32)
+        rad, lines = np.zeros(5 * n, np.float32), np.zeros((4 * n, 2), np.int32)
+        self._g("curves_to_lines")(n, yh.fptr(P), yh.fptr(width0), yh.fptr(width1), base_vertex, yh.fptr(pos),
+                                   yh.fptr(nrm), yh.fptr(rad), yh.iptr(lines))
+        return pos, nrm, rad, lines
 
     def fresnel(self, params8, normal, wo):
         params8, normal, wo = _f(params8), _f(normal), _f(wo)

@@ -148,6 +148,41 @@ def test_surface_bsdf_mixture_matches_oracle(ctx, oracle, yh):
     assert (want[:, 22:25] != 0).any(axis=1).mean() > 0.2
 
 
+def test_curve_conversion_bit_exact_on_device(ctx, yh, tmp_path):
+    """pbrt curve -> strand on the GPU (+ - * / sqrt only: bit-exact), through the ABI and through
+    the ycurves2ply command line (tokenizer + PLY writer) read back by the scene reader."""
+    import os, subprocess
+    g = golden("curves.npz")
+    pos, nrm, rad, lines = ctx.curves_to_lines(g["P"], g["width0"], g["width1"], int(g["base_vertex"]))
+    assert np.array_equal(pos, g["positions"]) and np.array_equal(nrm, g["normals"], equal_nan=True)
+    assert np.array_equal(rad, g["radius"]) and np.array_equal(lines, g["lines"])
+    assert ctx.curves_to_lines(np.zeros((0, 12)), [], [])[0].shape == (0, 3)
+    # command line: a pbrt file with comments, both parameter spellings and a non-curve shape
+    n = 64
+    pbrt = tmp_path / "hair.pbrt"
+    with open(pbrt, "w") as f:
+        f.write("# synthetic\nAttributeBegin\nShape \"trianglemesh\" \"integer indices\" [0 1 2] \"point P\" [0 0 0 1 0 0 0 1 0]\n")
+        for c in range(n):
+            pts = " ".join(repr(float(x)) for x in g["P"][c])
+            kind = "point3" if c % 2 else "point"
+            f.write(f'Shape "curve" "string type" [ "cylinder" ] "{kind} P" [ {pts} ] '
+                    f'"float width0" [ {float(g["width0"][c])!r} ] "float width1" {float(g["width1"][c])!r}\n')
+        f.write("AttributeEnd\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "yocto-hair_amd", "ycurves2ply")
+    ply = tmp_path / "hair.ply"
+    subprocess.check_call([exe, str(pbrt), str(ply)])
+    blob = open(ply, "rb").read()
+    head, body = blob.split(b"end_header\n", 1)
+    assert b"element vertex %d" % (5 * n) in head and b"element line %d" % (4 * n) in head
+    verts = np.frombuffer(body[: 28 * 5 * n], np.float32).reshape(-1, 7)
+    assert np.array_equal(verts[:, 0:3], g["positions"][: 5 * n]) and np.array_equal(verts[:, 6], g["radius"][: 5 * n])
+    assert np.array_equal(verts[:, 3:6], g["normals"][: 5 * n], equal_nan=True)
+    lrec = np.frombuffer(body[28 * 5 * n:], np.uint8).reshape(-1, 9)
+    assert (lrec[:, 0] == 2).all()
+    assert np.array_equal(lrec[:, 1:].copy().view(np.int32), g["lines"][: 4 * n] - int(g["base_vertex"]))
+
+
 def test_empty_and_invalid_batches(ctx, yh):
     z = np.zeros((0, 3), np.float32)
     assert ctx.hair_eval(np.zeros((0, 30), np.float32), z, z).shape == (0, 3)

@@ -71,6 +71,16 @@ def test_surface_lobes_bit_exact(oracle, yh):
         assert (want[:, 4:] != 0).any(axis=1).mean() > 0.4, kind
 
 
+def test_curve_conversion_bit_exact(oracle):
+    """pbrt curve -> five-vertex strand (yocto_pbrt.h:1751-1797)."""
+    g = golden("curves.npz")
+    pos, nrm, rad, lines = oracle.curves_to_lines(g["P"], g["width0"], g["width1"], int(g["base_vertex"]))
+    assert np.array_equal(pos, g["positions"]) and np.array_equal(nrm, g["normals"], equal_nan=True)
+    assert np.array_equal(rad, g["radius"]) and np.array_equal(lines, g["lines"])
+    assert lines.min() == 100 and lines.max() == 100 + 5 * len(g["P"]) - 1
+    assert np.array_equal(pos[0::5], g["P"][:, 0:3]) and np.array_equal(pos[4::5], g["P"][:, 9:12])
+
+
 def test_primitive_tests_bit_exact(oracle):
     g = golden("intersect.npz")
     h, uv, d = oracle.intersect_line(g["rays"], g["p0"], g["p1"], g["r0"], g["r1"])

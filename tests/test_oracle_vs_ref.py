@@ -57,6 +57,15 @@ def test_surface_lobes_random_inputs(oracle, ref, yh):
                               equal_nan=True), kind
 
 
+def test_curve_conversion_random_inputs(oracle, ref):
+    rng = np.random.default_rng(101)
+    n = 30000
+    P = rng.normal(size=(n, 12)).astype(np.float32)
+    w0, w1 = rng.uniform(0.001, 0.1, n).astype(np.float32), rng.uniform(0.0005, 0.05, n).astype(np.float32)
+    for a, b in zip(oracle.curves_to_lines(P, w0, w1, 3), ref.curves_to_lines(P, w0, w1, 3)):
+        assert np.array_equal(a, b, equal_nan=True)
+
+
 def test_selftests_match_reference(oracle, ref):
     # the reference prints "OK!"; ours returns 1. Only the two cheap ones here (the 300k-sample
     # furnace tests take ~12 s on the reference and are covered by the GPU self-tests).

@@ -501,6 +501,37 @@ __global__ void k_surface_bsdf(int n, const yhd_material* mats, const float* nor
   o[22] = f.x, o[23] = f.y, o[24] = f.z, o[25] = pdf, o[26] = w.x, o[27] = w.y, o[28] = w.z;
 }
 
+// pbrt "curve" -> five-vertex line strand (yocto_pbrt.h:1751-1797, number_sub = 4).
+// One lane per output VERTEX (5 per curve): the control points are read through
+// the cache by the five lanes of a curve, the 12 + 12 + 4 B vertex records and the
+// 8 B line records are written once. HBM-streaming: 56 B in, 172 B out per curve.
+__global__ void k_curves_to_lines(int n, const float* P, const float* width0, const float* width1, int base_vertex,
+    float* positions, float* normals, float* radius, int* lines) {
+  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 5ll * n) return;
+  int c = (int)(t / 5), i = (int)(t % 5);
+  const float* q = P + 12 * (size_t)c;
+  f3 p0 = ld3(q), p1 = ld3(q + 3), p2 = ld3(q + 6), p3 = ld3(q + 9);
+  f3    pos, tan;
+  float rad;
+  if (i == 0) {
+    pos = p0, tan = normalize(p1 - p0), rad = width0[c];
+  } else if (i == 4) {
+    pos = p3, tan = normalize(p3 - p2), rad = width1[c];
+  } else {
+    float u = (float)i / 4;
+    // interpolate_bezier / _derivative (math.h:3346-3357), lerp (math.h:1803)
+    pos = p0 * (1 - u) * (1 - u) * (1 - u) + p1 * 3 * u * (1 - u) * (1 - u) + p2 * 3 * u * u * (1 - u) + p3 * u * u * u;
+    tan = normalize((p1 - p0) * 3 * (1 - u) * (1 - u) + (p2 - p1) * 6 * u * (1 - u) + (p3 - p2) * 3 * u * u);
+    rad = width0[c] * (1 - u) + width1[c] * u;
+  }
+  size_t v = (size_t)t;
+  positions[3 * v] = pos.x, positions[3 * v + 1] = pos.y, positions[3 * v + 2] = pos.z;
+  normals[3 * v] = tan.x, normals[3 * v + 1] = tan.y, normals[3 * v + 2] = tan.z;
+  radius[v] = rad;
+  if (i < 4) lines[8 * (size_t)c + 2 * i] = base_vertex + (int)t, lines[8 * (size_t)c + 2 * i + 1] = base_vertex + (int)t + 1;
+}
+
 extern "C" {
 
 typedef void (*trace_kernel_t)(const yhd_scene, const yhd_state, int, yhd_counters*);
@@ -545,6 +576,13 @@ int yhk_unpack(const void* packed, int src_rank, int world, int ntiles_src, int 
   if (ntiles_src)
     hipLaunchKernelGGL(k_unpack, dim3(ntiles_src), dim3(64), 0, stream, (const yhd_float4*)packed, src_rank, world,
         num_tiles_total, tiles_x, width, height, (yhd_float4*)image);
+  return (int)hipGetLastError();
+}
+int yhk_curves_to_lines(int n, const float* P, const float* w0, const float* w1, int base_vertex, float* positions,
+    float* normals, float* radius, int* lines, hipStream_t s) {
+  long long threads = 5ll * n;
+  hipLaunchKernelGGL(k_curves_to_lines, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, n, P, w0, w1, base_vertex,
+      positions, normals, radius, lines);
   return (int)hipGetLastError();
 }
 int yhk_surface_lobe(int kind, int n, const float* params, const float* normal, const float* wo, const float* wi,

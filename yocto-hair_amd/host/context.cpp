@@ -44,6 +44,7 @@ int yhk_hair_eval(int, const float*, const float*, const float*, float*, hipStre
 int yhk_hair_pdf(int, const float*, const float*, const float*, float*, hipStream_t);
 int yhk_hair_sample(int, const float*, const float*, const float*, float*, hipStream_t);
 int yhk_intersect(const yhd_scene*, int, const float*, int*, int*, float*, float*, hipStream_t);
+int yhk_curves_to_lines(int, const float*, const float*, const float*, int, float*, float*, float*, int*, hipStream_t);
 int yhk_surface_lobe(int, int, const float*, const float*, const float*, const float*, const float*, float*, hipStream_t);
 int yhk_surface_bsdf(int, const void*, const float*, const float*, const float*, const float*, float*, hipStream_t);
 int yhk_selftest(int, float, float, uint64_t, uint64_t, int, const float*, double*, unsigned int*, hipStream_t);
@@ -920,6 +921,32 @@ int yh_hair_pdf_batch(yh_context* ctx, int n, const float* brdf, const float* wo
 }
 int yh_hair_eval_pdf_batch(yh_context* ctx, int n, const float* brdf, const float* wo, const float* wi, float* pdf) {
   return yh_hair_pdf_batch(ctx, n, brdf, wo, wi, pdf);
+}
+
+int yh_curves_to_lines(yh_context* ctx, int n, const float* P, const float* width0, const float* width1,
+    int base_vertex, float* positions, float* normals, float* radius, int* lines) {
+  if (!ctx || n < 0 || (n && (!P || !width0 || !width1 || !positions || !normals || !radius || !lines))) return YH_E_INVALID;
+  if (n == 0) return YH_OK;
+  if (n > 400000000 || base_vertex < 0 || (long long)base_vertex + 5ll * n > 2147483647ll)
+    return fail(ctx, YH_E_INVALID, "too many curves for 32-bit vertex indices");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  Staged s(ctx);
+  auto   dp = (float*)s.in(P, 48 * (size_t)n);
+  auto   d0 = (float*)s.in(width0, 4 * (size_t)n);
+  auto   d1 = (float*)s.in(width1, 4 * (size_t)n);
+  auto   op = (float*)s.out(60 * (size_t)n);
+  auto   on = (float*)s.out(60 * (size_t)n);
+  auto   orad = (float*)s.out(20 * (size_t)n);
+  auto   ol = (int*)s.out(32 * (size_t)n);
+  if (s.rc) return s.rc;
+  int e = yhk_curves_to_lines(n, dp, d0, d1, base_vertex, op, on, orad, ol, ctx->stream);
+  if (e) return fail(ctx, YH_E_DEVICE, "k_curves_to_lines launch: %s", hipGetErrorString((hipError_t)e));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, hipMemcpy(positions, op, 60 * (size_t)n, hipMemcpyDeviceToHost));
+  HIPCHK(ctx, hipMemcpy(normals, on, 60 * (size_t)n, hipMemcpyDeviceToHost));
+  HIPCHK(ctx, hipMemcpy(radius, orad, 20 * (size_t)n, hipMemcpyDeviceToHost));
+  HIPCHK(ctx, hipMemcpy(lines, ol, 32 * (size_t)n, hipMemcpyDeviceToHost));
+  return YH_OK;
 }
 
 int yh_bvh_build(int n, const float* boxes, float* nodes, int* primitives) {

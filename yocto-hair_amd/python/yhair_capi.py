@@ -134,6 +134,8 @@ _SIGS = {
     "yh_tile_costs": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_int]),
     "yh_hair_brdf_batch": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Material), c_float_p,
                                      c_float_p, c_float_p, c_float_p]),
+    "yh_curves_to_lines": (C.c_int, [C.c_void_p, C.c_int, c_float_p, c_float_p, c_float_p, C.c_int, c_float_p,
+                                     c_float_p, c_float_p, c_int_p]),
     "yh_bvh_build": (C.c_int, [C.c_int, c_float_p, c_float_p, c_int_p]),
     "yh_surface_lobe_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_float_p, c_float_p, c_float_p, c_float_p,
                                         c_float_p, c_float_p]),
@@ -313,6 +315,17 @@ class Context:
 
     def hair_pdf(self, brdf, wo, wi):
         return self._wowi(self.lib.yh_hair_pdf_batch, brdf, wo, wi, 1)
+
+    def curves_to_lines(self, P, width0, width1, base_vertex=0):
+        """pbrt curves (n, 12) -> positions (5n, 3), tangents (5n, 3), radius (5n), lines (4n, 2)."""
+        P = np.ascontiguousarray(P, np.float32).reshape(-1, 12)
+        w0, w1 = np.ascontiguousarray(width0, np.float32), np.ascontiguousarray(width1, np.float32)
+        n = len(P)
+        pos, nrm = np.zeros((5 * n, 3), np.float32), np.zeros((5 * n, 3), np.float32)
+        rad, lines = np.zeros(5 * n, np.float32), np.zeros((4 * n, 2), np.int32)
+        self._chk(self.lib.yh_curves_to_lines(self.h, n, fptr(P), fptr(w0), fptr(w1), base_vertex, fptr(pos), fptr(nrm),
+                                              fptr(rad), iptr(lines)))
+        return pos, nrm, rad, lines
 
     def surface_lobe(self, kind, params8, normal, wo, wi, rn3):
         """One YH_LOBE_* kind (yocto_math.h:4427-4755): (n, 7) = f*|cos| [3], pdf, sampled incoming [3]."""
