@@ -140,6 +140,10 @@ typedef struct yh_workcounts {
    * over lanes) and per lane (sum), live lanes per iteration                 */
   uint64_t cyc_trace, cyc_shade, ticks_tile, wave_iters, wave_steps, lane_steps, lane_iters;
   uint64_t cyc_geom, cyc_sample, cyc_eval, cyc_rest; /* split of cyc_shade */
+  /* divergence of the traversal loop: (wave trips that ran the code, lanes
+   * active in them) for wide-node, line-leaf, triangle-leaf, ENTER and
+   * scene-node steps                                                         */
+  uint64_t branch[10];
 } yh_workcounts;
 
 typedef struct yh_context yh_context;

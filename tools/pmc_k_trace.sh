@@ -1,0 +1,33 @@
+#!/bin/bash
+# PMC passes over `bench.py --steps 4` (k_trace). Each --pmc group is its own run (no trace
+# domains besides --kernel-trace). Usage on the GPU box: bash tools/pmc_k_trace.sh <tag>
+set -u
+TAG=${1:-pmc}
+cd "$(dirname "$0")/.." && ROOT=$PWD
+export TMPDIR=/tmp
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p "$OUT"
+i=0
+for grp in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES" \
+           "SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_FLAT SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" \
+           "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"; do
+  i=$((i+1))
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc $grp -d "$OUT/p$i" -o run -- python3 "$ROOT/bench.py" --steps 4 --warmup 1 > "$OUT/p$i.log" 2>&1)
+done
+python3 - "$OUT" <<'PY'
+import csv, glob, json, sys, collections
+out = sys.argv[1]
+res = {}
+for d in sorted(glob.glob(out + "/p*/")):
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        acc, cnt = collections.defaultdict(float), collections.defaultdict(set)
+        for r in csv.DictReader(open(f)):
+            if "k_trace<false" not in r["Kernel_Name"] and "k_traceILb0" not in r["Kernel_Name"]:
+                continue
+            acc[r["Counter_Name"]] += float(r["Counter_Value"])
+            cnt[r["Counter_Name"]].add(r["Dispatch_Id"])
+        for k in acc:
+            res[k] = acc[k] / max(1, len(cnt[k]))
+json.dump(res, open(out + "/k_trace_pmc.json", "w"), indent=1)
+print(json.dumps(res, indent=1))
+PY

@@ -22,6 +22,8 @@ t0 = time.time(); wc = ctx.trace_samples_counted(64).as_dict(); print("instrumen
 print("profile (64 spp, instrumented):", wc)
 wi = max(1, wc["wave_iters"])
 print(f"  per wave-iteration: trace {wc['cyc_trace']/wi:.0f} cyc, shade {wc['cyc_shade']/wi:.0f} cyc, traversal trips {wc['wave_steps']/wi:.1f} (lane avg {wc['lane_steps']/max(1,wc['lane_iters']):.1f}), live lanes {wc['lane_iters']/wi:.1f}; cycles per trip {wc['cyc_trace']/max(1,wc['wave_steps']):.0f}")
+print("  traversal divergence (code executed in X of the wave trips, with Y of 64 lanes active):",
+      {nm: (round(wc["trips_" + nm] / max(1, wc["wave_steps"]), 3), round(wc["lanes_" + nm] / max(1, wc["trips_" + nm]), 1)) for nm in ("node", "line", "tri", "enter", "scene")})
 print("  shade split (lane-0 cycles):", {k: round(wc[k] / max(1, wc["cyc_geom"] + wc["cyc_sample"] + wc["cyc_eval"] + wc["cyc_rest"]), 3) for k in ("cyc_geom", "cyc_sample", "cyc_eval", "cyc_rest")})
 top = np.argsort(c.ravel())[::-1][:8]
 print("heaviest tiles (ty,tx):", [(int(t // c.shape[1]), int(t % c.shape[1])) for t in top])

@@ -148,6 +148,10 @@ struct trace_ctx {
   const yhd_scene*      sc;
   const YH_LDS v4f*     lds_nodes;  // LDS copy of nodes[lds_node_base ..+count), or nullptr
   YH_LDS unsigned int*  lds_stack;  // this quad's LDS stack column
+  // LDS copy of the scene-level tables (k_trace stages them per block when they fit;
+  // NULL: read sc.objects / sc.scene_nodes / sc.scene_prims from memory):
+  // [objects: 8 float4 each][scene BVH nodes: 2 float4 each][scene BVH primitives]
+  const YH_LDS v4f*     lds_scene;
   struct stats_t*       stats;      // per-lane work counters of the instrumented build, else NULL
 };
 // Per-lane counters of the instrumented build (COUNT = true): kept in registers
@@ -156,7 +160,18 @@ struct trace_ctx {
 struct stats_t {
   unsigned int samples, rays, nodes, seg, tri, hair, surf, envl, envs;
   unsigned long long c_geom, c_sample, c_eval, c_rest;  // shader-clock stamps inside path_step
+  // divergence profile of the traversal loop: for each kind of step, how many wave trips
+  // executed its code (t_*) and how many lanes were active in it (l_*)
+  unsigned int t_node, l_node, t_line, l_line, t_tri, l_tri, t_enter, l_enter, t_scene, l_scene;
 };
+// Inside a divergent branch: one count per wave trip + the active lanes of that trip.
+template <bool COUNT>
+YH_DEV void count_branch(unsigned int& trips, unsigned int& lanes) {
+  if (COUNT) {
+    unsigned long long m = __ballot(1);
+    if ((int)__lane_id() == __ffsll((long long)m) - 1) trips++, lanes += (unsigned int)__popcll(m);
+  }
+}
 // one 16-byte load (never split into dwordx3 + dword)
 YH_DEV v4f ldg4(const yhd_float4* p) { return *(const v4f*)p; }
 YH_DEV f3  xyz(v4f a) { return f3{a.x, a.y, a.z}; }
@@ -199,6 +214,11 @@ YH_DEV hit_t trace_ray(const trace_ctx& tc, const ray_t& ray, int first_object, 
   unsigned long long n_nodes = 0, n_seg = 0, n_tri = 0;
   unsigned int       n_steps = 0;
 
+  const YH_LDS v4f* lds_snodes = tc.lds_scene ? tc.lds_scene + 8 * sc.num_objects : nullptr;
+  auto scene_prim = [&](int i) -> int {
+    if (tc.lds_scene) return ((const YH_LDS int*)(lds_snodes + 2 * sc.num_scene_nodes))[i];
+    return sc.scene_prims[i];
+  };
   unsigned int cur;
   if (first_object >= 0) {
     cur = YH_TAG_ENTER | (unsigned)first_object;
@@ -218,7 +238,58 @@ YH_DEV hit_t trace_ray(const trace_ctx& tc, const ray_t& ray, int first_object, 
       cur = pop();
     }
     unsigned int tag = cur & YH_TAG_MASK;
-    if (tag == YH_TAG_SHAPE || tag == YH_TAG_LEAF) {
+    // The scene level costs no trip of its own: a scene node (read from the LDS copy
+    // of the tiny scene BVH), the ENTER it leads to and the root fetch of the entered
+    // shape chain inside ONE iteration, so a ray pays one memory round trip per
+    // object it enters instead of three.
+    if (tag == YH_TAG_SCENE) {
+      // scene-level node (binary, reference layout; every lane of the quad does it)
+      if (COUNT) count_branch<COUNT>(tc.stats->t_scene, tc.stats->l_scene);
+      int idx = (int)(cur & ~YH_TAG_MASK);
+      v4f n0, n1;
+      if (lds_snodes) n0 = lds_snodes[2 * idx], n1 = lds_snodes[2 * idx + 1];
+      else n0 = ldg4(sc.scene_nodes + 2 * idx), n1 = ldg4(sc.scene_nodes + 2 * idx + 1);
+      if (q == 0) n_nodes++;
+      cur = YH_NONE;
+      if (intersect_bbox(ray.o, wdinv, ray.tmin, tmax, xyz(n0), xyz(n1))) {
+        int start = __float_as_int(n0.w), meta = __float_as_int(n1.w);
+        if (meta & 0x10000) {  // internal
+          int axis = (meta >> 24) & 3;
+          int near = (wsign >> axis) & 1;  // dsign set: visit start+1 first
+          push(YH_TAG_SCENE | (unsigned)(start + 1 - near));
+          cur = YH_TAG_SCENE | (unsigned)(start + near);
+        } else {
+          int num = meta & 0xffff;
+          for (int i = num - 1; i >= 1; i--) push(YH_TAG_ENTER | (unsigned)scene_prim(start + i));
+          if (num > 0) cur = YH_TAG_ENTER | (unsigned)scene_prim(start);
+        }
+      }
+      tag = cur & YH_TAG_MASK;
+      if (cur == YH_NONE || tag == YH_TAG_SCENE) continue;
+    }
+    if (tag == YH_TAG_ENTER) {
+      // transform_ray(inverse(object.frame, true), ray) (pt.cpp:1012-1013)
+      if (COUNT) count_branch<COUNT>(tc.stats->t_enter, tc.stats->l_enter);
+      cur_obj             = (int)(cur & ~YH_TAG_MASK);
+      frame inv;
+      if (tc.lds_scene) {  // yhd_object: frame[12] inv_frame[12] kind node_base prim_base ... (8 float4)
+        const YH_LDS v4f* ob = tc.lds_scene + 8 * cur_obj;
+        v4f a = ob[3], b = ob[4], c = ob[5], d = ob[6];
+        inv.x = {a.x, a.y, a.z}, inv.y = {a.w, b.x, b.y}, inv.z = {b.z, b.w, c.x}, inv.o = {c.y, c.z, c.w};
+        kind = __float_as_int(d.x), node_base = __float_as_int(d.y), prim_base = __float_as_int(d.z);
+      } else {
+        const yhd_object& o = sc.objects[cur_obj];
+        inv  = ldframe(o.inv_frame);
+        kind = o.kind, node_base = o.node_base, prim_base = o.prim_base;
+      }
+      lo    = transform_point(inv, ray.o);
+      ld    = transform_vector(inv, ray.d);
+      ldinv = {1 / ld.x, 1 / ld.y, 1 / ld.z};
+      lsign = (ldinv.x < 0 ? 1 : 0) | (ldinv.y < 0 ? 2 : 0) | (ldinv.z < 0 ? 4 : 0);
+      cur = YH_TAG_SHAPE | (unsigned)node_base;  // shape root: fetched in this same iteration
+      tag = YH_TAG_SHAPE;
+    }
+    {
       bool is_leaf    = tag == YH_TAG_LEAF;
       int  leaf_start = (int)(cur & 0x07FFFFFFu), leaf_num = (int)((cur >> 27) & 7u);
       int  rec        = kind == YH_KIND_LINES ? 4 : 6;  // float4 per leaf record
@@ -248,6 +319,7 @@ YH_DEV hit_t trace_ray(const trace_ctx& tc, const ray_t& ray, int first_object, 
       if (!is_leaf) {
         // ---- wide node: lane q tests slot q {min.xyz, max.x} {max.yz, ref, axes} ----
         if (q == 0) n_nodes++;
+        if (COUNT) count_branch<COUNT>(tc.stats->t_node, tc.stats->l_node);
         bool         h    = intersect_bbox(lo, ldinv, ray.tmin, tmax, f3{s0.x, s0.y, s0.z}, f3{s0.w, s1.x, s1.y});
         unsigned int ref  = __float_as_uint(s1.z);
         unsigned int axes = __float_as_uint(s1.w);
@@ -281,11 +353,13 @@ YH_DEV hit_t trace_ray(const trace_ctx& tc, const ray_t& ray, int first_object, 
         bool  ok = false;
         float uu = 0, vv = 0, dist = 0;
         if (kind == YH_KIND_LINES) {
+          if (COUNT) count_branch<COUNT>(tc.stats->t_line, tc.stats->l_line);
           if (mine) {
             n_seg++;
             ok = intersect_line(lo, ld, ray.tmin, tmax, xyz(s0), xyz(s1), s0.w, s1.w, uu, vv, dist);
           }
         } else {
+          if (COUNT) count_branch<COUNT>(tc.stats->t_tri, tc.stats->l_tri);
           v4f s2 = ldg4(addr + 2);
           if (mine) {
             n_tri++;
@@ -313,37 +387,6 @@ YH_DEV hit_t trace_ray(const trace_ctx& tc, const ray_t& ray, int first_object, 
           tmax = key_t;
         }
       }
-      continue;
-    }
-    if (tag == YH_TAG_ENTER) {
-      // transform_ray(inverse(object.frame, true), ray) (pt.cpp:1012-1013)
-      cur_obj             = (int)(cur & ~YH_TAG_MASK);
-      const yhd_object& o = sc.objects[cur_obj];
-      frame inv           = ldframe(o.inv_frame);
-      lo                  = transform_point(inv, ray.o);
-      ld                  = transform_vector(inv, ray.d);
-      ldinv               = {1 / ld.x, 1 / ld.y, 1 / ld.z};
-      lsign = (ldinv.x < 0 ? 1 : 0) | (ldinv.y < 0 ? 2 : 0) | (ldinv.z < 0 ? 4 : 0);
-      kind = o.kind, node_base = o.node_base, prim_base = o.prim_base;
-      cur = YH_TAG_SHAPE | (unsigned)node_base;  // shape root
-      continue;
-    }
-    // scene-level node (binary, reference layout; every lane of the quad does it)
-    int idx = (int)(cur & ~YH_TAG_MASK);
-    v4f n0 = ldg4(sc.scene_nodes + 2 * idx), n1 = ldg4(sc.scene_nodes + 2 * idx + 1);
-    if (q == 0) n_nodes++;
-    cur = YH_NONE;
-    if (!intersect_bbox(ray.o, wdinv, ray.tmin, tmax, xyz(n0), xyz(n1))) continue;
-    int start = __float_as_int(n0.w), meta = __float_as_int(n1.w);
-    if (meta & 0x10000) {  // internal
-      int axis = (meta >> 24) & 3;
-      int near = (wsign >> axis) & 1;  // dsign set: visit start+1 first
-      push(YH_TAG_SCENE | (unsigned)(start + 1 - near));
-      cur = YH_TAG_SCENE | (unsigned)(start + near);
-    } else {
-      int num = meta & 0xffff;
-      for (int i = num - 1; i >= 1; i--) push(YH_TAG_ENTER | (unsigned)sc.scene_prims[start + i]);
-      if (num > 0) cur = YH_TAG_ENTER | (unsigned)sc.scene_prims[start];
     }
   }
   if (COUNT) {

@@ -48,19 +48,32 @@ __global__ __launch_bounds__(YH_BLOCK, YH_MIN_WAVES) void k_trace(const yhd_scen
     int nsamples, yhd_counters* counters) {
   extern __shared__ v4f lds_dyn[];
   // LDS carve-out: [nodelets: 8 * lds_node_count float4][stacks: YH_QSTACK x YH_QUADS uint]
+  //                [scene table: objects | scene BVH nodes | scene BVH primitives] (lds_scene_f4 float4)
   YH_LDS v4f*          lds_nodes = (YH_LDS v4f*)lds_dyn;
   YH_LDS unsigned int* lds_stack = (YH_LDS unsigned int*)(lds_nodes + 8 * sc.lds_node_count);
+  YH_LDS v4f*          lds_scene = (YH_LDS v4f*)(lds_stack + YH_QSTACK * YH_QUADS);
   // stage the nodelets: the first lds_node_count wide nodes (breadth-first =
   // top levels) of the dominant hair shape, 128 B each, coalesced dwordx4 loads
   for (int i = threadIdx.x; i < 8 * sc.lds_node_count; i += blockDim.x)
     lds_nodes[i] = ldg4(sc.nodes + 8 * (size_t)sc.lds_node_base + i);
+  trace_ctx tc;
+  tc.sc = &sc;
+  tc.lds_scene = nullptr;
+  if (sc.lds_scene_f4 > 0) {
+    // the scene level (a handful of objects and BVH nodes) lives in LDS: its steps need no memory round trip
+    const int nobj = 8 * sc.num_objects, nnod = 2 * sc.num_scene_nodes, npri = (sc.num_objects + 3) / 4;
+    const v4f* gobj = (const v4f*)sc.objects;
+    const v4f* gpri = (const v4f*)sc.scene_prims;  // padded to a multiple of 4 ints by the host
+    for (int i = threadIdx.x; i < nobj; i += blockDim.x) lds_scene[i] = gobj[i];
+    for (int i = threadIdx.x; i < nnod; i += blockDim.x) lds_scene[nobj + i] = ldg4(sc.scene_nodes + i);
+    for (int i = threadIdx.x; i < npri; i += blockDim.x) lds_scene[nobj + nnod + i] = gpri[i];
+    tc.lds_scene = lds_scene;
+  }
   __syncthreads();
 
-  trace_ctx tc;
-  tc.sc        = &sc;
   tc.lds_nodes = sc.lds_node_count ? lds_nodes : nullptr;
   tc.lds_stack = lds_stack + (threadIdx.x >> 2);
-  stats_t stats = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  stats_t stats = {};
   tc.stats = COUNT ? &stats : nullptr;
 
   const int lane = threadIdx.x & 63;
@@ -136,7 +149,15 @@ __global__ __launch_bounds__(YH_BLOCK, YH_MIN_WAVES) void k_trace(const yhd_scen
         atomicAdd(&counters->c_geom, stats.c_geom), atomicAdd(&counters->c_sample, stats.c_sample);
         atomicAdd(&counters->c_eval, stats.c_eval), atomicAdd(&counters->c_rest, stats.c_rest);
       }
-      stats = stats_t{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      {
+        unsigned int b[10] = {stats.t_node, stats.l_node, stats.t_line, stats.l_line, stats.t_tri, stats.l_tri, stats.t_enter,
+            stats.l_enter, stats.t_scene, stats.l_scene};
+        for (int k = 0; k < 10; k++) {
+          for (int off = 32; off > 0; off >>= 1) b[k] += (unsigned int)__shfl_xor((int)b[k], off, 64);
+          if (lane == 0) atomicAdd(&counters->branch[k], (unsigned long long)b[k]);
+        }
+      }
+      stats = stats_t{};
     }
     if (owner && (lane & 3) == 0) {
       st.rng_state[pix] = rng.state;
@@ -298,7 +319,7 @@ __global__ __launch_bounds__(256) void k_intersect(const yhd_scene sc, int n, co
   bool valid = i < n;
   if (!valid) i = n - 1;  // whole quads stay converged; surplus quads redo the last ray
   trace_ctx tc;
-  tc.sc = &sc, tc.lds_nodes = nullptr, tc.stats = nullptr;
+  tc.sc = &sc, tc.lds_nodes = nullptr, tc.stats = nullptr, tc.lds_scene = nullptr;
   tc.lds_stack   = (YH_LDS unsigned int*)stacks + (threadIdx.x >> 2);
   const float* r = rays + 8 * (size_t)i;
   ray_t ray      = ray_t{ld3(r), ld3(r + 3), r[6], r[7]};
@@ -541,7 +562,7 @@ static trace_kernel_t trace_kernel(bool counted, bool general) {
 }
 int yhk_trace(const yhd_scene* sc, const yhd_state* st, int nsamples, yhd_counters* counters,
     int grid_blocks, hipStream_t stream) {
-  size_t lds = (size_t)sc->lds_node_count * 128 + (size_t)YH_QSTACK * YH_QUADS * 4;
+  size_t lds = (size_t)sc->lds_node_count * 128 + (size_t)YH_QSTACK * YH_QUADS * 4 + (size_t)sc->lds_scene_f4 * 16;
   static size_t lds_set[4] = {0, 0, 0, 0};
   int            which = (counters ? 1 : 0) + (sc->general_materials ? 2 : 0);
   trace_kernel_t k     = trace_kernel(counters != nullptr, sc->general_materials != 0);
@@ -555,7 +576,9 @@ int yhk_trace(const yhd_scene* sc, const yhd_state* st, int nsamples, yhd_counte
 }
 int yhk_block_threads(void) { return YH_BLOCK; }
 int yhk_stack_entries(void) { return YH_QSTACK; }
-int yhk_trace_lds_bytes(int lds_node_count) { return lds_node_count * 128 + YH_QSTACK * YH_QUADS * 4; }
+int yhk_trace_lds_bytes(int lds_node_count, int lds_scene_f4) {
+  return lds_node_count * 128 + YH_QSTACK * YH_QUADS * 4 + lds_scene_f4 * 16;
+}
 int yhk_trace_occupancy(int lds_bytes, int general) {
   int            blocks = 0;
   trace_kernel_t k      = trace_kernel(false, general != 0);

@@ -126,6 +126,7 @@ typedef struct yhd_scene {
   // number of leading nodes of the largest line shape staged in LDS
   int               num_nodes_total; // wide nodes in `nodes` (bounds checks of the debug build)
   int               num_prim_f4;     // float4 in `prims`
+  int               lds_scene_f4;       // float4 count of the scene-level LDS table (0: scene too big, read from memory)
   int               general_materials;  // some material has lobes beyond diffuse / hair: k_trace<.., true>
   int               lds_node_base;   // global index of that shape's root
   int               lds_node_count;
@@ -160,6 +161,8 @@ typedef struct yhd_counters {
   // lanes; per lane = sum over lanes) of the main rays
   unsigned long long cyc_trace, cyc_shade, cyc_tile, wave_iters, wave_steps, lane_steps, lane_iters;
   unsigned long long c_geom, c_sample, c_eval, c_rest;  // lane-0 cycles inside path_step: hit geometry, direction sampling, BSDF eval+pdf, the rest
+  // traversal divergence: (wave trips, active lanes) for node, line-leaf, triangle-leaf, ENTER, scene-node code
+  unsigned long long branch[10];
 } yhd_counters;
 
 #endif

@@ -34,7 +34,7 @@ extern "C" {
 int yhk_trace(const yhd_scene*, const yhd_state*, int, yhd_counters*, int, hipStream_t);
 int yhk_block_threads(void);
 int yhk_trace_occupancy(int lds_bytes, int general);
-int yhk_trace_lds_bytes(int lds_node_count);
+int yhk_trace_lds_bytes(int lds_node_count, int lds_scene_f4);
 int yhk_stack_entries(void);
 int yhk_resolve(const yhd_state*, int, int, void*, hipStream_t);
 int yhk_pack(const yhd_state*, int, int, void*, hipStream_t);
@@ -615,7 +615,9 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
   if ((rc = upload(ctx, ctx->d_objects, objects.data(), objects.size() * sizeof(yhd_object)))) return rc;
   if ((rc = upload(ctx, ctx->d_materials, materials.data(), materials.size() * sizeof(yhd_material)))) return rc;
   if ((rc = upload(ctx, ctx->d_scene_nodes, scene_nodes.data(), scene_nodes.size() * 16))) return rc;
-  if ((rc = upload(ctx, ctx->d_scene_prims, scene_tree.primitives.data(), scene_tree.primitives.size() * 4))) return rc;
+  std::vector<int> scene_prims_padded = scene_tree.primitives;
+  scene_prims_padded.resize((scene_prims_padded.size() + 3) / 4 * 4, 0);  // staged to LDS as float4
+  if ((rc = upload(ctx, ctx->d_scene_prims, scene_prims_padded.data(), scene_prims_padded.size() * 4))) return rc;
   if ((rc = upload(ctx, ctx->d_light_cdf, light_cdf.data(), light_cdf.size() * 4))) return rc;
   if ((rc = upload(ctx, ctx->d_env_texels, env_texels.data(), env_texels.size() * 16))) return rc;
   lap("hipMalloc + H2D copies");
@@ -632,6 +634,10 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
   sc.num_nodes_total = (int)(nodes.size() / 8), sc.num_prim_f4 = (int)prims.size();
   // nodelets: the top (breadth-first prefix) of the largest hair shape's BVH
   sc.general_materials = general_materials;
+  {  // scene-level LDS table: objects (8 float4 each), scene BVH nodes (2 float4 each), primitive ids
+    int f4 = 8 * sd->num_objects + 2 * (int)scene_tree.nodes.size() + (sd->num_objects + 3) / 4;
+    sc.lds_scene_f4 = f4 * 16 <= 8192 ? f4 : 0;
+  }
   sc.lds_node_base = 0, sc.lds_node_count = 0;
   if (best_shape >= 0) {
     sc.lds_node_base  = info[best_shape].node_base;
@@ -727,7 +733,7 @@ static int trace_impl(yh_context* ctx, int nsamples, bool counted, bool sync) {
     return YH_OK;
   }
   int waves_per_block = yhk_block_threads() / 64;  // one work item per wave at a time
-  int lds_bytes       = yhk_trace_lds_bytes(ctx->scene.lds_node_count);
+  int lds_bytes       = yhk_trace_lds_bytes(ctx->scene.lds_node_count, ctx->scene.lds_scene_f4);
   int resident        = ctx->num_cus * yhk_trace_occupancy(lds_bytes, ctx->scene.general_materials);
   int want            = (ctx->state.num_tiles + waves_per_block - 1) / waves_per_block;
   int grid            = std::max(1, std::min(want, resident));
@@ -782,6 +788,7 @@ int yh_trace_samples_counted(yh_context* ctx, int nsamples, yh_workcounts* out) 
   out->cyc_trace = c.cyc_trace, out->cyc_shade = c.cyc_shade, out->ticks_tile = c.cyc_tile, out->wave_iters = c.wave_iters;
   out->wave_steps = c.wave_steps, out->lane_steps = c.lane_steps, out->lane_iters = c.lane_iters;
   out->cyc_geom = c.c_geom, out->cyc_sample = c.c_sample, out->cyc_eval = c.c_eval, out->cyc_rest = c.c_rest;
+  for (int k = 0; k < 10; k++) out->branch[k] = c.branch[k];
   return YH_OK;
 }
 

@@ -76,10 +76,14 @@ class WorkCounts(C.Structure):
                                           "hair_shades", "surf_shades", "env_lookups",
                                           "env_samples", "cyc_trace", "cyc_shade", "ticks_tile",
                                           "wave_iters", "wave_steps", "lane_steps", "lane_iters", "cyc_geom", "cyc_sample",
-                                          "cyc_eval", "cyc_rest")]
+                                          "cyc_eval", "cyc_rest")] + [("branch", C.c_uint64 * 10)]
 
     def as_dict(self):
-        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+        d = {n: int(getattr(self, n)) for n, _ in self._fields_ if n != "branch"}
+        names = ("node", "line", "tri", "enter", "scene")
+        for k, nm in enumerate(names):
+            d["trips_" + nm], d["lanes_" + nm] = int(self.branch[2 * k]), int(self.branch[2 * k + 1])
+        return d
 
     def bytes_per_sample(self, spp_per_launch):
         """algorithmic bytes per sample of the reference algorithm."""
