@@ -30,6 +30,7 @@ GOLDEN_SCENES = [
     ("hair-curls", dict(scale=0.05), 64),
     ("lobes", dict(scale=0.05), 96),      # specular / metal / delta / transmission / opacity
     ("volumes", dict(scale=0.05), 96),    # refraction into homogeneous media, subsurface walk
+    ("sphere-hairblock", dict(scale=0.05, dof=True), 96),  # thin lens (aperture > 0), portrait film
 ]
 
 
@@ -178,6 +179,8 @@ def scenes_only(ref, rng, want):
             continue
         if name in ("lobes", "volumes"):
             rng = np.random.default_rng(20240609)
+        if kw.get("dof"):
+            rng = np.random.default_rng(20240611)
         sc = ref.scene(path)
         m = 4096
         if name in ("lobes", "volumes"):

@@ -73,6 +73,7 @@ GOLDEN_SCENES = [
     ("hair-curls", dict(scale=0.05)),
     ("lobes", dict(scale=0.05)),
     ("volumes", dict(scale=0.05)),
+    ("sphere-hairblock", dict(scale=0.05, dof=True)),
 ]
 
 

@@ -146,7 +146,7 @@ def _prep(outdir, name):
     return d
 
 
-def make_sphere_hairblock(outdir, scale=1.0, name="sphere-hairblock", zoom=False, hair=None):
+def make_sphere_hairblock(outdir, scale=1.0, name="sphere-hairblock", zoom=False, hair=None, dof=False):
     """C0/C1: variant of tests/sphere-hairblock/sphere-hairblock.json: aspect 1.0 and hair
     material {eumelanin 1.3} (the committed `color` would override melanin, ext.cpp:131-138)."""
     d = _prep(outdir, name)
@@ -156,6 +156,8 @@ def make_sphere_hairblock(outdir, scale=1.0, name="sphere-hairblock", zoom=False
     cam = {"lens": 0.05, "aperture": 0.0, "aspect": 1.0, "lookat": [-0.5, 1.5, 5, 0.25, 0.5, 0, 0, 1, 0]}
     if zoom:  # SURVEY.md appendix B.3 "hair fills frame"
         cam = {"lens": 0.22, "aperture": 0.0, "aspect": 1.0, "lookat": [-0.5, 1.5, 5, 0.5, 0.5, -0.5, 0, 1, 0]}
+    if dof:  # thin-lens branch of sample_camera (pt.cpp:211-229) and the portrait branch of init_state (pt.cpp:1933-1939)
+        cam = {"lens": 0.085, "aperture": 0.12, "aspect": 0.75, "lookat": [-0.5, 1.5, 5, 0.4, 0.5, -0.3, 0, 1, 0]}
     scene = {
         "asset": {"copyright": "synthetic hair block; sphere from the reference's test assets"},
         "cameras": {"default": cam},
