@@ -274,6 +274,33 @@ def test_images_match_reference_statistically(ctx, yh, name, kw):
     sf.close()
 
 
+@pytest.mark.parametrize("res,bounces,clamp,seed", [(50, 1, 100.0, 961748941), (37, 16, 1.0, 7), (64, 3, 100.0, 2 ** 40 + 5),
+                                                    (41, 64, 0.25, 961748941)])
+def test_trace_params_follow_the_oracle(ctx, oracle, yh, res, bounces, clamp, seed):
+    """trace_params (yocto_pathtrace.h:188-197) beyond the defaults: image sizes that are not a
+    multiple of the 8x8 tile or the 4x4 work item, one bounce (no Russian roulette), long paths
+    (roulette after bounce 3), an active clamp, 64-bit seeds. Compared with the oracle rendered
+    here with the same parameters."""
+    name, kw = "lobes", dict(scale=0.05)
+    sf = yh.SceneFile(scene_path(name, **kw))
+    ctx.upload_scene(sf.desc)
+    osc = oracle.scene(sf.desc)
+    p = yh.TraceParams(res, bounces, clamp, seed)
+    w, h = ctx.init_state(p)
+    ctx.trace_samples(1)
+    img, ref = ctx.download(), osc.render(p, 1)
+    assert img.shape == ref.shape == (h, w, 4)
+    close = _rel(img[..., :3], ref[..., :3]).max(axis=2) < 1e-3
+    assert close.mean() >= 0.60 and np.isfinite(img).all()
+    assert img[..., :3].max() <= clamp * (1 + 1e-6)
+    ctx.init_state(p)
+    ctx.trace_samples(16)
+    img16, ref16 = ctx.download(), osc.render(p, 16)
+    other = osc.render(yh.TraceParams(res, bounces, clamp, seed + 1), 16)
+    assert _relrmse(img16, ref16) <= 0.5 * _relrmse(other, ref16)
+    osc.close(), sf.close()
+
+
 def test_sample_batching_and_sharding_do_not_change_pixels(ctx, yh):
     """1x16 spp == 16x1 spp == 4+12 spp bitwise, and every shard of a 2- and 3-way tile split
     reproduces exactly the pixels of the single-GPU image."""
