@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Runs one BASELINE config at full scene size on the GPU: parity against the oracle at a reduced
-resolution (same full-size geometry) and throughput at the config's resolution."""
+"""TEST INFRASTRUCTURE (uses the oracle as the checker). Runs one BASELINE config at full scene
+size on the GPU: parity against the oracle at a reduced resolution (same full-size geometry) and
+throughput at the config's resolution."""
 import argparse, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

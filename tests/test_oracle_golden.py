@@ -121,3 +121,27 @@ def test_selftests_pass_on_oracle(oracle):
     for which in (2, 3):
         ok, worst = oracle.selftest(which)
         assert ok, (which, worst)
+
+
+def test_reference_work_counts_fixture(oracle, yh):
+    """the N_* of the algorithmic-bytes formula are counts of the REFERENCE algorithm
+    (binary BVH, <= 4 primitives per leaf) made by the instrumented oracle and committed per config
+    (tests/golden/workcounts.json, oracle/make_workcounts.py). C0 is re-counted here exactly; the
+    formula's bytes/sample of every config is re-derived from its committed counts."""
+    import json
+    import os
+    from conftest import GOLD
+    fx = json.load(open(os.path.join(GOLD, "workcounts.json")))
+    assert {"C0", "C1", "C2-beta_m0.1", "C2-beta_m0.25", "C2-beta_m0.6", "C3", "C4"} <= set(fx)
+    for name, c in fx.items():
+        p = c["per_sample"]
+        b = (32 * p["nodes"] + 44 * p["seg_tests"] + 52 * p["tri_tests"] + 104 * p["hair_shades"] +
+             48 * p["env_lookups"] + 88 * p["env_samples"] + 32.0 / c["spp_per_launch_assumed"])
+        assert abs(b - c["algorithmic_bytes_per_sample"]) < 0.6, name
+    c0 = fx["C0"]
+    sf = yh.SceneFile(scene_path("sphere-hairblock"))
+    osc = oracle.scene(sf.desc)
+    _, wc = osc.render(yh.TraceParams.default(resolution=c0["resolution"]), c0["spp_counted"], want_counts=True)
+    got = {k: round(v / wc.samples, 4) for k, v in wc.as_dict().items() if k in c0["per_sample"]}
+    assert got == c0["per_sample"]
+    osc.close(), sf.close()
