@@ -176,6 +176,7 @@ def main():
     t0 = time.perf_counter()
     n = ctx.shard_pixels(rank, world)
     packed = torch.zeros((n, 4), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()  # torch's fill is on torch's stream, the pack kernel on the context's
     ctx.pack_tiles_device(packed.data_ptr(), n)
     if cdev == "cpu":
         packed = packed.cpu()
@@ -228,7 +229,9 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_unit": "GB per launch",
                          "traffic_source": traffic_src, "algorithmic_gb_per_launch": round(bytes_per_launch / 1e9, 3),
                          "valu_issue_fraction": pmc.get("valu_issue_fraction") if traffic is not None else None,
-                         "wait_fraction": pmc.get("wait_any_fraction") if traffic is not None else None, "kernel": "k_trace",
+                         "wait_fraction": pmc.get("wait_any_fraction") if traffic is not None else None,
+                         "valu_lane_utilisation": pmc.get("valu_lane_utilisation") if traffic is not None else None,
+                         "kernel": "k_trace",
                          "avg_launch_ms": round(launch_s * 1e3, 3),
                          "algorithmic_bytes_per_sample": round(bytes_per_sample, 1),
                          "work_counts_from": counts_from,

@@ -197,7 +197,10 @@ int yh_synchronize(yh_context* ctx);
 int yh_download(yh_context* ctx, float* rgba);
 /* Packs the owned tiles' float4 pixels into a DEVICE buffer (the payload of
  * the RCCL gather). `capacity` in float4 pixels; *count receives the number
- * written. Tiles are in increasing tile_id order, 64 pixels per tile.        */
+ * written. Tiles are in increasing tile_id order, 64 pixels per tile. This
+ * call and yh_unpack_tiles_device run on the context's own non-blocking
+ * stream and return when done: earlier writes to the buffers from other
+ * streams (e.g. a torch allocation's fill) must have completed before.       */
 int yh_pack_tiles_device(yh_context* ctx, void* device_rgba, int64_t capacity,
     int64_t* count);
 /* Inverse on the gathering rank: scatters rank `src_rank`'s packed tiles into

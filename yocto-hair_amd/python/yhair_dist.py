@@ -70,6 +70,10 @@ def gather_framebuffer(packed, width, height, rank, world, ctx=None, dst=0):
             return None
         shards = [recv[r][: shard_pixels(width, height, r, world)] for r in range(world)]
     image = torch.zeros((height, width, 4), dtype=torch.float32, device=packed.device)
+    if image.is_cuda:
+        # the context launches on its own (non-blocking) stream: torch's fill of `image` and the
+        # collective's writes into the shards must have landed before its kernels touch them
+        torch.cuda.synchronize()
     for r, shard in enumerate(shards):
         if ctx is not None and image.is_cuda:
             shard = shard.contiguous()
