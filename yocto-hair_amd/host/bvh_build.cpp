@@ -8,8 +8,13 @@
 namespace yhh {
 
 namespace {
+// What the builder moves around: the centroid and the primitive id (16 bytes). The
+// reference partitions records that also carry the box (pt.cpp:553-556); boxes are
+// only needed once per node, so here they stay in the caller's array and a node's
+// box is formed bottom-up (leaf: union of its primitives' boxes, internal node: union
+// of its children's) — min / max are exact and order-independent, so the boxes, the
+// splits and the primitive order are the reference's.
 struct Prim {
-  Box   bbox;
   float center[3];
   int   primitive;
 };
@@ -19,7 +24,7 @@ const float flt_max = std::numeric_limits<float>::max();
 const float flt_min = std::numeric_limits<float>::lowest();
 
 // split_middle (pt.cpp:564-595)
-void split_middle(std::vector<Prim>& prims, int start, int end, int& mid, int& axis) {
+void split_middle(Prim* prims, int start, int end, int& mid, int& axis) {
   axis = 0;
   mid  = (start + end) / 2;
   float cmin[3] = {flt_max, flt_max, flt_max}, cmax[3] = {flt_min, flt_min, flt_min};
@@ -35,9 +40,8 @@ void split_middle(std::vector<Prim>& prims, int start, int end, int& mid, int& a
   if (cs[2] >= cs[0] && cs[2] >= cs[1]) axis = 2;
   int   ax     = axis;
   float middle = (cmin[ax] + cmax[ax]) / 2;
-  mid = (int)(std::partition(prims.data() + start, prims.data() + end,
-                  [ax, middle](const Prim& p) { return p.center[ax] < middle; }) -
-              prims.data());
+  mid = (int)(std::partition(prims + start, prims + end, [ax, middle](const Prim& p) { return p.center[ax] < middle; }) -
+              prims);
   if (mid == start || mid == end) mid = (start + end) / 2;
 }
 }  // namespace
@@ -45,7 +49,6 @@ void split_middle(std::vector<Prim>& prims, int start, int end, int& mid, int& a
 void build_bvh(Tree& tree, const std::vector<Box>& boxes) {
   std::vector<Prim> prims(boxes.size());
   for (size_t i = 0; i < boxes.size(); i++) {
-    prims[i].bbox = boxes[i];
     for (int k = 0; k < 3; k++) prims[i].center[k] = (boxes[i].min[k] + boxes[i].max[k]) / 2;
     prims[i].primitive = (int)i;
   }
@@ -55,23 +58,19 @@ void build_bvh(Tree& tree, const std::vector<Box>& boxes) {
   struct Item {
     int node, start, end, depth;
   };
-  std::deque<Item> queue{{0, 0, (int)prims.size(), 1}};
+  // breadth-first, as the reference: a node's children are allocated when it is dequeued
+  std::vector<Item> queue;
+  queue.reserve(prims.size() + 1);
+  queue.push_back({0, 0, (int)prims.size(), 1});
   nodes.emplace_back();
   tree.max_depth = 0;
-  while (!queue.empty()) {
-    Item it = queue.front();
-    queue.pop_front();
+  for (size_t head = 0; head < queue.size(); head++) {
+    Item it        = queue[head];
     tree.max_depth = std::max(tree.max_depth, it.depth);
     Node node;
-    for (int k = 0; k < 3; k++) node.bbox.min[k] = flt_max, node.bbox.max[k] = flt_min;
-    for (int i = it.start; i < it.end; i++)
-      for (int k = 0; k < 3; k++) {
-        node.bbox.min[k] = fmin_(node.bbox.min[k], prims[i].bbox.min[k]);
-        node.bbox.max[k] = fmax_(node.bbox.max[k], prims[i].bbox.max[k]);
-      }
     if (it.end - it.start > 4) {  // bvh_max_prims (pt.cpp:598)
       int mid, axis;
-      split_middle(prims, it.start, it.end, mid, axis);
+      split_middle(prims.data(), it.start, it.end, mid, axis);
       node.internal = true;
       node.axis     = (unsigned char)axis;
       node.num      = 2;
@@ -89,6 +88,22 @@ void build_bvh(Tree& tree, const std::vector<Box>& boxes) {
     nodes[it.node] = node;
   }
   nodes.shrink_to_fit();
+  // boxes bottom-up: children always have larger indices than their parent
+  for (size_t n = nodes.size(); n-- > 0;) {
+    Node& node = nodes[n];
+    for (int k = 0; k < 3; k++) node.bbox.min[k] = flt_max, node.bbox.max[k] = flt_min;
+    if (node.internal) {
+      for (int c = 0; c < 2; c++) {
+        const Box& b = nodes[(size_t)node.start + c].bbox;
+        for (int k = 0; k < 3; k++) node.bbox.min[k] = fmin_(node.bbox.min[k], b.min[k]), node.bbox.max[k] = fmax_(node.bbox.max[k], b.max[k]);
+      }
+    } else {
+      for (int i = node.start; i < node.start + node.num; i++) {
+        const Box& b = boxes[(size_t)prims[i].primitive];
+        for (int k = 0; k < 3; k++) node.bbox.min[k] = fmin_(node.bbox.min[k], b.min[k]), node.bbox.max[k] = fmax_(node.bbox.max[k], b.max[k]);
+      }
+    }
+  }
   tree.primitives.resize(prims.size());
   for (size_t i = 0; i < prims.size(); i++) tree.primitives[i] = prims[i].primitive;
 }
