@@ -55,14 +55,27 @@ typedef struct yh_shape {
   const int*   lines;     /* 2 * num_lines                                 */
   int          num_triangles;
   const int*   triangles; /* 3 * num_triangles                             */
+  const float* texcoords; /* 2 * num_vertices, or NULL (texcoord = element uv,
+                             yocto_pathtrace.cpp:295-311)                   */
 } yh_shape;
+
+/* A colour texture (ptr::texture colorf / colorb, yocto_pathtrace.h:282-287):
+ * RGB, row-major, top row first. Byte textures are sRGB-encoded unless the
+ * lookup asks for linear (lookup_texture, yocto_pathtrace.cpp:147-164).      */
+typedef struct yh_texture {
+  int         width, height;
+  int         is_byte; /* 1: pixels = uint8 RGB (colorb); 0: float RGB (colorf) */
+  const void* pixels;
+} yh_texture;
 
 /* ptr::material (yocto_pathtrace.h:293-329), restricted to the lobes the hair
  * configs reach: emission, diffuse colour and the hair parameters
  * (yocto_extension.h:86-95). Specular, metallic, transmission / refraction,
  * delta (roughness 0) and opacity lobes follow yocto_pathtrace.cpp:405-471,
- * homogeneous volumes :498-533,1403-1414,1458-1497. Textures other than the
- * environment map are not represented.                                      */
+ * homogeneous volumes :498-533,1403-1414,1458-1497. Of the material textures
+ * the colour ones are represented (emission_tex, color_tex, scattering_tex:
+ * 1-based index into yh_scene_desc::textures, 0 = none); the scalar ones
+ * (specular / metallic / roughness / opacity / normal maps) are not.         */
 typedef struct yh_material {
   float emission[3];
   float color[3];
@@ -75,6 +88,7 @@ typedef struct yh_material {
   float scattering[3];
   float scanisotropy;
   float trdepth;      /* 0.01 (yocto_pathtrace.h:305)                          */
+  int   emission_tex, color_tex, scattering_tex; /* 1-based, 0 = none          */
 } yh_material;
 
 /* ptr::object (yocto_pathtrace.h:369-373) */
@@ -112,6 +126,8 @@ typedef struct yh_scene_desc {
   int                   num_environments;
   const yh_environment* environments;
   yh_camera             camera;
+  int                   num_textures; /* material textures (environments carry their own) */
+  const yh_texture*     textures;
 } yh_scene_desc;
 
 /* trace_params (yocto_pathtrace.h:188-197); shader is always `path`.        */

@@ -568,7 +568,7 @@ struct BvhPrim {
 
 struct Shape {
   std::vector<V3>    positions, normals;
-  std::vector<float> radius;
+  std::vector<float> radius, texcoords;  // texcoords: 2 per vertex or empty
   std::vector<int>   lines, triangles;  // flattened pairs / triples
   BvhTree            bvh;
   int nlines() const { return (int)lines.size() / 2; }
@@ -579,8 +579,14 @@ struct Material {
   float        specular = 0, metallic = 0, roughness = 0, ior = 1.5f, transmission = 0, opacity = 1;
   V3           scattering{0, 0, 0};
   float        scanisotropy = 0, trdepth = 0.01f;
+  int          emission_tex = -1, color_tex = -1, scattering_tex = -1;  // index into yo_scene::textures
   HairMaterial hair;
   bool         thin;
+};
+struct Texture {  // ptr::texture colorf / colorb (pt.h:282-287)
+  int                        w = 0, h = 0;
+  std::vector<V3>            colorf;
+  std::vector<unsigned char> colorb;  // RGB
 };
 struct Object {
   Frame frame;
@@ -694,6 +700,7 @@ void init_shape_bvh(Shape& shape) {  // pt.cpp:713-752
 }  // namespace
 
 struct yo_scene {
+  std::vector<Texture>     textures;
   std::vector<Shape>       shapes;
   std::vector<Material>    materials;
   std::vector<Object>      objects;
@@ -823,6 +830,48 @@ V3 eval_position(const yo_scene& scene, int object, int element, const float uv[
   }
   return {0, 0, 0};
 }
+// eval_texcoord (pt.cpp:295-311): interpolate_triangle / interpolate_line (math.h:3322-3331)
+void eval_texcoord(const yo_scene& scene, int object, int element, const float uv[2], float tc[2]) {
+  auto& obj   = scene.objects[object];
+  auto& shape = scene.shapes[obj.shape];
+  if (shape.texcoords.empty()) {
+    tc[0] = uv[0], tc[1] = uv[1];
+  } else if (shape.ntriangles()) {
+    auto t = &shape.triangles[3 * element];
+    for (int k = 0; k < 2; k++)
+      tc[k] = shape.texcoords[2 * t[0] + k] * (1 - uv[0] - uv[1]) + shape.texcoords[2 * t[1] + k] * uv[0] +
+              shape.texcoords[2 * t[2] + k] * uv[1];
+  } else if (shape.nlines()) {
+    auto l = &shape.lines[2 * element];
+    for (int k = 0; k < 2; k++) tc[k] = shape.texcoords[2 * l[0] + k] * (1 - uv[0]) + shape.texcoords[2 * l[1] + k] * uv[0];
+  } else {
+    tc[0] = tc[1] = 0;
+  }
+}
+inline float srgb_to_rgb(float srgb) {  // math.h:3742-3745 (the comparison is in double)
+  return (srgb <= 0.04045) ? srgb / 12.92f : std::pow((srgb + 0.055f) / (1.0f + 0.055f), 2.4f);
+}
+V3 lookup_texture(const Texture& t, int i, int j, bool ldr_as_linear) {  // pt.cpp:147-164
+  if (!t.colorf.empty()) return t.colorf[(size_t)j * t.w + i];
+  auto b = &t.colorb[((size_t)j * t.w + i) * 3];
+  auto f = V3{b[0] / 255.0f, b[1] / 255.0f, b[2] / 255.0f};  // byte_to_float (math.h:3718-3730)
+  return ldr_as_linear ? f : V3{srgb_to_rgb(f.x), srgb_to_rgb(f.y), srgb_to_rgb(f.z)};
+}
+V3 eval_texture(const Texture* t, const float uv[2], bool ldr_as_linear = false) {  // pt.cpp:167-200
+  if (!t) return {1, 1, 1};
+  auto sx = t->w, sy = t->h;
+  auto s = std::fmod(uv[0], 1.0f) * sx;
+  if (s < 0) s += sx;
+  auto tt = std::fmod(uv[1], 1.0f) * sy;
+  if (tt < 0) tt += sy;
+  auto i = iclamp((int)s, 0, sx - 1), j = iclamp((int)tt, 0, sy - 1);
+  auto ii = (i + 1) % sx, jj = (j + 1) % sy;
+  auto u = s - i, v = tt - j;
+  return lookup_texture(*t, i, j, ldr_as_linear) * (1 - u) * (1 - v) + lookup_texture(*t, i, jj, ldr_as_linear) * (1 - u) * v +
+         lookup_texture(*t, ii, j, ldr_as_linear) * u * (1 - v) + lookup_texture(*t, ii, jj, ldr_as_linear) * u * v;
+}
+inline const Texture* texture_of(const yo_scene& scene, int id) { return id >= 0 ? &scene.textures[(size_t)id] : nullptr; }
+
 // transform_normal(frame, n) with non_rigid = false (math.h:3145-3152)
 V3 transform_normal(const Frame& a, V3 b) { return normalize(transform_vector(a, b)); }
 V3 eval_element_normal(const yo_scene& scene, int object, int element) {
@@ -1163,13 +1212,15 @@ struct Brdf {
   bool     hair = false;
   HairBrdf hair_brdf;
 };
-Brdf surface_brdf(const Material& mat, V3 normal, V3 outgoing) {  // pt.cpp:405-471
-  auto base         = mat.color * V3{1, 1, 1};
+// color_tex = eval_texture(color_tex, texcoord, false); emission_tex_x = eval_texture(emission_tex,
+// texcoord, true).x — the reference multiplies TRANSMISSION by the emission texture (pt.cpp:421-422)
+Brdf surface_brdf(const Material& mat, V3 normal, V3 outgoing, V3 color_tex = {1, 1, 1}, float emission_tex_x = 1.0f) {  // pt.cpp:405-471
+  auto base         = mat.color * color_tex;
   auto specular     = mat.specular * 1.0f;
   auto metallic     = mat.metallic * 1.0f;
   auto roughness    = mat.roughness * 1.0f;
   auto ior          = mat.ior;
-  auto transmission = mat.transmission * 1.0f;
+  auto transmission = mat.transmission * emission_tex_x;
   auto opacity      = mat.opacity * ((1.0f + 1.0f + 1.0f) / 3);
   auto thin         = mat.thin || !mat.transmission;
 
@@ -1214,7 +1265,10 @@ Brdf eval_brdf(const yo_scene& scene, int object, int element, const float uv[2]
   auto& obj   = scene.objects[object];
   auto& mat   = scene.materials[obj.material];
   auto& shape = scene.shapes[obj.shape];
-  auto  brdf  = surface_brdf(mat, normal, outgoing);
+  float tc[2];
+  eval_texcoord(scene, object, element, uv, tc);
+  auto brdf = surface_brdf(mat, normal, outgoing, eval_texture(texture_of(scene, mat.color_tex), tc, false),
+      eval_texture(texture_of(scene, mat.emission_tex), tc, true).x);
   brdf.hair   = shape.nlines() > 0;  // pt.cpp:474
   if (brdf.hair) {
     auto tangent   = eval_normal(scene, object, element, uv);
@@ -1506,16 +1560,16 @@ struct Vsdf {
   float anisotropy = 0;
 };
 inline bool has_volume(const Material& mat) { return !mat.thin && mat.transmission; }  // pt.cpp:531
-Vsdf eval_vsdf(const Material& mat) {  // pt.cpp:504-527, textures absent
-  auto base         = mat.color * V3{1, 1, 1};
-  auto transmission = mat.transmission * 1.0f;
+Vsdf eval_vsdf(const Material& mat, V3 color_tex, float emission_tex_x, V3 scattering_tex) {  // pt.cpp:504-527
+  auto base         = mat.color * color_tex;
+  auto transmission = mat.transmission * emission_tex_x;
   auto thin         = mat.thin || !mat.transmission;
   Vsdf v;
   if (transmission && !thin) {
     auto c    = V3{fclamp(base.x, 0.0001f, 1.0f), fclamp(base.y, 0.0001f, 1.0f), fclamp(base.z, 0.0001f, 1.0f)};
     v.density = -vlog(c) / mat.trdepth;
   }
-  v.scatter    = mat.scattering * V3{1, 1, 1};
+  v.scatter    = mat.scattering * scattering_tex;
   v.anisotropy = mat.scanisotropy;
   return v;
 }
@@ -1625,7 +1679,10 @@ Vec4 trace_path(const yo_scene& scene, const Ray& ray_, Rng& rng, int bounces) {
     auto outgoing = -ray.d;
     auto position = eval_position(scene, object, element, uv);
     auto normal   = eval_shading_normal(scene, object, element, uv, outgoing);
-    auto emission = scene.materials[scene.objects[object].material].emission * V3{1, 1, 1};
+    auto& hit_mat = scene.materials[scene.objects[object].material];
+    float tc[2];
+    eval_texcoord(scene, object, element, uv, tc);
+    auto emission = hit_mat.emission * eval_texture(texture_of(scene, hit_mat.emission_tex), tc);  // pt.cpp:397-402
     auto brdf     = eval_brdf(scene, object, element, uv, normal, outgoing);
     if (brdf.hair) tls_counters.hair++; else tls_counters.surf++;
     if (brdf.opacity < 1 && rand1f(rng) >= brdf.opacity) {  // pt.cpp:1429-1433
@@ -1660,7 +1717,10 @@ Vec4 trace_path(const yo_scene& scene, const Ray& ray_, Rng& rng, int bounces) {
     // entering / leaving a closed transmissive object (pt.cpp:1458-1467)
     if (has_volume(scene.materials[scene.objects[object].material]) &&
         dot(normal, outgoing) * dot(normal, incoming) < 0) {
-      if (volume_stack.empty()) volume_stack.push_back(eval_vsdf(scene.materials[scene.objects[object].material]));
+      if (volume_stack.empty())
+        volume_stack.push_back(eval_vsdf(hit_mat, eval_texture(texture_of(scene, hit_mat.color_tex), tc, false),
+            eval_texture(texture_of(scene, hit_mat.emission_tex), tc, true).x,
+            eval_texture(texture_of(scene, hit_mat.scattering_tex), tc, false)));
       else volume_stack.pop_back();
     }
     ray = Ray{position, incoming};
@@ -2020,6 +2080,19 @@ void yo_surface_bsdf(int n, const yh_material* materials, const float* normal,
 
 yo_scene* yo_scene_create(const yh_scene_desc* d) {
   auto sc = new yo_scene{};
+  for (int i = 0; i < d->num_textures; i++) {
+    auto&   t = d->textures[i];
+    Texture tx;
+    tx.w = t.width, tx.h = t.height;
+    size_t n = (size_t)t.width * t.height;
+    if (t.is_byte) {
+      tx.colorb.assign((const unsigned char*)t.pixels, (const unsigned char*)t.pixels + 3 * n);
+    } else {
+      tx.colorf.resize(n);
+      std::memcpy(tx.colorf.data(), t.pixels, sizeof(float) * 3 * n);
+    }
+    sc->textures.push_back(std::move(tx));
+  }
   for (int i = 0; i < d->num_shapes; i++) {
     auto& s = d->shapes[i];
     Shape sh;
@@ -2029,6 +2102,7 @@ yo_scene* yo_scene_create(const yh_scene_desc* d) {
       sh.normals.resize(s.num_vertices);
       std::memcpy(sh.normals.data(), s.normals, sizeof(float) * 3 * s.num_vertices);
     }
+    if (s.texcoords) sh.texcoords.assign(s.texcoords, s.texcoords + 2 * (size_t)s.num_vertices);
     if (s.radius) sh.radius.assign(s.radius, s.radius + s.num_vertices);
     else if (s.num_lines) sh.radius.assign(s.num_vertices, 0.001f);  // sceneio.cpp:390
     if (s.num_lines) sh.lines.assign(s.lines, s.lines + 2 * s.num_lines);
@@ -2044,6 +2118,7 @@ yo_scene* yo_scene_create(const yh_scene_desc* d) {
     mt.specular = m.specular, mt.metallic = m.metallic, mt.roughness = m.roughness;
     mt.ior = m.ior, mt.transmission = m.transmission, mt.opacity = m.opacity;
     mt.scattering = v3(m.scattering), mt.scanisotropy = m.scanisotropy, mt.trdepth = m.trdepth;
+    mt.emission_tex = m.emission_tex - 1, mt.color_tex = m.color_tex - 1, mt.scattering_tex = m.scattering_tex - 1;
     mt.hair.sigma_a = v3(m.sigma_a);
     mt.hair.beta_m = m.beta_m, mt.hair.beta_n = m.beta_n;
     mt.hair.alpha = m.alpha, mt.hair.eta = m.eta;

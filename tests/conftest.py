@@ -74,6 +74,7 @@ GOLDEN_SCENES = [
     ("lobes", dict(scale=0.05)),
     ("volumes", dict(scale=0.05)),
     ("sphere-hairblock", dict(scale=0.05, dof=True)),
+    ("textured", dict(scale=0.05)),
 ]
 
 

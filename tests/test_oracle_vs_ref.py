@@ -81,6 +81,7 @@ def test_selftests_match_reference(oracle, ref):
     ("lobes", dict(scale=0.1), 160, 8),
     ("volumes", dict(scale=0.1), 160, 8),
     ("sphere-hairblock", dict(scale=0.1, dof=True), 120, 4),
+    ("textured", dict(scale=0.1), 160, 8),
 ])
 def test_images_bit_identical_to_reference(oracle, ref, yh, name, kw, res, spp):
     path = scene_path(name, **kw)

@@ -263,6 +263,60 @@ def make_volumes(outdir, scale=1.0, name="volumes"):
     return os.path.join(d, name + ".json"), nseg
 
 
+def _write_uv_quad(path, half=2.0, tiles=2.0):
+    """A quad in the XY plane (normal +z) with texture coordinates that run past [0, 1] (tiling)."""
+    verts = [(-half, -half, 0, 0, 0, 1, 0, 0), (half, -half, 0, 0, 0, 1, tiles, 0),
+             (-half, half, 0, 0, 0, 1, 0, tiles), (half, half, 0, 0, 0, 1, tiles, tiles)]
+    with open(path, "w") as f:
+        f.write("ply\nformat ascii 1.0\nelement vertex 4\nproperty float x\nproperty float y\nproperty float z\n"
+                "property float nx\nproperty float ny\nproperty float nz\nproperty float u\nproperty float v\n"
+                "element face 1\nproperty list uchar int vertex_indices\nend_header\n")
+        for v in verts:
+            f.write(" ".join(repr(float(x)) for x in v) + "\n")
+        f.write("4 0 1 3 2\n")
+
+
+def make_textured(outdir, scale=1.0, name="textured"):
+    """Colour textures: the sloth scene's floor.png as color_tex on a tiled
+    floor with texture coordinates, as emission_tex on a light, as scattering_tex inside a volume
+    (the bold-man recipe), sky.hdr as a float colour texture on a sphere without texture coordinates."""
+    d = _prep(outdir, name)
+    shutil.copy(os.path.join(ASSETS, "sphere.ply"), os.path.join(d, "shapes", "sphere.ply"))
+    shutil.copy(os.path.join(ASSETS, "floor.png"), os.path.join(d, "textures", "floor.png"))
+    shutil.copy(os.path.join(ASSETS, "sky.hdr"), os.path.join(d, "textures", "sky.hdr"))
+    _write_uv_quad(os.path.join(d, "shapes", "uvquad.ply"))
+    nseg = write_hair_ply(os.path.join(d, "shapes", "hair-block.ply"),
+                          gen_hair_block(max(64, int(100_000 * scale))), 0.004, 0.001)
+    objects = {
+        "hairblock": {"frame": [1, 0, 0, 0, 0, 1, 0, -1, 0, 1.4, 1, -0.5], "shape": "hair-block", "material": "hair"},
+        "floor": {"frame": [2, 0, 0, 0, 0, -2, 0, 2, 0, 0.3, 0, 0], "shape": "uvquad", "material": "floor"},
+        "light": {"lookat": [0.3, 5, 2, 0.3, 0.5, 0, 0, 1, 0], "shape": "uvquad", "material": "panel"},
+        "ball0": {"frame": [0.8, 0, 0, 0, 0.8, 0, 0, 0, 0.8, -1.3, 0.0, 0.3], "shape": "sphere", "material": "marble"},
+        "ball1": {"frame": [0.8, 0, 0, 0, 0.8, 0, 0, 0, 0.8, -0.3, 0.0, 0.3], "shape": "sphere", "material": "skin"},
+        "ball2": {"frame": [0.8, 0, 0, 0, 0.8, 0, 0, 0, 0.8, 0.7, 0.0, 0.3], "shape": "sphere", "material": "glazed"},
+    }
+    materials = {
+        "hair": {"eumelanin": 0.3},
+        "floor": {"color": [0.7, 0.7, 0.7], "color_tex": "floor"},
+        "panel": {"emission": [14, 14, 14], "emission_tex": "floor"},
+        "marble": {"color": [0.9, 0.9, 0.9], "color_tex": "sky", "specular": 1.0, "roughness": 0.1},
+        "skin": {"color": [0.8, 0.8, 0.8], "color_tex": "floor", "specular": 1.0, "transmission": 1.0, "thin": False,
+                 "roughness": 0.5, "scattering": [1.0, 1.0, 1.0], "scattering_tex": "floor", "scanisotropy": -0.8,
+                 "trdepth": 0.001},
+        "glazed": {"color": [0.9, 0.8, 0.7], "color_tex": "floor", "emission": [0.2, 0.2, 0.2], "emission_tex": "sky",
+                   "transmission": 0.5, "thin": True, "roughness": 0.2, "specular": 1.0},
+    }
+    scene = {
+        "asset": {"copyright": "synthetic; sphere, floor.png and sky.hdr from the reference's test assets"},
+        "cameras": {"default": {"lens": 0.05, "aperture": 0.0, "aspect": 1.0, "lookat": [0.2, 2.2, 5.0, 0.2, 0.4, 0, 0, 1, 0]}},
+        "environments": {"sky": {"emission": [0.5, 0.5, 0.5]}},
+        "objects": objects,
+        "materials": materials,
+    }
+    _dump(scene, os.path.join(d, name + ".json"))
+    return os.path.join(d, name + ".json"), nseg
+
+
 def _head_scene(outdir, name, shape, pos, emission, lights, hair_mat):
     d = _prep(outdir, name)
     shutil.copy(os.path.join(ASSETS, "sky.hdr"), os.path.join(d, "textures", "sky.hdr"))
@@ -337,6 +391,7 @@ MAKERS = {
     "hair-curls": make_hair_curls,
     "lobes": make_lobes,
     "volumes": make_volumes,
+    "textured": make_textured,
 }
 
 

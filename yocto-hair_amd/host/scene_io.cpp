@@ -22,6 +22,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <zlib.h>
 #include <map>
 #include <memory>
 #include <stdexcept>
@@ -178,7 +179,7 @@ bool get_floats(const Json& j, const std::string& key, float* out, int n) {
 // PLY (ascii and binary_little_endian; the properties the hair path reads)
 // ---------------------------------------------------------------------------
 struct ShapeData {
-  std::vector<float> positions, normals, radius;
+  std::vector<float> positions, normals, radius, texcoords;
   std::vector<int>   lines, triangles;
 };
 enum PlyType { PLY_I8, PLY_U8, PLY_I16, PLY_U16, PLY_I32, PLY_U32, PLY_F32, PLY_F64, PLY_I64, PLY_U64 };
@@ -279,19 +280,23 @@ void load_ply(const std::string& path, ShapeData& shape) {
   std::vector<std::vector<int>> faces;
   bool has_normals = false, has_radius = false;
   for (auto& e : elems) {
-    int ix = -1, iy = -1, iz = -1, inx = -1, iny = -1, inz = -1, ir = -1;
+    int ix = -1, iy = -1, iz = -1, inx = -1, iny = -1, inz = -1, ir = -1, iu = -1, iv = -1, is = -1, it = -1;
     for (int k = 0; k < (int)e.props.size(); k++) {
       auto& nm = e.props[k].name;
       if (nm == "x") ix = k; else if (nm == "y") iy = k; else if (nm == "z") iz = k;
       else if (nm == "nx") inx = k; else if (nm == "ny") iny = k; else if (nm == "nz") inz = k;
       else if (nm == "radius") ir = k;
+      else if (nm == "u") iu = k; else if (nm == "v") iv = k; else if (nm == "s") is = k; else if (nm == "t") it = k;
     }
+    if (iu < 0 || iv < 0) iu = is, iv = it;  // get_texcoords (yocto_ply.h:1083-1094): u v, else s t
+    const bool has_uv = iu >= 0 && iv >= 0;
     if (e.name == "vertex") {
       has_normals = inx >= 0 && iny >= 0 && inz >= 0;
       has_radius  = ir >= 0;
       shape.positions.resize(3 * e.count);
       if (has_normals) shape.normals.resize(3 * e.count);
       if (has_radius) shape.radius.resize(e.count);
+      if (has_uv) shape.texcoords.resize(2 * e.count);
     }
     std::vector<double> row(e.props.size());
     std::vector<int>    idx;
@@ -308,6 +313,7 @@ void load_ply(const std::string& path, ShapeData& shape) {
         shape.positions[3 * i] = f(ix), shape.positions[3 * i + 1] = f(iy), shape.positions[3 * i + 2] = f(iz);
         if (has_normals) shape.normals[3 * i] = f(inx), shape.normals[3 * i + 1] = f(iny), shape.normals[3 * i + 2] = f(inz);
         if (has_radius) shape.radius[i] = f(ir);
+        if (has_uv) shape.texcoords[2 * i] = f(iu), shape.texcoords[2 * i + 1] = 1 - f(iv);  // load_shape flips v (yocto_shape.h:745)
       }
       continue;
     }
@@ -338,6 +344,7 @@ void load_ply(const std::string& path, ShapeData& shape) {
           shape.normals[3 * i + 2] = (float)row[inz];
         }
         if (has_radius) shape.radius[i] = (float)row[ir];
+        if (has_uv) shape.texcoords[2 * i] = (float)row[iu], shape.texcoords[2 * i + 1] = 1 - (float)row[iv];
       }
     }
   }
@@ -361,6 +368,86 @@ void load_ply(const std::string& path, ShapeData& shape) {
   if (shape.positions.empty()) throw std::runtime_error(path + ": empty shape");
   if (!shape.lines.empty() && shape.radius.empty())
     shape.radius.assign(shape.positions.size() / 3, 0.001f);  // add_radius
+}
+
+// ---------------------------------------------------------------------------
+// PNG (8-bit grey / grey+alpha / RGB / RGBA / palette, non-interlaced) -> RGB bytes,
+// the result the reference gets from stb_image with three requested channels
+// (yocto_image.cpp load_image -> image<vec3b>): alpha dropped, grey replicated.
+// ---------------------------------------------------------------------------
+void load_png(const std::string& path, int& w, int& h, std::vector<unsigned char>& rgb) {
+  std::string data;
+  if (!read_file(path, data)) throw std::runtime_error(path + ": file not found");
+  auto p = (const unsigned char*)data.data();
+  auto n = data.size();
+  static const unsigned char sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+  if (n < 8 || memcmp(p, sig, 8)) throw std::runtime_error(path + ": not a png file");
+  auto be32 = [](const unsigned char* q) { return ((unsigned)q[0] << 24) | ((unsigned)q[1] << 16) | ((unsigned)q[2] << 8) | q[3]; };
+  size_t pos = 8;
+  int    depth = 0, ctype = 0, interlace = 0;
+  std::vector<unsigned char> idat, palette;
+  w = h = 0;
+  while (pos + 12 <= n) {
+    unsigned len = be32(p + pos);
+    if (pos + 12 + (size_t)len > n) throw std::runtime_error(path + ": truncated png");
+    const unsigned char* type = p + pos + 4;
+    const unsigned char* body = p + pos + 8;
+    if (!memcmp(type, "IHDR", 4) && len >= 13) {
+      w = (int)be32(body), h = (int)be32(body + 4), depth = body[8], ctype = body[9], interlace = body[12];
+    } else if (!memcmp(type, "PLTE", 4)) {
+      palette.assign(body, body + len);
+    } else if (!memcmp(type, "IDAT", 4)) {
+      idat.insert(idat.end(), body, body + len);
+    } else if (!memcmp(type, "IEND", 4)) {
+      break;
+    }
+    pos += 12 + (size_t)len;
+  }
+  if (w <= 0 || h <= 0 || w > 32768 || h > 32768) throw std::runtime_error(path + ": bad png header");
+  if (depth != 8 || interlace != 0) throw std::runtime_error(path + ": only 8-bit non-interlaced png textures are supported");
+  int ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
+  if (!ch) throw std::runtime_error(path + ": unsupported png colour type");
+  size_t stride = (size_t)w * ch;
+  std::vector<unsigned char> raw((stride + 1) * (size_t)h);
+  uLongf out_len = (uLongf)raw.size();
+  if (uncompress(raw.data(), &out_len, idat.data(), (uLong)idat.size()) != Z_OK || out_len != raw.size())
+    throw std::runtime_error(path + ": corrupt png data");
+  std::vector<unsigned char> img(stride * (size_t)h);
+  for (int y = 0; y < h; y++) {  // undo the scanline filters (PNG spec 9.2)
+    const unsigned char* src  = raw.data() + (stride + 1) * (size_t)y;
+    unsigned char*       dst  = img.data() + stride * (size_t)y;
+    const unsigned char* prev = y ? dst - stride : nullptr;
+    int                  ft   = src[0];
+    for (size_t x = 0; x < stride; x++) {
+      int a = x >= (size_t)ch ? dst[x - ch] : 0, b = prev ? prev[x] : 0, c = (prev && x >= (size_t)ch) ? prev[x - ch] : 0;
+      int v = src[1 + x];
+      switch (ft) {
+        case 0: break;
+        case 1: v += a; break;
+        case 2: v += b; break;
+        case 3: v += (a + b) >> 1; break;
+        case 4: {
+          int pa = abs(b - c), pb = abs(a - c), pc = abs(a + b - 2 * c);
+          v += (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+        } break;
+        default: throw std::runtime_error(path + ": bad png filter");
+      }
+      dst[x] = (unsigned char)v;
+    }
+  }
+  rgb.resize((size_t)w * h * 3);
+  for (size_t i = 0; i < (size_t)w * h; i++) {
+    const unsigned char* q = img.data() + i * ch;
+    unsigned char*       o = rgb.data() + i * 3;
+    if (ctype == 2 || ctype == 6) {
+      o[0] = q[0], o[1] = q[1], o[2] = q[2];
+    } else if (ctype == 3) {
+      if ((size_t)q[0] * 3 + 2 >= palette.size()) throw std::runtime_error(path + ": palette index out of range");
+      o[0] = palette[q[0] * 3], o[1] = palette[q[0] * 3 + 1], o[2] = palette[q[0] * 3 + 2];
+    } else {
+      o[0] = o[1] = o[2] = q[0];
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -437,6 +524,8 @@ std::string dirname(const std::string& path) {
 struct yh_scene_file {
   std::vector<ShapeData>          shape_data;
   std::vector<std::vector<float>> tex_data;
+  std::vector<std::vector<unsigned char>> tex_bytes;  // material textures loaded from png
+  std::vector<yh_texture>         textures;   // material textures (yh_scene_desc::textures)
   std::vector<yh_shape>           shapes;
   std::vector<yh_material>        materials;
   std::vector<yh_object>          objects;
@@ -488,7 +577,7 @@ static yh_scene_file* load_scene(const std::string& path, const std::string& cam
 
   // textures are only supported on environments
   std::map<std::string, int> tex_index;
-  struct Tex { int w, h; };
+  struct Tex { int w, h, data; };  // data = index into sf->tex_data
   std::vector<Tex> texs;
   auto get_texture = [&](const std::string& name) {
     auto it = tex_index.find(name);
@@ -498,7 +587,7 @@ static yh_scene_file* load_scene(const std::string& path, const std::string& cam
     int w, h;
     sf->tex_data.emplace_back();
     load_hdr(file, w, h, sf->tex_data.back());
-    texs.push_back({w, h});
+    texs.push_back({w, h, (int)sf->tex_data.size() - 1});
     return tex_index[name] = (int)texs.size() - 1;
   };
 
@@ -513,10 +602,36 @@ static yh_scene_file* load_scene(const std::string& path, const std::string& cam
       if (e.has("emission_tex") && !e.at("emission_tex").str.empty()) {
         auto t         = get_texture(e.at("emission_tex").str);
         env.tex_width  = texs[t].w, env.tex_height = texs[t].h;
-        env.texels     = (const float*)(intptr_t)(t + 1);  // patched below
+        env.texels     = (const float*)(intptr_t)(texs[t].data + 1);  // patched below
       }
       sf->environments.push_back(env);
     }
+
+  // colour textures of materials (sceneio.cpp:1383-1391: textures/<name>.{hdr,exr,png,jpg}, first that exists)
+  std::map<std::string, int> mat_tex_index;
+  auto get_material_texture = [&](const std::string& tname) -> int {
+    auto it = mat_tex_index.find(tname);
+    if (it != mat_tex_index.end()) return it->second;
+    yh_texture t{};
+    for (const char* ext : {".hdr", ".exr", ".png", ".jpg"}) {
+      auto file = base + "/textures/" + tname + ext;
+      if (!file_exists(file)) continue;
+      if (!strcmp(ext, ".hdr")) {
+        sf->tex_data.emplace_back();
+        load_hdr(file, t.width, t.height, sf->tex_data.back());
+        t.is_byte = 0, t.pixels = (const void*)(intptr_t)sf->tex_data.size();  // patched below
+      } else if (!strcmp(ext, ".png")) {
+        sf->tex_bytes.emplace_back();
+        load_png(file, t.width, t.height, sf->tex_bytes.back());
+        t.is_byte = 1, t.pixels = (const void*)(intptr_t)sf->tex_bytes.size();
+      } else {
+        throw std::runtime_error(file + ": only .hdr and .png textures are supported");
+      }
+      sf->textures.push_back(t);
+      return mat_tex_index[tname] = (int)sf->textures.size();  // 1-based
+    }
+    throw std::runtime_error(base + "/textures/" + tname + ".hdr: file not found");
+  };
 
   // materials (sceneio.cpp:1268-1325; defaults yocto_sceneio.h:126-157)
   std::map<std::string, int> material_index;
@@ -536,9 +651,13 @@ static yh_scene_file* load_scene(const std::string& path, const std::string& cam
       get_floats(e, "scattering", m.scattering, 3), get_floats(e, "scanisotropy", &m.scanisotropy, 1);
       get_floats(e, "trdepth", &m.trdepth, 1);
       if (e.has("thin")) m.thin = e.at("thin").b ? 1 : 0;
-      for (auto& [k, v] : e.obj)
-        if (k.size() > 4 && k.substr(k.size() - 4) == "_tex" && !v.str.empty())
-          throw std::runtime_error(path + ": material textures are outside the hair path (" + name + "." + k + ")");
+      for (auto& [k, v] : e.obj) {
+        if (!(k.size() > 4 && k.substr(k.size() - 4) == "_tex" && !v.str.empty())) continue;
+        if (k == "emission_tex") m.emission_tex = get_material_texture(v.str);
+        else if (k == "color_tex") m.color_tex = get_material_texture(v.str);
+        else if (k == "scattering_tex") m.scattering_tex = get_material_texture(v.str);
+        else throw std::runtime_error(path + ": scalar and normal-map textures are not supported (" + name + "." + k + ")");
+      }
       material_index[name] = (int)sf->materials.size();
       sf->materials.push_back(m);
     }
@@ -591,11 +710,16 @@ static yh_scene_file* load_scene(const std::string& path, const std::string& cam
     s.lines         = sd.lines.empty() ? nullptr : sd.lines.data();
     s.num_triangles = s.num_lines ? 0 : (int)sd.triangles.size() / 3;
     s.triangles     = s.num_triangles ? sd.triangles.data() : nullptr;
+    s.texcoords     = sd.texcoords.empty() ? nullptr : sd.texcoords.data();
     sf->shapes.push_back(s);
   }
   for (auto& env : sf->environments)
     if (env.texels) env.texels = sf->tex_data[(int)(intptr_t)env.texels - 1].data();
 
+  for (auto& t : sf->textures)  // vectors no longer move
+    t.pixels = t.is_byte ? (const void*)sf->tex_bytes[(size_t)(intptr_t)t.pixels - 1].data()
+                         : (const void*)sf->tex_data[(size_t)(intptr_t)t.pixels - 1].data();
+  sf->desc.num_textures = (int)sf->textures.size(), sf->desc.textures = sf->textures.data();
   sf->desc.num_shapes = (int)sf->shapes.size(), sf->desc.shapes = sf->shapes.data();
   sf->desc.num_materials = (int)sf->materials.size(), sf->desc.materials = sf->materials.data();
   sf->desc.num_objects = (int)sf->objects.size(), sf->desc.objects = sf->objects.data();

@@ -27,7 +27,11 @@ c_int_p = C.POINTER(C.c_int)
 class Shape(C.Structure):
     _fields_ = [("num_vertices", C.c_int), ("positions", c_float_p), ("normals", c_float_p),
                 ("radius", c_float_p), ("num_lines", C.c_int), ("lines", c_int_p),
-                ("num_triangles", C.c_int), ("triangles", c_int_p)]
+                ("num_triangles", C.c_int), ("triangles", c_int_p), ("texcoords", c_float_p)]
+
+
+class Texture(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("is_byte", C.c_int), ("pixels", C.c_void_p)]
 
 
 class Material(C.Structure):
@@ -37,7 +41,8 @@ class Material(C.Structure):
                 ("sigma_a", C.c_float * 3), ("beta_m", C.c_float), ("beta_n", C.c_float),
                 ("alpha", C.c_float), ("eta", C.c_float), ("eumelanin", C.c_float),
                 ("pheomelanin", C.c_float), ("scattering", C.c_float * 3), ("scanisotropy", C.c_float),
-                ("trdepth", C.c_float)]
+                ("trdepth", C.c_float), ("emission_tex", C.c_int), ("color_tex", C.c_int),
+                ("scattering_tex", C.c_int)]
 
 
 class Object(C.Structure):
@@ -59,7 +64,7 @@ class SceneDesc(C.Structure):
                 ("num_materials", C.c_int), ("materials", C.POINTER(Material)),
                 ("num_objects", C.c_int), ("objects", C.POINTER(Object)),
                 ("num_environments", C.c_int), ("environments", C.POINTER(Environment)),
-                ("camera", Camera)]
+                ("camera", Camera), ("num_textures", C.c_int), ("textures", C.POINTER(Texture))]
 
 
 class TraceParams(C.Structure):
