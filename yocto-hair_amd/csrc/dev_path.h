@@ -246,12 +246,44 @@ YH_DEV bool path_continue(path_t& ps, rng_t& rng, int bounces) {
   return ps.bounce < bounces;
 }
 
-// Entering / leaving a closed transmissive object (pt.cpp:1458-1467).
-YH_DEV void medium_crossing(path_t& ps, const yhd_material& mat, f3 normal, f3 outgoing, f3 incoming) {
+// eval_texcoord (pt.cpp:295-311) of a hit: the element's vertex texture coordinates interpolated
+// like positions (math.h:3322-3331), or the element uv when the shape has none.
+YH_DEV void eval_texcoord(const yhd_scene& sc, const yhd_object& o, const hit_t& isec, float& tu, float& tv) {
+  tu = isec.u, tv = isec.v;
+  if (!o.has_texcoords) return;
+  const bool lines   = o.kind == YH_KIND_LINES;
+  int        element = __float_as_int(lines ? sc.prims[(size_t)o.prim_base + (size_t)isec.slot * 4 + 2].w
+                                            : sc.prims[(size_t)o.prim_base + (size_t)isec.slot * 6].w);
+  yhd_int4   e       = sc.elems[o.elem_base + element];
+  const float* t0 = sc.vtex + 2 * (size_t)(o.vert_base + e.x);
+  const float* t1 = sc.vtex + 2 * (size_t)(o.vert_base + e.y);
+  if (lines) {
+    tu = t0[0] * (1 - isec.u) + t1[0] * isec.u, tv = t0[1] * (1 - isec.u) + t1[1] * isec.u;
+  } else {
+    const float* t2 = sc.vtex + 2 * (size_t)(o.vert_base + e.z);
+    tu = t0[0] * (1 - isec.u - isec.v) + t1[0] * isec.u + t2[0] * isec.v;
+    tv = t0[1] * (1 - isec.u - isec.v) + t1[1] * isec.u + t2[1] * isec.v;
+  }
+}
+
+// Entering / leaving a closed transmissive object (pt.cpp:1458-1467); the medium entered is
+// eval_vsdf at the crossing point (pt.cpp:504-527).
+YH_DEV void medium_crossing(const yhd_scene& sc, path_t& ps, const yhd_material& mat, f3 normal, f3 outgoing,
+    f3 incoming, f3 color_tex, float emission_tex_x, float tu, float tv) {
   if (!mat.has_volume || !(dot(normal, outgoing) * dot(normal, incoming) < 0)) return;
   if (!ps.in_medium) {
-    ps.medium.density    = ld3(mat.vol_density);
-    ps.medium.scatter    = ld3(mat.vol_scatter);
+    if (mat.color_tex >= 0 || mat.emission_tex >= 0) {
+      f3    base         = ld3(mat.color) * color_tex;
+      float transmission = mat.transmission * emission_tex_x;
+      ps.medium.density  = mk3(0.0f);
+      if (transmission) {  // thin is false here (has_volume)
+        f3 c = {fclamp(base.x, 0.0001f, 1.0f), fclamp(base.y, 0.0001f, 1.0f), fclamp(base.z, 0.0001f, 1.0f)};
+        ps.medium.density = -f3{logf(c.x), logf(c.y), logf(c.z)} / mat.trdepth;
+      }
+    } else {
+      ps.medium.density = ld3(mat.vol_density);  // the same expression, evaluated on the host
+    }
+    ps.medium.scatter    = ld3(mat.vol_scatter) * eval_texture(sc, mat.scattering_tex, false, tu, tv);
     ps.medium.anisotropy = mat.vol_anisotropy;
   }
   ps.in_medium = !ps.in_medium;
@@ -319,8 +351,18 @@ YH_DEV bool path_step(const trace_ctx& tc, path_t& ps, const hit_t& isec, rng_t&
   if (COUNT) count_quad<COUNT>(is_hair ? tc.stats->hair : tc.stats->surf);
   const bool     general = GENERAL && !mat.plain;
   surface_brdf_t sb;
+  float          tu = isec.u, tv = isec.v, etex_x = 1.0f;  // texcoord; emission texture, linear (pt.cpp:421)
+  f3             ctex = mk3(1.0f), etex = mk3(1.0f);      // colour and emission texture values
   if (general) {
-    sb = surface_brdf(mat, normal, outgoing);
+    if (mat.color_tex >= 0 || mat.emission_tex >= 0 || mat.scattering_tex >= 0) {
+      eval_texcoord(sc, o, isec, tu, tv);
+      ctex = eval_texture(sc, mat.color_tex, false, tu, tv);
+      if (mat.emission_tex >= 0) {
+        etex   = eval_texture(sc, mat.emission_tex, false, tu, tv);
+        etex_x = eval_texture(sc, mat.emission_tex, true, tu, tv).x;
+      }
+    }
+    sb = surface_brdf(mat, normal, outgoing, ctex, etex_x);
     if (sb.opacity < 1 && rand1f(rng) >= sb.opacity) {  // pt.cpp:1429-1433: pass through, same bounce
       ps.ray = mkray(position + ps.ray.d * 1e-2f, ps.ray.d);
       if (COUNT) tc.stats->c_rest += clock64() - k0;
@@ -328,14 +370,14 @@ YH_DEV bool path_step(const trace_ctx& tc, path_t& ps, const hit_t& isec, rng_t&
     }
   }
   ps.hit      = true;
-  ps.radiance = ps.radiance + ps.weight * (ld3(mat.emission) * mk3(1.0f));
+  ps.radiance = ps.radiance + ps.weight * (ld3(mat.emission) * etex);
   if (general && is_delta(sb)) {  // pt.cpp:1452-1456 (also for a hair shape whose mixture is a delta)
     f3    incoming = surface_sample_delta(sb, normal, outgoing, rand1f(rng));
     f3    brdfcos;
     float pdf;
     surface_eval_pdf_delta(sb, normal, outgoing, incoming, brdfcos, pdf);
     ps.weight = ps.weight * (brdfcos / pdf);
-    medium_crossing(ps, mat, normal, outgoing, incoming);
+    medium_crossing(sc, ps, mat, normal, outgoing, incoming, ctex, etex_x, tu, tv);
     ps.ray    = mkray(position, incoming);
     if (COUNT) tc.stats->c_rest += clock64() - k0;
     return path_continue(ps, rng, bounces);
@@ -396,7 +438,7 @@ YH_DEV bool path_step(const trace_ctx& tc, path_t& ps, const hit_t& isec, rng_t&
   if (COUNT) k3 = clock64(), tc.stats->c_eval += k3 - k2;
   float light_pdf = sample_lights_pdf<COUNT, STRIDE>(tc, position, incoming);
   ps.weight = ps.weight * (brdfcos / (0.5f * brdf_pdf + 0.5f * light_pdf));
-  if (general) medium_crossing(ps, mat, normal, outgoing, incoming);
+  if (general) medium_crossing(sc, ps, mat, normal, outgoing, incoming, ctex, etex_x, tu, tv);
   ps.ray    = mkray(position, incoming);
   if (COUNT) tc.stats->c_rest += clock64() - k3;
   return path_continue(ps, rng, bounces);

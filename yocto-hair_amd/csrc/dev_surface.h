@@ -277,12 +277,16 @@ struct surface_brdf_t {
   f3    meta;  // metak is always zero (pt.cpp:440)
   float diffuse_pdf, specular_pdf, metal_pdf, transmission_pdf, refraction_pdf;
 };
-YH_DEV surface_brdf_t surface_brdf(const yhd_material& mat, f3 normal, f3 outgoing) {
-  f3    base         = ld3(mat.color) * mk3(1.0f);
+// color_tex = eval_texture(color_tex, texcoord) and emission_tex_x = eval_texture(emission_tex,
+// texcoord, ldr_as_linear).x — the reference scales TRANSMISSION by the emission texture
+// (pt.cpp:421-422); both are 1 for an untextured material.
+YH_DEV surface_brdf_t surface_brdf(const yhd_material& mat, f3 normal, f3 outgoing, f3 color_tex = {1.0f, 1.0f, 1.0f},
+    float emission_tex_x = 1.0f) {
+  f3    base         = ld3(mat.color) * color_tex;
   float specular     = mat.specular * 1.0f;
   float metallic     = mat.metallic * 1.0f;
   float roughness    = mat.roughness * 1.0f;
-  float transmission = mat.transmission * 1.0f;
+  float transmission = mat.transmission * emission_tex_x;
   bool  thin         = mat.thin || !mat.transmission;
   surface_brdf_t b;
   f3 weight      = mk3(1.0f);
@@ -295,7 +299,12 @@ YH_DEV surface_brdf_t surface_brdf(const yhd_material& mat, f3 normal, f3 outgoi
   b.transmission = thin ? (weight * transmission * base) : mk3(0.0f);
   weight         = weight * (1 - (thin ? transmission : 0));
   b.diffuse      = weight * base;
-  b.meta         = ld3(mat.meta);  // reflectivity_to_eta(base), host side
+  if (mat.color_tex >= 0) {  // reflectivity_to_eta(base) (math.h:4270-4273) of the textured colour
+    f3 r   = {fclamp(base.x, 0.0f, 0.99f), fclamp(base.y, 0.0f, 0.99f), fclamp(base.z, 0.0f, 0.99f)};
+    b.meta = {(1 + sqrtf(r.x)) / (1 - sqrtf(r.x)), (1 + sqrtf(r.y)) / (1 - sqrtf(r.y)), (1 + sqrtf(r.z)) / (1 - sqrtf(r.z))};
+  } else {
+    b.meta = ld3(mat.meta);  // the same, precomputed on the host
+  }
   b.roughness    = roughness * roughness;
   b.ior          = mat.ior;
   b.opacity      = mat.opacity;    // > 0.999 already snapped to 1 on the host
@@ -400,6 +409,24 @@ YH_DEV f3 surface_sample_delta(const surface_brdf_t& b, f3 normal, f3 outgoing, 
     if (rnl < cdf) return sample_delta_refraction(b.ior, normal, outgoing, rnl);
   }
   return mk3(0.0f);
+}
+
+// ---- colour textures (pt.cpp:167-200 on texels converted at upload, yh_device.h) ---------
+YH_DEV f3 eval_texture(const yhd_scene& sc, int tex, bool ldr_as_linear, float u_, float v_) {
+  if (tex < 0) return mk3(1.0f);
+  const yhd_texture& t  = sc.textures[tex];
+  int                sx = t.width, sy = t.height;
+  float s = fmodf(u_, 1.0f) * sx;
+  if (s < 0) s += sx;
+  float tt = fmodf(v_, 1.0f) * sy;
+  if (tt < 0) tt += sy;
+  int   i = iclamp((int)s, 0, sx - 1), j = iclamp((int)tt, 0, sy - 1);
+  int   ii = (i + 1) % sx, jj = (j + 1) % sy;
+  float u = s - i, v = tt - j;
+  const yhd_float4* tx = sc.tex_texels + (ldr_as_linear ? t.linear_base : t.srgb_base);
+  f3 a = xyz(tx[(size_t)j * sx + i]), b = xyz(tx[(size_t)jj * sx + i]);
+  f3 c = xyz(tx[(size_t)j * sx + ii]), d = xyz(tx[(size_t)jj * sx + ii]);
+  return a * (1 - u) * (1 - v) + b * (1 - u) * v + c * u * (1 - v) + d * u * v;
 }
 
 // ---- homogeneous volumes (math.h:4758-4822, pt.cpp:1360-1377) ---------------------

@@ -43,7 +43,7 @@ typedef struct yhd_object {
   int   elem_base;      // first element in elems
   int   has_normals;
   int   material;
-  int   pad;
+  int   has_texcoords;  // the shape has per-vertex texture coordinates (else texcoord = element uv)
 } yhd_object;
 
 // ptr::material + everything of hair_brdf that depends on the material only
@@ -78,7 +78,19 @@ typedef struct yhd_material {
   float  vol_density[3];   // -log(clamp(color, 1e-4, 1)) / trdepth
   float  vol_scatter[3];
   float  vol_anisotropy;
+  // colour textures (index into yhd_scene::textures, -1 = none); trdepth for the textured medium
+  int    emission_tex, color_tex, scattering_tex;
+  float  trdepth;
 } yhd_material;
+
+// A colour texture: float4 texels in yhd_scene::tex_texels, already converted per texel the way
+// lookup_texture (pt.cpp:147-164) does. `srgb_base`: byte textures decoded sRGB -> linear (float
+// textures as they are); `linear_base`: byte / 255 without decoding (only the transmission
+// factor reads it, pt.cpp:421-422), -1 when no material needs it.
+typedef struct yhd_texture {
+  int width, height;
+  int srgb_base, linear_base;
+} yhd_texture;
 
 typedef struct yhd_light {
   int object;       // >= 0: area light on that object
@@ -122,6 +134,9 @@ typedef struct yhd_scene {
   yhd_environment   environments[YH_MAX_ENVS];
   const float*      light_cdf;
   const yhd_float4* env_texels;
+  const yhd_texture* textures;   // material colour textures
+  const yhd_float4* tex_texels;
+  const float*      vtex;        // per vertex texture coordinates (2 floats), indexed like vpos
   yhd_camera        camera;
   // number of leading nodes of the largest line shape staged in LDS
   int               num_nodes_total; // wide nodes in `nodes` (bounds checks of the debug build)

@@ -161,7 +161,10 @@ void make_material(const yh_material& m, yhd_material& d) {
   d.transmission = m.transmission;
   d.opacity      = m.opacity * ((1.0f + 1.0f + 1.0f) / 3);  // mean of the {1,1,1} null texture (pt.cpp:425)
   if (d.opacity > 0.999f) d.opacity = 1;
-  d.plain = m.specular == 0 && m.metallic == 0 && m.transmission == 0 && d.opacity == 1;
+  d.emission_tex = m.emission_tex - 1, d.color_tex = m.color_tex - 1, d.scattering_tex = m.scattering_tex - 1;
+  d.trdepth = m.trdepth;
+  d.plain = m.specular == 0 && m.metallic == 0 && m.transmission == 0 && d.opacity == 1 && m.emission_tex == 0 &&
+            m.color_tex == 0 && m.scattering_tex == 0;
   for (int c = 0; c < 3; c++) {  // reflectivity_to_eta (math.h:4270-4273)
     float r   = fmin_(fmax_(m.color[c], 0.0f), 0.99f);
     d.meta[c] = (1 + std::sqrt(r)) / (1 - std::sqrt(r));
@@ -247,6 +250,7 @@ struct yh_context {
   bool             have_state = false;
   yhd_state        state{};
   yh_trace_params  params{};
+  DevBuf           d_textures, d_tex_texels, d_vtex;
   DevBuf           d_rng_state, d_rng_inc, d_accum, d_tiles, d_image, d_counters, d_tile_cursor, d_tile_cost;
   std::vector<int> owned;      // owned tile ids, increasing
   std::vector<unsigned int>  item_cost;  // per work item (tile * 4 + quadrant): last measured cost (scheduling hint, kept across init_state)
@@ -406,6 +410,7 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
   };
   std::vector<ShapeInfo>  info(sd->num_shapes);
   std::vector<yhd_float4> nodes, prims, vpos, vnrm;
+  std::vector<float>      vtex;  // 2 per vertex, zeros for shapes without texture coordinates
   std::vector<yhd_int4>   elems;
   int                     best_lines = -1, best_shape = -1;
   {  // one allocation per array: growing them shape by shape would re-copy the hair every time
@@ -416,7 +421,7 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
       size_t nel = (size_t)std::max(0, lines ? s.num_lines : s.num_triangles);
       np += nel * (lines ? 4 : 6), nv += (size_t)std::max(0, s.num_vertices), ne += nel;
     }
-    prims.reserve(np), vpos.reserve(nv), vnrm.reserve(nv), elems.reserve(ne), nodes.reserve(ne * 6);
+    prims.reserve(np), vpos.reserve(nv), vnrm.reserve(nv), vtex.reserve(2 * nv), elems.reserve(ne), nodes.reserve(ne * 6);
   }
   for (int si = 0; si < sd->num_shapes; si++) {
     auto& s = sd->shapes[si];
@@ -494,6 +499,8 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
     {
       const size_t at = vpos.size();
       vpos.resize(at + (size_t)s.num_vertices), vnrm.resize(at + (size_t)s.num_vertices);
+      vtex.resize(2 * (at + (size_t)s.num_vertices), 0.0f);
+      if (s.texcoords) memcpy(&vtex[2 * at], s.texcoords, sizeof(float) * 2 * (size_t)s.num_vertices);
       parallel_for(s.num_vertices, [&](int v) {
         F3 p = pos(v), n = nrm(v);
         vpos[at + (size_t)v] = {p.x, p.y, p.z, lines ? rad(v) : 0.0f};
@@ -521,7 +528,7 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
     memcpy(d.frame, o.frame, 48);
     inverse_frame(o.frame, true, d.inv_frame);
     d.kind = I.kind, d.node_base = I.node_base, d.prim_base = I.prim_base, d.vert_base = I.vert_base;
-    d.elem_base = I.elem_base, d.has_normals = I.has_normals, d.material = o.material, d.pad = 0;
+    d.elem_base = I.elem_base, d.has_normals = I.has_normals, d.material = o.material, d.has_texcoords = sd->shapes[o.shape].texcoords != nullptr;
     // transform_bbox (math.h:3174-3185)
     const yhh::Box& b = I.root;
     float lo[3] = {std::numeric_limits<float>::max(), std::numeric_limits<float>::max(), std::numeric_limits<float>::max()};
@@ -604,6 +611,47 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
     }
   }
   if (sc.num_lights == 0) return fail(ctx, YH_E_INVALID, "scene has no lights (the path sampler needs at least one)");
+  // ---- material colour textures (lookup_texture's per-texel conversion done once, pt.cpp:147-164) --------
+  std::vector<yhd_texture> textures((size_t)std::max(0, sd->num_textures));
+  std::vector<yhd_float4>  tex_texels;
+  {
+    std::vector<char> need_linear(textures.size(), 0);
+    for (int i = 0; i < sd->num_materials; i++) {
+      auto& m = sd->materials[i];
+      for (int id : {m.emission_tex, m.color_tex, m.scattering_tex})
+        if (id < 0 || id > sd->num_textures) return fail(ctx, YH_E_INVALID, "material %d references a missing texture", i);
+      if (m.emission_tex > 0) need_linear[(size_t)m.emission_tex - 1] = 1;  // transmission *= emission_tex.x, linear (pt.cpp:421)
+    }
+    auto srgb_to_rgb = [](float srgb) {  // math.h:3742-3745
+      return (srgb <= 0.04045) ? srgb / 12.92f : std::pow((srgb + 0.055f) / (1.0f + 0.055f), 2.4f);
+    };
+    for (size_t t = 0; t < textures.size(); t++) {
+      auto& src = sd->textures[t];
+      if (src.width <= 0 || src.height <= 0 || !src.pixels) return fail(ctx, YH_E_INVALID, "texture %d is empty", (int)t);
+      size_t n = (size_t)src.width * src.height;
+      auto&  d = textures[t];
+      d.width = src.width, d.height = src.height, d.srgb_base = (int)tex_texels.size(), d.linear_base = -1;
+      tex_texels.resize(tex_texels.size() + n);
+      yhd_float4* out = tex_texels.data() + d.srgb_base;
+      if (src.is_byte) {
+        auto b = (const unsigned char*)src.pixels;
+        parallel_for((int)n, [&](int i) {
+          out[i] = {srgb_to_rgb(b[3 * (size_t)i] / 255.0f), srgb_to_rgb(b[3 * (size_t)i + 1] / 255.0f),
+              srgb_to_rgb(b[3 * (size_t)i + 2] / 255.0f), 0};
+        });
+        if (need_linear[t]) {
+          d.linear_base = (int)tex_texels.size();
+          tex_texels.resize(tex_texels.size() + n);
+          yhd_float4* lin = tex_texels.data() + d.linear_base;
+          parallel_for((int)n, [&](int i) { lin[i] = {b[3 * (size_t)i] / 255.0f, b[3 * (size_t)i + 1] / 255.0f, b[3 * (size_t)i + 2] / 255.0f, 0}; });
+        }
+      } else {
+        auto f = (const float*)src.pixels;
+        parallel_for((int)n, [&](int i) { out[i] = {f[3 * (size_t)i], f[3 * (size_t)i + 1], f[3 * (size_t)i + 2], 0}; });
+        d.linear_base = d.srgb_base;
+      }
+    }
+  }
   lap("objects, materials, lights");
   // ---- upload ------------------------------------------------------------
   int rc;
@@ -620,6 +668,9 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
   if ((rc = upload(ctx, ctx->d_scene_prims, scene_prims_padded.data(), scene_prims_padded.size() * 4))) return rc;
   if ((rc = upload(ctx, ctx->d_light_cdf, light_cdf.data(), light_cdf.size() * 4))) return rc;
   if ((rc = upload(ctx, ctx->d_env_texels, env_texels.data(), env_texels.size() * 16))) return rc;
+  if ((rc = upload(ctx, ctx->d_textures, textures.data(), textures.size() * sizeof(yhd_texture)))) return rc;
+  if ((rc = upload(ctx, ctx->d_tex_texels, tex_texels.data(), tex_texels.size() * 16))) return rc;
+  if ((rc = upload(ctx, ctx->d_vtex, vtex.data(), vtex.size() * 4))) return rc;
   lap("hipMalloc + H2D copies");
   sc.nodes = (const yhd_float4*)ctx->d_nodes.p, sc.prims = (const yhd_float4*)ctx->d_prims.p;
   sc.vpos = (const yhd_float4*)ctx->d_vpos.p;
@@ -628,6 +679,8 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
   sc.scene_nodes = (const yhd_float4*)ctx->d_scene_nodes.p, sc.scene_prims = (const int*)ctx->d_scene_prims.p;
   sc.num_scene_nodes = (int)scene_tree.nodes.size(), sc.num_objects = sd->num_objects;
   sc.light_cdf = (const float*)ctx->d_light_cdf.p, sc.env_texels = (const yhd_float4*)ctx->d_env_texels.p;
+  sc.textures = (const yhd_texture*)ctx->d_textures.p, sc.tex_texels = (const yhd_float4*)ctx->d_tex_texels.p;
+  sc.vtex = (const float*)ctx->d_vtex.p;
   memcpy(sc.camera.frame, sd->camera.frame, 48);
   sc.camera.lens = sd->camera.lens, sc.camera.film_x = sd->camera.film[0], sc.camera.film_y = sd->camera.film[1];
   sc.camera.focus = sd->camera.focus, sc.camera.aperture = sd->camera.aperture;
