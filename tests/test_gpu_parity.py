@@ -385,14 +385,16 @@ def test_work_counters_match_oracle_on_identical_paths(ctx, oracle, yh):
     osc.close(), sf.close()
 
 
-def test_cli_matches_the_library(ctx, yh, tmp_path):
+@pytest.mark.parametrize("name", ["hair-curls", "textured"])
+def test_cli_matches_the_library(ctx, yh, tmp_path, name):
     """yscenetrace (the reference's command line on the C++ mirror of its API) writes the same
-    pixels yh_download returns, in the reference's .pfm layout (top row first, rgb)."""
+    pixels yh_download returns, in the reference's .pfm layout (top row first, rgb) — also for a
+    scene whose materials, textures and texture coordinates go through the mirror's setters."""
     import os
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = os.path.join(root, "yocto-hair_amd", "yscenetrace")
-    scene = scene_path("hair-curls", scale=0.05)
+    scene = scene_path(name, scale=0.05)
     out = str(tmp_path / "cli.pfm")
     r = subprocess.run([exe, scene, "-r", "48", "-s", "6", "-o", out, "--spp-per-launch", "4"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr

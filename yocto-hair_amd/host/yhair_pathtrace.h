@@ -148,9 +148,11 @@ using math::vec3f;
 using math::vec3i;
 using math::vec4f;
 
-struct texture {  // only float RGB textures (environment maps) are on the hair path
+struct vec3b { unsigned char x = 0, y = 0, z = 0; };
+struct texture {  // pt.h:282-287: the colour variants (colorf / colorb); scalar textures are not represented
   int                width = 0, height = 0;
   std::vector<vec3f> colorf;
+  std::vector<vec3b> colorb;
 };
 struct camera {  // pt.h:272-278
   frame3f frame;
@@ -159,8 +161,9 @@ struct camera {  // pt.h:272-278
   float   focus    = 10000;
   float   aperture = 0;
 };
-struct material {  // pt.h:293-329 (textures are not represented)
+struct material {  // pt.h:293-329 (of the textures: emission, colour, scattering)
   vec3f emission = {0, 0, 0}, color = {0, 0, 0};
+  texture *emission_tex = nullptr, *color_tex = nullptr, *scattering_tex = nullptr;
   float specular = 0, roughness = 0, metallic = 0, ior = 1.5f, transmission = 0, opacity = 1;
   bool  thin = false;
   vec3f scattering = {0, 0, 0};
@@ -173,6 +176,7 @@ struct shape {  // pt.h:335-366
   std::vector<vec2i> lines;
   std::vector<vec3i> triangles;
   std::vector<vec3f> positions, normals;
+  std::vector<vec2f> texcoords;
   std::vector<float> radius;
 };
 struct object {
@@ -241,16 +245,20 @@ inline void set_beta_m(material* m, float v) { m->beta_m = v; }
 inline void set_beta_n(material* m, float v) { m->beta_n = v; }
 inline void set_alpha(material* m, float v) { m->alpha = v; }
 inline void set_eta(material* m, float v) { m->eta = v; }
-inline void set_emission(material* m, const vec3f& e) { m->emission = e; }
-inline void set_color(material* m, const vec3f& c) { m->color = c; }
+inline void set_texture(texture* t, int width, int height, const std::vector<vec3b>& img) {
+  t->width = width, t->height = height, t->colorb = img, t->colorf.clear();
+}
+inline void set_emission(material* m, const vec3f& e, texture* tex = nullptr) { m->emission = e, m->emission_tex = tex; }
+inline void set_color(material* m, const vec3f& c, texture* tex = nullptr) { m->color = c, m->color_tex = tex; }
+inline void set_texcoords(shape* s, const std::vector<vec2f>& v) { s->texcoords = v; }
 inline void set_specular(material* m, float v = 1) { m->specular = v; }
 inline void set_ior(material* m, float v) { m->ior = v; }
 inline void set_metallic(material* m, float v) { m->metallic = v; }
 inline void set_transmission(material* m, float t, bool thin, float trdepth) {
   m->transmission = t, m->thin = thin, m->trdepth = trdepth;
 }
-inline void set_scattering(material* m, const vec3f& scattering, float scanisotropy) {
-  m->scattering = scattering, m->scanisotropy = scanisotropy;
+inline void set_scattering(material* m, const vec3f& scattering, float scanisotropy, texture* tex = nullptr) {
+  m->scattering = scattering, m->scanisotropy = scanisotropy, m->scattering_tex = tex;
 }
 inline void set_roughness(material* m, float v) { m->roughness = v; }
 inline void set_opacity(material* m, float v) { m->opacity = v; }
@@ -272,6 +280,23 @@ inline void upload_scene(const scene* sc, const camera* cam) {
   std::vector<yh_material>    materials;
   std::vector<yh_object>      objects;
   std::vector<yh_environment> envs;
+  std::vector<yh_texture>     textures;
+  std::vector<int>            texture_slot(sc->textures.size(), 0);  // 1-based slot in `textures`, 0 = not a material texture
+  auto material_texture = [&](const texture* t) -> int {
+    if (!t) return 0;
+    for (size_t i = 0; i < sc->textures.size(); i++) {
+      if (sc->textures[i].get() != t) continue;
+      if (!texture_slot[i]) {
+        yh_texture o{};
+        o.width = t->width, o.height = t->height, o.is_byte = t->colorf.empty();
+        o.pixels = o.is_byte ? (const void*)t->colorb.data() : (const void*)t->colorf.data();
+        textures.push_back(o);
+        texture_slot[i] = (int)textures.size();
+      }
+      return texture_slot[i];
+    }
+    throw std::runtime_error("yhair: material references a texture that is not in the scene");
+  };
   auto index_of = [](auto& vec, auto* p) {
     for (size_t i = 0; i < vec.size(); i++)
       if (vec[i].get() == p) return (int)i;
@@ -287,6 +312,7 @@ inline void upload_scene(const scene* sc, const camera* cam) {
     o.lines         = s->lines.empty() ? nullptr : (const int*)s->lines.data();
     o.num_triangles = s->lines.empty() ? (int)s->triangles.size() : 0;
     o.triangles     = o.num_triangles ? (const int*)s->triangles.data() : nullptr;
+    o.texcoords     = s->texcoords.size() == s->positions.size() && !s->texcoords.empty() ? (const float*)s->texcoords.data() : nullptr;
     shapes.push_back(o);
   }
   for (auto& m : sc->materials) {
@@ -300,6 +326,8 @@ inline void upload_scene(const scene* sc, const camera* cam) {
     o.eumelanin = m->eumelanin, o.pheomelanin = m->pheomelanin;
     o.scattering[0] = m->scattering.x, o.scattering[1] = m->scattering.y, o.scattering[2] = m->scattering.z;
     o.scanisotropy = m->scanisotropy, o.trdepth = m->trdepth;
+    o.emission_tex = material_texture(m->emission_tex), o.color_tex = material_texture(m->color_tex);
+    o.scattering_tex = material_texture(m->scattering_tex);
     materials.push_back(o);
   }
   for (auto& ob : sc->objects) {
@@ -324,6 +352,7 @@ inline void upload_scene(const scene* sc, const camera* cam) {
   d.num_materials = (int)materials.size(), d.materials = materials.data();
   d.num_objects = (int)objects.size(), d.objects = objects.data();
   d.num_environments = (int)envs.size(), d.environments = envs.data();
+  d.num_textures = (int)textures.size(), d.textures = textures.data();
   if (!cam) throw std::runtime_error("yhair: no camera");
   memcpy(d.camera.frame, &cam->frame, 48);
   d.camera.lens = cam->lens, d.camera.film[0] = cam->film.x, d.camera.film[1] = cam->film.y;

@@ -36,6 +36,23 @@ static ptr::camera* init_scene(ptr::scene* scene, const yh_scene_desc* d) {
   ptr::set_frame(camera, frame_of(d->camera.frame));
   camera->lens = d->camera.lens, camera->film = {d->camera.film[0], d->camera.film[1]};
   ptr::set_focus(camera, d->camera.aperture, d->camera.focus);
+  std::vector<ptr::texture*> textures;  // material colour textures (yh_scene_desc::textures)
+  for (int i = 0; i < d->num_textures; i++) {
+    auto&  t = d->textures[i];
+    auto   o = ptr::add_texture(scene);
+    size_t n = (size_t)t.width * t.height;
+    if (t.is_byte) {
+      std::vector<yhair::pathtrace::vec3b> img(n);
+      memcpy((void*)img.data(), t.pixels, 3 * n);
+      ptr::set_texture(o, t.width, t.height, img);
+    } else {
+      std::vector<vec3f> img(n);
+      memcpy((void*)img.data(), t.pixels, sizeof(float) * 3 * n);
+      ptr::set_texture(o, t.width, t.height, img);
+    }
+    textures.push_back(o);
+  }
+  auto texture_of = [&](int id) { return id > 0 ? textures[(size_t)id - 1] : nullptr; };
   std::vector<ptr::material*> materials;
   for (int i = 0; i < d->num_materials; i++) {
     auto& m = d->materials[i];
@@ -43,11 +60,11 @@ static ptr::camera* init_scene(ptr::scene* scene, const yh_scene_desc* d) {
     ptr::set_eumelanin(o, m.eumelanin), ptr::set_pheomelanin(o, m.pheomelanin);
     ptr::set_sigma_a(o, {m.sigma_a[0], m.sigma_a[1], m.sigma_a[2]});
     ptr::set_beta_m(o, m.beta_m), ptr::set_beta_n(o, m.beta_n), ptr::set_alpha(o, m.alpha), ptr::set_eta(o, m.eta);
-    ptr::set_emission(o, vec3f{m.emission[0], m.emission[1], m.emission[2]});
-    ptr::set_color(o, {m.color[0], m.color[1], m.color[2]});
+    ptr::set_emission(o, vec3f{m.emission[0], m.emission[1], m.emission[2]}, texture_of(m.emission_tex));
+    ptr::set_color(o, {m.color[0], m.color[1], m.color[2]}, texture_of(m.color_tex));
     ptr::set_specular(o, m.specular), ptr::set_ior(o, m.ior), ptr::set_metallic(o, m.metallic);
     ptr::set_transmission(o, m.transmission, m.thin != 0, m.trdepth);
-    ptr::set_scattering(o, {m.scattering[0], m.scattering[1], m.scattering[2]}, m.scanisotropy);
+    ptr::set_scattering(o, {m.scattering[0], m.scattering[1], m.scattering[2]}, m.scanisotropy, texture_of(m.scattering_tex));
     ptr::set_roughness(o, m.roughness), ptr::set_opacity(o, m.opacity), ptr::set_thin(o, m.thin != 0);
     materials.push_back(o);
   }
@@ -63,6 +80,11 @@ static ptr::camera* init_scene(ptr::scene* scene, const yh_scene_desc* d) {
     ptr::set_positions(o, v3(s.positions, s.num_vertices));
     if (s.normals) ptr::set_normals(o, v3(s.normals, s.num_vertices));
     if (s.radius) ptr::set_radius(o, std::vector<float>(s.radius, s.radius + s.num_vertices));
+    if (s.texcoords) {
+      std::vector<yhair::pathtrace::vec2f> tc((size_t)s.num_vertices);
+      memcpy((void*)tc.data(), s.texcoords, sizeof(float) * 2 * (size_t)s.num_vertices);
+      ptr::set_texcoords(o, tc);
+    }
     if (s.num_lines) {
       std::vector<vec2i> l(s.num_lines);
       memcpy(l.data(), s.lines, sizeof(int) * 2 * s.num_lines);
