@@ -31,6 +31,7 @@ GOLDEN_SCENES = [
     ("lobes", dict(scale=0.05), 96),      # specular / metal / delta / transmission / opacity
     ("volumes", dict(scale=0.05), 96),    # refraction into homogeneous media, subsurface walk
     ("sphere-hairblock", dict(scale=0.05, dof=True), 96),  # thin lens (aperture > 0), portrait film
+    ("crowd", dict(scale=0.05), 96),      # 72 objects: deep scene-level BVH, scene table larger than its LDS stage
     ("textured", dict(scale=0.05), 96),   # colour textures: color_tex / emission_tex / scattering_tex, png + hdr, tiling
 ]
 
@@ -178,13 +179,13 @@ def scenes_only(ref, rng, want):
         tag = os.path.basename(os.path.dirname(path))
         if not want("scene_" + tag):
             continue
-        if name in ("lobes", "volumes", "textured"):
+        if name in ("lobes", "volumes", "textured", "crowd"):
             rng = np.random.default_rng(20240609)
         if kw.get("dof"):
             rng = np.random.default_rng(20240611)
         sc = ref.scene(path)
         m = 4096
-        if name in ("lobes", "volumes", "textured"):
+        if name in ("lobes", "volumes", "textured", "crowd"):
             org = rng.uniform(-1, 1, (m, 3)) * [3, 1.2, 1] + [0.2, 2.0, 4.5]
             tgt = rng.uniform(-1, 1, (m, 3)) * [2.4, 0.6, 1.2] + [0.3, 0.4, 0]
         elif name == "sphere-hairblock":

@@ -75,6 +75,7 @@ GOLDEN_SCENES = [
     ("volumes", dict(scale=0.05)),
     ("sphere-hairblock", dict(scale=0.05, dof=True)),
     ("textured", dict(scale=0.05)),
+    ("crowd", dict(scale=0.05)),
 ]
 
 

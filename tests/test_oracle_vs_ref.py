@@ -82,6 +82,7 @@ def test_selftests_match_reference(oracle, ref):
     ("volumes", dict(scale=0.1), 160, 8),
     ("sphere-hairblock", dict(scale=0.1, dof=True), 120, 4),
     ("textured", dict(scale=0.1), 160, 8),
+    ("crowd", dict(scale=0.1), 128, 4),
 ])
 def test_images_bit_identical_to_reference(oracle, ref, yh, name, kw, res, spp):
     path = scene_path(name, **kw)

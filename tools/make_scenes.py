@@ -317,6 +317,46 @@ def make_textured(outdir, scale=1.0, name="textured"):
     return os.path.join(d, name + ".json"), nseg
 
 
+def make_crowd(outdir, scale=1.0, name="crowd", count=70):
+    """Many objects: a scene-level BVH several levels deep (the BASELINE configs have at most six
+    objects) and more objects than the kernel stages in LDS, so the in-memory fallback of the scene
+    level runs. `count` small spheres of four materials on a jittered grid around the hair block."""
+    d = _prep(outdir, name)
+    shutil.copy(os.path.join(ASSETS, "sphere.ply"), os.path.join(d, "shapes", "sphere.ply"))
+    shutil.copy(os.path.join(ASSETS, "arealight.ply"), os.path.join(d, "shapes", "arealight.ply"))
+    nseg = write_hair_ply(os.path.join(d, "shapes", "hair-block.ply"),
+                          gen_hair_block(max(64, int(100_000 * scale))), 0.004, 0.001)
+    rng = np.random.default_rng(11)
+    objects = {
+        "hairblock": {"frame": [1, 0, 0, 0, 0, 1, 0, -1, 0, 0.0, 1, -0.5], "shape": "hair-block", "material": "hair"},
+        "light": {"lookat": [0.3, 6, 2, 0.3, 0.5, 0, 0, 1, 0], "shape": "arealight", "material": "arealight"},
+    }
+    mats = ["red", "gold", "glass", "veil"]
+    side = int(np.ceil(np.sqrt(count)))
+    for k in range(count):
+        x = -3.0 + 6.0 * (k % side) / max(1, side - 1) + rng.uniform(-0.1, 0.1)
+        z = -2.5 + 5.0 * (k // side) / max(1, side - 1) + rng.uniform(-0.1, 0.1)
+        sz = float(rng.uniform(0.15, 0.3))
+        a = float(rng.uniform(0, 2 * np.pi))
+        c, sn = float(np.cos(a)) * sz, float(np.sin(a)) * sz  # rotated about y and scaled: a non-trivial inverse frame
+        objects["ball%03d" % k] = {"frame": [c, 0, -sn, 0, sz, 0, sn, 0, c, float(x), 0.0, float(z)], "shape": "sphere",
+                                   "material": mats[k % len(mats)]}
+    materials = {"hair": {"eumelanin": 1.3}, "arealight": {"emission": [15, 15, 15]},
+                 "red": {"color": [0.8, 0.2, 0.2]}, "gold": {"color": [0.9, 0.7, 0.3], "metallic": 1.0, "roughness": 0.25},
+                 "glass": {"color": [0.95, 0.97, 1.0], "specular": 1.0, "transmission": 1.0, "thin": False, "roughness": 0.0,
+                           "trdepth": 0.3},
+                 "veil": {"color": [0.2, 0.7, 0.3], "opacity": 0.6}}
+    scene = {
+        "asset": {"copyright": "synthetic; sphere and quad from the reference's test assets"},
+        "cameras": {"default": {"lens": 0.035, "aperture": 0.0, "aspect": 1.0, "lookat": [0.5, 3.5, 7.0, 0.0, 0.3, 0, 0, 1, 0]}},
+        "environments": {"sky": {"emission": [0.6, 0.6, 0.6]}},
+        "objects": objects,
+        "materials": materials,
+    }
+    _dump(scene, os.path.join(d, name + ".json"))
+    return os.path.join(d, name + ".json"), nseg
+
+
 def _head_scene(outdir, name, shape, pos, emission, lights, hair_mat):
     d = _prep(outdir, name)
     shutil.copy(os.path.join(ASSETS, "sky.hdr"), os.path.join(d, "textures", "sky.hdr"))
@@ -392,6 +432,7 @@ MAKERS = {
     "lobes": make_lobes,
     "volumes": make_volumes,
     "textured": make_textured,
+    "crowd": make_crowd,
 }
 
 
