@@ -125,6 +125,23 @@ YH_DEV bool intersect_bbox(f3 ro, f3 dinv, float tmin_, float tmax_, f3 bmin, f3
   return t0 <= t1;
 }
 
+// The same test when no operand can be a NaN (finite ray origin and finite 1 / d, i.e. no zero
+// direction component: 0 * inf is the only way the slabs produce one). Then `(a < b) ? a : b` and
+// the hardware's min / max pick the same value up to the sign of a zero, which no later
+// comparison distinguishes, and the test is 3 + 3 min / max and two 3-input min / max instead of a
+// dozen compare + select pairs. Callers choose it with a WAVE-UNIFORM condition (a per-lane select
+// makes the compiler evaluate both forms).
+YH_DEV bool intersect_bbox_nonan(f3 ro, f3 dinv, float tmin_, float tmax_, f3 bmin, f3 bmax) {
+  f3    it_min = (bmin - ro) * dinv;
+  f3    it_max = (bmax - ro) * dinv;
+  float t0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(it_min.x, it_max.x), __builtin_fminf(it_min.y, it_max.y)),
+      __builtin_fmaxf(__builtin_fminf(it_min.z, it_max.z), tmin_));
+  float t1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(it_min.x, it_max.x), __builtin_fmaxf(it_min.y, it_max.y)),
+      __builtin_fminf(__builtin_fmaxf(it_min.z, it_max.z), tmax_));
+  t1 *= 1.00000024f;
+  return t0 <= t1;
+}
+
 // ---------------------------------------------------------------------------
 // Traversal
 // ---------------------------------------------------------------------------
@@ -194,8 +211,13 @@ YH_DEV void count_quad(unsigned int& slot) {
 // identically. One leaf step = one primitive test per lane, then the
 // reference's sequential accept rule (math.h:3450: reject only t > tmax, so
 // among equal t the LATER primitive wins) applied as a quad reduction.
-template <bool COUNT, int STRIDE>
-YH_DEV hit_t trace_ray(const trace_ctx& tc, const ray_t& ray, int first_object, unsigned int* steps_out = nullptr) {
+// EXACT = false: box tests use intersect_bbox_nonan; a lane whose ray could put a NaN into a slab
+// (non-finite origin or 1 / d, in world space or in the space of an object it enters) stops and
+// reports `redo`, and trace_ray repeats that ray with EXACT = true, the reference's compare +
+// select form throughout. Results are identical either way; only axis-parallel rays take the
+// second pass.
+template <bool COUNT, int STRIDE, bool EXACT>
+YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_object, unsigned int* steps_out, bool& redo) {
   const yhd_scene&     sc   = *tc.sc;
   const unsigned int   q    = __lane_id() & 3u;
   int                  sp   = 0;
@@ -208,13 +230,21 @@ YH_DEV hit_t trace_ray(const trace_ctx& tc, const ray_t& ray, int first_object, 
   // world-space ray data for the scene level
   f3  wdinv = {1 / ray.d.x, 1 / ray.d.y, 1 / ray.d.z};
   int wsign = (wdinv.x < 0 ? 1 : 0) | (wdinv.y < 0 ? 2 : 0) | (wdinv.z < 0 ? 4 : 0);
+  const bool wnonan = finite3(wdinv) && finite3(ray.o);
+  auto box_test = [](f3 o, f3 dinv, float t0, float t1, f3 bmin, f3 bmax) {
+    return EXACT ? intersect_bbox(o, dinv, t0, t1, bmin, bmax) : intersect_bbox_nonan(o, dinv, t0, t1, bmin, bmax);
+  };
+  if (!EXACT && !wnonan) {
+    redo = true;
+    return hit;
+  }
   // instance-space ray data
   f3  lo = ray.o, ld = ray.d, ldinv = wdinv;
   int lsign = wsign, cur_obj = -1, kind = 0, node_base = 0, prim_base = 0;
   unsigned long long n_nodes = 0, n_seg = 0, n_tri = 0;
   unsigned int       n_steps = 0;
 
-  const YH_LDS v4f* lds_snodes = tc.lds_scene ? tc.lds_scene + 8 * sc.num_objects : nullptr;
+  const YH_LDS v4f* lds_snodes = tc.lds_scene ? tc.lds_scene + YH_OBJECT_F4 * sc.num_objects : nullptr;
   auto scene_prim = [&](int i) -> int {
     if (tc.lds_scene) return ((const YH_LDS int*)(lds_snodes + 2 * sc.num_scene_nodes))[i];
     return sc.scene_prims[i];
@@ -251,7 +281,7 @@ YH_DEV hit_t trace_ray(const trace_ctx& tc, const ray_t& ray, int first_object, 
       else n0 = ldg4(sc.scene_nodes + 2 * idx), n1 = ldg4(sc.scene_nodes + 2 * idx + 1);
       if (q == 0) n_nodes++;
       cur = YH_NONE;
-      if (intersect_bbox(ray.o, wdinv, ray.tmin, tmax, xyz(n0), xyz(n1))) {
+      if (box_test(ray.o, wdinv, ray.tmin, tmax, xyz(n0), xyz(n1))) {
         int start = __float_as_int(n0.w), meta = __float_as_int(n1.w);
         if (meta & 0x10000) {  // internal
           int axis = (meta >> 24) & 3;
@@ -271,9 +301,27 @@ YH_DEV hit_t trace_ray(const trace_ctx& tc, const ray_t& ray, int first_object, 
       // transform_ray(inverse(object.frame, true), ray) (pt.cpp:1012-1013)
       if (COUNT) count_branch<COUNT>(tc.stats->t_enter, tc.stats->l_enter);
       cur_obj             = (int)(cur & ~YH_TAG_MASK);
+      // A ray that misses the object's padded world box cannot hit anything in it: the reference
+      // would enter, test the shape's root box in object space and leave (pt.cpp:1012-1016); the
+      // result is the same without the inverse transform, the three divisions and the root fetch.
+      // Skipped for axis-parallel rays (a 0 * inf slab would make the test inconclusive).
+      if (wnonan) {
+        v4f bmin, bmax;
+        if (tc.lds_scene) {
+          const YH_LDS v4f* ob = tc.lds_scene + YH_OBJECT_F4 * cur_obj;
+          bmin = ob[8], bmax = ob[9];
+        } else {
+          const yhd_object& o = sc.objects[cur_obj];
+          bmin = v4f{o.wbox_min[0], o.wbox_min[1], o.wbox_min[2], 0}, bmax = v4f{o.wbox_max[0], o.wbox_max[1], o.wbox_max[2], 0};
+        }
+        if (!box_test(ray.o, wdinv, ray.tmin, tmax, xyz(bmin), xyz(bmax))) {
+          cur = YH_NONE;
+          continue;
+        }
+      }
       frame inv;
-      if (tc.lds_scene) {  // yhd_object: frame[12] inv_frame[12] kind node_base prim_base ... (8 float4)
-        const YH_LDS v4f* ob = tc.lds_scene + 8 * cur_obj;
+      if (tc.lds_scene) {  // yhd_object: frame[12] inv_frame[12] kind node_base prim_base ... (10 float4)
+        const YH_LDS v4f* ob = tc.lds_scene + YH_OBJECT_F4 * cur_obj;
         v4f a = ob[3], b = ob[4], c = ob[5], d = ob[6];
         inv.x = {a.x, a.y, a.z}, inv.y = {a.w, b.x, b.y}, inv.z = {b.z, b.w, c.x}, inv.o = {c.y, c.z, c.w};
         kind = __float_as_int(d.x), node_base = __float_as_int(d.y), prim_base = __float_as_int(d.z);
@@ -286,6 +334,10 @@ YH_DEV hit_t trace_ray(const trace_ctx& tc, const ray_t& ray, int first_object, 
       ld    = transform_vector(inv, ray.d);
       ldinv = {1 / ld.x, 1 / ld.y, 1 / ld.z};
       lsign = (ldinv.x < 0 ? 1 : 0) | (ldinv.y < 0 ? 2 : 0) | (ldinv.z < 0 ? 4 : 0);
+      if (!EXACT && !(finite3(ldinv) && finite3(lo))) {  // a slab of this object could hold a NaN: second pass
+        redo = true;
+        break;
+      }
       cur = YH_TAG_SHAPE | (unsigned)node_base;  // shape root: fetched in this same iteration
       tag = YH_TAG_SHAPE;
     }
@@ -320,7 +372,7 @@ YH_DEV hit_t trace_ray(const trace_ctx& tc, const ray_t& ray, int first_object, 
         // ---- wide node: lane q tests slot q {min.xyz, max.x} {max.yz, ref, axes} ----
         if (q == 0) n_nodes++;
         if (COUNT) count_branch<COUNT>(tc.stats->t_node, tc.stats->l_node);
-        bool         h    = intersect_bbox(lo, ldinv, ray.tmin, tmax, f3{s0.x, s0.y, s0.z}, f3{s0.w, s1.x, s1.y});
+        bool h = box_test(lo, ldinv, ray.tmin, tmax, f3{s0.x, s0.y, s0.z}, f3{s0.w, s1.x, s1.y});
         unsigned int ref  = __float_as_uint(s1.z);
         unsigned int axes = __float_as_uint(s1.w);
         h = h && ref != YH_NONE;  // an empty slot's inverted box still passes the min/max slab test
@@ -392,6 +444,16 @@ YH_DEV hit_t trace_ray(const trace_ctx& tc, const ray_t& ray, int first_object, 
   if (COUNT) {
     if (steps_out) *steps_out = n_steps;
     tc.stats->nodes += (unsigned int)n_nodes, tc.stats->seg += (unsigned int)n_seg, tc.stats->tri += (unsigned int)n_tri;
+  }
+  return hit;
+}
+
+template <bool COUNT, int STRIDE>
+YH_DEV hit_t trace_ray(const trace_ctx& tc, const ray_t& ray, int first_object, unsigned int* steps_out = nullptr) {
+  bool  redo = false;
+  hit_t hit  = trace_ray_loop<COUNT, STRIDE, false>(tc, ray, first_object, steps_out, redo);
+  if (__any(redo)) {
+    if (redo) hit = trace_ray_loop<COUNT, STRIDE, true>(tc, ray, first_object, steps_out, redo);
   }
   return hit;
 }

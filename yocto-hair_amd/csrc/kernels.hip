@@ -61,7 +61,7 @@ __global__ __launch_bounds__(YH_BLOCK, YH_MIN_WAVES) void k_trace(const yhd_scen
   tc.lds_scene = nullptr;
   if (sc.lds_scene_f4 > 0) {
     // the scene level (a handful of objects and BVH nodes) lives in LDS: its steps need no memory round trip
-    const int nobj = 8 * sc.num_objects, nnod = 2 * sc.num_scene_nodes, npri = (sc.num_objects + 3) / 4;
+    const int nobj = YH_OBJECT_F4 * sc.num_objects, nnod = 2 * sc.num_scene_nodes, npri = (sc.num_objects + 3) / 4;
     const v4f* gobj = (const v4f*)sc.objects;
     const v4f* gpri = (const v4f*)sc.scene_prims;  // padded to a multiple of 4 ints by the host
     for (int i = threadIdx.x; i < nobj; i += blockDim.x) lds_scene[i] = gobj[i];

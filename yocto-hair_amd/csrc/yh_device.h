@@ -44,7 +44,12 @@ typedef struct yhd_object {
   int   has_normals;
   int   material;
   int   has_texcoords;  // the shape has per-vertex texture coordinates (else texcoord = element uv)
+  // world-space box of the object (transform_bbox of the shape's root box, pt.cpp:806) grown by a
+  // safety margin: a ray that misses it by that much cannot hit anything in the object, so ENTER
+  // and the root fetch are skipped for it (dev_trace.h)
+  float wbox_min[4], wbox_max[4];
 } yhd_object;
+#define YH_OBJECT_F4 10 /* sizeof(yhd_object) / 16 */
 
 // ptr::material + everything of hair_brdf that depends on the material only
 // (ext.cpp:131-172), computed ONCE on the host at upload.

@@ -541,6 +541,12 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
       for (int k = 0; k < 3; k++) lo[k] = fmin_(lo[k], tv[k]), hi[k] = fmax_(hi[k], tv[k]);
     }
     for (int k = 0; k < 3; k++) obj_boxes[oi].min[k] = lo[k], obj_boxes[oi].max[k] = hi[k];
+    {  // the same box with a margin a thousand times the rounding of either box test
+      float ext = fmax_(fmax_(hi[0] - lo[0], hi[1] - lo[1]), hi[2] - lo[2]);
+      float eps = 1e-3f * ext + 1e-5f;
+      for (int k = 0; k < 3; k++) d.wbox_min[k] = lo[k] - eps, d.wbox_max[k] = hi[k] + eps;
+      d.wbox_min[3] = d.wbox_max[3] = 0;
+    }
   }
   yhh::Tree scene_tree;
   yhh::build_bvh(scene_tree, obj_boxes);
@@ -688,7 +694,8 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
   // nodelets: the top (breadth-first prefix) of the largest hair shape's BVH
   sc.general_materials = general_materials;
   {  // scene-level LDS table: objects (8 float4 each), scene BVH nodes (2 float4 each), primitive ids
-    int f4 = 8 * sd->num_objects + 2 * (int)scene_tree.nodes.size() + (sd->num_objects + 3) / 4;
+    static_assert(sizeof(yhd_object) == 16 * YH_OBJECT_F4, "yhd_object is staged to LDS as float4");
+    int f4 = YH_OBJECT_F4 * sd->num_objects + 2 * (int)scene_tree.nodes.size() + (sd->num_objects + 3) / 4;
     sc.lds_scene_f4 = f4 * 16 <= 8192 ? f4 : 0;
   }
   sc.lds_node_base = 0, sc.lds_node_count = 0;
