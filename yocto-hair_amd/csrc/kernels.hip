@@ -43,15 +43,18 @@ using namespace yhd;
 #define YH_QUADS (YH_BLOCK / 4)
 // GENERAL = the scene has materials with lobes beyond diffuse / hair (dev_surface.h); scenes
 // without them (all BASELINE configs) run the variant that does not carry that code.
-template <bool COUNT, bool GENERAL>
-__global__ __launch_bounds__(YH_BLOCK, YH_MIN_WAVES) void k_trace(const yhd_scene sc, const yhd_state st,
+// BLOCK x WAVES = the launch shape: 512 threads at 4 waves per SIMD (128 VGPRs) when the launch is
+// bound by a few expensive pixels (C1), 256 threads at 5 waves per SIMD (96 VGPRs, more spills but
+// more latency hiding) when every pixel is expensive (dense hair: +5-10 %, profiles/r01); the host picks.
+template <bool COUNT, bool GENERAL, int BLOCK, int WAVES>
+__global__ __launch_bounds__(BLOCK, WAVES) void k_trace(const yhd_scene sc, const yhd_state st,
     int nsamples, yhd_counters* counters) {
   extern __shared__ v4f lds_dyn[];
-  // LDS carve-out: [nodelets: 8 * lds_node_count float4][stacks: YH_QSTACK x YH_QUADS uint]
+  // LDS carve-out: [nodelets: 8 * lds_node_count float4][stacks: YH_QSTACK x (BLOCK / 4) uint]
   //                [scene table: objects | scene BVH nodes | scene BVH primitives] (lds_scene_f4 float4)
   YH_LDS v4f*          lds_nodes = (YH_LDS v4f*)lds_dyn;
   YH_LDS unsigned int* lds_stack = (YH_LDS unsigned int*)(lds_nodes + 8 * sc.lds_node_count);
-  YH_LDS v4f*          lds_scene = (YH_LDS v4f*)(lds_stack + YH_QSTACK * YH_QUADS);
+  YH_LDS v4f*          lds_scene = (YH_LDS v4f*)(lds_stack + YH_QSTACK * (BLOCK / 4));
   // stage the nodelets: the first lds_node_count wide nodes (breadth-first =
   // top levels) of the dominant hair shape, 128 B each, coalesced dwordx4 loads
   for (int i = threadIdx.x; i < 8 * sc.lds_node_count; i += blockDim.x)
@@ -113,7 +116,7 @@ __global__ __launch_bounds__(YH_BLOCK, YH_MIN_WAVES) void k_trace(const yhd_scen
       hit_t isec;
       if (alive) {
         if (COUNT) count_quad<COUNT>(stats.rays);
-        isec = trace_ray<COUNT, YH_QUADS>(tc, ps.ray, -1, &steps);
+        isec = trace_ray<COUNT, (BLOCK / 4)>(tc, ps.ray, -1, &steps);
       }
       if (COUNT) {
         c1 = clock64(), cyc_trace += c1 - c0;
@@ -122,7 +125,7 @@ __global__ __launch_bounds__(YH_BLOCK, YH_MIN_WAVES) void k_trace(const yhd_scen
         w_steps += smax, l_steps += (lane & 3) == 0 ? steps : 0;
       }
       if (alive) {
-        alive = path_step<COUNT, YH_QUADS, GENERAL>(tc, ps, isec, rng, st.bounces);
+        alive = path_step<COUNT, (BLOCK / 4), GENERAL>(tc, ps, isec, rng, st.bounces);
         if (!alive) {
           path_end(ps, st.clamp, acc);
           if (COUNT) count_quad<COUNT>(stats.samples);
@@ -556,34 +559,43 @@ __global__ void k_curves_to_lines(int n, const float* P, const float* width0, co
 extern "C" {
 
 typedef void (*trace_kernel_t)(const yhd_scene, const yhd_state, int, yhd_counters*);
-static trace_kernel_t trace_kernel(bool counted, bool general) {
-  return counted ? (general ? k_trace<true, true> : k_trace<true, false>)
-                 : (general ? k_trace<false, true> : k_trace<false, false>);
+// shape 0 = 512 threads x 4 waves per SIMD, shape 1 = 256 threads x 5 waves per SIMD
+static int shape_block(int shape) { return shape ? 256 : YH_BLOCK; }
+static trace_kernel_t trace_kernel(bool counted, bool general, int shape) {
+  if (shape)
+    return counted ? (general ? k_trace<true, true, 256, 5> : k_trace<true, false, 256, 5>)
+                   : (general ? k_trace<false, true, 256, 5> : k_trace<false, false, 256, 5>);
+  return counted ? (general ? k_trace<true, true, YH_BLOCK, YH_MIN_WAVES> : k_trace<true, false, YH_BLOCK, YH_MIN_WAVES>)
+                 : (general ? k_trace<false, true, YH_BLOCK, YH_MIN_WAVES> : k_trace<false, false, YH_BLOCK, YH_MIN_WAVES>);
+}
+static size_t trace_lds(int lds_node_count, int lds_scene_f4, int shape) {
+  return (size_t)lds_node_count * 128 + (size_t)YH_QSTACK * (shape_block(shape) / 4) * 4 + (size_t)lds_scene_f4 * 16;
 }
 int yhk_trace(const yhd_scene* sc, const yhd_state* st, int nsamples, yhd_counters* counters,
     int grid_blocks, hipStream_t stream) {
-  size_t lds = (size_t)sc->lds_node_count * 128 + (size_t)YH_QSTACK * YH_QUADS * 4 + (size_t)sc->lds_scene_f4 * 16;
-  static size_t lds_set[4] = {0, 0, 0, 0};
-  int            which = (counters ? 1 : 0) + (sc->general_materials ? 2 : 0);
-  trace_kernel_t k     = trace_kernel(counters != nullptr, sc->general_materials != 0);
+  const int shape = st->launch_shape ? 1 : 0;
+  size_t    lds   = trace_lds(sc->lds_node_count, sc->lds_scene_f4, shape);
+  static size_t lds_set[8] = {0};
+  int            which = (counters ? 1 : 0) + (sc->general_materials ? 2 : 0) + 4 * shape;
+  trace_kernel_t k     = trace_kernel(counters != nullptr, sc->general_materials != 0, shape);
   if (lds > lds_set[which]) {  // above 64 KB the dynamic-LDS limit must be raised explicitly
     hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     lds_set[which] = lds;
   }
-  hipLaunchKernelGGL(k, dim3(grid_blocks), dim3(YH_BLOCK), lds, stream, *sc, *st, nsamples, counters);
+  hipLaunchKernelGGL(k, dim3(grid_blocks), dim3(shape_block(shape)), lds, stream, *sc, *st, nsamples, counters);
   return (int)hipGetLastError();
 }
-int yhk_block_threads(void) { return YH_BLOCK; }
+int yhk_block_threads(int shape) { return shape_block(shape ? 1 : 0); }
 int yhk_stack_entries(void) { return YH_QSTACK; }
-int yhk_trace_lds_bytes(int lds_node_count, int lds_scene_f4) {
-  return lds_node_count * 128 + YH_QSTACK * YH_QUADS * 4 + lds_scene_f4 * 16;
+int yhk_trace_lds_bytes(int lds_node_count, int lds_scene_f4, int shape) {
+  return (int)trace_lds(lds_node_count, lds_scene_f4, shape ? 1 : 0);
 }
-int yhk_trace_occupancy(int lds_bytes, int general) {
+int yhk_trace_occupancy(int lds_bytes, int general, int shape) {
   int            blocks = 0;
-  trace_kernel_t k      = trace_kernel(false, general != 0);
+  trace_kernel_t k      = trace_kernel(false, general != 0, shape ? 1 : 0);
   (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k, YH_BLOCK, lds_bytes) != hipSuccess) return 1;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k, shape_block(shape ? 1 : 0), lds_bytes) != hipSuccess) return 1;
   return blocks < 1 ? 1 : blocks;
 }
 int yhk_resolve(const yhd_state* st, int owned_tiles, int samples, void* image, hipStream_t stream) {

@@ -32,9 +32,9 @@
 // launchers in csrc/kernels.hip
 extern "C" {
 int yhk_trace(const yhd_scene*, const yhd_state*, int, yhd_counters*, int, hipStream_t);
-int yhk_block_threads(void);
-int yhk_trace_occupancy(int lds_bytes, int general);
-int yhk_trace_lds_bytes(int lds_node_count, int lds_scene_f4);
+int yhk_block_threads(int shape);
+int yhk_trace_occupancy(int lds_bytes, int general, int shape);
+int yhk_trace_lds_bytes(int lds_node_count, int lds_scene_f4, int shape);
 int yhk_stack_entries(void);
 int yhk_resolve(const yhd_state*, int, int, void*, hipStream_t);
 int yhk_pack(const yhd_state*, int, int, void*, hipStream_t);
@@ -316,10 +316,32 @@ int tiles_of(int n) { return (n + YH_TILE - 1) / YH_TILE; }
 // Work items (yh_device.h: yhd_state::tiles) for the owned tiles with their
 // current split modes, most expensive first.
 void build_work_items(const yh_context* ctx, std::vector<int>& items);
+int  choose_launch_shape(const yh_context* ctx);
 
 }  // namespace
 
 namespace {
+// Launch shape for the next launch (kernels.hip: k_trace's BLOCK x WAVES). When every pixel is
+// expensive the kernel is latency-bound and a fifth wave per SIMD pays for its extra spills
+// (C2 +6 %, C3 +10 %, C4 +5 %); when a few expensive pixels bound the launch (C1: the hair covers
+// 11 % of the frame and barely fills the resident waves) it costs 11 %. Measure: the number of
+// max-cost work items the last launch was worth (sum of item costs over the largest) against the
+// resident wave slots — measured 3 066 (C1), 4 777 (C4), 8 989 (C2), 24 970 (C3) against 4 096: with
+// fewer expensive items than slots every wave that can run already does. YHAIR_SHAPE=0|1 overrides.
+int choose_launch_shape(const yh_context* ctx) {
+  if (const char* env = getenv("YHAIR_SHAPE")) return atoi(env) ? 1 : 0;
+  uint64_t sum = 0, mx = 0;
+  for (int t : ctx->owned)
+    for (int p = 0; p < 4; p++) {
+      uint64_t c = ctx->item_cost[(size_t)t * 4 + p];
+      sum += c, mx = std::max(mx, c);
+    }
+  if (mx == 0) return 0;  // nothing measured yet
+  int    lds      = yhk_trace_lds_bytes(ctx->scene.lds_node_count, ctx->scene.lds_scene_f4, 0);
+  double resident = (double)ctx->num_cus * yhk_trace_occupancy(lds, ctx->scene.general_materials, 0) * (yhk_block_threads(0) / 64);
+  if (getenv("YHAIR_TIMING")) fprintf(stderr, "[yhair] launch shape: worth %.0f items, resident waves %.0f\n", (double)sum / (double)mx, resident);
+  return (double)sum / (double)mx >= resident ? 1 : 0;
+}
 void build_work_items(const yh_context* ctx, std::vector<int>& items) {
   // Expensive items first, in decreasing cost (they bound the launch); the cheap
   // majority (background quadrants, within 8x of the median) follows unsorted:
@@ -768,6 +790,7 @@ int yh_init_state(yh_context* ctx, const yh_trace_params* params) {
   s.tile_cursor = (int*)ctx->d_tile_cursor.p, s.tile_cost = (unsigned int*)ctx->d_tile_cost.p;
   s.rng_state = (uint64_t*)ctx->d_rng_state.p, s.rng_inc = (uint64_t*)ctx->d_rng_inc.p;
   s.accum = (yhd_float4*)ctx->d_accum.p, s.tiles = (const int*)ctx->d_tiles.p;
+  s.launch_shape = choose_launch_shape(ctx);
   s.num_tiles = (int)tiles.size(), s.width = w, s.height = h, s.tiles_x = tx;
   s.samples_done = 0, s.bounces = params->bounces, s.clamp = params->clamp;
   s.shard_rank = ctx->rank, s.shard_world = ctx->world;
@@ -792,9 +815,10 @@ static int trace_impl(yh_context* ctx, int nsamples, bool counted, bool sync) {
     ctx->last_ms = 0, ctx->last_launches = 0;
     return YH_OK;
   }
-  int waves_per_block = yhk_block_threads() / 64;  // one work item per wave at a time
-  int lds_bytes       = yhk_trace_lds_bytes(ctx->scene.lds_node_count, ctx->scene.lds_scene_f4);
-  int resident        = ctx->num_cus * yhk_trace_occupancy(lds_bytes, ctx->scene.general_materials);
+  const int shape     = ctx->state.launch_shape;
+  int waves_per_block = yhk_block_threads(shape) / 64;  // one work item per wave at a time
+  int lds_bytes       = yhk_trace_lds_bytes(ctx->scene.lds_node_count, ctx->scene.lds_scene_f4, shape);
+  int resident        = ctx->num_cus * yhk_trace_occupancy(lds_bytes, ctx->scene.general_materials, shape);
   int want            = (ctx->state.num_tiles + waves_per_block - 1) / waves_per_block;
   int grid            = std::max(1, std::min(want, resident));
   HIPCHK(ctx, hipMemsetAsync(ctx->d_tile_cursor.p, 0, 4, ctx->stream));
@@ -816,6 +840,7 @@ static int trace_impl(yh_context* ctx, int nsamples, bool counted, bool sync) {
     std::vector<int> tiles;
     build_work_items(ctx, tiles);
     HIPCHK(ctx, hipMemcpy(ctx->d_tiles.p, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice));
+    ctx->state.launch_shape = choose_launch_shape(ctx);
   }
   return YH_OK;
 }
