@@ -22,7 +22,7 @@ for d in sorted(glob.glob(out + "/p*/")):
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         acc, cnt = collections.defaultdict(float), collections.defaultdict(set)
         for r in csv.DictReader(open(f)):
-            if "k_trace<false" not in r["Kernel_Name"] and "k_traceILb0" not in r["Kernel_Name"]:
+            if "k_trace<false, false, 512, 4>" not in r["Kernel_Name"]:  # the bench's (C1's) variant only
                 continue
             acc[r["Counter_Name"]] += float(r["Counter_Value"])
             cnt[r["Counter_Name"]].add(r["Dispatch_Id"])

@@ -258,6 +258,7 @@ struct yh_context {
   int              num_tiles_total = 0;
   float            last_ms = 0;
   int              last_launches = 0;
+  int              launch_shape = 0;  // decided from launches of at least 16 spp (shorter ones have flat, noisy item costs)
 };
 
 namespace {
@@ -730,6 +731,8 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
   ctx->scene      = sc;
   ctx->have_scene = true;
   ctx->have_state = false;
+  ctx->launch_shape = 0;  // a new scene: no measured costs yet
+  ctx->item_cost.clear();
   return YH_OK;
 }
 
@@ -790,7 +793,7 @@ int yh_init_state(yh_context* ctx, const yh_trace_params* params) {
   s.tile_cursor = (int*)ctx->d_tile_cursor.p, s.tile_cost = (unsigned int*)ctx->d_tile_cost.p;
   s.rng_state = (uint64_t*)ctx->d_rng_state.p, s.rng_inc = (uint64_t*)ctx->d_rng_inc.p;
   s.accum = (yhd_float4*)ctx->d_accum.p, s.tiles = (const int*)ctx->d_tiles.p;
-  s.launch_shape = choose_launch_shape(ctx);
+  s.launch_shape = getenv("YHAIR_SHAPE") ? choose_launch_shape(ctx) : ctx->launch_shape;
   s.num_tiles = (int)tiles.size(), s.width = w, s.height = h, s.tiles_x = tx;
   s.samples_done = 0, s.bounces = params->bounces, s.clamp = params->clamp;
   s.shard_rank = ctx->rank, s.shard_world = ctx->world;
@@ -840,7 +843,8 @@ static int trace_impl(yh_context* ctx, int nsamples, bool counted, bool sync) {
     std::vector<int> tiles;
     build_work_items(ctx, tiles);
     HIPCHK(ctx, hipMemcpy(ctx->d_tiles.p, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice));
-    ctx->state.launch_shape = choose_launch_shape(ctx);
+    if (nsamples >= 16 || getenv("YHAIR_SHAPE")) ctx->launch_shape = choose_launch_shape(ctx);
+    ctx->state.launch_shape = ctx->launch_shape;
   }
   return YH_OK;
 }
