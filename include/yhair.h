@@ -306,6 +306,11 @@ int yh_curves_to_lines(yh_context* ctx, int n, const float* P, const float* widt
  * ints (leaf order). Needs no GPU and no context. Returns the node count.     */
 int yh_bvh_build(int n, const float* boxes, float* nodes, int* primitives);
 
+/* The same tree built on the GPU (csrc/bvh_gpu.hip; what yh_upload_scene uses for
+ * shapes of 32 768 primitives and more). Same arguments and result as yh_bvh_build;
+ * the two are compared node for node in the tests.                            */
+int yh_bvh_build_gpu(yh_context* ctx, int n, const float* boxes, float* nodes, int* primitives);
+
 /* One surface lobe (kind = YH_LOBE_*) of yocto_math.h:1513-1620 (implementation
  * 4427-4755): eval_* (value times |cos|), sample_*_pdf and sample_* in one
  * call. params: 8n (ior, roughness [= brdf.roughness, already squared], eta[3],

@@ -183,6 +183,37 @@ def test_curve_conversion_bit_exact_on_device(ctx, yh, tmp_path):
     assert np.array_equal(lrec[:, 1:].copy().view(np.int32), g["lines"][: 4 * n] - int(g["base_vertex"]))
 
 
+@pytest.mark.parametrize("name,kw", [("sphere-hairblock", dict(scale=1.0)), ("hair-curls", dict(scale=0.05)),
+                                     ("curly-hair", dict(scale=0.05)), ("crowd", dict(scale=0.05))])
+def test_device_bvh_build_is_the_reference_tree(ctx, yh, name, kw):
+    """csrc/bvh_gpu.hip builds the reference's tree on the GPU (level-synchronous, std::partition's
+    permutation reproduced with a scan): nodes (boxes, children, counts, axes, breadth-first
+    numbering) and leaf order are bitwise those of the host builder, which tests/test_abi.py checks
+    against the oracle's tree — on small shapes, on the 1.6 M-segment hair block, on degenerate
+    inputs (all centres equal; fewer than five primitives)."""
+    from test_abi import _shape_boxes
+    lib = yh.load()
+    sf = yh.SceneFile(scene_path(name, **kw))
+    d = sf.desc.contents
+    cases = [np.ascontiguousarray(_shape_boxes(d.shapes[si])) for si in range(d.num_shapes)]
+    rng = np.random.default_rng(5)
+    same = np.tile(np.array([[0, 0, 0, 1, 1, 1]], np.float32), (37, 1))                 # identical centres: median splits
+    flat = np.concatenate([rng.uniform(0, 1, (300, 3)) * [1, 0, 0], np.zeros((300, 3))], 1).astype(np.float32)
+    flat[:, 3:] = flat[:, :3] + 0.01
+    cases += [same, flat, cases[0][:3], cases[0][:1]]
+    for boxes in cases:
+        n = len(boxes)
+        want_n = lib.yh_bvh_build(n, yh.fptr(boxes), None, None)
+        want, wp = np.zeros((want_n, 8), np.float32), np.zeros(n, np.int32)
+        lib.yh_bvh_build(n, yh.fptr(boxes), yh.fptr(want), yh.iptr(wp))
+        got, gp = np.zeros((2 * n + 1, 8), np.float32), np.zeros(n, np.int32)
+        got_n = lib.yh_bvh_build_gpu(ctx.h, n, yh.fptr(boxes), yh.fptr(got), yh.iptr(gp))
+        assert got_n == want_n, (n, got_n, want_n)
+        assert np.array_equal(gp, wp), n
+        assert np.array_equal(got[:got_n].view(np.uint32), want.view(np.uint32)), n
+    sf.close()
+
+
 def test_empty_and_invalid_batches(ctx, yh):
     z = np.zeros((0, 3), np.float32)
     assert ctx.hair_eval(np.zeros((0, 30), np.float32), z, z).shape == (0, 3)

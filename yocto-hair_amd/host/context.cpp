@@ -44,6 +44,7 @@ int yhk_hair_eval(int, const float*, const float*, const float*, float*, hipStre
 int yhk_hair_pdf(int, const float*, const float*, const float*, float*, hipStream_t);
 int yhk_hair_sample(int, const float*, const float*, const float*, float*, hipStream_t);
 int yhk_intersect(const yhd_scene*, int, const float*, int*, int*, float*, float*, hipStream_t);
+int yhk_bvh_build_gpu(int n, const float* boxes, float* nodes8, int* primitives, int* num_nodes, int* depth, hipStream_t);
 int yhk_curves_to_lines(int, const float*, const float*, const float*, int, float*, float*, float*, int*, hipStream_t);
 int yhk_surface_lobe(int, int, const float*, const float*, const float*, const float*, const float*, float*, hipStream_t);
 int yhk_surface_bsdf(int, const void*, const float*, const float*, const float*, const float*, float*, hipStream_t);
@@ -410,6 +411,8 @@ void yh_destroy(yh_context* ctx) {
 
 const char* yh_last_error(const yh_context* ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
 
+static int build_bvh_device(yh_context* ctx, const std::vector<yhh::Box>& boxes, yhh::Tree& tree);
+
 int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
   if (!ctx) return YH_E_INVALID;
   if (!sd) return fail(ctx, YH_E_INVALID, "scene is NULL");
@@ -485,7 +488,14 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
     });
     lap("primitive bounds");
     yhh::Tree tree;
-    yhh::build_bvh(tree, boxes);
+    // big shapes: the same tree, built on the device (YHAIR_BVH=host forces the host builder)
+    static const bool host_only = getenv("YHAIR_BVH") && !strcmp(getenv("YHAIR_BVH"), "host");
+    if (nel >= 32768 && !host_only) {
+      int rc = build_bvh_device(ctx, boxes, tree);
+      if (rc) return rc;
+    } else {
+      yhh::build_bvh(tree, boxes);
+    }
     lap("build_bvh (reference tree)");
     std::vector<yhh::WideNode> wide;
     I.depth = yhh::collapse_wide(tree, wide);
@@ -1043,6 +1053,46 @@ int yh_curves_to_lines(yh_context* ctx, int n, const float* P, const float* widt
   HIPCHK(ctx, hipMemcpy(radius, orad, 20 * (size_t)n, hipMemcpyDeviceToHost));
   HIPCHK(ctx, hipMemcpy(lines, ol, 32 * (size_t)n, hipMemcpyDeviceToHost));
   return YH_OK;
+}
+
+// The same tree built on the device (csrc/bvh_gpu.hip): fills `tree` like yhh::build_bvh.
+static int build_bvh_device(yh_context* ctx, const std::vector<yhh::Box>& boxes, yhh::Tree& tree) {
+  int                n = (int)boxes.size(), num_nodes = 0, depth = 0;
+  std::vector<float> nodes8((size_t)(2 * n + 1) * 8);
+  tree.primitives.resize((size_t)n);
+  static_assert(sizeof(yhh::Box) == 24, "boxes are passed as 6 floats");
+  int e = yhk_bvh_build_gpu(n, (const float*)boxes.data(), nodes8.data(), tree.primitives.data(), &num_nodes, &depth, ctx->stream);
+  if (e) return fail(ctx, YH_E_DEVICE, "device BVH build: %s", hipGetErrorString((hipError_t)e));
+  tree.nodes.resize((size_t)num_nodes);
+  tree.max_depth = depth;
+  for (int i = 0; i < num_nodes; i++) {
+    const float* o  = &nodes8[(size_t)i * 8];
+    yhh::Node&   nd = tree.nodes[(size_t)i];
+    memcpy(nd.bbox.min, o, 12), memcpy(nd.bbox.max, o + 3, 12);
+    int start, meta;
+    memcpy(&start, o + 6, 4), memcpy(&meta, o + 7, 4);
+    nd.start = start, nd.num = (short)(meta & 0xFFFF), nd.internal = (meta >> 16) & 1, nd.axis = (unsigned char)((meta >> 24) & 3);
+  }
+  return YH_OK;
+}
+int yh_bvh_build_gpu(yh_context* ctx, int n, const float* boxes, float* nodes, int* primitives) {
+  if (!ctx || n < 0 || (n && !boxes)) return YH_E_INVALID;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  std::vector<yhh::Box> b((size_t)n);
+  if (n) memcpy((void*)b.data(), boxes, sizeof(yhh::Box) * (size_t)n);
+  yhh::Tree tree;
+  int       rc = build_bvh_device(ctx, b, tree);
+  if (rc) return rc;
+  if (nodes)
+    for (size_t i = 0; i < tree.nodes.size(); i++) {
+      auto&  nd = tree.nodes[i];
+      float* o  = nodes + 8 * i;
+      memcpy(o, nd.bbox.min, 12), memcpy(o + 3, nd.bbox.max, 12);
+      int a = nd.start, c = (int)nd.num | ((int)nd.internal << 16) | ((int)nd.axis << 24);
+      memcpy(o + 6, &a, 4), memcpy(o + 7, &c, 4);
+    }
+  if (primitives && n) memcpy(primitives, tree.primitives.data(), sizeof(int) * (size_t)n);
+  return (int)tree.nodes.size();
 }
 
 int yh_bvh_build(int n, const float* boxes, float* nodes, int* primitives) {

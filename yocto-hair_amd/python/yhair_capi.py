@@ -145,6 +145,7 @@ _SIGS = {
                                      c_float_p, c_float_p, c_float_p]),
     "yh_curves_to_lines": (C.c_int, [C.c_void_p, C.c_int, c_float_p, c_float_p, c_float_p, C.c_int, c_float_p,
                                      c_float_p, c_float_p, c_int_p]),
+    "yh_bvh_build_gpu": (C.c_int, [C.c_void_p, C.c_int, c_float_p, c_float_p, c_int_p]),
     "yh_bvh_build": (C.c_int, [C.c_int, c_float_p, c_float_p, c_int_p]),
     "yh_surface_lobe_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_float_p, c_float_p, c_float_p, c_float_p,
                                         c_float_p, c_float_p]),
