@@ -39,7 +39,7 @@ typedef struct yhd_object {
   int   kind;           // YH_KIND_*
   int   node_base;      // first BVH node of the shape in `nodes`
   int   prim_base;      // first leaf-ordered record of the shape (float4 units)
-  int   vert_base;      // first vertex in vpos / vnrm
+  int   vert_base;      // first vertex in vpos / vtex (shapes that need them, host/context.cpp)
   int   elem_base;      // first element in elems
   int   has_normals;
   int   material;
@@ -123,7 +123,6 @@ typedef struct yhd_scene {
   const yhd_float4* nodes;      // 8 float4 per 4-wide node
   const yhd_float4* prims;      // leaf-ordered records (4 or 6 float4 each)
   const yhd_float4* vpos;       // per vertex {pos, radius}
-  const yhd_float4* vnrm;       // per vertex {normal/tangent, 0}
   const yhd_int4*   elems;      // per element vertex indices (shape-local)
   const yhd_object* objects;
   const yhd_material* materials;

@@ -244,7 +244,7 @@ struct yh_context {
   // scene
   bool      have_scene = false;
   yhd_scene scene{};
-  DevBuf    d_nodes, d_prims, d_vpos, d_vnrm, d_elems, d_objects, d_materials, d_scene_nodes,
+  DevBuf    d_nodes, d_prims, d_vpos, d_elems, d_objects, d_materials, d_scene_nodes,
       d_scene_prims, d_light_cdf, d_env_texels;
   int       stack_need = 0;
   // state
@@ -435,7 +435,7 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
     int num_nodes;
   };
   std::vector<ShapeInfo>  info(sd->num_shapes);
-  std::vector<yhd_float4> nodes, prims, vpos, vnrm;
+  std::vector<yhd_float4> nodes, prims, vpos;
   std::vector<float>      vtex;  // 2 per vertex, zeros for shapes without texture coordinates
   std::vector<yhd_int4>   elems;
   int                     best_lines = -1, best_shape = -1;
@@ -447,7 +447,7 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
       size_t nel = (size_t)std::max(0, lines ? s.num_lines : s.num_triangles);
       np += nel * (lines ? 4 : 6), nv += (size_t)std::max(0, s.num_vertices), ne += nel;
     }
-    prims.reserve(np), vpos.reserve(nv), vnrm.reserve(nv), vtex.reserve(2 * nv), elems.reserve(ne), nodes.reserve(ne * 6);
+    prims.reserve(np), vpos.reserve(nv), vtex.reserve(2 * nv), elems.reserve(ne), nodes.reserve(ne * 6);
   }
   for (int si = 0; si < sd->num_shapes; si++) {
     auto& s = sd->shapes[si];
@@ -530,21 +530,29 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
       });
     }
     {
-      const size_t at = vpos.size();
-      vpos.resize(at + (size_t)s.num_vertices), vnrm.resize(at + (size_t)s.num_vertices);
-      vtex.resize(2 * (at + (size_t)s.num_vertices), 0.0f);
-      if (s.texcoords) memcpy(&vtex[2 * at], s.texcoords, sizeof(float) * 2 * (size_t)s.num_vertices);
-      parallel_for(s.num_vertices, [&](int v) {
-        F3 p = pos(v), n = nrm(v);
-        vpos[at + (size_t)v] = {p.x, p.y, p.z, lines ? rad(v) : 0.0f};
-        vnrm[at + (size_t)v] = {n.x, n.y, n.z, 0};
-      });
-      const size_t ea = elems.size();
-      elems.resize(ea + (size_t)nel);
-      parallel_for(nel, [&](int e) {
-        elems[ea + (size_t)e] = lines ? yhd_int4{idx[2 * e], idx[2 * e + 1], 0, 0}
-                                      : yhd_int4{idx[3 * e], idx[3 * e + 1], idx[3 * e + 2], 0};
-      });
+      // Per-vertex positions and per-element indices are read on the device only to sample a point
+      // on an area light (triangles, pt.cpp:1287-1292) and to interpolate texture coordinates; the
+      // traversal and the shading of a hit use the leaf records. Hair without texture coordinates —
+      // nearly all of a scene's bytes — therefore has no entry in these arrays.
+      const bool per_vertex = !lines || s.texcoords != nullptr;
+      if (!per_vertex) {
+        I.vert_base = 0, I.elem_base = 0;
+      } else {
+        const size_t at = vpos.size();
+        vpos.resize(at + (size_t)s.num_vertices);
+        vtex.resize(2 * (at + (size_t)s.num_vertices), 0.0f);
+        if (s.texcoords) memcpy(&vtex[2 * at], s.texcoords, sizeof(float) * 2 * (size_t)s.num_vertices);
+        parallel_for(s.num_vertices, [&](int v) {
+          F3 p = pos(v);
+          vpos[at + (size_t)v] = {p.x, p.y, p.z, lines ? rad(v) : 0.0f};
+        });
+        const size_t ea = elems.size();
+        elems.resize(ea + (size_t)nel);
+        parallel_for(nel, [&](int e) {
+          elems[ea + (size_t)e] = lines ? yhd_int4{idx[2 * e], idx[2 * e + 1], 0, 0}
+                                        : yhd_int4{idx[3 * e], idx[3 * e + 1], idx[3 * e + 2], 0};
+        });
+      }
     }
     if (lines && s.num_lines > best_lines) best_lines = s.num_lines, best_shape = si;
     lap("leaf records + vertex arrays");
@@ -697,7 +705,6 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
   if ((rc = upload(ctx, ctx->d_nodes, nodes.data(), nodes.size() * 16))) return rc;
   if ((rc = upload(ctx, ctx->d_prims, prims.data(), prims.size() * 16))) return rc;
   if ((rc = upload(ctx, ctx->d_vpos, vpos.data(), vpos.size() * 16))) return rc;
-  if ((rc = upload(ctx, ctx->d_vnrm, vnrm.data(), vnrm.size() * 16))) return rc;
   if ((rc = upload(ctx, ctx->d_elems, elems.data(), elems.size() * 16))) return rc;
   if ((rc = upload(ctx, ctx->d_objects, objects.data(), objects.size() * sizeof(yhd_object)))) return rc;
   if ((rc = upload(ctx, ctx->d_materials, materials.data(), materials.size() * sizeof(yhd_material)))) return rc;
@@ -713,7 +720,7 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
   lap("hipMalloc + H2D copies");
   sc.nodes = (const yhd_float4*)ctx->d_nodes.p, sc.prims = (const yhd_float4*)ctx->d_prims.p;
   sc.vpos = (const yhd_float4*)ctx->d_vpos.p;
-  sc.vnrm = (const yhd_float4*)ctx->d_vnrm.p, sc.elems = (const yhd_int4*)ctx->d_elems.p;
+  sc.elems = (const yhd_int4*)ctx->d_elems.p;
   sc.objects = (const yhd_object*)ctx->d_objects.p, sc.materials = (const yhd_material*)ctx->d_materials.p;
   sc.scene_nodes = (const yhd_float4*)ctx->d_scene_nodes.p, sc.scene_prims = (const int*)ctx->d_scene_prims.p;
   sc.num_scene_nodes = (int)scene_tree.nodes.size(), sc.num_objects = sd->num_objects;
