@@ -72,6 +72,10 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_trace(const yhd_scene sc, cons
     for (int i = threadIdx.x; i < npri; i += blockDim.x) lds_scene[nobj + nnod + i] = gpri[i];
     tc.lds_scene = lds_scene;
   }
+  // the camera too: as kernel arguments its 17 floats end up in spilled SGPRs that path_begin
+  // reloads one v_readlane at a time
+  YH_LDS float* lds_cam = (YH_LDS float*)(lds_scene + sc.lds_scene_f4);
+  if (threadIdx.x < 17) lds_cam[threadIdx.x] = ((const float*)&sc.camera)[threadIdx.x];
   __syncthreads();
 
   tc.lds_nodes = sc.lds_node_count ? lds_nodes : nullptr;
@@ -105,7 +109,10 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_trace(const yhd_scene sc, cons
     unsigned int       w_iters = 0, w_steps = 0, l_steps = 0, l_iters = 0;
     while (true) {
       if (!alive && left > 0) {
-        path_begin(sc.camera, ps, rng, i, j, st.width, st.height);
+        yhd_camera cam;
+        for (int k = 0; k < 12; k++) cam.frame[k] = lds_cam[k];
+        cam.lens = lds_cam[12], cam.film_x = lds_cam[13], cam.film_y = lds_cam[14], cam.focus = lds_cam[15], cam.aperture = lds_cam[16];
+        path_begin(cam, ps, rng, i, j, st.width, st.height);
         left--;
         alive = true;
       }
@@ -569,7 +576,7 @@ static trace_kernel_t trace_kernel(bool counted, bool general, int shape) {
                  : (general ? k_trace<false, true, YH_BLOCK, YH_MIN_WAVES> : k_trace<false, false, YH_BLOCK, YH_MIN_WAVES>);
 }
 static size_t trace_lds(int lds_node_count, int lds_scene_f4, int shape) {
-  return (size_t)lds_node_count * 128 + (size_t)YH_QSTACK * (shape_block(shape) / 4) * 4 + (size_t)lds_scene_f4 * 16;
+  return (size_t)lds_node_count * 128 + (size_t)YH_QSTACK * (shape_block(shape) / 4) * 4 + (size_t)lds_scene_f4 * 16 + 80;
 }
 int yhk_trace(const yhd_scene* sc, const yhd_state* st, int nsamples, yhd_counters* counters,
     int grid_blocks, hipStream_t stream) {
