@@ -9,7 +9,7 @@ while [ $# -gt 0 ] && [ "$1" != "--" ]; do variants+=("$1"); shift; done
 mkdir -p /tmp/yh_sweep
 for v in "${variants[@]}"; do
   name=${v%%:*}; flags=${v#*:}
-  /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -fPIC -std=c++17 -I$R/include -I$R/yocto-hair_amd/csrc $flags \
+  /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -fno-vectorize -fPIC -std=c++17 -I$R/include -I$R/yocto-hair_amd/csrc $flags \
       -c $R/yocto-hair_amd/csrc/kernels.hip -o /tmp/yh_sweep/k_$name.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o /tmp/yh_sweep/libyhair_$name.so /tmp/yh_sweep/k_$name.o $R/yocto-hair_amd/csrc/bvh_gpu.o \
       $R/yocto-hair_amd/host/context.o $R/yocto-hair_amd/host/bvh_build.o $R/yocto-hair_amd/host/scene_io.o -lpthread -lz
