@@ -44,7 +44,7 @@ using namespace yhd;
 // GENERAL = the scene has materials with lobes beyond diffuse / hair (dev_surface.h); scenes
 // without them (all BASELINE configs) run the variant that does not carry that code.
 // BLOCK x WAVES = the launch shape: 512 threads at 4 waves per SIMD (128 VGPRs) when the launch is
-// bound by a few expensive pixels (C1), 256 threads at 5 waves per SIMD (96 VGPRs, more spills but
+// bound by a few expensive pixels (C1), 256 threads at 6 waves per SIMD (80 VGPRs, more spills but
 // more latency hiding) when every pixel is expensive (dense hair: +5-10 %, profiles/r01); the host picks.
 template <bool COUNT, bool GENERAL, int BLOCK, int WAVES>
 __global__ __launch_bounds__(BLOCK, WAVES) void k_trace(const yhd_scene sc, const yhd_state st,
@@ -566,12 +566,15 @@ __global__ void k_curves_to_lines(int n, const float* P, const float* width0, co
 extern "C" {
 
 typedef void (*trace_kernel_t)(const yhd_scene, const yhd_state, int, yhd_counters*);
-// shape 0 = 512 threads x 4 waves per SIMD, shape 1 = 256 threads x 5 waves per SIMD
+#ifndef YH_DENSE_WAVES
+#define YH_DENSE_WAVES 6
+#endif
+// shape 0 = 512 threads x 4 waves per SIMD, shape 1 = 256 threads x YH_DENSE_WAVES (6) waves per SIMD
 static int shape_block(int shape) { return shape ? 256 : YH_BLOCK; }
 static trace_kernel_t trace_kernel(bool counted, bool general, int shape) {
   if (shape)
-    return counted ? (general ? k_trace<true, true, 256, 5> : k_trace<true, false, 256, 5>)
-                   : (general ? k_trace<false, true, 256, 5> : k_trace<false, false, 256, 5>);
+    return counted ? (general ? k_trace<true, true, 256, YH_DENSE_WAVES> : k_trace<true, false, 256, YH_DENSE_WAVES>)
+                   : (general ? k_trace<false, true, 256, YH_DENSE_WAVES> : k_trace<false, false, 256, YH_DENSE_WAVES>);
   return counted ? (general ? k_trace<true, true, YH_BLOCK, YH_MIN_WAVES> : k_trace<true, false, YH_BLOCK, YH_MIN_WAVES>)
                  : (general ? k_trace<false, true, YH_BLOCK, YH_MIN_WAVES> : k_trace<false, false, YH_BLOCK, YH_MIN_WAVES>);
 }

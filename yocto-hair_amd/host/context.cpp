@@ -324,8 +324,8 @@ int  choose_launch_shape(const yh_context* ctx);
 
 namespace {
 // Launch shape for the next launch (kernels.hip: k_trace's BLOCK x WAVES). When every pixel is
-// expensive the kernel is latency-bound and a fifth wave per SIMD pays for its extra spills
-// (C2 +6 %, C3 +10 %, C4 +5 %); when a few expensive pixels bound the launch (C1: the hair covers
+// expensive the kernel is latency-bound and six waves per SIMD pay for their extra spills
+// (C2 +19 %, C3 +7-20 %, C4 +2-5 % over four); when a few expensive pixels bound the launch (C1: the hair covers
 // 11 % of the frame and barely fills the resident waves) it costs 11 %. Measure: the number of
 // max-cost work items the last launch was worth (sum of item costs over the largest) against the
 // resident wave slots — measured 3 066 (C1), 4 777 (C4), 8 989 (C2), 24 970 (C3) against 4 096: with
