@@ -202,10 +202,12 @@ YH_DEV void hair_eval_pdf(const yhd_material& m, const hair_hit& hh, f3 outgoing
 // shared by sample_hair_scattering and the fused eval + pdf — the reference
 // recomputes the same expressions in each of the three functions, so sharing
 // them changes no bit.
+// (Members, not arrays: a per-lane `p` indexing an array member keeps the whole struct in scratch —
+// 80 B written and re-read per shaded hit, 3.6 GB of HBM writes per C1 launch before this.)
 struct hair_out {
   float sin_theta_o, cos_theta_o, phi_o, gamma_t;
-  f3    apv[p_max + 1];       // Ap for f: T from sin_theta_o = outgoing.x (ext.cpp:281-295)
-  float ap_pdf[p_max + 1];    // lobe pdfs: T from sin_theta_o = sqrt(1 - cos^2) (ext.cpp:372)
+  f3    ap0, ap1, ap2, ap3;      // Ap for f: T from sin_theta_o = outgoing.x (ext.cpp:281-295)
+  float pdf0, pdf1, pdf2, pdf3;  // lobe pdfs: T from sin_theta_o = sqrt(1 - cos^2) (ext.cpp:372)
 };
 YH_DEV hair_out hair_prepare(const yhd_material& m, const hair_hit& hh, f3 outgoing_) {
   hair_out o;
@@ -214,8 +216,12 @@ YH_DEV hair_out hair_prepare(const yhd_material& m, const hair_hit& hh, f3 outgo
   o.cos_theta_o = safe_sqrt(1 - sqr(o.sin_theta_o));
   o.phi_o       = atan2f(outgoing.z, outgoing.y);
   f3 T          = transmittance(m, hh.h, o.sin_theta_o, o.cos_theta_o, o.gamma_t);
-  ap(o.cos_theta_o, m.eta, hh.h, T, o.apv);
-  compute_ap_pdf(m, hh.h, o.cos_theta_o, o.ap_pdf);
+  f3    apv[p_max + 1];
+  float ap_pdf[p_max + 1];
+  ap(o.cos_theta_o, m.eta, hh.h, T, apv);
+  compute_ap_pdf(m, hh.h, o.cos_theta_o, ap_pdf);
+  o.ap0 = apv[0], o.ap1 = apv[1], o.ap2 = apv[2], o.ap3 = apv[3];
+  o.pdf0 = ap_pdf[0], o.pdf1 = ap_pdf[1], o.pdf2 = ap_pdf[2], o.pdf3 = ap_pdf[3];
   return o;
 }
 
@@ -239,8 +245,14 @@ YH_DEV void hair_eval_pdf_quad(const yhd_material& m, const hair_hit& hh, const 
   if (p < p_max) cos_theta_op = fabs_(cos_theta_op);
   float mpv  = mp(m, p, cos_theta_i, cos_theta_op, sin_theta_i, sin_theta_op);
   float npv  = p < p_max ? np(m, phi, p, hh.gamma_o, ho.gamma_t) : 0.0f;
-  f3    apq  = p == 0 ? ho.apv[0] : p == 1 ? ho.apv[1] : p == 2 ? ho.apv[2] : ho.apv[3];
-  float appq = p == 0 ? ho.ap_pdf[0] : p == 1 ? ho.ap_pdf[1] : p == 2 ? ho.ap_pdf[2] : ho.ap_pdf[3];
+  // values first, then selects: selecting between member loads becomes a load from a selected
+  // address, which pins `ho` in scratch
+  const f3    a0 = ho.ap0, a1 = ho.ap1, a2 = ho.ap2, a3 = ho.ap3;
+  const float q0 = ho.pdf0, q1 = ho.pdf1, q2 = ho.pdf2, q3 = ho.pdf3;
+  const bool  is0 = p == 0, is1 = p == 1, is2 = p == 2;
+  f3    apq  = f3{is0 ? a0.x : is1 ? a1.x : is2 ? a2.x : a3.x, is0 ? a0.y : is1 ? a1.y : is2 ? a2.y : a3.y,
+      is0 ? a0.z : is1 ? a1.z : is2 ? a2.z : a3.z};
+  float appq = is0 ? q0 : is1 ? q1 : is2 ? q2 : q3;
   f3    tf   = p < p_max ? mpv * apq * npv : mpv * apq / (2 * pif);
   float tp   = p < p_max ? mpv * appq * npv : mpv * appq * (1 / (2 * pif));
   f   = mk3(0.0f);
@@ -281,11 +293,10 @@ YH_DEV f3 hair_sample(const yhd_material& m, const hair_hit& hh, const hair_out&
   float u00, u01, u10, u11;
   demux_float(rnx, u00, u01);
   demux_float(rny, u10, u11);
-  int p = 0;
-  for (p = 0; p < p_max; p++) {
-    if (u00 < ho.ap_pdf[p]) break;
-    u00 -= ho.ap_pdf[p];
-  }
+  // the reference's loop `for (p = 0; p < p_max; p++) { if (u[0][0] < ap_pdf[p]) break; u[0][0] -= ap_pdf[p]; }`
+  int   p  = 0;
+  float u1 = u00 - ho.pdf0, u2 = u1 - ho.pdf1;
+  if (!(u00 < ho.pdf0)) p = !(u1 < ho.pdf1) ? (!(u2 < ho.pdf2) ? 3 : 2) : 1;
   float sin_theta_op, cos_theta_op;
   tilt(m, p, sin_theta_o, cos_theta_o, sin_theta_op, cos_theta_op);
   u10 = fmax_(u10, 1e-5f);
