@@ -130,12 +130,23 @@ typedef struct yh_scene_desc {
   const yh_texture*     textures;
 } yh_scene_desc;
 
-/* trace_params (yocto_pathtrace.h:188-197); shader is always `path`.        */
+/* shader_type (yocto_pathtrace.h:177-182), same values as the reference's enum */
+enum {
+  YH_SHADER_NAIVE    = 0, /* trace_naive    (pt.cpp:1514-1581): brdf sampling only, no MIS, no volumes */
+  YH_SHADER_PATH     = 1, /* trace_path     (pt.cpp:1380-1511): the hot path                            */
+  YH_SHADER_EYELIGHT = 2, /* trace_eyelight (pt.cpp:1584-1641): light at the eye, delta chains only     */
+  YH_SHADER_NORMAL   = 3, /* trace_normal   (pt.cpp:1644-1658): shading normal as a colour              */
+  YH_SHADER_COUNT    = 4
+};
+
+/* trace_params (yocto_pathtrace.h:188-197). NOTE: a zeroed struct selects
+ * shader 0 = naive, as a zeroed reference trace_params would; fill `shader`. */
 typedef struct yh_trace_params {
   int      resolution; /* 720                                               */
   int      bounces;    /* 8                                                 */
   float    clamp;      /* 100                                               */
   uint64_t seed;       /* 961748941                                         */
+  int      shader;     /* YH_SHADER_PATH; others: "sampler unknown" error   */
 } yh_trace_params;
 
 /* Per-sample work counters of the reference algorithm: what

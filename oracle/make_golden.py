@@ -17,6 +17,13 @@ import make_scenes  # noqa: E402
 import oracle_capi as oc  # noqa: E402
 
 yh = oc.yh
+# scenes the naive / eyelight / normal shader fixtures are rendered on (name, variant, resolution)
+SHADER_SCENES = [
+    ("sphere-hairblock", dict(scale=0.05, zoom=True), 40),
+    ("hair-curls", dict(scale=0.05), 40),
+    ("lobes", dict(scale=0.05), 48),
+    ("textured", dict(scale=0.05), 48),
+]
 GOLD = os.path.join(ROOT, "tests", "golden")
 
 # The small scene variants every image / closest-hit fixture is rendered on. Geometry comes
@@ -120,6 +127,19 @@ def main():
         pos, nrm, rad, lines = ref.curves_to_lines(P, w0, w1, 100)
         np.savez_compressed(os.path.join(GOLD, "curves.npz"), P=P, width0=w0, width1=w1, base_vertex=100,
                             positions=pos, normals=nrm, radius=rad, lines=lines)
+    # ---- the other shaders: trace_naive / trace_eyelight / trace_normal (pt.cpp:1514-1672) --------
+    if want("shaders.npz"):
+        out = {}
+        for name, kw, res in SHADER_SCENES:
+            path = make_scenes.ensure_scene(name, "/tmp/yhair_golden_scenes", **kw)
+            tag = os.path.basename(os.path.dirname(path))
+            sc = ref.scene(path)
+            for shader in ("naive", "eyelight", "normal"):
+                p = yh.TraceParams.default(resolution=res, shader=shader)
+                out[f"{tag}|{shader}|1"] = sc.render(p, 1)
+                out[f"{tag}|{shader}|8"], out[f"{tag}|{shader}|rng8"] = sc.render(p, 8, want_rng=True)
+            sc.close()
+        np.savez_compressed(os.path.join(GOLD, "shaders.npz"), **out)
     rng = np.random.default_rng(20240607)
     if only:
         scenes_only(ref, rng, want)

@@ -339,7 +339,7 @@ void ref_scene_intersect(void* h, int n, const float* rays, int* object,
 // query the size only. Returns 0 on success.
 int ref_scene_render(void* h, int resolution, int samples, uint64_t seed,
     int bounces, float clamp, int noparallel, int* width, int* height,
-    float* rgba, uint64_t* rng_state_inc) {
+    float* rgba, uint64_t* rng_state_inc, int shader) {
   auto rs           = (ref_scene*)h;
   auto params       = yp::trace_params{};
   params.resolution = resolution;
@@ -348,6 +348,7 @@ int ref_scene_render(void* h, int resolution, int samples, uint64_t seed,
   params.bounces    = bounces;
   params.clamp      = clamp;
   params.noparallel = noparallel != 0;
+  params.shader     = (yp::shader_type)shader;  // naive, path, eyelight, normal
   auto state        = std::make_unique<yp::state>();
   yp::init_state(state.get(), rs->scene.get(), rs->camera, params);
   auto size = state->render.size();

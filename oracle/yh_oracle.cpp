@@ -1734,18 +1734,129 @@ Vec4 trace_path(const yo_scene& scene, const Ray& ray_, Rng& rng, int bounces) {
   return {radiance.x, radiance.y, radiance.z, hit ? 1.0f : 0.0f};
 }
 
+// trace_naive (pt.cpp:1514-1581): brdf sampling only (no light sampling, no MIS), no volumes.
+Vec4 trace_naive(const yo_scene& scene, const Ray& ray_, Rng& rng, int bounces) {
+  auto radiance = V3{0, 0, 0};
+  auto weight   = V3{1, 1, 1};
+  auto ray      = ray_;
+  auto hit      = false;
+  for (auto bounce = 0; bounce < bounces; bounce++) {
+    int   object = -1, element = -1;
+    float uv[2] = {0, 0}, distance = 0;
+    if (!intersect_scene_bvh(scene, ray, object, element, uv, distance)) {
+      radiance = radiance + weight * eval_environment(scene, ray.d);
+      break;
+    }
+    auto outgoing = -ray.d;
+    auto position = eval_position(scene, object, element, uv);
+    auto normal   = eval_shading_normal(scene, object, element, uv, outgoing);
+    auto& hit_mat = scene.materials[scene.objects[object].material];
+    float tc[2];
+    eval_texcoord(scene, object, element, uv, tc);
+    auto emission = hit_mat.emission * eval_texture(texture_of(scene, hit_mat.emission_tex), tc);
+    auto brdf     = eval_brdf(scene, object, element, uv, normal, outgoing);
+    if (brdf.hair) tls_counters.hair++; else tls_counters.surf++;
+    if (brdf.opacity < 1 && rand1f(rng) >= brdf.opacity) {
+      ray = Ray{position + ray.d * 1e-2f, ray.d};
+      bounce -= 1;
+      continue;
+    }
+    hit      = true;
+    radiance = radiance + weight * emission;
+    auto incoming = V3{0, 0, 0};
+    if (!is_delta(brdf)) {
+      // sample_brdfcos(brdf, normal, outgoing, rand1f(rng), rand2f(rng)): g++ draws rn first
+      auto rnx = rand1f(rng), rny = rand1f(rng);
+      auto rnl = rand1f(rng);
+      incoming = sample_brdfcos(brdf, normal, outgoing, rnl, rnx, rny);
+      weight   = weight * (eval_brdfcos(brdf, normal, outgoing, incoming) /
+                            sample_brdfcos_pdf(brdf, normal, outgoing, incoming));
+    } else {
+      incoming = sample_delta(brdf, normal, outgoing, rand1f(rng));
+      weight   = weight * (eval_delta(brdf, normal, outgoing, incoming) /
+                            sample_delta_pdf(brdf, normal, outgoing, incoming));
+    }
+    if (weight == V3{0, 0, 0} || !finite3(weight)) break;
+    if (bounce > 3) {
+      auto rr_prob = fmin_((float)0.99, hmax(weight));
+      if (rand1f(rng) >= rr_prob) break;
+      weight = weight * (1 / rr_prob);
+    }
+    ray = Ray{position, incoming};
+  }
+  return {radiance.x, radiance.y, radiance.z, hit ? 1.0f : 0.0f};
+}
+
+// trace_eyelight (pt.cpp:1584-1641): the light sits at the eye; only delta chains continue.
+Vec4 trace_eyelight(const yo_scene& scene, const Ray& ray_, Rng& rng, int bounces) {
+  auto radiance = V3{0, 0, 0};
+  auto weight   = V3{1, 1, 1};
+  auto ray      = ray_;
+  auto hit      = false;
+  for (auto bounce = 0; bounce < (bounces > 4 ? bounces : 4); bounce++) {
+    int   object = -1, element = -1;
+    float uv[2] = {0, 0}, distance = 0;
+    if (!intersect_scene_bvh(scene, ray, object, element, uv, distance)) {
+      radiance = radiance + weight * eval_environment(scene, ray.d);
+      break;
+    }
+    auto outgoing = -ray.d;
+    auto position = eval_position(scene, object, element, uv);
+    auto normal   = eval_shading_normal(scene, object, element, uv, outgoing);
+    auto& hit_mat = scene.materials[scene.objects[object].material];
+    float tc[2];
+    eval_texcoord(scene, object, element, uv, tc);
+    auto emission = hit_mat.emission * eval_texture(texture_of(scene, hit_mat.emission_tex), tc);
+    auto brdf     = eval_brdf(scene, object, element, uv, normal, outgoing);
+    if (brdf.hair) tls_counters.hair++; else tls_counters.surf++;
+    if (brdf.opacity < 1 && rand1f(rng) >= brdf.opacity) {
+      ray = Ray{position + ray.d * 1e-2f, ray.d};
+      bounce -= 1;
+      continue;
+    }
+    hit      = true;
+    radiance = radiance + weight * emission;
+    auto incoming = outgoing;
+    radiance = radiance + weight * pif * eval_brdfcos(brdf, normal, outgoing, incoming);
+    if (!is_delta(brdf)) break;
+    incoming = sample_delta(brdf, normal, outgoing, rand1f(rng));
+    weight   = weight * (eval_delta(brdf, normal, outgoing, incoming) /
+                          sample_delta_pdf(brdf, normal, outgoing, incoming));
+    if (weight == V3{0, 0, 0} || !finite3(weight)) break;
+    ray = Ray{position, incoming};
+  }
+  return {radiance.x, radiance.y, radiance.z, hit ? 1.0f : 0.0f};
+}
+
+// trace_normal (pt.cpp:1644-1658): alpha is 1 for hits and misses alike.
+Vec4 trace_normal(const yo_scene& scene, const Ray& ray, Rng&, int) {
+  int   object = -1, element = -1;
+  float uv[2] = {0, 0}, distance = 0;
+  if (!intersect_scene_bvh(scene, ray, object, element, uv, distance)) {
+    auto e = eval_environment(scene, ray.d);
+    return {e.x, e.y, e.z, 1};
+  }
+  auto normal = eval_shading_normal(scene, object, element, uv, -ray.d);
+  auto c      = normal * 0.5f + 0.5f;
+  return {c.x, c.y, c.z, 1};
+}
+
 struct Pixel {  // pt.h:419-423
   Vec4 accumulated = {0, 0, 0, 0};
   int  samples     = 0;
   Rng  rng;
 };
 Vec4 trace_sample(const yo_scene& scene, Pixel& pixel, int i, int j, int w, int h,
-    int bounces, float clamp) {  // pt.cpp:1676-1689
+    int bounces, float clamp, int shader = YH_SHADER_PATH) {  // pt.cpp:1676-1689
   // argument order under g++: lens uv first, then pixel uv
   auto lu = rand1f(pixel.rng), lv = rand1f(pixel.rng);
   auto pu = rand1f(pixel.rng), pv = rand1f(pixel.rng);
   auto ray    = sample_camera(scene.camera, i, j, w, h, pu, pv, lu, lv);
-  auto shaded = trace_path(scene, ray, pixel.rng, bounces);
+  // get_trace_shader_func (pt.cpp:1660-1672)
+  auto shaded = shader == YH_SHADER_NAIVE      ? trace_naive(scene, ray, pixel.rng, bounces)
+                : shader == YH_SHADER_EYELIGHT ? trace_eyelight(scene, ray, pixel.rng, bounces)
+                : shader == YH_SHADER_NORMAL   ? trace_normal(scene, ray, pixel.rng, bounces)
+                                               : trace_path(scene, ray, pixel.rng, bounces);
   auto rgb    = V3{shaded.x, shaded.y, shaded.z};
   if (!finite3(rgb)) rgb = {0, 0, 0};
   if (hmax(rgb) > clamp) rgb = rgb * (clamp / hmax(rgb));
@@ -2202,6 +2313,7 @@ int yo_render(const yo_scene* scene, const yh_trace_params* params, int samples,
     int nthreads, int* width, int* height, float* rgba, uint64_t* rng_out,
     yh_workcounts* counts) {
   int w, h;
+  if (params->shader < 0 || params->shader >= YH_SHADER_COUNT) return 1;  // "sampler unknown" (pt.cpp:1669)
   image_size(scene->camera, params->resolution, w, h);
   *width = w, *height = h;
   if (!rgba) return 0;
@@ -2222,7 +2334,7 @@ int yo_render(const yo_scene* scene, const yh_trace_params* params, int samples,
         if (j >= h) break;
         for (auto i = 0; i < w; i++) {
           auto r = trace_sample(*scene, pixels[(size_t)j * w + i], i, j, w, h,
-              params->bounces, params->clamp);
+              params->bounces, params->clamp, params->shader);
           auto o = rgba + 4 * ((size_t)j * w + i);
           o[0] = r.x, o[1] = r.y, o[2] = r.z, o[3] = r.w;
         }

@@ -197,7 +197,8 @@ class OracleScene:
 
     def render(self, params, samples, nthreads=0, want_rng=False, want_counts=False):
         w, h = C.c_int(), C.c_int()
-        self.o.lib.yo_render(self.h, C.byref(params), 0, nthreads, C.byref(w), C.byref(h), None, None, None)
+        if self.o.lib.yo_render(self.h, C.byref(params), 0, nthreads, C.byref(w), C.byref(h), None, None, None):
+            raise ValueError("sampler unknown")  # pt.cpp:1669
         img = np.zeros((h.value, w.value, 4), np.float32)
         rng = np.zeros((h.value * w.value, 2), np.uint64) if want_rng else None
         wc = yh.WorkCounts() if want_counts else None
@@ -228,7 +229,7 @@ class Ref(_UnitApi):
         lib.ref_scene_close.argtypes = [C.c_void_p]
         lib.ref_scene_intersect.argtypes = [C.c_void_p, C.c_int, fp, ip, ip, fp, fp]
         lib.ref_scene_render.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_float, C.c_int,
-                                         ip, ip, fp, u64p]
+                                         ip, ip, fp, u64p, C.c_int]
         lib.ref_scene_num_lights.argtypes = [C.c_void_p]
 
     def scene(self, json_path, camera=""):
@@ -265,10 +266,10 @@ class RefScene:
     def render(self, params, samples, noparallel=False, want_rng=False):
         w, h = C.c_int(), C.c_int()
         self.r.lib.ref_scene_render(self.h, params.resolution, 0, params.seed, params.bounces, params.clamp, 0,
-                                    C.byref(w), C.byref(h), None, None)
+                                    C.byref(w), C.byref(h), None, None, params.shader)
         img = np.zeros((h.value, w.value, 4), np.float32)
         rng = np.zeros((h.value * w.value, 2), np.uint64) if want_rng else None
         self.r.lib.ref_scene_render(self.h, params.resolution, samples, params.seed, params.bounces, params.clamp,
                                     int(noparallel), C.byref(w), C.byref(h), yh.fptr(img),
-                                    rng.ctypes.data_as(u64p) if want_rng else None)
+                                    rng.ctypes.data_as(u64p) if want_rng else None, params.shader)
         return (img, rng) if want_rng else img

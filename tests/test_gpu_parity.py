@@ -316,7 +316,7 @@ def test_trace_params_follow_the_oracle(ctx, oracle, yh, res, bounces, clamp, se
     sf = yh.SceneFile(scene_path(name, **kw))
     ctx.upload_scene(sf.desc)
     osc = oracle.scene(sf.desc)
-    p = yh.TraceParams(res, bounces, clamp, seed)
+    p = yh.TraceParams.default(res, bounces, clamp, seed)
     w, h = ctx.init_state(p)
     ctx.trace_samples(1)
     img, ref = ctx.download(), osc.render(p, 1)
@@ -327,9 +327,58 @@ def test_trace_params_follow_the_oracle(ctx, oracle, yh, res, bounces, clamp, se
     ctx.init_state(p)
     ctx.trace_samples(16)
     img16, ref16 = ctx.download(), osc.render(p, 16)
-    other = osc.render(yh.TraceParams(res, bounces, clamp, seed + 1), 16)
+    other = osc.render(yh.TraceParams.default(res, bounces, clamp, seed + 1), 16)
     assert _relrmse(img16, ref16) <= 0.5 * _relrmse(other, ref16)
     osc.close(), sf.close()
+
+
+SHADER_SCENES = [("sphere-hairblock", dict(scale=0.05, zoom=True)), ("hair-curls", dict(scale=0.05)),
+                 ("lobes", dict(scale=0.05)), ("textured", dict(scale=0.05))]
+
+
+@pytest.mark.parametrize("shader", ["naive", "eyelight", "normal"])
+@pytest.mark.parametrize("name,kw", SHADER_SCENES, ids=[n for n, _ in SHADER_SCENES])
+def test_other_shaders_match_reference(ctx, oracle, yh, name, kw, shader):
+    """shader_type naive / eyelight / normal (pt.cpp:1514-1672) against the reference's own images
+    (tests/golden/shaders.npz) and, for the noise floor, the oracle at another seed."""
+    g = golden("shaders.npz")
+    tag = scene_tag(name, kw)
+    ref1, ref8 = g[f"{tag}|{shader}|1"], g[f"{tag}|{shader}|8"]
+    sf = yh.SceneFile(scene_path(name, **kw))
+    ctx.upload_scene(sf.desc)
+    p = yh.TraceParams.default(resolution=ref1.shape[0], shader=shader)
+    assert ctx.init_state(p) == (ref1.shape[1], ref1.shape[0])
+    ctx.trace_samples(1)
+    img = ctx.download()
+    assert np.isfinite(img).all()
+    assert np.mean(img[..., 3] == ref1[..., 3]) > 0.999
+    close = _rel(img[..., :3], ref1[..., :3]).max(axis=2) < 1e-3
+    if shader == "normal":  # no sampling beyond the camera ray: only rounding of the normal differs
+        assert close.mean() >= 0.97, f"{close.mean():.3f}"
+        assert np.abs(img[..., :3] - ref1[..., :3]).max() < 2e-2   # a hit that flips between neighbouring hairs
+    else:
+        assert close.mean() >= 0.60, f"only {close.mean():.3f} of pixels within rel 1e-3 at 1 spp"
+    ctx.init_state(p)
+    ctx.trace_samples(8)
+    img8 = ctx.download()
+    if shader == "normal":
+        assert _relrmse(img8, ref8) < 2e-3
+    else:
+        osc = oracle.scene(sf.desc)
+        other = osc.render(yh.TraceParams.default(resolution=ref1.shape[0], shader=shader, seed=777), 8)
+        assert _relrmse(img8, ref8) <= 0.5 * _relrmse(other, ref8)
+        osc.close()
+    with pytest.raises(Exception):  # the instrumented kernel exists for the path shader only
+        ctx.trace_samples_counted(1)
+    sf.close()
+
+
+def test_unknown_shader_is_rejected(ctx, yh):
+    sf = yh.SceneFile(scene_path("lobes", scale=0.05))
+    ctx.upload_scene(sf.desc)
+    with pytest.raises(Exception, match="sampler unknown"):  # pt.cpp:1669
+        ctx.init_state(yh.TraceParams.default(resolution=32, shader=7))
+    sf.close()
 
 
 def test_sample_batching_and_sharding_do_not_change_pixels(ctx, yh):
@@ -439,9 +488,16 @@ def test_cli_matches_the_library(ctx, yh, tmp_path, name):
     ctx.init_state(yh.TraceParams.default(resolution=48))
     ctx.trace_samples(6)
     assert np.array_equal(cli, ctx.download()[..., :3])
-    # reference CLI behaviour: debug shaders are refused loudly, bad scenes exit(1) with the message
-    r = subprocess.run([exe, scene, "-t", "eyelight"], capture_output=True, text=True)
-    assert r.returncode == 1 and "only 'path'" in r.stdout
+    # --shader,-t as in the reference (cli.cpp:213): the other shaders go through the same mirror
+    r = subprocess.run([exe, scene, "-r", "48", "-s", "3", "-t", "eyelight", "-o", out], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    cli = np.frombuffer(open(out, "rb").read()[len(head):], np.float32).reshape(48, 48, 3)
+    ctx.init_state(yh.TraceParams.default(resolution=48, shader="eyelight"))
+    ctx.trace_samples(3)
+    assert np.array_equal(cli, ctx.download()[..., :3])
+    # reference CLI behaviour: unknown shaders and bad scenes exit(1) with the message
+    r = subprocess.run([exe, scene, "-t", "whitted"], capture_output=True, text=True)
+    assert r.returncode == 1 and "unknown shader" in r.stdout
     r = subprocess.run([exe, str(tmp_path / "missing.json")], capture_output=True, text=True)
     assert r.returncode == 1 and "file not found" in r.stdout
     sf.close()

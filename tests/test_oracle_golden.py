@@ -115,6 +115,31 @@ def test_scene_hits_and_images_bit_exact(oracle, yh, name, kw):
     sf.close()
 
 
+def test_other_shaders_bit_exact(oracle, yh):
+    """trace_naive / trace_eyelight / trace_normal (pt.cpp:1514-1672) against the reference's images."""
+    g = golden("shaders.npz")
+    tags = sorted({k.split("|")[0] for k in g.files})
+    by_tag = {scene_tag(n, k): (n, k) for n, k in GOLDEN_SCENES}
+    assert len(tags) == 4
+    for tag in tags:
+        name, kw = by_tag[tag]
+        sf = yh.SceneFile(scene_path(name, **kw))
+        sc = oracle.scene(sf.desc)
+        for shader in ("naive", "eyelight", "normal"):
+            p = yh.TraceParams.default(resolution=g[f"{tag}|{shader}|1"].shape[0], shader=shader)
+            assert np.array_equal(sc.render(p, 1), g[f"{tag}|{shader}|1"], equal_nan=True)
+            img, rng = sc.render(p, 8, want_rng=True)
+            assert np.array_equal(img, g[f"{tag}|{shader}|8"], equal_nan=True)
+            assert np.array_equal(rng, g[f"{tag}|{shader}|rng8"])
+        sc.close(), sf.close()
+    # an unknown shader is an error, as in get_trace_shader_func (pt.cpp:1669)
+    sf = yh.SceneFile(scene_path(by_tag[tags[0]][0], **by_tag[tags[0]][1]))
+    sc = oracle.scene(sf.desc)
+    with pytest.raises(Exception):
+        sc.render(yh.TraceParams.default(resolution=16, shader=9), 1)
+    sc.close(), sf.close()
+
+
 def test_selftests_pass_on_oracle(oracle):
     """The four Monte-Carlo self-tests of the reference (ext.cpp:555-693) restated; the two
     cheap ones run here, all four run against the GPU in test_gpu_parity.py."""

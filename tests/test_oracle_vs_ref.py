@@ -95,3 +95,21 @@ def test_images_bit_identical_to_reference(oracle, ref, yh, name, kw, res, spp):
     assert np.array_equal(a, b, equal_nan=True)
     assert np.array_equal(arng, brng)
     osc.close(), rsc.close(), sf.close()
+
+
+@pytest.mark.parametrize("shader", ["naive", "eyelight", "normal"])
+@pytest.mark.parametrize("name,kw,res,spp", [
+    ("hair-curls", dict(scale=0.1), 64, 4),
+    ("lobes", dict(scale=0.1), 128, 4),
+    ("volumes", dict(scale=0.1), 96, 4),
+    ("textured", dict(scale=0.1), 96, 4),
+])
+def test_other_shaders_bit_identical_to_reference(oracle, ref, yh, name, kw, res, spp, shader):
+    path = scene_path(name, **kw)
+    sf = yh.SceneFile(path)
+    osc, rsc = oracle.scene(sf.desc), ref.scene(path)
+    p = yh.TraceParams.default(resolution=res, shader=shader)
+    a, arng = osc.render(p, spp, want_rng=True)
+    b, brng = rsc.render(p, spp, want_rng=True)
+    assert np.array_equal(a, b, equal_nan=True) and np.array_equal(arng, brng)
+    osc.close(), rsc.close(), sf.close()

@@ -444,6 +444,90 @@ YH_DEV bool path_step(const trace_ctx& tc, path_t& ps, const hit_t& isec, rng_t&
   return path_continue(ps, rng, bounces);
 }
 
+// The reference's other shaders (get_trace_shader_func, pt.cpp:1660-1672), one loop iteration each
+// like path_step: trace_naive (pt.cpp:1514-1581: brdf sampling only, no MIS, no volumes),
+// trace_eyelight (pt.cpp:1584-1641: light at the eye, only delta chains continue, at least 4
+// bounces) and trace_normal (pt.cpp:1644-1658: one hit, alpha 1 for hits and misses alike).
+// Preview / debugging shaders: they always take the general lobe mixture (dev_surface.h).
+template <bool COUNT, int STRIDE, int SHADER>
+YH_DEV bool shade_step(const trace_ctx& tc, path_t& ps, const hit_t& isec, rng_t& rng, int bounces) {
+  const yhd_scene& sc = *tc.sc;
+  if (isec.object < 0) {
+    f3 env = eval_environment<COUNT>(tc, ps.ray.d);
+    if (SHADER == YH_SHADER_NORMAL) ps.radiance = env, ps.hit = true;
+    else ps.radiance = ps.radiance + ps.weight * env;
+    return false;
+  }
+  f3 outgoing = -ps.ray.d;
+  const yhd_object&   o   = sc.objects[isec.object];
+  const yhd_material& mat = sc.materials[o.material];
+  hit_geom hg = eval_hit(sc, o, isec.slot, isec.u, isec.v);
+  f3   position = hg.position, nrm = hg.normal;
+  bool is_hair  = o.kind == YH_KIND_LINES;
+  f3   normal   = is_hair ? orthonormalize(outgoing, nrm) : ((!mat.thin || dot(nrm, outgoing) >= 0) ? nrm : -nrm);
+  if (SHADER == YH_SHADER_NORMAL) {
+    ps.radiance = normal * 0.5f + mk3(0.5f), ps.hit = true;
+    return false;
+  }
+  if (COUNT) count_quad<COUNT>(is_hair ? tc.stats->hair : tc.stats->surf);
+  float tu = isec.u, tv = isec.v, etex_x = 1.0f;
+  f3    ctex = mk3(1.0f), etex = mk3(1.0f);
+  if (mat.color_tex >= 0 || mat.emission_tex >= 0) {
+    eval_texcoord(sc, o, isec, tu, tv);
+    ctex = eval_texture(sc, mat.color_tex, false, tu, tv);
+    if (mat.emission_tex >= 0) {
+      etex   = eval_texture(sc, mat.emission_tex, false, tu, tv);
+      etex_x = eval_texture(sc, mat.emission_tex, true, tu, tv).x;
+    }
+  }
+  surface_brdf_t sb = surface_brdf(mat, normal, outgoing, ctex, etex_x);
+  if (sb.opacity < 1 && rand1f(rng) >= sb.opacity) {  // pass through, same bounce
+    ps.ray = mkray(position + ps.ray.d * 1e-2f, ps.ray.d);
+    return true;
+  }
+  ps.hit      = true;
+  ps.radiance = ps.radiance + ps.weight * (ld3(mat.emission) * etex);
+  hair_hit hh;
+  hair_out ho;
+  if (is_hair) {
+    hh = hair_setup(isec.v, normal, nrm);
+    ho = hair_prepare(mat, hh, outgoing);
+  }
+  f3    incoming, brdfcos;
+  float pdf;
+  if (SHADER == YH_SHADER_EYELIGHT) {
+    if (is_hair) hair_eval_pdf_quad(mat, hh, ho, outgoing, brdfcos, pdf);  // eval_brdfcos: hair first (pt.cpp:1071)
+    else surface_eval_pdf(sb, normal, outgoing, outgoing, brdfcos, pdf);
+    ps.radiance = ps.radiance + ps.weight * pif * brdfcos;
+    if (!is_delta(sb)) return false;
+    incoming = surface_sample_delta(sb, normal, outgoing, rand1f(rng));
+    surface_eval_pdf_delta(sb, normal, outgoing, incoming, brdfcos, pdf);
+    ps.weight = ps.weight * (brdfcos / pdf);
+    if (is_zero(ps.weight) || !finite3(ps.weight)) return false;
+    ps.ray = mkray(position, incoming);
+    ps.bounce++;
+    return ps.bounce < (bounces > 4 ? bounces : 4);
+  }
+  if (!is_delta(sb)) {
+    // sample_brdfcos(brdf, normal, outgoing, rand1f(rng), rand2f(rng)): g++ draws rn first
+    float rnx = rand1f(rng), rny = rand1f(rng);
+    float rnl = rand1f(rng);
+    if (is_hair) {
+      incoming = hair_sample(mat, hh, ho, rnx, rny);
+      hair_eval_pdf_quad(mat, hh, ho, incoming, brdfcos, pdf);
+    } else {
+      incoming = surface_sample(sb, normal, outgoing, rnl, rnx, rny);
+      surface_eval_pdf(sb, normal, outgoing, incoming, brdfcos, pdf);
+    }
+  } else {
+    incoming = surface_sample_delta(sb, normal, outgoing, rand1f(rng));
+    surface_eval_pdf_delta(sb, normal, outgoing, incoming, brdfcos, pdf);
+  }
+  ps.weight = ps.weight * (brdfcos / pdf);
+  ps.ray    = mkray(position, incoming);
+  return path_continue(ps, rng, bounces);
+}
+
 // Start of trace_sample (pt.cpp:1676-1682): the four draws and the camera ray.
 YH_DEV void path_begin(const yhd_camera& cam, path_t& ps, rng_t& rng, int i, int j, int w, int h) {
   float lu = rand1f(rng), lv = rand1f(rng);

@@ -15,6 +15,7 @@
 // Compiled with -ffp-contract=off (see dev_math.h).
 #include <hip/hip_runtime.h>
 
+#include "yhair.h"
 #include "dev_path.h"
 
 using namespace yhd;
@@ -46,9 +47,10 @@ using namespace yhd;
 // BLOCK x WAVES = the launch shape: 512 threads at 4 waves per SIMD (128 VGPRs) when the launch is
 // bound by a few expensive pixels (C1), 256 threads at 6 waves per SIMD (80 VGPRs, more spills but
 // more latency hiding) when every pixel is expensive (dense hair: +5-10 %, profiles/r01); the host picks.
-template <bool COUNT, bool GENERAL, int BLOCK, int WAVES>
-__global__ __launch_bounds__(BLOCK, WAVES) void k_trace(const yhd_scene sc, const yhd_state st,
-    int nsamples, yhd_counters* counters) {
+// SHADER = the reference's shader_type (YH_SHADER_*): trace_path is the product path (k_trace), the
+// preview / debug shaders (naive, eyelight, normal) share everything but the bounce step (k_trace_shader).
+template <bool COUNT, bool GENERAL, int BLOCK, int SHADER>
+YH_DEV void trace_items(const yhd_scene& sc, const yhd_state& st, int nsamples, yhd_counters* counters) {
   extern __shared__ v4f lds_dyn[];
   // LDS carve-out: [nodelets: 8 * lds_node_count float4][stacks: YH_QSTACK x (BLOCK / 4) uint]
   //                [scene table: objects | scene BVH nodes | scene BVH primitives] (lds_scene_f4 float4)
@@ -132,7 +134,8 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_trace(const yhd_scene sc, cons
         w_steps += smax, l_steps += (lane & 3) == 0 ? steps : 0;
       }
       if (alive) {
-        alive = path_step<COUNT, (BLOCK / 4), GENERAL>(tc, ps, isec, rng, st.bounces);
+        if constexpr (SHADER == YH_SHADER_PATH) alive = path_step<COUNT, (BLOCK / 4), GENERAL>(tc, ps, isec, rng, st.bounces);
+        else alive = shade_step<COUNT, (BLOCK / 4), SHADER>(tc, ps, isec, rng, st.bounces);
         if (!alive) {
           path_end(ps, st.clamp, acc);
           if (COUNT) count_quad<COUNT>(stats.samples);
@@ -179,6 +182,16 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_trace(const yhd_scene sc, cons
       if (COUNT) atomicAdd(&counters->cyc_tile, (unsigned long long)dt);
     }
   }
+}
+template <bool COUNT, bool GENERAL, int BLOCK, int WAVES>
+__global__ __launch_bounds__(BLOCK, WAVES) void k_trace(const yhd_scene sc, const yhd_state st,
+    int nsamples, yhd_counters* counters) {
+  trace_items<COUNT, GENERAL, BLOCK, YH_SHADER_PATH>(sc, st, nsamples, counters);
+}
+template <int SHADER>
+__global__ __launch_bounds__(YH_BLOCK, YH_MIN_WAVES) void k_trace_shader(const yhd_scene sc, const yhd_state st,
+    int nsamples, yhd_counters* counters) {
+  trace_items<false, true, YH_BLOCK, SHADER>(sc, st, nsamples, counters);
 }
 
 // render[ij] = accumulated / samples (pt.cpp:1688) into a full W*H image
@@ -571,7 +584,10 @@ typedef void (*trace_kernel_t)(const yhd_scene, const yhd_state, int, yhd_counte
 #endif
 // shape 0 = 512 threads x 4 waves per SIMD, shape 1 = 256 threads x YH_DENSE_WAVES (6) waves per SIMD
 static int shape_block(int shape) { return shape ? 256 : YH_BLOCK; }
-static trace_kernel_t trace_kernel(bool counted, bool general, int shape) {
+static trace_kernel_t trace_kernel(bool counted, bool general, int shape, int shader = YH_SHADER_PATH) {
+  if (shader == YH_SHADER_NAIVE) return k_trace_shader<YH_SHADER_NAIVE>;
+  if (shader == YH_SHADER_EYELIGHT) return k_trace_shader<YH_SHADER_EYELIGHT>;
+  if (shader == YH_SHADER_NORMAL) return k_trace_shader<YH_SHADER_NORMAL>;
   if (shape)
     return counted ? (general ? k_trace<true, true, 256, YH_DENSE_WAVES> : k_trace<true, false, 256, YH_DENSE_WAVES>)
                    : (general ? k_trace<false, true, 256, YH_DENSE_WAVES> : k_trace<false, false, 256, YH_DENSE_WAVES>);
@@ -583,11 +599,13 @@ static size_t trace_lds(int lds_node_count, int lds_scene_f4, int shape) {
 }
 int yhk_trace(const yhd_scene* sc, const yhd_state* st, int nsamples, yhd_counters* counters,
     int grid_blocks, hipStream_t stream) {
-  const int shape = st->launch_shape ? 1 : 0;
+  const bool path  = st->shader == YH_SHADER_PATH;
+  const int  shape = path && st->launch_shape ? 1 : 0;  // the other shaders have one shape (512 x 4)
+  if (!path && counters) return (int)hipErrorInvalidValue;
   size_t    lds   = trace_lds(sc->lds_node_count, sc->lds_scene_f4, shape);
-  static size_t lds_set[8] = {0};
-  int            which = (counters ? 1 : 0) + (sc->general_materials ? 2 : 0) + 4 * shape;
-  trace_kernel_t k     = trace_kernel(counters != nullptr, sc->general_materials != 0, shape);
+  static size_t lds_set[8 + YH_SHADER_COUNT] = {0};
+  int            which = path ? (counters ? 1 : 0) + (sc->general_materials ? 2 : 0) + 4 * shape : 8 + st->shader;
+  trace_kernel_t k     = trace_kernel(counters != nullptr, sc->general_materials != 0, shape, st->shader);
   if (lds > lds_set[which]) {  // above 64 KB the dynamic-LDS limit must be raised explicitly
     hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;

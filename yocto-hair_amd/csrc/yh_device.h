@@ -162,6 +162,7 @@ typedef struct yhd_state {
   int*        tile_cursor;  // next position in `tiles` (zeroed before every launch)
   unsigned int* tile_cost;  // per item: wall-clock ticks (100 MHz) its last launch took
   int         num_tiles;  // number of work items in `tiles`
+  int         shader;        // YH_SHADER_* (yhair.h): path is the product path, the others preview / debug
   int         launch_shape;  // 0: 512 threads x 4 waves per SIMD; 1: 256 threads x 6 waves per SIMD (dense scenes)
   int         width, height;
   int         tiles_x;

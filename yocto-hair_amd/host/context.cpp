@@ -766,6 +766,8 @@ int yh_init_state(yh_context* ctx, const yh_trace_params* params) {
   if (!ctx->have_scene) return fail(ctx, YH_E_STATE, "yh_init_state before yh_upload_scene");
   if (!params || params->resolution <= 0 || params->bounces < 0)
     return fail(ctx, YH_E_INVALID, "bad trace params");
+  if (params->shader < 0 || params->shader >= YH_SHADER_COUNT)
+    return fail(ctx, YH_E_INVALID, "sampler unknown");  // get_trace_shader_func's throw (pt.cpp:1669)
   HIPCHK(ctx, hipSetDevice(ctx->device));
   ctx->params = *params;
   // image size (pt.cpp:1933-1939)
@@ -812,7 +814,7 @@ int yh_init_state(yh_context* ctx, const yh_trace_params* params) {
   s.accum = (yhd_float4*)ctx->d_accum.p, s.tiles = (const int*)ctx->d_tiles.p;
   s.launch_shape = getenv("YHAIR_SHAPE") ? choose_launch_shape(ctx) : ctx->launch_shape;
   s.num_tiles = (int)tiles.size(), s.width = w, s.height = h, s.tiles_x = tx;
-  s.samples_done = 0, s.bounces = params->bounces, s.clamp = params->clamp;
+  s.samples_done = 0, s.bounces = params->bounces, s.clamp = params->clamp, s.shader = params->shader;
   s.shard_rank = ctx->rank, s.shard_world = ctx->world;
   ctx->have_state = true;
   return YH_OK;
@@ -835,7 +837,9 @@ static int trace_impl(yh_context* ctx, int nsamples, bool counted, bool sync) {
     ctx->last_ms = 0, ctx->last_launches = 0;
     return YH_OK;
   }
-  const int shape     = ctx->state.launch_shape;
+  const bool path = ctx->state.shader == YH_SHADER_PATH;
+  if (counted && !path) return fail(ctx, YH_E_INVALID, "work counters exist for the path shader only");
+  const int shape     = path ? ctx->state.launch_shape : 0;  // the preview shaders have one launch shape
   int waves_per_block = yhk_block_threads(shape) / 64;  // one work item per wave at a time
   int lds_bytes       = yhk_trace_lds_bytes(ctx->scene.lds_node_count, ctx->scene.lds_scene_f4, shape);
   int resident        = ctx->num_cus * yhk_trace_occupancy(lds_bytes, ctx->scene.general_materials, shape);
@@ -860,7 +864,7 @@ static int trace_impl(yh_context* ctx, int nsamples, bool counted, bool sync) {
     std::vector<int> tiles;
     build_work_items(ctx, tiles);
     HIPCHK(ctx, hipMemcpy(ctx->d_tiles.p, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice));
-    if (nsamples >= 16 || getenv("YHAIR_SHAPE")) ctx->launch_shape = choose_launch_shape(ctx);
+    if (path && (nsamples >= 16 || getenv("YHAIR_SHAPE"))) ctx->launch_shape = choose_launch_shape(ctx);
     ctx->state.launch_shape = ctx->launch_shape;
   }
   return YH_OK;

@@ -372,11 +372,12 @@ inline void init_lights(scene* sc, const trace_params&, progress_callback progre
 }
 // init_state (pt.cpp:1931-1946)
 inline void init_state(state* st, const scene* sc, const camera* cam, const trace_params& params) {
-  if (params.shader != shader_type::path) throw std::runtime_error("sampler unknown");  // pt.cpp:1669
+  if ((int)params.shader < 0 || (int)params.shader > (int)shader_type::normal)
+    throw std::runtime_error("sampler unknown");  // pt.cpp:1669
   if (!sc->bvh_requested || !sc->lights_requested)
     throw std::runtime_error("yhair: init_state before init_bvh / init_lights");
   if (sc->uploaded_for != cam) upload_scene(sc, cam);
-  yh_trace_params p{params.resolution, params.bounces, params.clamp, params.seed};
+  yh_trace_params p{params.resolution, params.bounces, params.clamp, params.seed, (int)params.shader};
   auto            ctx = detail::require_context();
   detail::check(yh_init_state(ctx, &p));
   detail::check(yh_image_size(ctx, &st->width, &st->height));

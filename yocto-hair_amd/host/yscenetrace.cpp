@@ -126,7 +126,7 @@ int main(int argc, const char* argv[]) {
   int  spp_per_launch = 64;
 
   auto usage = [&]() {
-    printf("usage: yscenetrace [--camera NAME] [--resolution,-r N] [--samples,-s N] [--shader,-t path]\n"
+    printf("usage: yscenetrace [--camera NAME] [--resolution,-r N] [--samples,-s N] [--shader,-t naive|path|eyelight|normal]\n"
            "                   [--bounces,-b N] [--clamp F] [--save-batch] [--output-image,-o FILE]\n"
            "                   [--seed N] [--device N] [--spp-per-launch N] scene\n"
            "Offline path tracing of hair scenes on MI355X\n");
@@ -157,8 +157,6 @@ int main(int argc, const char* argv[]) {
   for (size_t i = 0; i < ptr::shader_names.size(); i++)
     if (ptr::shader_names[i] == shader) params.shader = (ptr::shader_type)i, known = true;
   if (!known) print_fatal("unknown shader " + shader);
-  if (params.shader != ptr::shader_type::path)
-    print_fatal("shader '" + shader + "' is a debug shader outside the hair path; only 'path' is available");
 
   try {
     char error[512];

@@ -67,13 +67,16 @@ class SceneDesc(C.Structure):
                 ("camera", Camera), ("num_textures", C.c_int), ("textures", C.POINTER(Texture))]
 
 
+SHADER_NAMES = ["naive", "path", "eyelight", "normal"]  # shader_type, yocto_pathtrace.h:177-199
+
+
 class TraceParams(C.Structure):
     _fields_ = [("resolution", C.c_int), ("bounces", C.c_int), ("clamp", C.c_float),
-                ("seed", C.c_uint64)]
+                ("seed", C.c_uint64), ("shader", C.c_int)]
 
     @staticmethod
-    def default(resolution=720, bounces=8, clamp=100.0, seed=961748941):
-        return TraceParams(resolution, bounces, clamp, seed)
+    def default(resolution=720, bounces=8, clamp=100.0, seed=961748941, shader="path"):
+        return TraceParams(resolution, bounces, clamp, seed, SHADER_NAMES.index(shader) if isinstance(shader, str) else shader)
 
 
 class WorkCounts(C.Structure):
