@@ -33,9 +33,67 @@ struct hair_hit {
   frame w2b;  // world_to_brdf: rows of the local frame, o = -0
 };
 
+// Arithmetic of the BSDF. Its values are pinned to the reference within 1e-4 relative (sampled
+// directions 5e-5), not bit for bit: libm differs between glibc and the device in the last ulp
+// anyway, so paths through hair leave the reference's after a bounce or two regardless. Inside
+// that tolerance the hardware's 1-ulp reciprocal / square root / log2 / sin / cos and asinf replace
+// the IEEE division sequences and the library calls (YH_HAIR_FAST=0: the exact forms). Kept exact:
+// everything that enters Mp's exponent — the local frame, sin / cos theta of both directions, the
+// tilt, a = cos cos / v, b = sin sin / v and log I0 — because for a narrow longitudinal lobe
+// (beta_m 0.05: 1 / v = 680) the exponent cancels terms of that magnitude and one ulp of an input
+// is 1e-4 of the result. Geometry — traversal, intersection, positions, camera rays, the surface
+// lobes — stays exact throughout.
+#ifndef YH_HAIR_FAST
+#define YH_HAIR_FAST 1
+#endif
+#ifndef YH_FAST_DIV
+#define YH_FAST_DIV YH_HAIR_FAST
+#endif
+#ifndef YH_FAST_EXP
+#define YH_FAST_EXP 0
+#endif
+#ifndef YH_FAST_LOG
+#define YH_FAST_LOG YH_HAIR_FAST
+#endif
+#ifndef YH_FAST_TRIG
+#define YH_FAST_TRIG YH_HAIR_FAST
+#endif
+#ifndef YH_FAST_ASIN
+#define YH_FAST_ASIN YH_HAIR_FAST
+#endif
+YH_DEV float h_rcp(float x) { return YH_FAST_DIV ? __builtin_amdgcn_rcpf(x) : 1 / x; }
+YH_DEV float h_div(float a, float b) { return YH_FAST_DIV ? a * __builtin_amdgcn_rcpf(b) : a / b; }
+// quotient that feeds an exponential: one Newton step on the reciprocal (0.5 ulp), so that the
+// relative error does not grow with the magnitude of the exponent
+YH_DEV float h_div_n(float a, float b) {
+  if (!YH_FAST_DIV) return a / b;
+  float r = __builtin_amdgcn_rcpf(b);
+  r       = __builtin_fmaf(__builtin_fmaf(-b, r, 1.0f), r, r);
+  return a * r;
+}
+YH_DEV float h_sqrt(float x) { return YH_FAST_DIV ? __builtin_amdgcn_sqrtf(x) : sqrtf(x); }
+// exp stays the library's: v_exp_f32(x log2 e) loses |x| * 1e-7 of the result (the azimuthal
+// logistic reaches exponents of -275), carrying the product's rounding error along costs the dense
+// configs 5-10 %, and neither is faster on C1 (A/B on one box, profiles/r01/README.md)
+YH_DEV float h_exp(float x) { return YH_FAST_EXP ? __builtin_amdgcn_exp2f(x * 1.44269504f) : expf(x); }
+YH_DEV float h_log(float x) { return YH_FAST_LOG ? __builtin_amdgcn_logf(x) * 0.693147181f : logf(x); }
+YH_DEV float h_sin(float x) { return YH_FAST_TRIG ? __builtin_amdgcn_sinf(x * 0.159154943f) : sinf(x); }  // |x| well inside 256 turns
+YH_DEV float h_cos(float x) { return YH_FAST_TRIG ? __builtin_amdgcn_cosf(x * 0.159154943f) : cosf(x); }
+YH_DEV float h_cos_turns(float t) { return YH_FAST_TRIG ? __builtin_amdgcn_cosf(t) : cosf(2 * pif * t); }  // cos(2 pi t)
+// the reference's asin is the double overload (ext.cpp:111)
+YH_DEV float h_asin(float x) { return YH_FAST_ASIN ? asinf(x) : (float)asin((double)x); }
+YH_DEV f3    h_normalize(f3 a) {
+  if (!YH_FAST_DIV) return normalize(a);
+  float l2 = dot(a, a);
+  return l2 != 0 ? a * __builtin_amdgcn_rsqf(l2) : a;
+}
+YH_DEV f3 h_div(f3 a, float b) { float r = h_rcp(b); return YH_FAST_DIV ? a * r : a / b; }
+YH_DEV f3 h_transform_direction(const frame& a, f3 b) { return h_normalize(transform_vector(a, b)); }
+
 YH_DEV float sqr(float v) { return v * v; }
-YH_DEV float safe_asin(float x) { return (float)asin((double)fclamp(x, -1.0f, 1.0f)); }
-YH_DEV float safe_sqrt(float x) { return sqrtf(fmax_(0.0f, x)); }
+YH_DEV float safe_asin(float x) { return h_asin(fclamp(x, -1.0f, 1.0f)); }
+YH_DEV float safe_sqrt(float x) { return h_sqrt(fmax_(0.0f, x)); }
+YH_DEV float exact_safe_sqrt(float x) { return sqrtf(fmax_(0.0f, x)); }
 
 // ext.cpp:148-151,174 with math.h:2898-2903 (frame_fromzx) and the rigid
 // inverse (transpose).
@@ -72,15 +130,18 @@ YH_DEV float log_i0(float x) {  // ext.cpp:194-199
 YH_DEV float mp(const yhd_material& m, int p, float cos_theta_i, float cos_theta_o,
     float sin_theta_i, float sin_theta_o) {
   float v = m.v[p];
+  // exact divisions: for small v the exponent below cancels terms of magnitude 1 / v (hundreds), so
+  // one ulp of a or b is 1e-5 of the result
   float a = cos_theta_i * cos_theta_o / v;
   float b = sin_theta_i * sin_theta_o / v;
   if (v <= 0.1f) {
-    return expf(log_i0(a) - b - m.inv_v[p] + 0.6931f + m.log_inv_2v[p]);
+    return h_exp(log_i0(a) - b - m.inv_v[p] + 0.6931f + m.log_inv_2v[p]);
   } else {
+    if (YH_HAIR_FAST) return h_div(h_exp(-b) * i0(a), (float)m.mp_den[p]);
     return (float)((double)(expf(-b) * i0(a)) / m.mp_den[p]);
   }
 }
-// fresnel_dielectric with dot(normal, outgoing) = cos (math.h:4215-4235)
+// fresnel_dielectric with dot(normal, outgoing) = cos (math.h:4215-4235); exact form (surface lobes)
 YH_DEV float fresnel_dielectric_cos(float eta, float cosw_) {
   float cosw  = fabs_(cosw_);
   float sin2  = 1 - cosw * cosw;
@@ -94,28 +155,44 @@ YH_DEV float fresnel_dielectric_cos(float eta, float cosw_) {
   float rp = (t0 - t2) / (t0 + t2);
   return (rs * rs + rp * rp) / 2;
 }
+// the same inside the hair BSDF (ap)
+YH_DEV float h_fresnel_dielectric_cos(float eta, float cosw_) {
+  float cosw  = fabs_(cosw_);
+  float sin2  = 1 - cosw * cosw;
+  float eta2  = eta * eta;
+  float cos2t = 1 - h_div(sin2, eta2);
+  if (cos2t < 0) return 1;
+  float t0 = h_sqrt(cos2t);
+  float t1 = eta * t0;
+  float t2 = eta * cosw;
+  float rs = h_div(cosw - t1, cosw + t1);
+  float rp = h_div(t0 - t2, t0 + t2);
+  return (rs * rs + rp * rp) / 2;
+}
 // ap (ext.cpp:209-230)
 YH_DEV void ap(float cos_theta_o, float eta, float h, f3 T, f3 out[p_max + 1]) {
   float cos_gamma_o = safe_sqrt(1 - h * h);
   float cos_theta   = cos_theta_o * cos_gamma_o;
-  float f = fresnel_dielectric_cos(eta, 0.0f * 0.0f + 0.0f * 0.0f + 1.0f * cos_theta);
+  float f = h_fresnel_dielectric_cos(eta, 0.0f * 0.0f + 0.0f * 0.0f + 1.0f * cos_theta);
   out[0]  = mk3(f);
   out[1]  = sqr(1 - f) * T;
   out[2]  = out[1] * T * f;
-  out[3]  = out[2] * f * T / (mk3(1.f) - T * f);
+  f3 den  = mk3(1.f) - T * f;
+  f3 num  = out[2] * f * T;
+  out[3]  = f3{h_div(num.x, den.x), h_div(num.y, den.y), h_div(num.z, den.z)};
 }
 // T for a given (sin_theta_o, cos_theta_o) (ext.cpp:281-291 / 375-384)
 YH_DEV f3 transmittance(const yhd_material& m, float h, float sin_theta_o, float cos_theta_o,
     float& gamma_t) {
-  float sin_theta_t = sin_theta_o / m.eta;
+  float sin_theta_t = h_div(sin_theta_o, m.eta);
   float cos_theta_t = safe_sqrt(1 - sqr(sin_theta_t));
-  float etap        = sqrtf(m.eta * m.eta - sqr(sin_theta_o)) / cos_theta_o;
-  float sin_gamma_t = h / etap;
+  float etap        = h_div(h_sqrt(m.eta * m.eta - sqr(sin_theta_o)), cos_theta_o);
+  float sin_gamma_t = h_div(h, etap);
   float cos_gamma_t = safe_sqrt(1 - sqr(sin_gamma_t));
   gamma_t           = safe_asin(sin_gamma_t);
-  float k           = 2 * cos_gamma_t / cos_theta_t;
+  float k           = h_div_n(2 * cos_gamma_t, cos_theta_t);
   f3    sa          = ld3(m.sigma_a);
-  return f3{expf(-sa.x * k), expf(-sa.y * k), expf(-sa.z * k)};
+  return f3{h_exp(-sa.x * k), h_exp(-sa.y * k), h_exp(-sa.z * k)};
 }
 YH_DEV float phi_fn(int p, float gamma_o, float gamma_t) {  // ext.cpp:232-234
   return 2 * p * gamma_t - 2 * gamma_o + p * pif;
@@ -126,8 +203,8 @@ YH_DEV float np(const yhd_material& m, float phi, int p, float gamma_o, float ga
   while (dphi > pif) dphi -= 2 * pif;
   while (dphi < -pif) dphi += 2 * pif;
   float x = fabs_(dphi);
-  float e = expf(-x / m.s);
-  return (e / (m.s * sqr(1 + e))) / m.tl_norm;
+  float e = h_exp(-h_div_n(x, m.s));
+  return h_div(h_div(e, m.s * sqr(1 + e)), m.tl_norm);
 }
 // scale tilt of lobe p (ext.cpp:299-322)
 YH_DEV void tilt(const yhd_material& m, int p, float sin_theta_o, float cos_theta_o,
@@ -158,7 +235,7 @@ YH_DEV void compute_ap_pdf(const yhd_material& m, float h, float cos_theta_o,
 #pragma unroll
   for (int i = 0; i <= p_max; i++) sum_y += luminance(apv[i]);
 #pragma unroll
-  for (int i = 0; i <= p_max; i++) ap_pdf[i] = luminance(apv[i]) / sum_y;
+  for (int i = 0; i <= p_max; i++) ap_pdf[i] = h_div(luminance(apv[i]), sum_y);
 }
 
 // Fused eval_hair_scattering + sample_hair_scattering_pdf.
@@ -168,10 +245,10 @@ YH_DEV void hair_eval_pdf(const yhd_material& m, const hair_hit& hh, f3 outgoing
   f3    outgoing    = transform_direction(hh.w2b, outgoing_);
   f3    incoming    = transform_direction(hh.w2b, incoming_);
   float sin_theta_o = outgoing.x;
-  float cos_theta_o = safe_sqrt(1 - sqr(sin_theta_o));
+  float cos_theta_o = exact_safe_sqrt(1 - sqr(sin_theta_o));
   float phi_o       = atan2f(outgoing.z, outgoing.y);
   float sin_theta_i = incoming.x;
-  float cos_theta_i = safe_sqrt(1 - sqr(sin_theta_i));
+  float cos_theta_i = exact_safe_sqrt(1 - sqr(sin_theta_i));
   float phi_i       = atan2f(incoming.z, incoming.y);
   float gamma_t;
   f3    T   = transmittance(m, hh.h, sin_theta_o, cos_theta_o, gamma_t);
@@ -193,7 +270,7 @@ YH_DEV void hair_eval_pdf(const yhd_material& m, const hair_hit& hh, f3 outgoing
     if (WANT_PDF) pdf += mpv * ap_pdf[p] * npv;
   }
   float mpl = mp(m, p_max, cos_theta_i, cos_theta_o, sin_theta_i, sin_theta_o);
-  if (WANT_F) f = f + mpl * apv[p_max] / (2 * pif);
+  if (WANT_F) f = f + h_div(mpl * apv[p_max], 2 * pif);
   if (WANT_PDF) pdf += mpl * ap_pdf[p_max] * (1 / (2 * pif));
 }
 
@@ -213,7 +290,7 @@ YH_DEV hair_out hair_prepare(const yhd_material& m, const hair_hit& hh, f3 outgo
   hair_out o;
   f3 outgoing   = transform_direction(hh.w2b, outgoing_);
   o.sin_theta_o = outgoing.x;
-  o.cos_theta_o = safe_sqrt(1 - sqr(o.sin_theta_o));
+  o.cos_theta_o = exact_safe_sqrt(1 - sqr(o.sin_theta_o));
   o.phi_o       = atan2f(outgoing.z, outgoing.y);
   f3 T          = transmittance(m, hh.h, o.sin_theta_o, o.cos_theta_o, o.gamma_t);
   f3    apv[p_max + 1];
@@ -236,7 +313,7 @@ YH_DEV void hair_eval_pdf_quad(const yhd_material& m, const hair_hit& hh, const 
   f3    incoming    = transform_direction(hh.w2b, incoming_);
   float sin_theta_o = ho.sin_theta_o, cos_theta_o = ho.cos_theta_o;
   float sin_theta_i = incoming.x;
-  float cos_theta_i = safe_sqrt(1 - sqr(sin_theta_i));
+  float cos_theta_i = exact_safe_sqrt(1 - sqr(sin_theta_i));
   float phi_i       = atan2f(incoming.z, incoming.y);
   float phi         = phi_i - ho.phi_o;
   // this lane's lobe
@@ -253,7 +330,7 @@ YH_DEV void hair_eval_pdf_quad(const yhd_material& m, const hair_hit& hh, const 
   f3    apq  = f3{is0 ? a0.x : is1 ? a1.x : is2 ? a2.x : a3.x, is0 ? a0.y : is1 ? a1.y : is2 ? a2.y : a3.y,
       is0 ? a0.z : is1 ? a1.z : is2 ? a2.z : a3.z};
   float appq = is0 ? q0 : is1 ? q1 : is2 ? q2 : q3;
-  f3    tf   = p < p_max ? mpv * apq * npv : mpv * apq / (2 * pif);
+  f3    tf   = p < p_max ? mpv * apq * npv : h_div(mpv * apq, 2 * pif);
   float tp   = p < p_max ? mpv * appq * npv : mpv * appq * (1 / (2 * pif));
   f   = mk3(0.0f);
   pdf = 0.0f;
@@ -304,23 +381,23 @@ YH_DEV f3 hair_sample(const yhd_material& m, const hair_hit& hh, const hair_out&
   // select without dynamic indexing into the struct
   vp   = p == 0 ? m.v[0] : p == 1 ? m.v[1] : m.v[2];  // v[3] == v[2]
   em2v = p == 0 ? m.exp_m2_inv_v[0] : p == 1 ? m.exp_m2_inv_v[1] : m.exp_m2_inv_v[2];
-  float cos_theta   = 1 + vp * logf(u10 + (1 - u10) * em2v);
+  float cos_theta   = 1 + vp * h_log(u10 + (1 - u10) * em2v);
   float sin_theta   = safe_sqrt(1 - sqr(cos_theta));
-  float cos_phi     = cosf(2 * pif * u11);
+  float cos_phi     = h_cos_turns(u11);
   float sin_theta_i = -cos_theta * sin_theta_op + sin_theta * cos_phi * cos_theta_op;
   float cos_theta_i = safe_sqrt(1 - sqr(sin_theta_i));
   // gamma_t (ext.cpp:463-465) is the same expression as in eval: ho.gamma_t
   float dphi;
   if (p < p_max) {
     // sample_trimmed_logistic (ext.cpp:359-363)
-    float x = -m.s * logf(1 / (u01 * m.tl_norm + m.tl_cdf_a) - 1);
+    float x = -m.s * h_log(h_rcp(u01 * m.tl_norm + m.tl_cdf_a) - 1);
     dphi    = phi_fn(p, hh.gamma_o, ho.gamma_t) + fclamp(x, -pif, pif);
   } else {
     dphi = 2 * pif * u01;
   }
   float phi_i    = phi_o + dphi;
-  f3    incoming = f3{sin_theta_i, cos_theta_i * cosf(phi_i), cos_theta_i * sinf(phi_i)};
-  return transform_direction(transpose_rot(hh.w2b), incoming);
+  f3    incoming = f3{sin_theta_i, cos_theta_i * h_cos(phi_i), cos_theta_i * h_sin(phi_i)};
+  return h_transform_direction(transpose_rot(hh.w2b), incoming);
 }
 YH_DEV f3 hair_sample(const yhd_material& m, const hair_hit& hh, f3 outgoing_, float rnx, float rny) {
   hair_out ho = hair_prepare(m, hh, outgoing_);

@@ -289,7 +289,7 @@ __global__ void k_hair_brdf(int n, const yh_material_in* mats, const float* v, c
   o[6] = v0, o[7] = 0.25f * v0, o[8] = 4 * v0, o[9] = 4 * v0;
   o[10] = 0.626657069f * (0.265f * bn + 1.194f * sqr(bn) + 5.372f * powt<22>(bn));
   float s0 = sinf(pif / 180 * m.alpha);
-  float c0 = safe_sqrt(1 - sqr(s0));
+  float c0 = exact_safe_sqrt(1 - sqr(s0));
   float s1 = 2 * c0 * s0, c1 = sqr(c0) - sqr(s0);
   float s2 = 2 * c1 * s1, c2 = sqr(c1) - sqr(s1);
   o[11] = s0, o[12] = s1, o[13] = s2, o[14] = c0, o[15] = c1, o[16] = c2;
@@ -404,7 +404,7 @@ __global__ void k_selftest(selftest_args a, double* sums, unsigned int* worst_bi
     m.v[0] = sqr(0.726f * bm + 0.812f * sqr(bm) + 3.7f * powt<20>(bm));
     m.v[1] = 0.25f * m.v[0], m.v[2] = 4 * m.v[0], m.v[3] = m.v[2];
     m.s    = 0.626657069f * (0.265f * bn + 1.194f * sqr(bn) + 5.372f * powt<22>(bn));
-    float s_0 = sinf(pif / 180 * m.alpha), c_0 = safe_sqrt(1 - sqr(s_0));
+    float s_0 = sinf(pif / 180 * m.alpha), c_0 = exact_safe_sqrt(1 - sqr(s_0));
     m.sin_2k_alpha[0] = s_0, m.cos_2k_alpha[0] = c_0;
     for (int k = 1; k < 3; k++) {
       m.sin_2k_alpha[k] = 2 * m.cos_2k_alpha[k - 1] * m.sin_2k_alpha[k - 1];
