@@ -97,13 +97,16 @@ YH_DEV float exact_safe_sqrt(float x) { return sqrtf(fmax_(0.0f, x)); }
 
 // ext.cpp:148-151,174 with math.h:2898-2903 (frame_fromzx) and the rigid
 // inverse (transpose).
+// QUAD: called by the four lanes of a quad with identical arguments (the integrator): the exact
+// divisions of the normalisations are spread over the lanes (dev_math.h), same bits.
+template <bool QUAD = false>
 YH_DEV hair_hit hair_setup(float v, f3 normal, f3 tangent) {
   hair_hit hh;
   hh.h       = -1 + 2 * v;
   hh.gamma_o = safe_asin(hh.h);
-  f3 z       = normalize(normal);
-  f3 x       = orthonormalize(tangent, z);
-  f3 y       = normalize(cross(z, x));
+  f3 z       = QUAD ? quad_normalize(normal) : normalize(normal);
+  f3 x       = QUAD ? quad_orthonormalize(tangent, z) : orthonormalize(tangent, z);
+  f3 y       = QUAD ? quad_normalize(cross(z, x)) : normalize(cross(z, x));
   hh.w2b     = transpose_rot(frame{x, y, z, mk3(0.0f)});
   return hh;
 }
@@ -286,9 +289,10 @@ struct hair_out {
   f3    ap0, ap1, ap2, ap3;      // Ap for f: T from sin_theta_o = outgoing.x (ext.cpp:281-295)
   float pdf0, pdf1, pdf2, pdf3;  // lobe pdfs: T from sin_theta_o = sqrt(1 - cos^2) (ext.cpp:372)
 };
+template <bool QUAD = false>
 YH_DEV hair_out hair_prepare(const yhd_material& m, const hair_hit& hh, f3 outgoing_) {
   hair_out o;
-  f3 outgoing   = transform_direction(hh.w2b, outgoing_);
+  f3 outgoing   = QUAD ? quad_normalize(transform_vector(hh.w2b, outgoing_)) : transform_direction(hh.w2b, outgoing_);
   o.sin_theta_o = outgoing.x;
   o.cos_theta_o = exact_safe_sqrt(1 - sqr(o.sin_theta_o));
   o.phi_o       = atan2f(outgoing.z, outgoing.y);
@@ -310,7 +314,7 @@ YH_DEV hair_out hair_prepare(const yhd_material& m, const hair_hit& hh, f3 outgo
 YH_DEV void hair_eval_pdf_quad(const yhd_material& m, const hair_hit& hh, const hair_out& ho, f3 incoming_,
     f3& f, float& pdf) {
   const int p       = (int)(__lane_id() & 3u);
-  f3    incoming    = transform_direction(hh.w2b, incoming_);
+  f3    incoming    = quad_normalize(transform_vector(hh.w2b, incoming_));  // quad-uniform up to here
   float sin_theta_o = ho.sin_theta_o, cos_theta_o = ho.cos_theta_o;
   float sin_theta_i = incoming.x;
   float cos_theta_i = exact_safe_sqrt(1 - sqr(sin_theta_i));
@@ -345,7 +349,7 @@ YH_DEV void hair_eval_pdf_quad(const yhd_material& m, const hair_hit& hh, const 
 }
 YH_DEV void hair_eval_pdf_quad(const yhd_material& m, const hair_hit& hh, f3 outgoing_, f3 incoming_,
     f3& f, float& pdf) {
-  hair_out ho = hair_prepare(m, hh, outgoing_);
+  hair_out ho = hair_prepare<true>(m, hh, outgoing_);
   hair_eval_pdf_quad(m, hh, ho, incoming_, f, pdf);
 }
 

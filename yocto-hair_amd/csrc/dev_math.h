@@ -97,6 +97,26 @@ template <int K>
 YH_DEV float quad_bcast_f(float v) { return dpp_f<K * 0x55>(v); }
 #define YH_QUAD_XOR1 0xB1 /* quad_perm [1,0,3,2] */
 #define YH_QUAD_XOR2 0x4E /* quad_perm [2,3,0,1] */
+// The four lanes of a quad run the same path, so an IEEE division (ten instructions: scale, rcp,
+// three fma refinements, fmas, fixup) of each component of a vector is computed four times over.
+// These forms give component q to lane q (lane 3 repeats component 2) and broadcast the three
+// quotients: one division per lane instead of three, the same instruction on the same operands, so
+// the same bits. ONLY where all four lanes of the quad are active and hold identical operands.
+YH_DEV float quad_pick(f3 a) {
+  unsigned int q = __lane_id() & 3u;
+  return q == 0 ? a.x : (q == 1 ? a.y : a.z);
+}
+YH_DEV f3 quad_spread(float r) { return f3{quad_bcast_f<0>(r), quad_bcast_f<1>(r), quad_bcast_f<2>(r)}; }
+#ifndef YH_QUAD_DIV
+#define YH_QUAD_DIV 1  /* 0: every lane divides all three components (A/B switch, tools/ab_sweep.sh) */
+#endif
+YH_DEV f3 quad_div(f3 a, float b) { return YH_QUAD_DIV ? quad_spread(quad_pick(a) / b) : a / b; }
+YH_DEV f3 quad_rcp(f3 b) { return YH_QUAD_DIV ? quad_spread(1 / quad_pick(b)) : f3{1 / b.x, 1 / b.y, 1 / b.z}; }
+YH_DEV f3 quad_normalize(f3 a) {  // normalize (math.h:2036-2039)
+  float l = length(a);
+  return (l != 0) ? quad_div(a, l) : a;
+}
+YH_DEV f3 quad_orthonormalize(f3 a, f3 b) { return quad_normalize(a - b * dot(a, b)); }
 // 4-bit mask of `p` over the lanes of this lane's quad
 YH_DEV unsigned int quad_ballot(bool p) {
   unsigned long long b = __ballot(p);

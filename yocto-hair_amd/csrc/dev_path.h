@@ -20,9 +20,12 @@ namespace yhd {
 // pt.cpp:211-229 with sample_disk (math.h:4895-4899)
 YH_DEV ray_t sample_camera(const yhd_camera& cam, int i, int j, int w, int h, float pu, float pv,
     float lu, float lv) {
-  float uvx = ((float)i + pu) / (float)w, uvy = ((float)j + pv) / (float)h;
+  // (called by the four lanes of a quad with identical arguments: divisions spread over the lanes)
+  const unsigned int ql = __lane_id() & 3u;
+  float uvq = (ql == 0 ? (float)i + pu : (float)j + pv) / (ql == 0 ? (float)w : (float)h);
+  float uvx = quad_bcast_f<0>(uvq), uvy = quad_bcast_f<1>(uvq);
   f3    q  = {cam.film_x * (0.5f - uvx), cam.film_y * (uvy - 0.5f), cam.lens};
-  f3    dc = -normalize(q);
+  f3    dc = -quad_normalize(q);
   f3    e  = mk3(0.0f);
   if (cam.aperture != 0) {  // pinhole: lens point = finite * 0 / 2 = 0 whatever sample_disk returns
     float r   = sqrtf(lv);
@@ -30,13 +33,14 @@ YH_DEV ray_t sample_camera(const yhd_camera& cam, int i, int j, int w, int h, fl
     float lx = cosf(phi) * r, ly = sinf(phi) * r;
     e = f3{lx * cam.aperture / 2, ly * cam.aperture / 2, 0};
   }
-  f3    p  = dc * cam.focus / fabs_(dc.z);
-  f3    d  = normalize(p - e);
+  f3    p  = quad_div(dc * cam.focus, fabs_(dc.z));
+  f3    d  = quad_normalize(p - e);
   frame f  = ldframe(cam.frame);
-  return mkray(transform_point(f, e), transform_direction(f, d));
+  return mkray(transform_point(f, e), quad_normalize(transform_vector(f, d)));
 }
 
 YH_DEV f3 transform_normal(const frame& a, f3 b) { return normalize(transform_vector(a, b)); }
+YH_DEV f3 quad_transform_normal(const frame& a, f3 b) { return quad_normalize(transform_vector(a, b)); }
 
 // eval_position (pt.cpp:232-250) of a point on ELEMENT `element` (used to
 // sample area lights by triangle index): goes through elems / vpos.
@@ -59,6 +63,7 @@ YH_DEV f3 eval_position(const yhd_scene& sc, const yhd_object& o, int element, f
 struct hit_geom {
   f3 position, normal, element_normal;
 };
+// (quad-uniform: the normalisations use the quad forms of dev_math.h)
 YH_DEV hit_geom eval_hit(const yhd_scene& sc, const yhd_object& o, int slot, float u, float v) {
   frame    fr = ldframe(o.frame);
   hit_geom g;
@@ -66,10 +71,10 @@ YH_DEV hit_geom eval_hit(const yhd_scene& sc, const yhd_object& o, int slot, flo
     const yhd_float4* rec = sc.prims + (size_t)o.prim_base + (size_t)slot * 6;
     f3 p0 = xyz(ldg4(rec)), p1 = xyz(ldg4(rec + 1)), p2 = xyz(ldg4(rec + 2));
     g.position       = transform_point(fr, p0 * (1 - u - v) + p1 * u + p2 * v);
-    g.element_normal = transform_normal(fr, normalize(cross(p1 - p0, p2 - p0)));
+    g.element_normal = quad_transform_normal(fr, quad_normalize(cross(p1 - p0, p2 - p0)));
     if (o.has_normals) {
       f3 n0 = xyz(ldg4(rec + 3)), n1 = xyz(ldg4(rec + 4)), n2 = xyz(ldg4(rec + 5));
-      g.normal = transform_normal(fr, normalize(n0 * (1 - u - v) + n1 * u + n2 * v));
+      g.normal = quad_transform_normal(fr, quad_normalize(n0 * (1 - u - v) + n1 * u + n2 * v));
     } else {
       g.normal = g.element_normal;
     }
@@ -77,10 +82,10 @@ YH_DEV hit_geom eval_hit(const yhd_scene& sc, const yhd_object& o, int slot, flo
     const yhd_float4* rec = sc.prims + (size_t)o.prim_base + (size_t)slot * 4;
     f3 p0 = xyz(ldg4(rec)), p1 = xyz(ldg4(rec + 1));
     g.position       = transform_point(fr, p0 * (1 - u) + p1 * u);
-    g.element_normal = transform_normal(fr, normalize(p1 - p0));
+    g.element_normal = quad_transform_normal(fr, quad_normalize(p1 - p0));
     if (o.has_normals) {
       f3 n0 = xyz(ldg4(rec + 2)), n1 = xyz(ldg4(rec + 3));
-      g.normal = transform_normal(fr, normalize(n0 * (1 - u) + n1 * u));
+      g.normal = quad_transform_normal(fr, quad_normalize(n0 * (1 - u) + n1 * u));
     } else {
       g.normal = g.element_normal;
     }
@@ -342,7 +347,7 @@ YH_DEV bool path_step(const trace_ctx& tc, path_t& ps, const hit_t& isec, rng_t&
   f3 normal;  // eval_shading_normal (pt.cpp:350-369)
   bool is_hair = o.kind == YH_KIND_LINES;
   if (is_hair) {
-    normal = orthonormalize(outgoing, nrm);
+    normal = quad_orthonormalize(outgoing, nrm);
   } else {
     normal = (!mat.thin || dot(nrm, outgoing) >= 0) ? nrm : -nrm;
   }
@@ -385,8 +390,8 @@ YH_DEV bool path_step(const trace_ctx& tc, path_t& ps, const hit_t& isec, rng_t&
   hair_hit hh;
   hair_out ho;
   if (is_hair) {
-    hh = hair_setup(isec.v, normal, nrm);  // tangent = eval_normal (pt.cpp:487)
-    ho = hair_prepare(mat, hh, outgoing);  // shared by sample / eval / pdf
+    hh = hair_setup<true>(isec.v, normal, nrm);  // tangent = eval_normal (pt.cpp:487)
+    ho = hair_prepare<true>(mat, hh, outgoing);  // shared by sample / eval / pdf
   }
 
   if (COUNT) k1 = clock64(), tc.stats->c_geom += k1 - k0;
@@ -464,7 +469,7 @@ YH_DEV bool shade_step(const trace_ctx& tc, path_t& ps, const hit_t& isec, rng_t
   hit_geom hg = eval_hit(sc, o, isec.slot, isec.u, isec.v);
   f3   position = hg.position, nrm = hg.normal;
   bool is_hair  = o.kind == YH_KIND_LINES;
-  f3   normal   = is_hair ? orthonormalize(outgoing, nrm) : ((!mat.thin || dot(nrm, outgoing) >= 0) ? nrm : -nrm);
+  f3   normal   = is_hair ? quad_orthonormalize(outgoing, nrm) : ((!mat.thin || dot(nrm, outgoing) >= 0) ? nrm : -nrm);
   if (SHADER == YH_SHADER_NORMAL) {
     ps.radiance = normal * 0.5f + mk3(0.5f), ps.hit = true;
     return false;
@@ -490,8 +495,8 @@ YH_DEV bool shade_step(const trace_ctx& tc, path_t& ps, const hit_t& isec, rng_t
   hair_hit hh;
   hair_out ho;
   if (is_hair) {
-    hh = hair_setup(isec.v, normal, nrm);
-    ho = hair_prepare(mat, hh, outgoing);
+    hh = hair_setup<true>(isec.v, normal, nrm);
+    ho = hair_prepare<true>(mat, hh, outgoing);
   }
   f3    incoming, brdfcos;
   float pdf;

@@ -228,7 +228,7 @@ YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_obj
   hit.object = -1, hit.slot = -1, hit.u = 0, hit.v = 0, hit.distance = 0;
   float tmax = ray.tmax;
   // world-space ray data for the scene level
-  f3  wdinv = {1 / ray.d.x, 1 / ray.d.y, 1 / ray.d.z};
+  f3  wdinv = quad_rcp(ray.d);  // one division per lane of the quad (dev_math.h)
   int wsign = (wdinv.x < 0 ? 1 : 0) | (wdinv.y < 0 ? 2 : 0) | (wdinv.z < 0 ? 4 : 0);
   const bool wnonan = finite3(wdinv) && finite3(ray.o);
   auto box_test = [](f3 o, f3 dinv, float t0, float t1, f3 bmin, f3 bmax) {
@@ -332,7 +332,7 @@ YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_obj
       }
       lo    = transform_point(inv, ray.o);
       ld    = transform_vector(inv, ray.d);
-      ldinv = {1 / ld.x, 1 / ld.y, 1 / ld.z};
+      ldinv = quad_rcp(ld);
       lsign = (ldinv.x < 0 ? 1 : 0) | (ldinv.y < 0 ? 2 : 0) | (ldinv.z < 0 ? 4 : 0);
       if (!EXACT && !(finite3(ldinv) && finite3(lo))) {  // a slab of this object could hold a NaN: second pass
         redo = true;
