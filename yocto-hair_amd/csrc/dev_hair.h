@@ -289,6 +289,9 @@ struct hair_out {
   f3    ap0, ap1, ap2, ap3;      // Ap for f: T from sin_theta_o = outgoing.x (ext.cpp:281-295)
   float pdf0, pdf1, pdf2, pdf3;  // lobe pdfs: T from sin_theta_o = sqrt(1 - cos^2) (ext.cpp:372)
 };
+#ifndef YH_QUAD_AP
+#define YH_QUAD_AP 1  /* A/B switch (tools/ab_sweep.sh) */
+#endif
 template <bool QUAD = false>
 YH_DEV hair_out hair_prepare(const yhd_material& m, const hair_hit& hh, f3 outgoing_) {
   hair_out o;
@@ -296,6 +299,27 @@ YH_DEV hair_out hair_prepare(const yhd_material& m, const hair_hit& hh, f3 outgo
   o.sin_theta_o = outgoing.x;
   o.cos_theta_o = exact_safe_sqrt(1 - sqr(o.sin_theta_o));
   o.phi_o       = atan2f(outgoing.z, outgoing.y);
+  if (QUAD && YH_QUAD_AP) {
+    // The reference evaluates the transmittance and Ap twice, with sin_theta_o = outgoing.x for f
+    // (ext.cpp:281-295) and with sqrt(1 - cos^2) for the lobe pdfs (ext.cpp:372-397): lanes 0-1 of
+    // the quad take the first, lanes 2-3 the second, in one pass over the same code.
+    const bool for_pdf = (__lane_id() & 2u) != 0;
+    float      st      = for_pdf ? safe_sqrt(1 - o.cos_theta_o * o.cos_theta_o) : o.sin_theta_o;
+    float      gt;
+    f3         T = transmittance(m, hh.h, st, o.cos_theta_o, gt);
+    f3         a[p_max + 1];
+    ap(o.cos_theta_o, m.eta, hh.h, T, a);
+    float l0 = luminance(a[0]), l1 = luminance(a[1]), l2 = luminance(a[2]), l3 = luminance(a[3]);
+    float sum_y = 0.0f + l0 + l1 + l2 + l3;
+    o.gamma_t = quad_bcast_f<0>(gt);
+    o.ap0 = f3{quad_bcast_f<0>(a[0].x), quad_bcast_f<0>(a[0].y), quad_bcast_f<0>(a[0].z)};
+    o.ap1 = f3{quad_bcast_f<0>(a[1].x), quad_bcast_f<0>(a[1].y), quad_bcast_f<0>(a[1].z)};
+    o.ap2 = f3{quad_bcast_f<0>(a[2].x), quad_bcast_f<0>(a[2].y), quad_bcast_f<0>(a[2].z)};
+    o.ap3 = f3{quad_bcast_f<0>(a[3].x), quad_bcast_f<0>(a[3].y), quad_bcast_f<0>(a[3].z)};
+    o.pdf0 = quad_bcast_f<2>(h_div(l0, sum_y)), o.pdf1 = quad_bcast_f<2>(h_div(l1, sum_y));
+    o.pdf2 = quad_bcast_f<2>(h_div(l2, sum_y)), o.pdf3 = quad_bcast_f<2>(h_div(l3, sum_y));
+    return o;
+  }
   f3 T          = transmittance(m, hh.h, o.sin_theta_o, o.cos_theta_o, o.gamma_t);
   f3    apv[p_max + 1];
   float ap_pdf[p_max + 1];
