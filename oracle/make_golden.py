@@ -17,6 +17,7 @@ import make_scenes  # noqa: E402
 import oracle_capi as oc  # noqa: E402
 
 yh = oc.yh
+REF_SCENE_NAMES = ["sloth", "bold-man", "straight-hair", "curly-hair", "hair-curls", "sphere-hairblock"]
 # scenes the naive / eyelight / normal shader fixtures are rendered on (name, variant, resolution)
 SHADER_SCENES = [
     ("sphere-hairblock", dict(scale=0.05, zoom=True), 40),
@@ -140,6 +141,19 @@ def main():
                 out[f"{tag}|{shader}|8"], out[f"{tag}|{shader}|rng8"] = sc.render(p, 8, want_rng=True)
             sc.close()
         np.savez_compressed(os.path.join(GOLD, "shaders.npz"), **out)
+    # ---- the reference's own scene files, loaded by the reference's own loader -------------------
+    if want("refscenes.npz"):
+        out = {}
+        for which in REF_SCENE_NAMES:
+            path = make_scenes.ensure_scene("ref-" + which, "/tmp/yhair_golden_scenes", scale=0.05)
+            sc = ref.scene(path)
+            p = yh.TraceParams.default(resolution=48)
+            out[f"{which}|1"] = sc.render(p, 1)
+            out[f"{which}|8"], out[f"{which}|rng8"] = sc.render(p, 8, want_rng=True)
+            out[f"{which}|8_seed777"] = sc.render(yh.TraceParams.default(resolution=48, seed=777), 8)
+            out[f"{which}|lights"] = np.int32(sc.num_lights())
+            sc.close()
+        np.savez_compressed(os.path.join(GOLD, "refscenes.npz"), **out)
     rng = np.random.default_rng(20240607)
     if only:
         scenes_only(ref, rng, want)

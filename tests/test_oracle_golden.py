@@ -140,6 +140,25 @@ def test_other_shaders_bit_exact(oracle, yh):
     sc.close(), sf.close()
 
 
+REF_SCENE_NAMES = ["sloth", "bold-man", "straight-hair", "curly-hair", "hair-curls", "sphere-hairblock"]
+
+
+@pytest.mark.parametrize("which", REF_SCENE_NAMES)
+def test_reference_scene_files_bit_exact(oracle, yh, which):
+    """The reference's own scene descriptions (tests/golden/ref_scenes/*.json, verbatim; stand-in
+    geometry from tools/make_scenes.py) read by THIS build's loader and rendered by the oracle,
+    against images the reference rendered from the same files through its own loader."""
+    g = golden("refscenes.npz")
+    sf = yh.SceneFile(scene_path("ref-" + which, scale=0.05))
+    sc = oracle.scene(sf.desc)
+    assert sc.num_lights() == int(g[f"{which}|lights"])
+    p = yh.TraceParams.default(resolution=48)
+    assert np.array_equal(sc.render(p, 1), g[f"{which}|1"], equal_nan=True)
+    img, rng = sc.render(p, 8, want_rng=True)
+    assert np.array_equal(img, g[f"{which}|8"], equal_nan=True) and np.array_equal(rng, g[f"{which}|rng8"])
+    sc.close(), sf.close()
+
+
 def test_selftests_pass_on_oracle(oracle):
     """The four Monte-Carlo self-tests of the reference (ext.cpp:555-693) restated; the two
     cheap ones run here, all four run against the GPU in test_gpu_parity.py."""

@@ -424,6 +424,58 @@ def make_hair_curls(outdir, scale=1.0, name="hair-curls", beta_n=0.9, alpha=2):
     return os.path.join(d, name + ".json"), nseg * 4
 
 
+# ---------------------------------------------------------------------------------------------
+# The reference's OWN scene descriptions (tests/golden/ref_scenes/*.json: data files of the
+# reference's test directory, verbatim) with stand-ins for the models it does not distribute
+# (tests/.gitignore there): synthetic hair by shape name, the reference's sphere for every mesh,
+# a uv quad for the floor; textures it does ship (sky.hdr, floor.png) under their own names.
+# ---------------------------------------------------------------------------------------------
+REF_SCENES = os.path.join(ROOT, "tests", "golden", "ref_scenes")
+
+
+def make_reference_scene(outdir, scale=1.0, name=None, which="sloth"):
+    d = _prep(outdir, name)
+    with open(os.path.join(REF_SCENES, which + ".json")) as f:
+        scene = json.load(f)
+    shapes, textures = set(), set()
+    for o in scene.get("objects", {}).values():
+        if "shape" in o:
+            shapes.add(o["shape"])
+    for group in ("materials", "environments"):
+        for m in scene.get(group, {}).values():
+            textures.update(v for k, v in m.items() if k.endswith("_tex"))
+    nseg = 0
+    for sh in sorted(shapes):
+        dst = os.path.join(d, "shapes", sh + ".ply")
+        if sh == "hair-block":
+            nseg += write_hair_ply(dst, gen_hair_block(max(64, int(100_000 * scale))), 0.004, 0.001)
+        elif sh == "straight-hair":
+            nseg += write_hair_ply(dst, gen_head_hair(max(64, int(50_000 * scale)), 32, False), 0.006, 0.003)
+        elif sh == "curly-hair":
+            nseg += write_hair_ply(dst, gen_head_hair(max(64, int(50_000 * scale)), 64, True), 0.006, 0.003)
+        elif sh == "hair-curl":
+            nseg += write_hair_ply(dst, gen_hair_curl(max(64, int(10_000 * scale))), 0.008, 0.004)
+        elif "hair" in sh:  # sloth's fur patches
+            nseg += write_hair_ply(dst, gen_hair_curl(max(64, int(4_000 * scale)), 40), 0.008, 0.004)
+        elif sh == "arealight":
+            shutil.copy(os.path.join(ASSETS, "arealight_straight.ply" if which == "straight-hair" else "arealight.ply"), dst)
+        elif sh == "floor":
+            _write_uv_quad(dst, half=12.0, tiles=6.0)
+        else:
+            shutil.copy(os.path.join(ASSETS, "sphere.ply"), dst)
+    for t in sorted(textures):
+        if t in ("floor", "texture1"):
+            shutil.copy(os.path.join(ASSETS, "floor.png"), os.path.join(d, "textures", t + ".png"))
+        else:
+            shutil.copy(os.path.join(ASSETS, "sky.hdr"), os.path.join(d, "textures", t + ".hdr"))
+    shutil.copy(os.path.join(REF_SCENES, which + ".json"), os.path.join(d, name + ".json"))  # verbatim
+    return os.path.join(d, name + ".json"), nseg
+
+
+def _ref_maker(which):
+    return lambda outdir, scale=1.0, name=None: make_reference_scene(outdir, scale, name or ("ref-" + which), which)
+
+
 MAKERS = {
     "sphere-hairblock": make_sphere_hairblock,
     "straight-hair": make_straight_hair,
@@ -434,6 +486,10 @@ MAKERS = {
     "textured": make_textured,
     "crowd": make_crowd,
 }
+
+
+for _w in ("sloth", "bold-man", "straight-hair", "curly-hair", "hair-curls", "sphere-hairblock"):
+    MAKERS["ref-" + _w] = _ref_maker(_w)
 
 
 def ensure_scene(name, outdir, scale=1.0, **kw):

@@ -575,20 +575,38 @@ static yh_scene_file* load_scene(const std::string& path, const std::string& cam
   sf->desc.camera.film[1] = cam->aspect >= 1 ? cam->film / cam->aspect : cam->film;
   sf->desc.camera.focus = cam->focus, sf->desc.camera.aperture = cam->aperture;
 
-  // textures are only supported on environments
+  // environment textures (sceneio.cpp:1383-1391: textures/<name>.{hdr,exr,png,jpg}, first that exists);
+  // 8-bit images become float texels here with the reference's lookup-time conversion
+  // srgb_to_rgb(byte / 255) (pt.cpp:147-164, math.h:3742-3745), so environments keep one texel format
   std::map<std::string, int> tex_index;
   struct Tex { int w, h, data; };  // data = index into sf->tex_data
   std::vector<Tex> texs;
   auto get_texture = [&](const std::string& name) {
     auto it = tex_index.find(name);
     if (it != tex_index.end()) return it->second;
-    auto file = base + "/textures/" + name + ".hdr";
-    if (!file_exists(file)) throw std::runtime_error(file + ": file not found (only .hdr textures are supported)");
-    int w, h;
-    sf->tex_data.emplace_back();
-    load_hdr(file, w, h, sf->tex_data.back());
-    texs.push_back({w, h, (int)sf->tex_data.size() - 1});
-    return tex_index[name] = (int)texs.size() - 1;
+    for (const char* ext : {".hdr", ".exr", ".png", ".jpg"}) {
+      auto file = base + "/textures/" + name + ext;
+      if (!file_exists(file)) continue;
+      int w, h;
+      sf->tex_data.emplace_back();
+      if (!strcmp(ext, ".hdr")) {
+        load_hdr(file, w, h, sf->tex_data.back());
+      } else if (!strcmp(ext, ".png")) {
+        std::vector<unsigned char> bytes;
+        load_png(file, w, h, bytes);
+        auto srgb_to_rgb = [](float srgb) {
+          return (srgb <= 0.04045) ? srgb / 12.92f : std::pow((srgb + 0.055f) / (1.0f + 0.055f), 2.4f);
+        };
+        auto& f = sf->tex_data.back();
+        f.resize(bytes.size());
+        for (size_t i = 0; i < bytes.size(); i++) f[i] = srgb_to_rgb(bytes[i] / 255.0f);
+      } else {
+        throw std::runtime_error(file + ": only .hdr and .png textures are supported");
+      }
+      texs.push_back({w, h, (int)sf->tex_data.size() - 1});
+      return tex_index[name] = (int)texs.size() - 1;
+    }
+    throw std::runtime_error(base + "/textures/" + name + ".hdr: file not found");
   };
 
   if (js.has("environments"))
