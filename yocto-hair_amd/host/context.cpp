@@ -259,6 +259,7 @@ struct yh_context {
   int              num_tiles_total = 0;
   float            last_ms = 0;
   int              last_launches = 0;
+  unsigned         launches_of_state = 0;  // synchronous launches since yh_init_state (re-planning schedule)
   int              launch_shape = 0;  // decided from launches of at least 16 spp (shorter ones have flat, noisy item costs)
 };
 
@@ -814,6 +815,7 @@ int yh_init_state(yh_context* ctx, const yh_trace_params* params) {
   s.accum = (yhd_float4*)ctx->d_accum.p, s.tiles = (const int*)ctx->d_tiles.p;
   s.launch_shape = getenv("YHAIR_SHAPE") ? choose_launch_shape(ctx) : ctx->launch_shape;
   s.num_tiles = (int)tiles.size(), s.width = w, s.height = h, s.tiles_x = tx;
+  ctx->launches_of_state = 0;
   s.samples_done = 0, s.bounces = params->bounces, s.clamp = params->clamp, s.shader = params->shader;
   s.shard_rank = ctx->rank, s.shard_world = ctx->world;
   ctx->have_state = true;
@@ -860,12 +862,18 @@ static int trace_impl(yh_context* ctx, int nsamples, bool counted, bool sync) {
     // Longest-processing-time-first for the next launch (pixel results do not
     // depend on the order): a pixel's samples are sequential, so the items that
     // start last bound the launch; hair quadrants cost 10-100x background ones.
-    HIPCHK(ctx, hipMemcpy(ctx->item_cost.data(), ctx->d_tile_cost.p, ctx->item_cost.size() * 4, hipMemcpyDeviceToHost));
-    std::vector<int> tiles;
-    build_work_items(ctx, tiles);
-    HIPCHK(ctx, hipMemcpy(ctx->d_tiles.p, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice));
-    if (path && (nsamples >= 16 || getenv("YHAIR_SHAPE"))) ctx->launch_shape = choose_launch_shape(ctx);
-    ctx->state.launch_shape = ctx->launch_shape;
+    // Re-planned after launches 1, 2, 4, 8, ... of a state: the relative costs of the items settle
+    // after the first launches (they are a property of the image), and the read-back, sort and
+    // upload are a few hundred microseconds of a 16 ms launch.
+    const unsigned li = ++ctx->launches_of_state;
+    if ((li & (li - 1)) == 0) {
+      HIPCHK(ctx, hipMemcpy(ctx->item_cost.data(), ctx->d_tile_cost.p, ctx->item_cost.size() * 4, hipMemcpyDeviceToHost));
+      std::vector<int> tiles;
+      build_work_items(ctx, tiles);
+      HIPCHK(ctx, hipMemcpy(ctx->d_tiles.p, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice));
+      if (path && (nsamples >= 16 || getenv("YHAIR_SHAPE"))) ctx->launch_shape = choose_launch_shape(ctx);
+      ctx->state.launch_shape = ctx->launch_shape;
+    }
   }
   return YH_OK;
 }
