@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Quick end-to-end check of the HIP path against the CPU oracle on one GPU (developer tool;
+"""TEST INFRASTRUCTURE (uses the oracle as the checker). Quick end-to-end check of the HIP path against the CPU oracle on one GPU (developer tool;
 the judged versions of these checks live in tests/ under -m gpu)."""
 import argparse
 import os

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Developer tool: camera-ray traversal micro-benchmark (k_intersect) on the C1 scene. Run under
+"""TEST INFRASTRUCTURE (uses the oracle for reference work counts). Developer tool: camera-ray traversal micro-benchmark (k_intersect) on the C1 scene. Run under
 rocprofv3 --kernel-trace to get per-dispatch durations; prints the reference work counts of each
 ray set so that cycles per node / per wave-trip can be derived."""
 import os, sys, time
