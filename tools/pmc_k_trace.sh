@@ -1,6 +1,7 @@
 #!/bin/bash
 # PMC passes over `bench.py --steps 4` (k_trace). Each --pmc group is its own run (no trace
 # domains besides --kernel-trace). Usage on the GPU box: bash tools/pmc_k_trace.sh <tag>
+# Other configs: PMC_KERNEL='k_trace<false, false, 256, 6>' PMC_ARGS='--scene straight-hair ...' bash tools/pmc_k_trace.sh <tag>
 set -u
 TAG=${1:-pmc}
 cd "$(dirname "$0")/.." && ROOT=$PWD
@@ -12,9 +13,9 @@ for grp in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCL
            "SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_FLAT SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" \
            "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
-  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc $grp -d "$OUT/p$i" -o run -- python3 "$ROOT/bench.py" --steps 4 --warmup 1 > "$OUT/p$i.log" 2>&1)
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc $grp -d "$OUT/p$i" -o run -- python3 "$ROOT/bench.py" --no-cpu-baseline ${PMC_ARGS:-} --steps 4 --warmup ${PMC_WARMUP:-1} > "$OUT/p$i.log" 2>&1)
 done
-python3 - "$OUT" <<'PY'
+python3 - "$OUT" "${PMC_KERNEL:-k_trace<false, false, 512, 4>}" <<'PY'
 import csv, glob, json, sys, collections
 out = sys.argv[1]
 res = {}
@@ -22,7 +23,7 @@ for d in sorted(glob.glob(out + "/p*/")):
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         acc, cnt = collections.defaultdict(float), collections.defaultdict(set)
         for r in csv.DictReader(open(f)):
-            if "k_trace<false, false, 512, 4>" not in r["Kernel_Name"]:  # the bench's (C1's) variant only
+            if sys.argv[2] not in r["Kernel_Name"]:  # the launch shape of the config under test only
                 continue
             acc[r["Counter_Name"]] += float(r["Counter_Value"])
             cnt[r["Counter_Name"]].add(r["Dispatch_Id"])
