@@ -73,11 +73,32 @@ struct hit_t {
 };
 
 // math.h:3426-3469
+// STRAIGHT: the reference's three early returns as one predicate. The lanes of a wave test
+// different primitives, so in dense hair an early return almost never skips the rest for the whole
+// wave while each one costs an exec-mask save / branch / restore on the scalar unit (dense launch
+// shape: +2 % on C2); in C1 leaf steps run with a few lanes and the returns do skip (-3 %), so
+// the 512-thread shape keeps them. A zero det makes t and s inf or NaN and every comparison false,
+// as the first return would.
+template <bool STRAIGHT = false>
 YH_DEV bool intersect_line(f3 ro, f3 rd, float tmin, float tmax, f3 p0, f3 p1, float r0,
     float r1, float& uu, float& vv, float& dist) {
   f3    u = rd, v = p1 - p0, w = ro - p0;
   float a = dot(u, u), b = dot(u, v), c = dot(v, v), d = dot(u, w), e = dot(v, w);
   float det = a * c - b * b;
+  if (STRAIGHT) {
+    float t   = (b * e - c * d) / det;
+    float s   = (a * e - b * d) / det;
+    bool  ok  = det != 0 && !(t < tmin || t > tmax);
+    s         = fclamp(s, 0.0f, 1.0f);
+    f3    pr  = ro + rd * t;
+    f3    pl  = p0 + (p1 - p0) * s;
+    f3    prl = pr - pl;
+    float d2  = dot(prl, prl);
+    float r   = r0 * (1 - s) + r1 * s;
+    ok        = ok && !(d2 > r * r);
+    if (ok) uu = s, vv = sqrtf(d2) / r, dist = t;
+    return ok;
+  }
   if (det == 0) return false;
   float t = (b * e - c * d) / det;
   float s = (a * e - b * d) / det;
@@ -408,7 +429,7 @@ YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_obj
           if (COUNT) count_branch<COUNT>(tc.stats->t_line, tc.stats->l_line);
           if (mine) {
             n_seg++;
-            ok = intersect_line(lo, ld, ray.tmin, tmax, xyz(s0), xyz(s1), s0.w, s1.w, uu, vv, dist);
+            ok = intersect_line<(STRIDE == 64)>(lo, ld, ray.tmin, tmax, xyz(s0), xyz(s1), s0.w, s1.w, uu, vv, dist);  // dense shape: 256 threads = 64 quads
           }
         } else {
           if (COUNT) count_branch<COUNT>(tc.stats->t_tri, tc.stats->l_tri);
