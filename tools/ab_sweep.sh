@@ -12,8 +12,10 @@ mkdir -p /tmp/yh_sweep
 for v in "${variants[@]}"; do
   name=${v%%:*}; flags=${v#*:}
   [ -f /tmp/yh_sweep/libyhair_$name.so ] && continue
-  /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -fno-vectorize -fPIC -std=c++17 -I$R/include -I$R/yocto-hair_amd/csrc $flags \
-      -c $R/yocto-hair_amd/csrc/kernels.hip -o /tmp/yh_sweep/k_$name.o &
+  src=$R/yocto-hair_amd/csrc
+  case $name in old*) src=$R/tools/_old_csrc;; esac   # a snapshot of an earlier csrc/ placed there by hand
+  /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -fno-vectorize -fPIC -std=c++17 -I$R/include -I$src $flags \
+      -c $src/kernels.hip -o /tmp/yh_sweep/k_$name.o &
 done
 wait
 for v in "${variants[@]}"; do
