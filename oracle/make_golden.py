@@ -41,6 +41,9 @@ GOLDEN_SCENES = [
     ("sphere-hairblock", dict(scale=0.05, dof=True), 96),  # thin lens (aperture > 0), portrait film
     ("crowd", dict(scale=0.05), 96),      # 72 objects: deep scene-level BVH, scene table larger than its LDS stage
     ("textured", dict(scale=0.05), 96),   # colour textures: color_tex / emission_tex / scattering_tex, png + hdr, tiling
+    # C2's beta_m sweep {0.1, 0.25, 0.6}: 0.1 and 0.25 take Mp's v <= 0.1 branch (ext.cpp:201-207), 0.6 the other
+    ("straight-hair", dict(scale=0.05, beta_m=0.25), 64),
+    ("straight-hair", dict(scale=0.05, beta_m=0.6), 64),
 ]
 
 
@@ -217,6 +220,8 @@ def scenes_only(ref, rng, want):
             rng = np.random.default_rng(20240609)
         if kw.get("dof"):
             rng = np.random.default_rng(20240611)
+        if kw.get("beta_m") in (0.25, 0.6):  # added in round 2: own generator, older fixtures never move
+            rng = np.random.default_rng(20240612)
         sc = ref.scene(path)
         m = 4096
         if name in ("lobes", "volumes", "textured", "crowd"):

@@ -76,6 +76,8 @@ GOLDEN_SCENES = [
     ("sphere-hairblock", dict(scale=0.05, dof=True)),
     ("textured", dict(scale=0.05)),
     ("crowd", dict(scale=0.05)),
+    ("straight-hair", dict(scale=0.05, beta_m=0.25)),
+    ("straight-hair", dict(scale=0.05, beta_m=0.6)),
 ]
 
 

@@ -21,6 +21,11 @@ pytestmark = pytest.mark.gpu
 
 REL_BSDF = 1e-4   # stated float tolerance for f and pdf
 ABS_DIR = 5e-5    # stated tolerance for sampled directions
+# Share of 1-spp pixels within rel 1e-3 of the reference. Measured 0.95-1.00 on every golden scene
+# (oracle/divergence_report.py, profiles/); the same reference rebuilt with FMA contraction keeps 0.95
+# in dense hair, a wrong RNG order or algorithm gives ~0.
+BAR_1SPP = 0.90
+K_SIGMA = 4.0     # per-pixel |gpu - ref| <= k sqrt(var_ref / N + var_gpu / N) for >= 99 % of pixels
 
 
 def _rel(a, b, floor=1e-6):
@@ -282,7 +287,7 @@ def test_images_match_reference_statistically(ctx, yh, name, kw):
     ref = g["img_1"]
     assert np.isfinite(img).all()
     close = _rel(img[..., :3], ref[..., :3]).max(axis=2) < 1e-3
-    assert close.mean() >= 0.60, f"only {close.mean():.3f} of pixels within rel 1e-3 at 1 spp"
+    assert close.mean() >= BAR_1SPP, f"only {close.mean():.3f} of pixels within rel 1e-3 at 1 spp"
     hit = ref[..., 3] > 0
     assert np.mean(img[..., 3] == ref[..., 3]) > 0.999  # primary visibility is exact
     # camera rays that escape: bit-identical under a constant environment; with the lat-long
@@ -293,7 +298,7 @@ def test_images_match_reference_statistically(ctx, yh, name, kw):
         assert np.mean(_rel(img[~hit][:, :3], ref[~hit][:, :3]).max(axis=1) < 1e-3) > 0.99
     # rng state after one sample agrees for the pixels whose path did not diverge
     rng1 = ctx.download_rng()
-    assert np.mean(rng1[:, 0] == g["rng_1"][:, 0]) >= 0.60
+    assert np.mean(rng1[:, 0] == g["rng_1"][:, 0]) >= BAR_1SPP
     # --- 16 spp ------------------------------------------------------------------------------
     ctx.init_state(p)
     ctx.trace_samples(16)
@@ -322,7 +327,7 @@ def test_trace_params_follow_the_oracle(ctx, oracle, yh, res, bounces, clamp, se
     img, ref = ctx.download(), osc.render(p, 1)
     assert img.shape == ref.shape == (h, w, 4)
     close = _rel(img[..., :3], ref[..., :3]).max(axis=2) < 1e-3
-    assert close.mean() >= 0.60 and np.isfinite(img).all()
+    assert close.mean() >= BAR_1SPP and np.isfinite(img).all()
     assert img[..., :3].max() <= clamp * (1 + 1e-6)
     ctx.init_state(p)
     ctx.trace_samples(16)
@@ -357,7 +362,7 @@ def test_other_shaders_match_reference(ctx, oracle, yh, name, kw, shader):
         assert close.mean() >= 0.97, f"{close.mean():.3f}"
         assert np.abs(img[..., :3] - ref1[..., :3]).max() < 2e-2   # a hit that flips between neighbouring hairs
     else:
-        assert close.mean() >= 0.60, f"only {close.mean():.3f} of pixels within rel 1e-3 at 1 spp"
+        assert close.mean() >= BAR_1SPP, f"only {close.mean():.3f} of pixels within rel 1e-3 at 1 spp"
     ctx.init_state(p)
     ctx.trace_samples(8)
     img8 = ctx.download()
@@ -388,7 +393,7 @@ def test_reference_scene_files_render_like_the_reference(ctx, yh, which):
     assert np.isfinite(img).all()
     assert np.mean(img[..., 3] == ref1[..., 3]) > 0.995
     close = _rel(img[..., :3], ref1[..., :3]).max(axis=2) < 1e-3
-    assert close.mean() >= 0.60, f"only {close.mean():.3f} of pixels within rel 1e-3 at 1 spp"
+    assert close.mean() >= BAR_1SPP, f"only {close.mean():.3f} of pixels within rel 1e-3 at 1 spp"
     # 8 spp against the seed-to-seed floor. Bar 0.75 instead of the golden scenes' 0.5: the
     # reference's sphere-hairblock material is light hair (colour 0.8: eight-bounce paths, each bounce
     # a chance to leave the reference's path), measured 0.52-0.62 there and 0.00-0.43 on the others
@@ -546,3 +551,147 @@ def test_full_size_properties(ctx, yh):
     assert 0.3 < bg.mean() < 0.95
     assert np.array_equal(a[bg][:, :3], np.ones((bg.sum(), 3), np.float32))  # constant env (1,1,1)
     sf.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# round 2: per-pixel k-sigma bar, launch shapes, BASELINE configs C2-C4 at full size
+# ---------------------------------------------------------------------------------------------
+HAIR_GOLDEN = [(n, k) for n, k in GOLDEN_SCENES if n in ("sphere-hairblock", "straight-hair", "curly-hair", "hair-curls")
+               and not k.get("dof")]
+
+
+def _k_sigma_share(ctx, osc, yh, res, spp, ref_img, seeds=(961748941, 12345, 777, 31337, 2024, 99)):
+    """Share of pixels with |gpu - ref| <= K_SIGMA sqrt(var_ref + var_gpu), the variances of an spp-sample
+    pixel mean estimated from renders at independent seeds on both sides."""
+    gpu, ref = [], []
+    for sd in seeds:
+        p = yh.TraceParams.default(resolution=res, seed=sd)
+        ctx.init_state(p)
+        ctx.trace_samples(spp)
+        gpu.append(ctx.download()[..., :3])
+        ref.append(osc.render(p, spp)[..., :3] if sd != seeds[0] or ref_img is None else ref_img[..., :3])
+    gpu, ref = np.stack(gpu), np.stack(ref)
+    var = gpu.var(axis=0, ddof=1) + ref.var(axis=0, ddof=1)
+    delta = np.abs(gpu[0] - ref[0])
+    # pixels without variance (background under a constant environment) must agree to rounding
+    ok = delta <= K_SIGMA * np.sqrt(var) + 1e-3 * np.abs(ref[0]) + 1e-6
+    return float(ok.all(axis=2).mean()), float(np.sqrt(np.mean(delta ** 2)) / ref[0].mean())
+
+
+@pytest.mark.parametrize("name,kw", HAIR_GOLDEN, ids=[f"{n}-{'-'.join(map(str, k.values()))}" for n, k in HAIR_GOLDEN])
+def test_per_pixel_error_within_k_sigma(ctx, oracle, yh, name, kw):
+    """16 spp against the reference's golden image, 64 spp against the oracle (bit-identical to the
+    reference): >= 99 % of pixels within K_SIGMA standard errors."""
+    g = golden(f"scene_{scene_tag(name, kw)}.npz")
+    sf = yh.SceneFile(scene_path(name, **kw))
+    ctx.upload_scene(sf.desc)
+    osc = oracle.scene(sf.desc)
+    res = g["img_16"].shape[0]
+    share16, err16 = _k_sigma_share(ctx, osc, yh, res, 16, g["img_16"])
+    assert share16 >= 0.99, f"16 spp: {share16:.4f} of pixels within {K_SIGMA} sigma (relRMSE {err16:.4f})"
+    share64, err64 = _k_sigma_share(ctx, osc, yh, res, 64, None, seeds=(961748941, 12345, 777, 31337))
+    assert share64 >= 0.99, f"64 spp: {share64:.4f} of pixels within {K_SIGMA} sigma (relRMSE {err64:.4f})"
+    osc.close(), sf.close()
+
+
+@pytest.mark.parametrize("name,kw", [("sphere-hairblock", dict(scale=0.05, zoom=True)), ("straight-hair", dict(scale=0.05)),
+                                     ("hair-curls", dict(scale=0.05)), ("lobes", dict(scale=0.05))],
+                         ids=["sphere-hairblock", "straight-hair", "hair-curls", "lobes"])
+def test_launch_shapes_and_kernels_render_identical_pixels(ctx, yh, name, kw, monkeypatch):
+    """The host picks k_trace's launch shape (512 x 4 or 256 x 6 with the single-predicate line test) and
+    the integrator kernel from the previous launch's item costs, so which kernel a render runs depends on
+    history. Every choice must give the same bits: the forced variants are compared pairwise."""
+    sf = yh.SceneFile(scene_path(name, **kw))
+    ctx.upload_scene(sf.desc)
+    p = yh.TraceParams.default(resolution=88)
+    images = {}
+    for shape in ("0", "1") + (("pool",) if hasattr(yh, "HAVE_POOL") else ()):
+        monkeypatch.setenv("YHAIR_SHAPE", shape)
+        ctx.init_state(p)
+        ctx.trace_samples(3), ctx.trace_samples(5)
+        images[shape] = (ctx.download(), ctx.download_rng())
+    monkeypatch.delenv("YHAIR_SHAPE")
+    ctx.init_state(p)
+    ctx.trace_samples(3), ctx.trace_samples(5)
+    images["auto"] = (ctx.download(), ctx.download_rng())
+    base = images["0"]
+    assert base[0][..., 3].max() > 0
+    for k, (img, rng) in images.items():
+        assert np.array_equal(img, base[0]), f"shape {k} renders different pixels"
+        assert np.array_equal(rng, base[1]), f"shape {k} leaves different RNG states"
+    sf.close()
+
+
+FULL_CONFIGS = [
+    ("C2-beta_m0.1", "straight-hair", dict(scale=1.0, beta_m=0.1), 720),
+    ("C2-beta_m0.25", "straight-hair", dict(scale=1.0, beta_m=0.25), 720),
+    ("C2-beta_m0.6", "straight-hair", dict(scale=1.0, beta_m=0.6), 720),
+    ("C3", "curly-hair", dict(scale=1.0), 1280),
+    ("C4", "hair-curls", dict(scale=1.0), 1280),
+]
+
+
+@pytest.mark.parametrize("tag,name,kw,res", FULL_CONFIGS, ids=[c[0] for c in FULL_CONFIGS])
+def test_baseline_configs_at_full_size(ctx, oracle, yh, tag, name, kw, res):
+    """BASELINE.json configs[2..4] with their full geometry (1.6 M / 3.2 M / 4 x 1.0 M segments): (1) at the
+    config's resolution, the size-independent properties of test_full_size_properties; (2) the same
+    geometry at 96 x 96 against the oracle with the image bars of the golden scenes."""
+    sf = yh.SceneFile(scene_path(name, **kw))
+    d = sf.desc.contents
+    segments = sum(d.shapes[i].num_lines for i in range(d.num_shapes))
+    assert segments >= 1_000_000
+    ctx.upload_scene(sf.desc)
+    p = yh.TraceParams.default(resolution=res)
+    assert ctx.init_state(p) == (res, res)
+    ctx.trace_samples(1), ctx.trace_samples(2)
+    a = ctx.download()
+    ctx.init_state(p)
+    ctx.trace_samples(3)
+    assert np.array_equal(ctx.download(), a)                       # determinism; 1 + 2 spp == 3 spp
+    assert np.isfinite(a).all() and a.min() >= 0 and a[..., :3].max() <= 100.0 * (1 + 1e-6)
+    hit = a[..., 3] > 0
+    assert 0.2 < hit.mean() < 0.98
+    # camera rays that escape see the sky texture times the environment's emission: bounded by its
+    # brightest texel, and never black
+    env = d.environments[0]
+    n_tex = env.tex_width * env.tex_height
+    texmax = np.ctypeslib.as_array(env.texels, (n_tex, 3)).max(axis=0) * np.array(list(env.emission), np.float32)
+    assert (a[~hit][:, :3] <= texmax * (1 + 1e-5)).all() and a[~hit][:, :3].max(axis=1).min() > 0
+    # (2) full geometry, 96 x 96, against the oracle
+    osc = oracle.scene(sf.desc)
+    q = yh.TraceParams.default(resolution=96)
+    ctx.init_state(q)
+    ctx.trace_samples(1)
+    g1, r1 = ctx.download(), osc.render(q, 1)
+    assert np.mean(g1[..., 3] == r1[..., 3]) > 0.999
+    close = _rel(g1[..., :3], r1[..., :3]).max(axis=2) < 1e-3
+    assert close.mean() >= BAR_1SPP, f"{tag}: only {close.mean():.3f} of pixels within rel 1e-3 at 1 spp"
+    ctx.init_state(q)
+    ctx.trace_samples(16)
+    g16, r16 = ctx.download(), osc.render(q, 16)
+    other = osc.render(yh.TraceParams.default(resolution=96, seed=12345), 16)
+    err, floor = _relrmse(g16, r16), _relrmse(other, r16)
+    assert err <= 0.5 * floor, f"{tag}: relRMSE {err:.4f} vs seed floor {floor:.4f}"
+    osc.close(), sf.close()
+
+
+def test_light_sampling_matches_oracle_at_unit_level(ctx, oracle, yh):
+    """a20 (sample_lights / sample_lights_pdf, pt.cpp:1283-1358) isolated from the BSDF: a scene whose
+    only surfaces are diffuse (no hair, so no libm-driven divergence before the light code runs) under
+    two area lights and the textured sky, at 1 bounce: every radiance value is emission + one
+    MIS-weighted light / BRDF sample, i.e. sample_lights, the env-CDF upper_bound and both pdf branches."""
+    sf = yh.SceneFile(scene_path("lights-unit", scale=0.05))
+    ctx.upload_scene(sf.desc)
+    osc = oracle.scene(sf.desc)
+    for bounces, spp in ((2, 4), (8, 4)):
+        p = yh.TraceParams.default(resolution=96, bounces=bounces)
+        ctx.init_state(p)
+        ctx.trace_samples(spp)
+        img, rng = ctx.download(), ctx.download_rng()
+        ref, rref = osc.render(p, spp, want_rng=True)
+        # diffuse-only paths: every draw count and nearly every value follows the reference exactly
+        assert np.mean(rng[:, 0] == rref[:, 0]) > 0.995
+        close = _rel(img[..., :3], ref[..., :3]).max(axis=2) < 1e-3
+        assert close.mean() > 0.99, f"bounces {bounces}: {close.mean():.4f}"
+        assert (ref[..., 3] > 0).mean() > 0.3
+    osc.close(), sf.close()

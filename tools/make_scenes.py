@@ -476,7 +476,37 @@ def _ref_maker(which):
     return lambda outdir, scale=1.0, name=None: make_reference_scene(outdir, scale, name or ("ref-" + which), which)
 
 
+def make_lights_unit(outdir, scale=1.0, name="lights-unit"):
+    """Light sampling in isolation (pt.cpp:1283-1358): diffuse spheres and a floor — no hair, so no
+    libm-driven path divergence ahead of the light code — under two area lights (the uniform light
+    pick, triangle CDF, the 100-step area pdf walk through both quads) and the textured sky (texel CDF
+    upper_bound, texel pdf)."""
+    d = _prep(outdir, name)
+    shutil.copy(os.path.join(ASSETS, "sphere.ply"), os.path.join(d, "shapes", "sphere.ply"))
+    shutil.copy(os.path.join(ASSETS, "arealight.ply"), os.path.join(d, "shapes", "arealight.ply"))
+    shutil.copy(os.path.join(ASSETS, "sky.hdr"), os.path.join(d, "textures", "sky.hdr"))
+    objects = {
+        "floor": {"frame": [3, 0, 0, 0, 0, -3, 0, 3, 0, 0.0, 0, 0], "shape": "arealight", "material": "floor"},
+        "ball0": {"frame": [1, 0, 0, 0, 1, 0, 0, 0, 1, -0.7, 0.0, 0.2], "shape": "sphere", "material": "red"},
+        "ball1": {"frame": [0.6, 0, 0, 0, 0.6, 0, 0, 0, 0.6, 0.8, 0.0, 0.6], "shape": "sphere", "material": "white"},
+        # one light behind the other as seen from the floor: the area pdf walk crosses both quads
+        "light1": {"lookat": [0.5, 4, 1.5, 0.0, 0.5, 0, 0, 1, 0], "shape": "arealight", "material": "arealight"},
+        "light2": {"lookat": [1.0, 8, 3.0, 0.0, 0.5, 0, 0, 1, 0], "shape": "arealight", "material": "arealight2"},
+    }
+    scene = {
+        "asset": {"copyright": "synthetic; sphere, quad and sky.hdr from the reference's test assets"},
+        "cameras": {"default": {"lens": 0.05, "aperture": 0.0, "aspect": 1.0, "lookat": [0.0, 2.4, 5.5, 0.0, 0.5, 0, 0, 1, 0]}},
+        "environments": {"sky": {"emission": [1.5, 1.5, 1.5], "emission_tex": "sky", "frame": IDENT}},
+        "objects": objects,
+        "materials": {"floor": {"color": [0.7, 0.7, 0.7]}, "red": {"color": [0.8, 0.2, 0.2]}, "white": {"color": [0.9, 0.9, 0.9]},
+                      "arealight": {"emission": [10, 10, 10]}, "arealight2": {"emission": [30, 25, 20]}},
+    }
+    _dump(scene, os.path.join(d, name + ".json"))
+    return os.path.join(d, name + ".json"), 0
+
+
 MAKERS = {
+    "lights-unit": make_lights_unit,
     "sphere-hairblock": make_sphere_hairblock,
     "straight-hair": make_straight_hair,
     "curly-hair": make_curly_hair,

@@ -1,10 +1,11 @@
 // kernels.hip — gfx950 kernels of the hair path and their launchers.
 //
-//   k_trace          the sample loop (trace_samples, pt.cpp:1992-2007): one
-//                    64-lane wavefront owns one 8x8 pixel tile, each lane one
-//                    pixel with its own PCG32 stream; tiles are pulled from the
-//                    owned-tile list; the top of the hair BVH and nothing else
-//                    lives in LDS.
+//   k_trace          the sample loop (trace_samples, pt.cpp:1992-2007): persistent
+//                    wavefronts pull 4x4-pixel work items (most expensive first);
+//                    a QUAD of four lanes owns one pixel / one path (its PCG32
+//                    stream is sequential) and splits BVH steps and hair lobes
+//                    over its lanes; traversal stacks, the scene-level tables and
+//                    the camera live in LDS (nodelets optional, YHAIR_LDS_NODES).
 //   k_hair_*         unit-level batches of the four yocto::extension functions
 //   k_intersect      unit-level closest-hit batch
 //   k_selftest       the four Monte-Carlo self-tests (ext.cpp:555-693), made
@@ -603,13 +604,11 @@ int yhk_trace(const yhd_scene* sc, const yhd_state* st, int nsamples, yhd_counte
   const int  shape = path && st->launch_shape ? 1 : 0;  // the other shaders have one shape (512 x 4)
   if (!path && counters) return (int)hipErrorInvalidValue;
   size_t    lds   = trace_lds(sc->lds_node_count, sc->lds_scene_f4, shape);
-  static size_t lds_set[8 + YH_SHADER_COUNT] = {0};
-  int            which = path ? (counters ? 1 : 0) + (sc->general_materials ? 2 : 0) + 4 * shape : 8 + st->shader;
   trace_kernel_t k     = trace_kernel(counters != nullptr, sc->general_materials != 0, shape, st->shader);
-  if (lds > lds_set[which]) {  // above 64 KB the dynamic-LDS limit must be raised explicitly
+  if (lds > 64 * 1024) {  // above 64 KB the dynamic-LDS limit must be raised explicitly; the attribute is per
+                          // device, so it is set for the current device at every such launch (no process-wide cache)
     hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    lds_set[which] = lds;
   }
   hipLaunchKernelGGL(k, dim3(grid_blocks), dim3(shape_block(shape)), lds, stream, *sc, *st, nsamples, counters);
   return (int)hipGetLastError();
@@ -622,9 +621,11 @@ int yhk_trace_lds_bytes(int lds_node_count, int lds_scene_f4, int shape) {
 int yhk_trace_occupancy(int lds_bytes, int general, int shape) {
   int            blocks = 0;
   trace_kernel_t k      = trace_kernel(false, general != 0, shape ? 1 : 0);
-  (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  if (lds_bytes > 64 * 1024 &&
+      hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
+    return 0;  // the kernel cannot be launched with this much LDS: the caller reports it
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k, shape_block(shape ? 1 : 0), lds_bytes) != hipSuccess) return 1;
-  return blocks < 1 ? 1 : blocks;
+  return blocks < 1 ? 0 : blocks;
 }
 int yhk_resolve(const yhd_state* st, int owned_tiles, int samples, void* image, hipStream_t stream) {
   if (owned_tiles) hipLaunchKernelGGL(k_resolve, dim3(owned_tiles), dim3(64), 0, stream, *st, samples, (yhd_float4*)image);

@@ -58,6 +58,10 @@ std::string g_create_error = "no error";
 struct DevBuf {
   void*  p = nullptr;
   size_t bytes = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;  // owns a hipMalloc pointer
+  DevBuf& operator=(const DevBuf&) = delete;
+  DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr, o.bytes = 0; }
   ~DevBuf() { reset(); }
   void reset() {
     if (p) (void)hipFree(p);
@@ -341,7 +345,7 @@ int choose_launch_shape(const yh_context* ctx) {
     }
   if (mx == 0) return 0;  // nothing measured yet
   int    lds      = yhk_trace_lds_bytes(ctx->scene.lds_node_count, ctx->scene.lds_scene_f4, 0);
-  double resident = (double)ctx->num_cus * yhk_trace_occupancy(lds, ctx->scene.general_materials, 0) * (yhk_block_threads(0) / 64);
+  double resident = (double)ctx->num_cus * std::max(1, yhk_trace_occupancy(lds, ctx->scene.general_materials, 0)) * (yhk_block_threads(0) / 64);
   if (getenv("YHAIR_TIMING")) fprintf(stderr, "[yhair] launch shape: worth %.0f items, resident waves %.0f\n", (double)sum / (double)mx, resident);
   return (double)sum / (double)mx >= resident ? 1 : 0;
 }
@@ -456,6 +460,8 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
     bool lines = s.num_lines > 0;
     if (!lines && s.num_triangles <= 0) return fail(ctx, YH_E_INVALID, "shape %d has no lines or triangles", si);
     int nel = lines ? s.num_lines : s.num_triangles;
+    // a leaf reference packs its first record into 27 bits (host/bvh_build.cpp: count << 27 | start)
+    if (nel >= (1 << 27)) return fail(ctx, YH_E_INVALID, "shape %d has %d elements (limit %d)", si, nel, (1 << 27) - 1);
     const int* idx = lines ? s.lines : s.triangles;
     for (int k = 0; k < nel * (lines ? 2 : 3); k++)
       if (idx[k] < 0 || idx[k] >= s.num_vertices) return fail(ctx, YH_E_INVALID, "shape %d: vertex index out of range", si);
@@ -590,6 +596,10 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
       d.wbox_min[3] = d.wbox_max[3] = 0;
     }
   }
+  // array offsets on the device are 32-bit float4 indices
+  if (prims.size() > (size_t)std::numeric_limits<int>::max() || nodes.size() > (size_t)std::numeric_limits<int>::max() ||
+      vpos.size() > (size_t)std::numeric_limits<int>::max())
+    return fail(ctx, YH_E_INVALID, "scene too large for 32-bit record offsets (%zu primitive, %zu node float4)", prims.size(), nodes.size());
   yhh::Tree scene_tree;
   yhh::build_bvh(scene_tree, obj_boxes);
   std::vector<yhd_float4> scene_nodes;
@@ -743,8 +753,10 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
   if (best_shape >= 0) {
     sc.lds_node_base  = info[best_shape].node_base;
     int want = 0;  // LDS nodelets are optional (YHAIR_LDS_NODES): measured no gain once a step is a single fetch, see DESIGN.md
-    if (const char* env = getenv("YHAIR_LDS_NODES")) want = std::max(0, std::min(atoi(env), 3000));
-    sc.lds_node_count = std::min(info[best_shape].num_nodes, want);
+    if (const char* env = getenv("YHAIR_LDS_NODES")) want = std::max(0, atoi(env));
+    // 128 B per nodelet next to the stacks and the scene table of the larger launch shape: stay inside the CU's 160 KB
+    int room = (160 * 1024 - yhk_trace_lds_bytes(0, sc.lds_scene_f4, 0)) / 128;
+    sc.lds_node_count = std::max(0, std::min({info[best_shape].num_nodes, want, room}));
   }
   ctx->scene      = sc;
   ctx->have_scene = true;
@@ -844,7 +856,9 @@ static int trace_impl(yh_context* ctx, int nsamples, bool counted, bool sync) {
   const int shape     = path ? ctx->state.launch_shape : 0;  // the preview shaders have one launch shape
   int waves_per_block = yhk_block_threads(shape) / 64;  // one work item per wave at a time
   int lds_bytes       = yhk_trace_lds_bytes(ctx->scene.lds_node_count, ctx->scene.lds_scene_f4, shape);
-  int resident        = ctx->num_cus * yhk_trace_occupancy(lds_bytes, ctx->scene.general_materials, shape);
+  int occupancy       = yhk_trace_occupancy(lds_bytes, ctx->scene.general_materials, shape);
+  if (occupancy < 1) return fail(ctx, YH_E_DEVICE, "k_trace cannot run with %d bytes of LDS per block", lds_bytes);
+  int resident        = ctx->num_cus * occupancy;
   int want            = (ctx->state.num_tiles + waves_per_block - 1) / waves_per_block;
   int grid            = std::max(1, std::min(want, resident));
   HIPCHK(ctx, hipMemsetAsync(ctx->d_tile_cursor.p, 0, 4, ctx->stream));
