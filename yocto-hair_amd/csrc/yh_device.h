@@ -172,6 +172,22 @@ typedef struct yhd_state {
   int         shard_rank, shard_world;  // tile ids owned: rank, rank + world, ...
 } yhd_state;
 
+// Path pool of the wavefront integrator (csrc/wavefront.hip): SoA ray / hit / path-state buffers in
+// HBM, `slots_per_block` consecutive slots per workgroup (a block only ever touches its own range, so
+// the records stay in its XCD's L2). One path per slot; a pixel has one path in flight at a time
+// (its PCG32 stream is sequential), so the pixel's RNG state and accumulator are read and written in
+// place in yhd_state.
+typedef struct yhd_pool {
+  yhd_float4* ray_o;     // origin.xyz; w = distance of the closest hit (written by the traversal stage)
+  yhd_float4* ray_d;     // direction.xyz; w = int bits: bounce | hit << 8 | in_medium << 9
+  yhd_float4* weight;    // path weight.xyz
+  yhd_float4* radiance;  // radiance collected so far .xyz
+  yhd_int4*   hit;       // closest hit: object (-1 = miss), leaf slot, u bits, v bits
+  yhd_float4* medium;    // scenes with volumes only, 2 per slot: {density.xyz, anisotropy} {scatter.xyz, 0}
+  int         slots_per_block;
+  int         stack_entries;  // traversal stack depth per quad (LDS), >= the scene's need
+} yhd_pool;
+
 // Work counters (one 64-bit slot each), accumulated with atomics by the
 // instrumented kernel variant only.
 typedef struct yhd_counters {

@@ -36,6 +36,10 @@ int yhk_block_threads(int shape);
 int yhk_trace_occupancy(int lds_bytes, int general, int shape);
 int yhk_trace_lds_bytes(int lds_node_count, int lds_scene_f4, int shape);
 int yhk_stack_entries(void);
+int yhk_wavefront(const yhd_scene*, const yhd_state*, int, const yhd_pool*, int k, int grid_blocks, hipStream_t);
+int yhk_wavefront_slots(int k);
+int yhk_wavefront_lds_bytes(int stack_entries, int lds_scene_f4, int k);
+int yhk_wavefront_occupancy(int lds_bytes, int general, int k);
 int yhk_resolve(const yhd_state*, int, int, void*, hipStream_t);
 int yhk_pack(const yhd_state*, int, int, void*, hipStream_t);
 int yhk_unpack(const void*, int, int, int, int, int, int, int, void*, hipStream_t);
@@ -265,6 +269,10 @@ struct yh_context {
   int              last_launches = 0;
   unsigned         launches_of_state = 0;  // synchronous launches since yh_init_state (re-planning schedule)
   int              launch_shape = 0;  // decided from launches of at least 16 spp (shorter ones have flat, noisy item costs)
+  // path pool of the wavefront integrator (csrc/wavefront.hip), allocated at its first launch
+  DevBuf           d_pool_ray_o, d_pool_ray_d, d_pool_weight, d_pool_radiance, d_pool_hit, d_pool_medium;
+  size_t           pool_slots = 0;
+  yhd_pool         pool{};
 };
 
 namespace {
@@ -336,7 +344,7 @@ namespace {
 // resident wave slots — measured 3 066 (C1), 4 777 (C4), 8 989 (C2), 24 970 (C3) against 4 096: with
 // fewer expensive items than slots every wave that can run already does. YHAIR_SHAPE=0|1 overrides.
 int choose_launch_shape(const yh_context* ctx) {
-  if (const char* env = getenv("YHAIR_SHAPE")) return atoi(env) ? 1 : 0;
+  if (const char* env = getenv("YHAIR_SHAPE")) return std::max(0, std::min(2, atoi(env)));
   uint64_t sum = 0, mx = 0;
   for (int t : ctx->owned)
     for (int p = 0; p < 4; p++) {
@@ -841,6 +849,65 @@ int yh_image_size(const yh_context* ctx, int* width, int* height) {
   return YH_OK;
 }
 
+// Bookkeeping after a synchronous launch: longest-processing-time-first order and launch shape
+// for the next one (the pixel results do not depend on either).
+static int replan_after_launch(yh_context* ctx, int nsamples) {
+  // A pixel's samples are sequential, so the items that start last bound the launch; hair quadrants
+  // cost 10-100x background ones. Re-planned after launches 1, 2, 4, 8, ... of a state: the relative
+  // costs of the items settle after the first launches (they are a property of the image), and the
+  // read-back, sort and upload are a few hundred microseconds of a 16 ms launch.
+  const unsigned li = ++ctx->launches_of_state;
+  if ((li & (li - 1)) != 0) return YH_OK;
+  HIPCHK(ctx, hipMemcpy(ctx->item_cost.data(), ctx->d_tile_cost.p, ctx->item_cost.size() * 4, hipMemcpyDeviceToHost));
+  std::vector<int> tiles;
+  build_work_items(ctx, tiles);
+  HIPCHK(ctx, hipMemcpy(ctx->d_tiles.p, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice));
+  if (ctx->state.shader == YH_SHADER_PATH && (nsamples >= 16 || getenv("YHAIR_SHAPE"))) ctx->launch_shape = choose_launch_shape(ctx);
+  ctx->state.launch_shape = ctx->launch_shape;
+  return YH_OK;
+}
+
+// One launch of the wavefront integrator (csrc/wavefront.hip): persistent workgroups, one path pool each.
+static int wavefront_impl(yh_context* ctx, int nsamples, bool sync) {
+  int k = 1;
+  if (const char* env = getenv("YHAIR_WF_SLOTS")) k = atoi(env) >= 2 ? 2 : 1;  // path slots per thread (developer switch)
+  const int P         = yhk_wavefront_slots(k);
+  const int stack     = std::max(8, (ctx->stack_need + 7) / 8 * 8);
+  const int lds_bytes = yhk_wavefront_lds_bytes(stack, ctx->scene.lds_scene_f4, k);
+  const int occupancy = yhk_wavefront_occupancy(lds_bytes, ctx->scene.general_materials, k);
+  if (occupancy < 1) return fail(ctx, YH_E_DEVICE, "k_wavefront cannot run with %d bytes of LDS per block", lds_bytes);
+  const int64_t pixels = (int64_t)ctx->state.num_tiles * 16;  // work items are 4x4 pixel quadrants
+  const int     grid   = (int)std::max<int64_t>(1, std::min<int64_t>((pixels + P - 1) / P, (int64_t)ctx->num_cus * occupancy));
+  const size_t  slots  = (size_t)grid * P;
+  if (slots > ctx->pool_slots || (ctx->scene.general_materials && !ctx->d_pool_medium.p)) {
+    int rc;
+    if ((rc = alloc_zero(ctx, ctx->d_pool_ray_o, slots * 16)) || (rc = alloc_zero(ctx, ctx->d_pool_ray_d, slots * 16)) ||
+        (rc = alloc_zero(ctx, ctx->d_pool_weight, slots * 16)) || (rc = alloc_zero(ctx, ctx->d_pool_radiance, slots * 16)) ||
+        (rc = alloc_zero(ctx, ctx->d_pool_hit, slots * 16)) ||
+        (rc = alloc_zero(ctx, ctx->d_pool_medium, ctx->scene.general_materials ? slots * 32 : 16)))
+      return rc;
+    ctx->pool_slots = slots;
+    ctx->pool.ray_o = (yhd_float4*)ctx->d_pool_ray_o.p, ctx->pool.ray_d = (yhd_float4*)ctx->d_pool_ray_d.p;
+    ctx->pool.weight = (yhd_float4*)ctx->d_pool_weight.p, ctx->pool.radiance = (yhd_float4*)ctx->d_pool_radiance.p;
+    ctx->pool.hit = (yhd_int4*)ctx->d_pool_hit.p, ctx->pool.medium = (yhd_float4*)ctx->d_pool_medium.p;
+  }
+  ctx->pool.slots_per_block = P, ctx->pool.stack_entries = stack;
+  HIPCHK(ctx, hipMemsetAsync(ctx->d_tile_cursor.p, 0, 4, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(ctx->d_tile_cost.p, 0, (size_t)ctx->num_tiles_total * 16, ctx->stream));
+  HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  int e = yhk_wavefront(&ctx->scene, &ctx->state, nsamples, &ctx->pool, k, grid, ctx->stream);
+  if (e) return fail(ctx, YH_E_DEVICE, "k_wavefront launch: %s", hipGetErrorString((hipError_t)e));
+  HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  ctx->state.samples_done += nsamples;
+  ctx->last_launches = 1;
+  if (sync) {
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipEventElapsedTime(&ctx->last_ms, ctx->ev0, ctx->ev1));
+    return replan_after_launch(ctx, nsamples);
+  }
+  return YH_OK;
+}
+
 static int trace_impl(yh_context* ctx, int nsamples, bool counted, bool sync) {
   if (!ctx) return YH_E_INVALID;
   if (!ctx->have_state) return fail(ctx, YH_E_STATE, "yh_trace_samples before yh_init_state");
@@ -853,7 +920,9 @@ static int trace_impl(yh_context* ctx, int nsamples, bool counted, bool sync) {
   }
   const bool path = ctx->state.shader == YH_SHADER_PATH;
   if (counted && !path) return fail(ctx, YH_E_INVALID, "work counters exist for the path shader only");
-  const int shape     = path ? ctx->state.launch_shape : 0;  // the preview shaders have one launch shape
+  int shape = path ? ctx->state.launch_shape : 0;  // the preview shaders have one launch shape
+  if (shape == 2 && counted) shape = 1;            // the instrumented build exists for k_trace only
+  if (shape == 2) return wavefront_impl(ctx, nsamples, sync);
   int waves_per_block = yhk_block_threads(shape) / 64;  // one work item per wave at a time
   int lds_bytes       = yhk_trace_lds_bytes(ctx->scene.lds_node_count, ctx->scene.lds_scene_f4, shape);
   int occupancy       = yhk_trace_occupancy(lds_bytes, ctx->scene.general_materials, shape);
@@ -873,21 +942,7 @@ static int trace_impl(yh_context* ctx, int nsamples, bool counted, bool sync) {
   if (sync) {
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     HIPCHK(ctx, hipEventElapsedTime(&ctx->last_ms, ctx->ev0, ctx->ev1));
-    // Longest-processing-time-first for the next launch (pixel results do not
-    // depend on the order): a pixel's samples are sequential, so the items that
-    // start last bound the launch; hair quadrants cost 10-100x background ones.
-    // Re-planned after launches 1, 2, 4, 8, ... of a state: the relative costs of the items settle
-    // after the first launches (they are a property of the image), and the read-back, sort and
-    // upload are a few hundred microseconds of a 16 ms launch.
-    const unsigned li = ++ctx->launches_of_state;
-    if ((li & (li - 1)) == 0) {
-      HIPCHK(ctx, hipMemcpy(ctx->item_cost.data(), ctx->d_tile_cost.p, ctx->item_cost.size() * 4, hipMemcpyDeviceToHost));
-      std::vector<int> tiles;
-      build_work_items(ctx, tiles);
-      HIPCHK(ctx, hipMemcpy(ctx->d_tiles.p, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice));
-      if (path && (nsamples >= 16 || getenv("YHAIR_SHAPE"))) ctx->launch_shape = choose_launch_shape(ctx);
-      ctx->state.launch_shape = ctx->launch_shape;
-    }
+    return replan_after_launch(ctx, nsamples);
   }
   return YH_OK;
 }
