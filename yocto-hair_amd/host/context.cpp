@@ -271,7 +271,7 @@ struct yh_context {
   int              launch_shape = 0;  // decided from launches of at least 16 spp (shorter ones have flat, noisy item costs)
   // path pool of the wavefront integrator (csrc/wavefront.hip), allocated at its first launch
   DevBuf           d_pool_ray_o, d_pool_ray_d, d_pool_weight, d_pool_radiance, d_pool_hit, d_pool_medium;
-  size_t           pool_slots = 0;
+  size_t           pool_slots = 0, pool_medium_slots = 0;  // capacity of the per-slot arrays / of the medium array (general scenes only)
   yhd_pool         pool{};
 };
 
@@ -879,17 +879,24 @@ static int wavefront_impl(yh_context* ctx, int nsamples, bool sync) {
   const int64_t pixels = (int64_t)ctx->state.num_tiles * 16;  // work items are 4x4 pixel quadrants
   const int     grid   = (int)std::max<int64_t>(1, std::min<int64_t>((pixels + P - 1) / P, (int64_t)ctx->num_cus * occupancy));
   const size_t  slots  = (size_t)grid * P;
-  if (slots > ctx->pool_slots || (ctx->scene.general_materials && !ctx->d_pool_medium.p)) {
+  if (slots > ctx->pool_slots) {
     int rc;
     if ((rc = alloc_zero(ctx, ctx->d_pool_ray_o, slots * 16)) || (rc = alloc_zero(ctx, ctx->d_pool_ray_d, slots * 16)) ||
         (rc = alloc_zero(ctx, ctx->d_pool_weight, slots * 16)) || (rc = alloc_zero(ctx, ctx->d_pool_radiance, slots * 16)) ||
-        (rc = alloc_zero(ctx, ctx->d_pool_hit, slots * 16)) ||
-        (rc = alloc_zero(ctx, ctx->d_pool_medium, ctx->scene.general_materials ? slots * 32 : 16)))
+        (rc = alloc_zero(ctx, ctx->d_pool_hit, slots * 16)))
       return rc;
     ctx->pool_slots = slots;
     ctx->pool.ray_o = (yhd_float4*)ctx->d_pool_ray_o.p, ctx->pool.ray_d = (yhd_float4*)ctx->d_pool_ray_d.p;
     ctx->pool.weight = (yhd_float4*)ctx->d_pool_weight.p, ctx->pool.radiance = (yhd_float4*)ctx->d_pool_radiance.p;
-    ctx->pool.hit = (yhd_int4*)ctx->d_pool_hit.p, ctx->pool.medium = (yhd_float4*)ctx->d_pool_medium.p;
+    ctx->pool.hit = (yhd_int4*)ctx->d_pool_hit.p;
+  }
+  // the medium of a path inside a volume: two float4 per slot, general scenes only (a plain scene's kernel never
+  // touches it). Its capacity is tracked on its own: a context that rendered a plain scene first has none yet.
+  if (ctx->scene.general_materials && slots > ctx->pool_medium_slots) {
+    int rc;
+    if ((rc = alloc_zero(ctx, ctx->d_pool_medium, slots * 32))) return rc;
+    ctx->pool_medium_slots = slots;
+    ctx->pool.medium       = (yhd_float4*)ctx->d_pool_medium.p;
   }
   ctx->pool.slots_per_block = P, ctx->pool.stack_entries = stack;
   HIPCHK(ctx, hipMemsetAsync(ctx->d_tile_cursor.p, 0, 4, ctx->stream));
