@@ -28,7 +28,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "check":
         sf = yh.SceneFile(make_scenes.ensure_scene(name, SCENES, **kw))
         ctx.upload_scene(sf.desc)
         a, ra, _ = render(sf, res, (1, 3, 4), 0)
-        b, rb, _ = render(sf, res, (1, 3, 4), 2)
+        b, rb, _ = render(sf, res, (1, 3, 4), int(os.environ.get("WF_SHAPE", "2")))
         print(f"{name:18s} res {res}: images equal {np.array_equal(a, b)}  rng equal {np.array_equal(ra, rb)}  "
               f"max |d| {np.abs(a - b).max():.3g}  differing px {int(np.any(a != b, axis=2).sum())}", flush=True)
         sf.close()

@@ -373,6 +373,34 @@ YH_DEV void hair_eval_pdf_quad(const yhd_material& m, const hair_hit& hh, const 
   f   = f + f3{quad_bcast_f<3>(tf.x), quad_bcast_f<3>(tf.y), quad_bcast_f<3>(tf.z)};
   pdf += quad_bcast_f<3>(tp);
 }
+// The same with ONE lane per path (YH_LANE, csrc/stream.hip): the four lobes one after the other, each
+// term the expression of the quad form above and summed in the same order, so the same bits.
+YH_DEV void hair_eval_pdf_lane(const yhd_material& m, const hair_hit& hh, const hair_out& ho, f3 incoming_,
+    f3& f, float& pdf) {
+  f3    incoming    = normalize(transform_vector(hh.w2b, incoming_));
+  float sin_theta_o = ho.sin_theta_o, cos_theta_o = ho.cos_theta_o;
+  float sin_theta_i = incoming.x;
+  float cos_theta_i = exact_safe_sqrt(1 - sqr(sin_theta_i));
+  float phi_i       = atan2f(incoming.z, incoming.y);
+  float phi         = phi_i - ho.phi_o;
+  f   = mk3(0.0f);
+  pdf = 0.0f;
+  const f3    apv[p_max]  = {ho.ap0, ho.ap1, ho.ap2};
+  const float appv[p_max] = {ho.pdf0, ho.pdf1, ho.pdf2};
+#pragma unroll
+  for (int p = 0; p < p_max; p++) {
+    float sin_theta_op, cos_theta_op;
+    tilt(m, p, sin_theta_o, cos_theta_o, sin_theta_op, cos_theta_op);
+    cos_theta_op = fabs_(cos_theta_op);
+    float mpv    = mp(m, p, cos_theta_i, cos_theta_op, sin_theta_i, sin_theta_op);
+    float npv    = np(m, phi, p, hh.gamma_o, ho.gamma_t);
+    f            = f + mpv * apv[p] * npv;
+    pdf += mpv * appv[p] * npv;
+  }
+  float mpl = mp(m, p_max, cos_theta_i, cos_theta_o, sin_theta_i, sin_theta_o);
+  f         = f + h_div(mpl * ho.ap3, 2 * pif);
+  pdf += mpl * ho.pdf3 * (1 / (2 * pif));
+}
 YH_DEV void hair_eval_pdf_quad(const yhd_material& m, const hair_hit& hh, f3 outgoing_, f3 incoming_,
     f3& f, float& pdf) {
   hair_out ho = hair_prepare<true>(m, hh, outgoing_);

@@ -1,0 +1,300 @@
+// dev_lane.h — the two-level BVH traversal with ONE LANE PER RAY (csrc/stream.hip).
+//
+// Same algorithm, same visiting order and the same closest hits as dev_trace.h's quad form
+// (intersect_scene_bvh / intersect_shape_bvh, pt.cpp:821-1053) — what changes is who does the work:
+//
+//   dev_trace.h   a QUAD of four lanes per ray: one box / one primitive per lane, everything else
+//                 repeated four times. Right when rays are scarce (a few expensive pixels bound the
+//                 launch: the chain of one path is what counts).
+//   dev_lane.h    one lane per ray, 64 rays per wavefront: a node step tests the four slots of the
+//                 wide node one after the other, a leaf step tests the leaf's primitives in the
+//                 reference's own sequential form (shrinking tmax after each accepted hit,
+//                 pt.cpp:905-923). Nothing is computed twice, so a ray costs about a third of the
+//                 vector instructions; right when every pixel is expensive (dense hair) and
+//                 throughput is what counts.
+//
+// A step is still ONE dependent fetch: whatever a lane holds — a wide node or a leaf — it loads
+// four 32-byte records (the node's slots, or the test halves of the leaf's primitives) with the
+// same eight dwordx4 loads; only the arithmetic diverges.
+//
+// The traversal is a STEP function over explicit state (lane_trav), not a loop, so that the caller
+// can refill finished lanes from a ray list between steps and SUSPEND the unfinished rays of a wave
+// while it shades (stream.hip): a ray's state survives in registers, its stack in the lane's column.
+//
+// Stack: a window of YH_LSTACK entries per lane in LDS (column `lane` of a [depth][64] array,
+// conflict-free) over an overflow array in global memory ([depth][64] per wave, coalesced). The
+// window holds the top of the stack; pushing into a full window spills its oldest entry, popping
+// below it reads the overflow array. Typical depths never leave the window.
+#ifndef YH_DEV_LANE_H_
+#define YH_DEV_LANE_H_
+#include "dev_trace.h"
+
+namespace yhd {
+
+#ifndef YH_LSTACK
+#define YH_LSTACK 16 /* LDS stack window per lane, entries (power of two) */
+#endif
+
+struct lane_stack {
+  YH_LDS unsigned int* lds;  // this lane's column of the window: entry i at lds[(i & (YH_LSTACK - 1)) * 64]
+  unsigned int*        ovf;  // this lane's column of the overflow array: entry i at ovf[i * 64]
+  int                  sp;   // entries on the stack
+  int                  base; // entries [base, sp) are in the window, [0, base) in the overflow array
+};
+YH_DEV void lane_push(lane_stack& s, unsigned int v) {
+  if (s.sp - s.base == YH_LSTACK) {  // window full: its oldest entry goes to memory
+    s.ovf[(size_t)s.base * 64] = s.lds[(s.base & (YH_LSTACK - 1)) * 64];
+    s.base++;
+  }
+  s.lds[(s.sp & (YH_LSTACK - 1)) * 64] = v;
+  s.sp++;
+}
+YH_DEV unsigned int lane_pop(lane_stack& s) {
+  s.sp--;
+  if (s.sp < s.base) {  // below the window
+    s.base = s.sp;
+    return s.ovf[(size_t)s.sp * 64];
+  }
+  return s.lds[(s.sp & (YH_LSTACK - 1)) * 64];
+}
+
+// State of one ray in flight.
+struct lane_trav {
+  f3           ro, rd, wdinv;  // world-space ray, 1 / d
+  f3           lo, ld, ldinv;  // the ray in the space of the object it is in
+  int          wsign, lsign;   // sign bits of 1 / d (x | y << 1 | z << 2)
+  int          cur_obj, kind, node_base, prim_base;
+  unsigned int cur;            // the entry being visited (YH_NONE: pop the next one)
+  float        tmax;
+  hit_t        hit;
+  bool         hit_lines;      // the closest hit so far is on a line shape (hair)
+  unsigned int steps;
+  bool         wnonan;         // no slab of a world-space box test can hold a NaN (dev_trace.h)
+};
+
+// Starts a ray: the whole scene (first_object < 0) or one instance (intersect_instance_bvh, pt.cpp:1031-1037).
+YH_DEV void lane_begin(const yhd_scene& sc, lane_trav& t, f3 ro, f3 rd, int first_object) {
+  t.ro = ro, t.rd = rd;
+  t.wdinv  = f3{1 / rd.x, 1 / rd.y, 1 / rd.z};
+  t.wsign  = (t.wdinv.x < 0 ? 1 : 0) | (t.wdinv.y < 0 ? 2 : 0) | (t.wdinv.z < 0 ? 4 : 0);
+  t.wnonan = finite3(t.wdinv) && finite3(ro);
+  t.lo = ro, t.ld = rd, t.ldinv = t.wdinv, t.lsign = t.wsign;
+  t.cur_obj = -1, t.kind = 0, t.node_base = 0, t.prim_base = 0;
+  t.tmax = flt_max, t.steps = 0;
+  t.hit.object = -1, t.hit.slot = -1, t.hit.u = 0, t.hit.v = 0, t.hit.distance = 0;
+  t.hit_lines = false;
+  if (first_object >= 0) t.cur = YH_TAG_ENTER | (unsigned)first_object;
+  else t.cur = sc.num_scene_nodes ? (YH_TAG_SCENE | 0u) : YH_NONE;
+}
+
+#ifndef YH_LEAF_STEP
+#define YH_LEAF_STEP 2 /* primitives of a leaf tested per step (a longer leaf takes another step) */
+#endif
+
+// One step of the ray in `t`. Returns true when the ray is finished (closest hit in t.hit), or —
+// EXACT = false only — when it has to be traced again by the EXACT form (`redo` set: a slab of a
+// box test could hold a NaN, dev_trace.h). `sp0` = stack height at which this ray started.
+template <bool EXACT>
+YH_DEV bool lane_step(const trace_ctx& tc, lane_trav& t, lane_stack& s, int sp0, bool& redo) {
+  const yhd_scene& sc = *tc.sc;
+  auto box_test = [](f3 o, f3 dinv, float t0, float t1, f3 bmin, f3 bmax) {
+    return EXACT ? intersect_bbox(o, dinv, t0, t1, bmin, bmax) : intersect_bbox_nonan(o, dinv, t0, t1, bmin, bmax);
+  };
+  const YH_LDS v4f* lds_snodes = tc.lds_scene ? tc.lds_scene + YH_OBJECT_F4 * sc.num_objects : nullptr;
+  auto scene_prim = [&](int i) -> int {
+    if (tc.lds_scene) return ((const YH_LDS int*)(lds_snodes + 2 * sc.num_scene_nodes))[i];
+    return sc.scene_prims[i];
+  };
+  if (!EXACT && !t.wnonan) {
+    redo = true;
+    return true;
+  }
+  if (t.cur == YH_NONE && s.sp > sp0) t.cur = lane_pop(s);
+  t.steps++;
+  unsigned int tag  = t.cur & YH_TAG_MASK;
+  bool         skip = t.cur == YH_NONE;  // only a scene without objects
+  if (!skip && tag == YH_TAG_SCENE) {  // scene-level node (binary, the reference's layout)
+    int idx = (int)(t.cur & ~YH_TAG_MASK);
+    v4f n0, n1;
+    if (lds_snodes) n0 = lds_snodes[2 * idx], n1 = lds_snodes[2 * idx + 1];
+    else n0 = ldg4(sc.scene_nodes + 2 * idx), n1 = ldg4(sc.scene_nodes + 2 * idx + 1);
+    t.cur = YH_NONE;
+    if (box_test(t.ro, t.wdinv, ray_eps, t.tmax, xyz(n0), xyz(n1))) {
+      int start = __float_as_int(n0.w), meta = __float_as_int(n1.w);
+      if (meta & 0x10000) {  // internal: near side first (pt.cpp:995-1003)
+        int axis = (meta >> 24) & 3;
+        int near = (t.wsign >> axis) & 1;
+        lane_push(s, YH_TAG_SCENE | (unsigned)(start + 1 - near));
+        t.cur = YH_TAG_SCENE | (unsigned)(start + near);
+      } else {
+        int num = meta & 0xffff;
+        for (int i = num - 1; i >= 1; i--) lane_push(s, YH_TAG_ENTER | (unsigned)scene_prim(start + i));
+        if (num > 0) t.cur = YH_TAG_ENTER | (unsigned)scene_prim(start);
+      }
+    }
+    tag  = t.cur & YH_TAG_MASK;
+    skip = t.cur == YH_NONE || tag == YH_TAG_SCENE;
+  }
+  if (!skip && tag == YH_TAG_ENTER) {  // transform_ray(inverse(object.frame, true), ray) (pt.cpp:1012-1013)
+    t.cur_obj  = (int)(t.cur & ~YH_TAG_MASK);
+    bool enter = true;
+    if (t.wnonan) {  // the object's padded world box (dev_trace.h)
+      v4f bmin, bmax;
+      if (tc.lds_scene) {
+        const YH_LDS v4f* ob = tc.lds_scene + YH_OBJECT_F4 * t.cur_obj;
+        bmin = ob[8], bmax = ob[9];
+      } else {
+        const yhd_object& o = sc.objects[t.cur_obj];
+        bmin = v4f{o.wbox_min[0], o.wbox_min[1], o.wbox_min[2], 0}, bmax = v4f{o.wbox_max[0], o.wbox_max[1], o.wbox_max[2], 0};
+      }
+      enter = box_test(t.ro, t.wdinv, ray_eps, t.tmax, xyz(bmin), xyz(bmax));
+    }
+    if (!enter) {
+      t.cur = YH_NONE, skip = true;
+    } else {
+      frame inv;
+      if (tc.lds_scene) {
+        const YH_LDS v4f* ob = tc.lds_scene + YH_OBJECT_F4 * t.cur_obj;
+        v4f a = ob[3], b = ob[4], c = ob[5], d = ob[6];
+        inv.x = {a.x, a.y, a.z}, inv.y = {a.w, b.x, b.y}, inv.z = {b.z, b.w, c.x}, inv.o = {c.y, c.z, c.w};
+        t.kind = __float_as_int(d.x), t.node_base = __float_as_int(d.y), t.prim_base = __float_as_int(d.z);
+      } else {
+        const yhd_object& o = sc.objects[t.cur_obj];
+        inv    = ldframe(o.inv_frame);
+        t.kind = o.kind, t.node_base = o.node_base, t.prim_base = o.prim_base;
+      }
+      t.lo    = transform_point(inv, t.ro);
+      t.ld    = transform_vector(inv, t.rd);
+      t.ldinv = f3{1 / t.ld.x, 1 / t.ld.y, 1 / t.ld.z};
+      t.lsign = (t.ldinv.x < 0 ? 1 : 0) | (t.ldinv.y < 0 ? 2 : 0) | (t.ldinv.z < 0 ? 4 : 0);
+      if (!EXACT && !(finite3(t.ldinv) && finite3(t.lo))) {
+        redo = true;
+        return true;
+      }
+      t.cur = YH_TAG_SHAPE | (unsigned)t.node_base;  // the shape's root: fetched in this same step
+      tag   = YH_TAG_SHAPE;
+    }
+  }
+  if (!skip) {
+    const bool is_leaf    = tag == YH_TAG_LEAF;
+    const bool lines      = t.kind == YH_KIND_LINES;
+    const int  leaf_start = (int)(t.cur & 0x07FFFFFFu), leaf_num = (int)((t.cur >> 27) & 7u);
+    const int  rec        = lines ? 4 : 6;
+    // records 0..3: the node's slots (32 B apart), or the test halves of the leaf's first primitives
+    const int         last   = is_leaf ? min(leaf_num, YH_LEAF_STEP) - 1 : 3;
+    const int         stride = is_leaf ? rec : 2;
+    const yhd_float4* a      = is_leaf ? sc.prims + (size_t)t.prim_base + (size_t)leaf_start * rec : sc.nodes + 8 * (size_t)t.cur;
+    const yhd_float4 *a1 = a + min(1, last) * stride, *a2 = a + min(2, last) * stride, *a3 = a + min(3, last) * stride;
+    v4f A0 = ldg4(a), B0 = ldg4(a + 1), A1 = ldg4(a1), B1 = ldg4(a1 + 1);
+    v4f A2, B2, A3, B3;
+    if (YH_LEAF_STEP > 2 || !is_leaf) A2 = ldg4(a2), B2 = ldg4(a2 + 1), A3 = ldg4(a3), B3 = ldg4(a3 + 1);
+    if (!is_leaf) {
+      // ---- wide node: the four slots {min.xyz, max.x} {max.yz, ref, axes} ----
+      const unsigned int axes = __float_as_uint(B0.w);
+      unsigned int r0 = __float_as_uint(B0.z), r1 = __float_as_uint(B1.z), r2 = __float_as_uint(B2.z), r3 = __float_as_uint(B3.z);
+      unsigned int hm = 0;
+      hm |= (box_test(t.lo, t.ldinv, ray_eps, t.tmax, f3{A0.x, A0.y, A0.z}, f3{A0.w, B0.x, B0.y}) && r0 != YH_NONE) ? 1u : 0u;
+      hm |= (box_test(t.lo, t.ldinv, ray_eps, t.tmax, f3{A1.x, A1.y, A1.z}, f3{A1.w, B1.x, B1.y}) && r1 != YH_NONE) ? 2u : 0u;
+      hm |= (box_test(t.lo, t.ldinv, ray_eps, t.tmax, f3{A2.x, A2.y, A2.z}, f3{A2.w, B2.x, B2.y}) && r2 != YH_NONE) ? 4u : 0u;
+      hm |= (box_test(t.lo, t.ldinv, ray_eps, t.tmax, f3{A3.x, A3.y, A3.z}, f3{A3.w, B3.x, B3.y}) && r3 != YH_NONE) ? 8u : 0u;
+      // Visiting order of the slots (pt.cpp:887-893 at both collapsed levels, dev_trace.h): the pair
+      // on the near side of the node's axis first, inside a pair the slot on the near side of that
+      // child's axis. Slots are taken in REVERSE visiting order: each hit pushes the one found
+      // before it, so the first in visiting order ends up in `cur` and the others pop in order.
+      const unsigned int s0  = ((unsigned)t.lsign >> (axes & 3)) & 1;
+      const unsigned int sg0 = ((unsigned)t.lsign >> ((axes >> 2) & 3)) & 1, sg1 = ((unsigned)t.lsign >> ((axes >> 4) & 3)) & 1;
+      t.cur = YH_NONE;
+#pragma unroll
+      for (int r = 3; r >= 0; r--) {
+        const unsigned int pair = ((unsigned)r >> 1) ^ s0;
+        const unsigned int q    = (pair << 1) | (((unsigned)r & 1) ^ (pair ? sg1 : sg0));
+        if ((hm >> q) & 1) {
+          unsigned int ref = (q & 2) ? ((q & 1) ? r3 : r2) : ((q & 1) ? r1 : r0);
+          if ((ref & YH_TAG_MASK) == 0) ref += (unsigned)t.node_base;  // child wide nodes are shape-local indices
+          if (t.cur != YH_NONE) lane_push(s, t.cur);
+          t.cur = ref;
+        }
+      }
+    } else {
+      // ---- leaf: its primitives in leaf order, tmax shrinking after each accepted hit (pt.cpp:905-923) ----
+      const int n = min(leaf_num, YH_LEAF_STEP);
+      t.cur       = leaf_num > YH_LEAF_STEP ? (YH_TAG_LEAF | ((unsigned)(leaf_num - YH_LEAF_STEP) << 27) | (unsigned)(leaf_start + YH_LEAF_STEP)) : YH_NONE;
+      if (lines) {
+#define YH_LANE_LINE(I, A, B)                                                                             \
+  {                                                                                                       \
+    float uu = 0, vv = 0, dist = 0;                                                                       \
+    bool  ok = intersect_line<true>(t.lo, t.ld, ray_eps, t.tmax, xyz(A), xyz(B), A.w, B.w, uu, vv, dist); \
+    if (ok && I < n) {                                                                                    \
+      t.hit.object = t.cur_obj, t.hit.slot = leaf_start + I;                                              \
+      t.hit.u = uu, t.hit.v = vv, t.hit.distance = dist;                                                  \
+      t.tmax = dist, t.hit_lines = true;                                                                  \
+    }                                                                                                     \
+  }
+        YH_LANE_LINE(0, A0, B0)
+        YH_LANE_LINE(1, A1, B1)
+        if (YH_LEAF_STEP > 2) {
+          YH_LANE_LINE(2, A2, B2)
+          YH_LANE_LINE(3, A3, B3)
+        }
+#undef YH_LANE_LINE
+      } else {
+        for (int i = 0; i < n; i++) {
+          const yhd_float4* p = a + i * 6;
+          v4f  P0 = ldg4(p), P1 = ldg4(p + 1), P2 = ldg4(p + 2);
+          float uu = 0, vv = 0, dist = 0;
+          if (intersect_triangle(t.lo, t.ld, ray_eps, t.tmax, xyz(P0), xyz(P1), xyz(P2), uu, vv, dist)) {
+            t.hit.object = t.cur_obj, t.hit.slot = leaf_start + i;
+            t.hit.u = uu, t.hit.v = vv, t.hit.distance = dist;
+            t.tmax = dist, t.hit_lines = false;
+          }
+        }
+      }
+    }
+  }
+  return t.cur == YH_NONE && s.sp == sp0;
+}
+
+// A whole ray with the reference's compare-and-select box test throughout (axis-parallel rays: rare).
+// Out of line — one copy of the EXACT step for every caller — and everything by value, so that the
+// callers' stack and ray state stay in registers.
+struct lane_exact_result {
+  hit_t hit;
+  int   hit_lines;
+  int   base;  // the stack's window base afterwards (sp is back where it was)
+};
+__device__ __attribute__((noinline)) lane_exact_result lane_trace_exact(const yhd_scene* sc, const YH_LDS v4f* lds_scene,
+    YH_LDS unsigned int* lds, unsigned int* ovf, int sp, int base, f3 ro, f3 rd, int first_object) {
+  trace_ctx tc;
+  tc.sc = sc, tc.lds_nodes = nullptr, tc.lds_stack = nullptr, tc.lds_scene = lds_scene, tc.stats = nullptr, tc.ls = nullptr, tc.sc_dev = sc;
+  lane_stack s;
+  s.lds = lds, s.ovf = ovf, s.sp = sp, s.base = base;
+  lane_trav t;
+  lane_begin(*sc, t, ro, rd, first_object);
+  bool dummy = false;
+  while (!lane_step<true>(tc, t, s, sp, dummy)) {
+  }
+  lane_exact_result r;
+  r.hit = t.hit, r.hit_lines = t.hit_lines ? 1 : 0, r.base = s.base;
+  return r;
+}
+
+// A whole ray in one call (the light-pdf rays of sample_lights_pdf, pt.cpp:1315-1334): closest hit
+// against one instance, pushing above whatever the lane's stack already holds (a suspended ray).
+YH_DEV hit_t lane_trace(const trace_ctx& tc, lane_stack& s, f3 ro, f3 rd, int first_object) {
+  lane_trav t;
+  lane_begin(*tc.sc, t, ro, rd, first_object);
+  const int sp0  = s.sp;
+  bool      redo = false;
+  while (!lane_step<false>(tc, t, s, sp0, redo)) {
+  }
+  if (redo) {
+    while (s.sp > sp0) (void)lane_pop(s);
+    lane_exact_result r = lane_trace_exact(tc.sc_dev, tc.lds_scene, s.lds, s.ovf, s.sp, s.base, ro, rd, first_object);
+    s.base = r.base;
+    return r.hit;
+  }
+  return t.hit;
+}
+
+}  // namespace yhd
+#endif

@@ -107,8 +107,14 @@ YH_DEV float quad_pick(f3 a) {
   return q == 0 ? a.x : (q == 1 ? a.y : a.z);
 }
 YH_DEV f3 quad_spread(float r) { return f3{quad_bcast_f<0>(r), quad_bcast_f<1>(r), quad_bcast_f<2>(r)}; }
+// YH_LANE = 1 (csrc/stream.hip): ONE LANE PER PATH instead of a quad. The quad_* forms below become the
+// plain per-lane expressions (same operations on the same operands, so the same bits), and the
+// callers pick the lane forms of the few functions that exchange data inside a quad (dev_path.h).
+#ifndef YH_LANE
+#define YH_LANE 0
+#endif
 #ifndef YH_QUAD_DIV
-#define YH_QUAD_DIV 1  /* 0: every lane divides all three components (A/B switch, tools/ab_sweep.sh) */
+#define YH_QUAD_DIV (!YH_LANE)  /* 0: every lane divides all three components (also an A/B switch, tools/ab_sweep.sh) */
 #endif
 YH_DEV f3 quad_div(f3 a, float b) { return YH_QUAD_DIV ? quad_spread(quad_pick(a) / b) : a / b; }
 YH_DEV f3 quad_rcp(f3 b) { return YH_QUAD_DIV ? quad_spread(1 / quad_pick(b)) : f3{1 / b.x, 1 / b.y, 1 / b.z}; }

@@ -14,6 +14,9 @@
 #include "dev_hair.h"
 #include "dev_surface.h"
 #include "dev_trace.h"
+#if YH_LANE
+#include "dev_lane.h"
+#endif
 
 namespace yhd {
 
@@ -37,6 +40,25 @@ YH_DEV ray_t sample_camera(const yhd_camera& cam, int i, int j, int w, int h, fl
   f3    d  = quad_normalize(p - e);
   frame f  = ldframe(cam.frame);
   return mkray(transform_point(f, e), quad_normalize(transform_vector(f, d)));
+}
+
+// The same by ONE lane (the staged integrators, wavefront.hip / stream.hip): the expressions of the quad
+// form above, which only spreads their divisions over four lanes, so the same bits.
+YH_DEV ray_t sample_camera_lane(const yhd_camera& cam, int i, int j, int w, int h, float pu, float pv, float lu, float lv) {
+  float uvx = ((float)i + pu) / (float)w, uvy = ((float)j + pv) / (float)h;
+  f3    q   = {cam.film_x * (0.5f - uvx), cam.film_y * (uvy - 0.5f), cam.lens};
+  f3    dc  = -normalize(q);
+  f3    e   = mk3(0.0f);
+  if (cam.aperture != 0) {
+    float r   = sqrtf(lv);
+    float phi = 2 * pif * lu;
+    float lx = cosf(phi) * r, ly = sinf(phi) * r;
+    e = f3{lx * cam.aperture / 2, ly * cam.aperture / 2, 0};
+  }
+  f3    p = (dc * cam.focus) / fabs_(dc.z);
+  f3    d = normalize(p - e);
+  frame f = ldframe(cam.frame);
+  return mkray(transform_point(f, e), normalize(transform_vector(f, d)));
 }
 
 YH_DEV f3 transform_normal(const frame& a, f3 b) { return normalize(transform_vector(a, b)); }
@@ -193,7 +215,12 @@ YH_DEV float sample_lights_pdf(const trace_ctx& tc, f3 position, f3 direction) {
       float lpdf = 0.0f;
       f3    next_position = position;
       for (int bounce = 0; bounce < 100; bounce++) {
-        hit_t isec = trace_ray<COUNT, STRIDE>(tc, mkray(next_position, direction), light.object);
+        hit_t isec;
+#if YH_LANE
+        isec = lane_trace(tc, *tc.ls, next_position, direction, light.object);
+#else
+        isec = trace_ray<COUNT, STRIDE>(tc, mkray(next_position, direction), light.object);
+#endif
         if (isec.object < 0) break;
         hit_geom lg        = eval_hit(sc, o, isec.slot, isec.u, isec.v);
         f3       lposition = lg.position;
@@ -390,8 +417,8 @@ YH_DEV bool path_step(const trace_ctx& tc, path_t& ps, const hit_t& isec, rng_t&
   hair_hit hh;
   hair_out ho;
   if (is_hair) {
-    hh = hair_setup<true>(isec.v, normal, nrm);  // tangent = eval_normal (pt.cpp:487)
-    ho = hair_prepare<true>(mat, hh, outgoing);  // shared by sample / eval / pdf
+    hh = hair_setup<!YH_LANE>(isec.v, normal, nrm);  // tangent = eval_normal (pt.cpp:487)
+    ho = hair_prepare<!YH_LANE>(mat, hh, outgoing);  // shared by sample / eval / pdf
   }
 
   if (COUNT) k1 = clock64(), tc.stats->c_geom += k1 - k0;
@@ -419,7 +446,11 @@ YH_DEV bool path_step(const trace_ctx& tc, path_t& ps, const hit_t& isec, rng_t&
   f3    brdfcos;
   float brdf_pdf;
   if (is_hair) {
+#if YH_LANE
+    hair_eval_pdf_lane(mat, hh, ho, incoming, brdfcos, brdf_pdf);
+#else
     hair_eval_pdf_quad(mat, hh, ho, incoming, brdfcos, brdf_pdf);
+#endif
   } else if (general) {
     surface_eval_pdf(sb, normal, outgoing, incoming, brdfcos, brdf_pdf);
   } else {  // eval_brdfcos / sample_brdfcos_pdf, diffuse lobe (math.h:4427,4572)

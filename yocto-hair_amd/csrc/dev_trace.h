@@ -182,6 +182,7 @@ YH_DEV bool intersect_bbox_nonan(f3 ro, f3 dinv, float tmin_, float tmax_, f3 bm
 #define YH_LDS __attribute__((address_space(3)))
 typedef float v4f __attribute__((ext_vector_type(4)));
 
+struct lane_stack;  // dev_lane.h
 struct trace_ctx {
   const yhd_scene*      sc;
   const YH_LDS v4f*     lds_nodes;  // LDS copy of nodes[lds_node_base ..+count), or nullptr
@@ -191,6 +192,9 @@ struct trace_ctx {
   // [objects: 8 float4 each][scene BVH nodes: 2 float4 each][scene BVH primitives]
   const YH_LDS v4f*     lds_scene;
   struct stats_t*       stats;      // per-lane work counters of the instrumented build, else NULL
+  lane_stack*           ls;         // one lane per path (YH_LANE, dev_lane.h): this lane's stack, else unused
+  const yhd_scene*      sc_dev;     // YH_LANE: a copy of *sc in device memory, for out-of-line callees (the kernel
+                                    // argument itself must not have its address escape: it would be copied to scratch)
 };
 // Per-lane counters of the instrumented build (COUNT = true): kept in registers
 // for a whole work item and flushed once, so that the instrumented kernel runs

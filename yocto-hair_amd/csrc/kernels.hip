@@ -64,7 +64,7 @@ YH_DEV void trace_items(const yhd_scene& sc, const yhd_state& st, int nsamples, 
     lds_nodes[i] = ldg4(sc.nodes + 8 * (size_t)sc.lds_node_base + i);
   trace_ctx tc;
   tc.sc = &sc;
-  tc.lds_scene = nullptr;
+  tc.lds_scene = nullptr, tc.ls = nullptr, tc.sc_dev = nullptr;
   if (sc.lds_scene_f4 > 0) {
     // the scene level (a handful of objects and BVH nodes) lives in LDS: its steps need no memory round trip
     const int nobj = YH_OBJECT_F4 * sc.num_objects, nnod = 2 * sc.num_scene_nodes, npri = (sc.num_objects + 3) / 4;
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(256) void k_intersect(const yhd_scene sc, int n, co
   bool valid = i < n;
   if (!valid) i = n - 1;  // whole quads stay converged; surplus quads redo the last ray
   trace_ctx tc;
-  tc.sc = &sc, tc.lds_nodes = nullptr, tc.stats = nullptr, tc.lds_scene = nullptr;
+  tc.sc = &sc, tc.lds_nodes = nullptr, tc.stats = nullptr, tc.lds_scene = nullptr, tc.ls = nullptr, tc.sc_dev = nullptr;
   tc.lds_stack   = (YH_LDS unsigned int*)stacks + (threadIdx.x >> 2);
   const float* r = rays + 8 * (size_t)i;
   ray_t ray      = ray_t{ld3(r), ld3(r + 3), r[6], r[7]};

@@ -1,0 +1,346 @@
+// stream.hip — the streaming integrator (gfx950): trace_samples (pt.cpp:1992-2007) with ONE LANE PER PATH
+// and a pool of paths per WAVEFRONT, for scenes where every pixel is expensive (dense hair:
+// BASELINE configs C2-C4).
+//
+// k_trace (kernels.hip) gives a path four lanes and a whole loop iteration; that is the right shape
+// when a few expensive pixels bound the launch (C1) and wasteful when there are more expensive pixels
+// than lanes: the counters of C2 show 28 % of the vector lanes active, everything outside box /
+// primitive / lobe steps computed four times, and a wave waiting for its longest ray every iteration.
+// Here a wavefront owns `slots_per_wave` path slots (SoA in HBM, yhd_stream) and moves them through
+// STAGES, 64 paths of one kind at a time, with the lists between the stages in its own LDS:
+//
+//   items    free slots take pixels from the launch's work-item list
+//   finish   ended samples are clamped and accumulated (trace_sample, pt.cpp:1683-1688), misses look up
+//            the environment first; pixels with samples left get their next camera ray
+//   trace    one ray per lane (dev_lane.h); a lane that finishes its ray takes the next one of the ray
+//            list; when the list is dry and fewer than YH_SUSPEND_LANES lanes are busy the wave goes
+//            shading and the unfinished rays stay where they are — in registers, their stacks in the
+//            lanes' LDS columns — until the next trace stage
+//   sort     finished rays by what they hit: hair / surface / miss
+//   shade    path_step (dev_path.h) on 64 hair hits, or 64 surface hits; partial batches only when the
+//            wave has nothing else to fill its lanes with
+//
+// A wave synchronises with nobody: no workgroup barrier after the scene table is staged, no atomics but
+// the work-item cursor. Every pixel still has ONE path in flight and draws from its own PCG32 stream in
+// the reference's order, and every stage runs the arithmetic of dev_path.h / dev_trace.h in its
+// one-lane forms (YH_LANE), so images are BIT-IDENTICAL to k_trace's
+// (tests/test_gpu_parity.py::test_launch_shapes_and_kernels_render_identical_pixels).
+#define YH_LANE 1
+#include <hip/hip_runtime.h>
+
+#include "yhair.h"
+#include "dev_path.h"
+
+using namespace yhd;
+
+#ifndef YH_ST_BLOCK
+#define YH_ST_BLOCK 256
+#endif
+#ifndef YH_ST_WAVES
+#define YH_ST_WAVES 4 /* waves per SIMD the register allocator must allow */
+#endif
+#ifndef YH_REFILL_LANES
+#define YH_REFILL_LANES 8 /* idle lanes of a wave before the (divergent) refill code runs */
+#endif
+#ifndef YH_SUSPEND_LANES
+#define YH_SUSPEND_LANES 32 /* ray list dry and at most this many lanes busy: go shading */
+#endif
+
+enum { K_HAIR = 0, K_SURF = 1, K_MISS = 2, K_REDO = 3 };  // what a finished ray found (bits 12-13 of a done-list entry)
+enum { H_MISS = -1, H_ENDED = -2, H_NEW = -3 };            // yhd_stream::hit.x of a slot in the finish list
+
+YH_DEV int lane_rank(unsigned long long m) {  // set bits of m below this lane
+  return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
+// Appends `value` of the lanes with `pred` to a list of this wave (all lanes of the wave call it together).
+YH_DEV int list_push(YH_LDS unsigned short* list, int n, bool pred, int value) {
+  unsigned long long m = __ballot(pred);
+  if (pred) list[n + lane_rank(m)] = (unsigned short)value;
+  return n + (int)__popcll(m);
+}
+// Closest hit of a finished ray into its slot; returns what it hit.
+YH_DEV int publish(const yhd_stream& pl, size_t g, const hit_t& hit, bool hit_lines, unsigned int steps) {
+  pl.hit[g]                 = yhd_int4{hit.object, hit.slot, __float_as_int(hit.u), __float_as_int(hit.v)};
+  ((float*)&pl.ray_o[g])[3] = hit.distance;
+  atomicAdd((unsigned int*)&pl.meta[g].w, steps);  // scheduling hint of the pixel's work item (no return value: not waited for)
+  return hit.object < 0 ? K_MISS : (hit_lines ? K_HAIR : K_SURF);
+}
+YH_DEV int path_flags(const path_t& ps) { return (ps.bounce & 255) | (ps.hit ? 256 : 0) | (ps.in_medium ? 512 : 0); }
+
+template <bool GENERAL, int WAVES>
+__global__ __launch_bounds__(YH_ST_BLOCK, WAVES) void k_stream(const yhd_scene sc, const yhd_scene* sc_dev, const yhd_state st, int nsamples,
+    const yhd_stream pl) {
+  constexpr int WPB = YH_ST_BLOCK / 64;
+  extern __shared__ v4f lds_dyn[];
+  const int P = pl.slots_per_wave;
+  // LDS: [scene table][camera][per wave: stack window 64 x YH_LSTACK | six lists of P slot ids]
+  YH_LDS v4f*   lds_scene = (YH_LDS v4f*)lds_dyn;
+  YH_LDS float* lds_cam   = (YH_LDS float*)(lds_scene + sc.lds_scene_f4);
+  const int     wave_lds  = 64 * YH_LSTACK * 4 + 6 * P * 2;
+  const int     lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+  YH_LDS unsigned char*  wbase   = (YH_LDS unsigned char*)(lds_cam + 20) + wib * wave_lds;
+  YH_LDS unsigned int*   w_stack = (YH_LDS unsigned int*)wbase;
+  YH_LDS unsigned short* l_ray   = (YH_LDS unsigned short*)(w_stack + 64 * YH_LSTACK);
+  YH_LDS unsigned short* l_done  = l_ray + P;
+  YH_LDS unsigned short* l_hair  = l_done + P;
+  YH_LDS unsigned short* l_surf  = l_hair + P;
+  YH_LDS unsigned short* l_fin   = l_surf + P;
+  YH_LDS unsigned short* l_free  = l_fin + P;
+  const size_t wave_id = (size_t)blockIdx.x * WPB + wib;
+  const size_t base    = wave_id * (size_t)P;  // this wave's first slot
+
+  trace_ctx tc;
+  tc.sc = &sc, tc.sc_dev = sc_dev, tc.lds_nodes = nullptr, tc.lds_stack = nullptr, tc.stats = nullptr, tc.lds_scene = nullptr;
+  if (sc.lds_scene_f4 > 0) {  // the scene level in LDS (as in k_trace), shared by the block's waves
+    const int nobj = YH_OBJECT_F4 * sc.num_objects, nnod = 2 * sc.num_scene_nodes, npri = (sc.num_objects + 3) / 4;
+    const v4f* gobj = (const v4f*)sc.objects;
+    const v4f* gpri = (const v4f*)sc.scene_prims;
+    for (int i = threadIdx.x; i < nobj; i += YH_ST_BLOCK) lds_scene[i] = gobj[i];
+    for (int i = threadIdx.x; i < nnod; i += YH_ST_BLOCK) lds_scene[nobj + i] = ldg4(sc.scene_nodes + i);
+    for (int i = threadIdx.x; i < npri; i += YH_ST_BLOCK) lds_scene[nobj + nnod + i] = gpri[i];
+    tc.lds_scene = lds_scene;
+  }
+  if (threadIdx.x < 17) lds_cam[threadIdx.x] = ((const float*)&sc.camera)[threadIdx.x];
+  for (int s = lane; s < P; s += 64) l_free[s] = (unsigned short)s;
+  __syncthreads();  // the only workgroup barrier: from here on every wave runs on its own
+
+  lane_stack stk;
+  stk.lds = w_stack + lane, stk.ovf = pl.stack_ovf + wave_id * (size_t)pl.ovf_entries * 64 + lane, stk.sp = 0, stk.base = 0;
+  tc.ls   = &stk;
+  // lists (wave-uniform counts) and the ray this lane holds
+  int       n_ray = 0, n_done = 0, n_hair = 0, n_surf = 0, n_fin = 0, n_free = P;
+  bool      nomore = false;
+  bool      have = false;
+  int       slot = 0;
+  lane_trav t;
+  lane_begin(sc, t, mk3(0.0f), mk3(1.0f), -1);
+
+  enum { A_ITEMS, A_SORT, A_FINISH, A_HAIR, A_SURF, A_TRACE };
+  // One stage per trip, each stage's code exactly once in the kernel. Order of preference: new pixels, sorting
+  // what the last trace stage finished, then full batches of 64 (finish, hair, surface); partial batches
+  // only when the rays at hand cannot fill the lanes; tracing when nothing else is due.
+  while (true) {
+    const int  nact  = (int)__popcll(__ballot(have));
+    const bool flush = n_ray + nact < 64;
+    int        act;
+    if (!nomore && n_free >= 64) act = A_ITEMS;
+    else if (n_done > 0) act = A_SORT;
+    else if (n_fin >= 64 || (flush && n_fin > 0)) act = A_FINISH;
+    else if (n_hair >= 64 || (flush && n_hair > 0)) act = A_HAIR;
+    else if (n_surf >= 64 || (flush && n_surf > 0)) act = A_SURF;
+    else if (n_ray > 0 || nact > 0) act = A_TRACE;
+    else break;  // every slot is free and the work items are used up
+
+    if (act == A_ITEMS) {
+      // ---- items: free slots take the pixels of the next work items (4 items = 64 pixels) ------------------
+      int t0 = 0;
+      if (lane == 0) t0 = atomicAdd(st.tile_cursor, 4);
+      t0            = __builtin_amdgcn_readfirstlane(t0);
+      const int got = max(0, min(4, st.num_tiles - t0));
+      if (got < 4) nomore = true;
+      int pixel = -1, item = 0;
+      if (lane < 16 * got) {
+        item     = st.tiles[t0 + (lane >> 4)];
+        int tile = item >> 2, part = item & 3, pq = lane & 15;
+        int i    = (tile % st.tiles_x) * YH_TILE + (part & 1) * 4 + (pq & 3);
+        int j    = (tile / st.tiles_x) * YH_TILE + (part >> 1) * 4 + (pq >> 2);
+        pixel    = (i < st.width && j < st.height) ? j * st.width + i : -1;
+      }
+      const bool               valid = pixel >= 0;
+      const unsigned long long m     = __ballot(valid);
+      int                      sl    = 0;
+      if (valid) {
+        sl                = l_free[n_free - 1 - lane_rank(m)];
+        const size_t   g  = base + sl;
+        const uint64_t rs = st.rng_state[pixel], ri = st.rng_inc[pixel];
+        pl.meta[g]        = yhd_int4{pixel, nsamples, item, 0};
+        pl.rng[g]         = yhd_int4{(int)(unsigned)rs, (int)(unsigned)(rs >> 32), (int)(unsigned)ri, (int)(unsigned)(ri >> 32)};
+        pl.hit[g]         = yhd_int4{H_NEW, 0, 0, 0};
+      }
+      n_free -= (int)__popcll(m);
+      n_fin = list_push(l_fin, n_fin, valid, sl);
+    } else if (act == A_SORT) {
+      // ---- sort: the rays the trace stage finished, by what they hit ----------------------------------------
+      for (int i0 = 0; i0 < n_done; i0 += 64) {
+        const bool on = i0 + lane < n_done;
+        const int  e  = on ? (int)l_done[i0 + lane] : 0;
+        const int  sl = e & 0xFFF;
+        int        kd = on ? (e >> 12) : -1;
+        if (__ballot(kd == K_REDO) != 0) {
+          if (kd == K_REDO) {  // axis-parallel ray: the reference's compare-and-select box test (dev_trace.h)
+            const size_t g = base + sl;
+            yhd_float4 o = pl.ray_o[g], d = pl.ray_d[g];
+            lane_exact_result r = lane_trace_exact(sc_dev, tc.lds_scene, stk.lds, stk.ovf, stk.sp, stk.base, f3{o.x, o.y, o.z},
+                f3{d.x, d.y, d.z}, -1);
+            stk.base = r.base;
+            kd       = publish(pl, base + sl, r.hit, r.hit_lines != 0, 1u);
+          }
+        }
+        n_hair = list_push(l_hair, n_hair, kd == K_HAIR, sl);
+        n_surf = list_push(l_surf, n_surf, kd == K_SURF, sl);
+        n_fin  = list_push(l_fin, n_fin, kd == K_MISS, sl);
+      }
+      n_done = 0;
+    } else if (act == A_FINISH) {
+      // ---- finish: account the sample that ended, start the pixel's next one ---------------------------------
+      const int  cnt = min(n_fin, 64);
+      const bool on  = lane < cnt;
+      const int  sl  = on ? l_fin[n_fin - cnt + lane] : 0;
+      n_fin -= cnt;
+      bool next = false, freed = false;
+      if (on) {
+        const size_t   g  = base + sl;
+        const yhd_int4 mt = pl.meta[g];
+        const int      h  = pl.hit[g].x, p = mt.x, left = mt.y;
+        if (h != H_NEW) {  // trace_sample's tail (pt.cpp:1683-1688)
+          yhd_float4 rad = pl.radiance[g], d = pl.ray_d[g];
+          path_t     ps;
+          ps.radiance = f3{rad.x, rad.y, rad.z};
+          ps.hit      = (__float_as_int(d.w) & 256) != 0;
+          if (h == H_MISS) {  // pt.cpp:1397-1400
+            yhd_float4 w = pl.weight[g];
+            ps.radiance  = ps.radiance + f3{w.x, w.y, w.z} * eval_environment<false>(tc, f3{d.x, d.y, d.z});
+          }
+          yhd_float4 acc = st.accum[p];
+          path_end(ps, st.clamp, acc);
+          st.accum[p] = acc;
+        }
+        const yhd_int4 r4 = pl.rng[g];
+        rng_t          rng;
+        rng.state = (uint64_t)(unsigned)r4.x | ((uint64_t)(unsigned)r4.y << 32);
+        rng.inc   = (uint64_t)(unsigned)r4.z | ((uint64_t)(unsigned)r4.w << 32);
+        if (left > 0) {  // the pixel's next sample (trace_sample, pt.cpp:1676-1682)
+          float lu = rand1f(rng), lv = rand1f(rng);
+          float pu = rand1f(rng), pv = rand1f(rng);
+          yhd_camera cam;
+          for (int k = 0; k < 12; k++) cam.frame[k] = lds_cam[k];
+          cam.lens = lds_cam[12], cam.film_x = lds_cam[13], cam.film_y = lds_cam[14], cam.focus = lds_cam[15], cam.aperture = lds_cam[16];
+          ray_t r = sample_camera_lane(cam, p % st.width, p / st.width, st.width, st.height, pu, pv, lu, lv);
+          pl.ray_o[g]    = yhd_float4{r.o.x, r.o.y, r.o.z, 0.0f};
+          pl.ray_d[g]    = yhd_float4{r.d.x, r.d.y, r.d.z, __int_as_float(0)};
+          pl.weight[g]   = yhd_float4{1.0f, 1.0f, 1.0f, 0.0f};
+          pl.radiance[g] = yhd_float4{0.0f, 0.0f, 0.0f, 0.0f};
+          pl.rng[g]      = yhd_int4{(int)(unsigned)rng.state, (int)(unsigned)(rng.state >> 32), r4.z, r4.w};
+          pl.meta[g].y   = left - 1;
+          next           = true;
+        } else {  // the pixel has all its samples: hand its stream back, report its work, free the slot
+          st.rng_state[p] = rng.state;
+          if (mt.w) atomicAdd(&st.tile_cost[mt.z], (unsigned int)mt.w);
+          freed = true;
+        }
+      }
+      n_ray  = list_push(l_ray, n_ray, next, sl);
+      n_free = list_push(l_free, n_free, freed, sl);
+    } else if (act == A_HAIR || act == A_SURF) {
+      // ---- shade: up to 64 hits of ONE kind, one path per lane (trace_path's loop body, pt.cpp:1395-1508) -------
+      YH_LDS unsigned short* list = act == A_HAIR ? l_hair : l_surf;
+      const int  n   = act == A_HAIR ? n_hair : n_surf;
+      const int  cnt = min(n, 64);
+      const bool on  = lane < cnt;
+      const int  sl  = on ? list[n - cnt + lane] : 0;
+      if (act == A_HAIR) n_hair -= cnt;
+      else n_surf -= cnt;
+      bool alive = false;
+      if (on) {
+        const size_t g = base + sl;
+        yhd_float4 o = pl.ray_o[g], d = pl.ray_d[g], w = pl.weight[g], rad = pl.radiance[g];
+        yhd_int4   h = pl.hit[g], r4 = pl.rng[g];
+        path_t     ps;
+        ps.ray      = ray_t{f3{o.x, o.y, o.z}, f3{d.x, d.y, d.z}, ray_eps, flt_max};
+        ps.weight   = f3{w.x, w.y, w.z}, ps.radiance = f3{rad.x, rad.y, rad.z};
+        const int fl = __float_as_int(d.w);
+        ps.bounce = fl & 255, ps.hit = (fl & 256) != 0, ps.in_medium = (fl & 512) != 0;
+        if (GENERAL && ps.in_medium) {
+          yhd_float4 m0 = pl.medium[2 * g], m1 = pl.medium[2 * g + 1];
+          ps.medium.density = f3{m0.x, m0.y, m0.z}, ps.medium.anisotropy = m0.w, ps.medium.scatter = f3{m1.x, m1.y, m1.z};
+        }
+        hit_t isec;
+        isec.object = h.x, isec.slot = h.y, isec.u = __int_as_float(h.z), isec.v = __int_as_float(h.w), isec.distance = o.w;
+        rng_t rng;
+        rng.state = (uint64_t)(unsigned)r4.x | ((uint64_t)(unsigned)r4.y << 32);
+        rng.inc   = (uint64_t)(unsigned)r4.z | ((uint64_t)(unsigned)r4.w << 32);
+        alive     = path_step<false, 64, GENERAL>(tc, ps, isec, rng, st.bounces);
+        pl.rng[g]      = yhd_int4{(int)(unsigned)rng.state, (int)(unsigned)(rng.state >> 32), r4.z, r4.w};
+        pl.radiance[g] = yhd_float4{ps.radiance.x, ps.radiance.y, ps.radiance.z, 0.0f};
+        pl.ray_d[g]    = yhd_float4{ps.ray.d.x, ps.ray.d.y, ps.ray.d.z, __int_as_float(path_flags(ps))};
+        if (alive) {
+          pl.ray_o[g]  = yhd_float4{ps.ray.o.x, ps.ray.o.y, ps.ray.o.z, 0.0f};
+          pl.weight[g] = yhd_float4{ps.weight.x, ps.weight.y, ps.weight.z, 0.0f};
+          if (GENERAL && ps.in_medium) {
+            pl.medium[2 * g]     = yhd_float4{ps.medium.density.x, ps.medium.density.y, ps.medium.density.z, ps.medium.anisotropy};
+            pl.medium[2 * g + 1] = yhd_float4{ps.medium.scatter.x, ps.medium.scatter.y, ps.medium.scatter.z, 0.0f};
+          }
+        } else {
+          pl.hit[g].x = H_ENDED;
+        }
+      }
+      n_ray = list_push(l_ray, n_ray, on && alive, sl);
+      n_fin = list_push(l_fin, n_fin, on && !alive, sl);
+    } else {
+      // ---- trace: one ray per lane; finished lanes refill from the ray list; leaves with rays suspended ---------
+      while (true) {
+        {  // refill: the (divergent) refill code runs only when enough lanes are idle, or none is busy
+          const unsigned long long idle  = __ballot(!have);
+          const int                nidle = (int)__popcll(idle);
+          if (n_ray > 0 && (nidle >= YH_REFILL_LANES || nidle == 64)) {
+            if (!have && lane_rank(idle) < n_ray) {
+              slot           = l_ray[n_ray - 1 - lane_rank(idle)];
+              const size_t g = base + slot;
+              yhd_float4 o = pl.ray_o[g], d = pl.ray_d[g];
+              lane_begin(sc, t, f3{o.x, o.y, o.z}, f3{d.x, d.y, d.z}, -1);
+              have = true;
+            }
+            n_ray -= min(nidle, n_ray);
+          }
+        }
+        const int busy = (int)__popcll(__ballot(have));
+        if (busy == 0) break;
+        if (n_ray == 0 && busy <= YH_SUSPEND_LANES && (n_done | n_hair | n_surf | n_fin) != 0) break;
+        bool fin  = false;
+        int  kind = 0;
+        if (have) {
+          bool redo = false;
+          if (lane_step<false>(tc, t, stk, 0, redo)) {
+            have = false, fin = true;
+            if (redo) {
+              kind   = K_REDO;  // traced again by the exact form in the sort stage
+              stk.sp = 0, stk.base = 0;
+            } else {
+              kind = publish(pl, base + slot, t.hit, t.hit_lines, t.steps);
+            }
+          }
+        }
+        if (__ballot(fin) != 0) n_done = list_push(l_done, n_done, fin, slot | (kind << 12));
+      }
+    }
+  }
+}
+
+extern "C" {
+
+typedef void (*stream_kernel_t)(const yhd_scene, const yhd_scene*, const yhd_state, int, const yhd_stream);
+static stream_kernel_t stream_kernel(bool general) { return general ? k_stream<true, YH_ST_WAVES> : k_stream<false, YH_ST_WAVES>; }
+int yhk_stream_block_threads(void) { return YH_ST_BLOCK; }
+int yhk_stream_lds_bytes(int lds_scene_f4, int slots_per_wave) {
+  return lds_scene_f4 * 16 + 80 + (YH_ST_BLOCK / 64) * (64 * YH_LSTACK * 4 + 6 * slots_per_wave * 2);
+}
+int yhk_stream_occupancy(int lds_bytes, int general) {
+  int             blocks = 0;
+  stream_kernel_t kern   = stream_kernel(general != 0);
+  if (lds_bytes > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
+    return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kern, YH_ST_BLOCK, lds_bytes) != hipSuccess) return 0;
+  return blocks;
+}
+int yhk_stream(const yhd_scene* sc, const yhd_scene* sc_dev, const yhd_state* st, int nsamples, const yhd_stream* pl, int grid_blocks,
+    hipStream_t stream) {
+  int             lds  = yhk_stream_lds_bytes(sc->lds_scene_f4, pl->slots_per_wave);
+  stream_kernel_t kern = stream_kernel(sc->general_materials != 0);
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid_blocks), dim3(YH_ST_BLOCK), lds, stream, *sc, sc_dev, *st, nsamples, *pl);
+  return (int)hipGetLastError();
+}
+}

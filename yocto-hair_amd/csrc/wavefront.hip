@@ -34,25 +34,6 @@ using namespace yhd;
 #define YH_WF_WAVES 6 /* waves per SIMD the register allocator must allow */
 #endif
 
-// sample_camera (pt.cpp:211-229) by ONE lane: the expressions of dev_path.h's quad form (which spreads the
-// divisions of the same expressions over four lanes), so the same bits.
-YH_DEV ray_t sample_camera_lane(const yhd_camera& cam, int i, int j, int w, int h, float pu, float pv, float lu, float lv) {
-  float uvx = ((float)i + pu) / (float)w, uvy = ((float)j + pv) / (float)h;
-  f3    q   = {cam.film_x * (0.5f - uvx), cam.film_y * (uvy - 0.5f), cam.lens};
-  f3    dc  = -normalize(q);
-  f3    e   = mk3(0.0f);
-  if (cam.aperture != 0) {
-    float r   = sqrtf(lv);
-    float phi = 2 * pif * lu;
-    float lx = cosf(phi) * r, ly = sinf(phi) * r;
-    e = f3{lx * cam.aperture / 2, ly * cam.aperture / 2, 0};
-  }
-  f3    p = (dc * cam.focus) / fabs_(dc.z);
-  f3    d = normalize(p - e);
-  frame f = ldframe(cam.frame);
-  return mkray(transform_point(f, e), normalize(transform_vector(f, d)));
-}
-
 enum { C_HEAD0, C_HEAD1, C_NTRACE0, C_NTRACE1, C_NHAIR, C_NSURF, C_NREDO, C_HEADX, C_NFREE, C_GOT_BASE, C_GOT_N, C_NOMORE, C_COUNT = 16 };
 
 YH_DEV int   path_flags(const path_t& ps) { return (ps.bounce & 255) | (ps.hit ? 256 : 0) | (ps.in_medium ? 512 : 0); }
@@ -83,7 +64,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_wavefront(const yhd_scene sc, 
   for (int s = tid; s < P; s += BLOCK) s_state[s] = YH_SLOT_FREE, l_free[s] = (unsigned short)s, s_work[s] = 0;
   if (tid < C_COUNT) ctr[tid] = tid == C_NFREE ? P : 0;
   trace_ctx tc;
-  tc.sc = &sc, tc.lds_nodes = nullptr, tc.stats = nullptr, tc.lds_scene = nullptr;
+  tc.sc = &sc, tc.lds_nodes = nullptr, tc.stats = nullptr, tc.lds_scene = nullptr, tc.ls = nullptr, tc.sc_dev = nullptr;
   if (sc.lds_scene_f4 > 0) {  // the scene level in LDS (as in k_trace)
     const int nobj = YH_OBJECT_F4 * sc.num_objects, nnod = 2 * sc.num_scene_nodes, npri = (sc.num_objects + 3) / 4;
     const v4f* gobj = (const v4f*)sc.objects;

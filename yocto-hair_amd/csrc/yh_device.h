@@ -163,7 +163,7 @@ typedef struct yhd_state {
   unsigned int* tile_cost;  // per item: wall-clock ticks (100 MHz) its last launch took
   int         num_tiles;  // number of work items in `tiles`
   int         shader;        // YH_SHADER_* (yhair.h): path is the product path, the others preview / debug
-  int         launch_shape;  // 0: 512 threads x 4 waves per SIMD; 1: 256 threads x 6 waves per SIMD (dense scenes)
+  int         launch_shape;  // 0: k_trace 512 threads x 4 waves per SIMD; 1: k_trace 256 x 6 (dense scenes); 2: k_wavefront; 3: k_stream
   int         width, height;
   int         tiles_x;
   int         samples_done;
@@ -187,6 +187,22 @@ typedef struct yhd_pool {
   int         slots_per_block;
   int         stack_entries;  // traversal stack depth per quad (LDS), >= the scene's need
 } yhd_pool;
+
+// Path pool of the streaming integrator (csrc/stream.hip): one lane per path, `slots_per_wave` slots owned by
+// each WAVEFRONT (no workgroup-level synchronisation), SoA over the slots.
+typedef struct yhd_stream {
+  yhd_float4* ray_o;     // origin.xyz; w = distance of the closest hit
+  yhd_float4* ray_d;     // direction.xyz; w = int bits: bounce | hit << 8 | in_medium << 9
+  yhd_float4* weight;    // path weight.xyz
+  yhd_float4* radiance;  // radiance collected so far .xyz
+  yhd_int4*   hit;       // object (-1 miss, -2 path ended in shading, -3 new pixel), leaf slot, u bits, v bits
+  yhd_int4*   meta;      // pixel, samples left to start, work item, traversal steps so far
+  yhd_int4*   rng;       // the pixel's PCG32 stream while it owns the slot: state lo, hi, inc lo, hi
+  yhd_float4* medium;    // scenes with volumes only, 2 per slot
+  unsigned int* stack_ovf;  // per wave: ovf_entries x 64 lanes, what the LDS stack window spills (dev_lane.h)
+  int         slots_per_wave;  // multiple of 64, <= 4096
+  int         ovf_entries;
+} yhd_stream;
 
 // Work counters (one 64-bit slot each), accumulated with atomics by the
 // instrumented kernel variant only.

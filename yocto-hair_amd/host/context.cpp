@@ -40,6 +40,10 @@ int yhk_wavefront(const yhd_scene*, const yhd_state*, int, const yhd_pool*, int 
 int yhk_wavefront_slots(int k);
 int yhk_wavefront_lds_bytes(int stack_entries, int lds_scene_f4, int k);
 int yhk_wavefront_occupancy(int lds_bytes, int general, int k);
+int yhk_stream(const yhd_scene*, const yhd_scene* sc_dev, const yhd_state*, int, const yhd_stream*, int grid_blocks, hipStream_t);
+int yhk_stream_block_threads(void);
+int yhk_stream_lds_bytes(int lds_scene_f4, int slots_per_wave);
+int yhk_stream_occupancy(int lds_bytes, int general);
 int yhk_resolve(const yhd_state*, int, int, void*, hipStream_t);
 int yhk_pack(const yhd_state*, int, int, void*, hipStream_t);
 int yhk_unpack(const void*, int, int, int, int, int, int, int, void*, hipStream_t);
@@ -271,6 +275,10 @@ struct yh_context {
   int              launch_shape = 0;  // decided from launches of at least 16 spp (shorter ones have flat, noisy item costs)
   // path pool of the wavefront integrator (csrc/wavefront.hip), allocated at its first launch
   DevBuf           d_pool_ray_o, d_pool_ray_d, d_pool_weight, d_pool_radiance, d_pool_hit, d_pool_medium;
+  // path pool of the streaming integrator (csrc/stream.hip): per-wave slots, allocated at its first launch
+  DevBuf           d_st_ray_o, d_st_ray_d, d_st_weight, d_st_radiance, d_st_hit, d_st_meta, d_st_rng, d_st_medium, d_st_ovf, d_scene_copy;
+  size_t           st_slots = 0, st_medium_slots = 0, st_ovf_words = 0;
+  yhd_stream       stream_pool{};
   size_t           pool_slots = 0, pool_medium_slots = 0;  // capacity of the per-slot arrays / of the medium array (general scenes only)
   yhd_pool         pool{};
 };
@@ -344,7 +352,7 @@ namespace {
 // resident wave slots — measured 3 066 (C1), 4 777 (C4), 8 989 (C2), 24 970 (C3) against 4 096: with
 // fewer expensive items than slots every wave that can run already does. YHAIR_SHAPE=0|1 overrides.
 int choose_launch_shape(const yh_context* ctx) {
-  if (const char* env = getenv("YHAIR_SHAPE")) return std::max(0, std::min(2, atoi(env)));
+  if (const char* env = getenv("YHAIR_SHAPE")) return std::max(0, std::min(3, atoi(env)));
   uint64_t sum = 0, mx = 0;
   for (int t : ctx->owned)
     for (int p = 0; p < 4; p++) {
@@ -767,6 +775,7 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
     sc.lds_node_count = std::max(0, std::min({info[best_shape].num_nodes, want, room}));
   }
   ctx->scene      = sc;
+  ctx->d_scene_copy.reset();  // (stream_impl uploads the new table at its first launch)
   ctx->have_scene = true;
   ctx->have_state = false;
   ctx->launch_shape = 0;  // a new scene: no measured costs yet
@@ -915,6 +924,65 @@ static int wavefront_impl(yh_context* ctx, int nsamples, bool sync) {
   return YH_OK;
 }
 
+// One launch of the streaming integrator (csrc/stream.hip): persistent wavefronts, one path pool each, one lane per path.
+static int stream_impl(yh_context* ctx, int nsamples, bool sync) {
+  // Slots per wave and waves per CU: the pixels of the launch spread over the waves so that every wave has
+  // a few paths per lane to keep its lanes full between stages (YHAIR_ST_SLOTS / YHAIR_ST_WAVES: developer switches).
+  int P = 256;
+  if (const char* env = getenv("YHAIR_ST_SLOTS")) P = std::max(64, std::min(4096, atoi(env) / 64 * 64));
+  const int wpb       = yhk_stream_block_threads() / 64;
+  const int lds_bytes = yhk_stream_lds_bytes(ctx->scene.lds_scene_f4, P);
+  int       occupancy = yhk_stream_occupancy(lds_bytes, ctx->scene.general_materials);
+  if (occupancy < 1) return fail(ctx, YH_E_DEVICE, "k_stream cannot run with %d bytes of LDS per block", lds_bytes);
+  if (const char* env = getenv("YHAIR_ST_WAVES")) occupancy = std::max(1, std::min(occupancy, (atoi(env) + wpb - 1) / wpb));  // waves per CU
+  const int64_t pixels = (int64_t)ctx->state.num_tiles * 16;  // work items are 4x4 pixel quadrants
+  const int64_t want   = (pixels + (int64_t)P * wpb - 1) / ((int64_t)P * wpb);
+  const int     grid   = (int)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)ctx->num_cus * occupancy));
+  const size_t  waves  = (size_t)grid * wpb, slots = waves * P;
+  // overflow of the per-lane LDS stack windows (dev_lane.h): a main ray plus a light-pdf ray above it
+  const int    ovf_entries = 2 * std::max(8, ctx->stack_need);
+  const size_t ovf_words   = waves * (size_t)ovf_entries * 64;
+  int rc;
+  if (slots > ctx->st_slots) {
+    if ((rc = alloc_zero(ctx, ctx->d_st_ray_o, slots * 16)) || (rc = alloc_zero(ctx, ctx->d_st_ray_d, slots * 16)) ||
+        (rc = alloc_zero(ctx, ctx->d_st_weight, slots * 16)) || (rc = alloc_zero(ctx, ctx->d_st_radiance, slots * 16)) ||
+        (rc = alloc_zero(ctx, ctx->d_st_hit, slots * 16)) || (rc = alloc_zero(ctx, ctx->d_st_meta, slots * 16)) ||
+        (rc = alloc_zero(ctx, ctx->d_st_rng, slots * 16)))
+      return rc;
+    ctx->st_slots = slots;
+    auto& pl = ctx->stream_pool;
+    pl.ray_o = (yhd_float4*)ctx->d_st_ray_o.p, pl.ray_d = (yhd_float4*)ctx->d_st_ray_d.p, pl.weight = (yhd_float4*)ctx->d_st_weight.p;
+    pl.radiance = (yhd_float4*)ctx->d_st_radiance.p, pl.hit = (yhd_int4*)ctx->d_st_hit.p, pl.meta = (yhd_int4*)ctx->d_st_meta.p;
+    pl.rng = (yhd_int4*)ctx->d_st_rng.p;
+  }
+  if (ctx->scene.general_materials && slots > ctx->st_medium_slots) {
+    if ((rc = alloc_zero(ctx, ctx->d_st_medium, slots * 32))) return rc;
+    ctx->st_medium_slots = slots, ctx->stream_pool.medium = (yhd_float4*)ctx->d_st_medium.p;
+  }
+  if (ovf_words > ctx->st_ovf_words) {
+    if ((rc = alloc_zero(ctx, ctx->d_st_ovf, ovf_words * 4))) return rc;
+    ctx->st_ovf_words = ovf_words, ctx->stream_pool.stack_ovf = (unsigned int*)ctx->d_st_ovf.p;
+  }
+  ctx->stream_pool.slots_per_wave = P, ctx->stream_pool.ovf_entries = ovf_entries;
+  if (!ctx->d_scene_copy.p) {  // the scene table in device memory, for the kernel's out-of-line callees
+    if ((rc = upload(ctx, ctx->d_scene_copy, &ctx->scene, sizeof(yhd_scene)))) return rc;
+  }
+  HIPCHK(ctx, hipMemsetAsync(ctx->d_tile_cursor.p, 0, 4, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(ctx->d_tile_cost.p, 0, (size_t)ctx->num_tiles_total * 16, ctx->stream));
+  HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  int e = yhk_stream(&ctx->scene, (const yhd_scene*)ctx->d_scene_copy.p, &ctx->state, nsamples, &ctx->stream_pool, grid, ctx->stream);
+  if (e) return fail(ctx, YH_E_DEVICE, "k_stream launch: %s", hipGetErrorString((hipError_t)e));
+  HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  ctx->state.samples_done += nsamples;
+  ctx->last_launches = 1;
+  if (sync) {
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipEventElapsedTime(&ctx->last_ms, ctx->ev0, ctx->ev1));
+    return replan_after_launch(ctx, nsamples);
+  }
+  return YH_OK;
+}
+
 static int trace_impl(yh_context* ctx, int nsamples, bool counted, bool sync) {
   if (!ctx) return YH_E_INVALID;
   if (!ctx->have_state) return fail(ctx, YH_E_STATE, "yh_trace_samples before yh_init_state");
@@ -928,8 +996,9 @@ static int trace_impl(yh_context* ctx, int nsamples, bool counted, bool sync) {
   const bool path = ctx->state.shader == YH_SHADER_PATH;
   if (counted && !path) return fail(ctx, YH_E_INVALID, "work counters exist for the path shader only");
   int shape = path ? ctx->state.launch_shape : 0;  // the preview shaders have one launch shape
-  if (shape == 2 && counted) shape = 1;            // the instrumented build exists for k_trace only
+  if (shape >= 2 && counted) shape = 1;            // the instrumented build exists for k_trace only
   if (shape == 2) return wavefront_impl(ctx, nsamples, sync);
+  if (shape == 3) return stream_impl(ctx, nsamples, sync);
   int waves_per_block = yhk_block_threads(shape) / 64;  // one work item per wave at a time
   int lds_bytes       = yhk_trace_lds_bytes(ctx->scene.lds_node_count, ctx->scene.lds_scene_f4, shape);
   int occupancy       = yhk_trace_occupancy(lds_bytes, ctx->scene.general_materials, shape);
