@@ -87,10 +87,6 @@ YH_DEV void lane_begin(const yhd_scene& sc, lane_trav& t, f3 ro, f3 rd, int firs
   else t.cur = sc.num_scene_nodes ? (YH_TAG_SCENE | 0u) : YH_NONE;
 }
 
-#ifndef YH_LEAF_STEP
-#define YH_LEAF_STEP 2 /* primitives of a leaf tested per step (a longer leaf takes another step) */
-#endif
-
 // One step of the ray in `t`. Returns true when the ray is finished (closest hit in t.hit), or —
 // EXACT = false only — when it has to be traced again by the EXACT form (`redo` set: a slab of a
 // box test could hold a NaN, dev_trace.h). `sp0` = stack height at which this ray started.
@@ -180,14 +176,22 @@ YH_DEV bool lane_step(const trace_ctx& tc, lane_trav& t, lane_stack& s, int sp0,
     const bool lines      = t.kind == YH_KIND_LINES;
     const int  leaf_start = (int)(t.cur & 0x07FFFFFFu), leaf_num = (int)((t.cur >> 27) & 7u);
     const int  rec        = lines ? 4 : 6;
-    // records 0..3: the node's slots (32 B apart), or the test halves of the leaf's first primitives
-    const int         last   = is_leaf ? min(leaf_num, YH_LEAF_STEP) - 1 : 3;
-    const int         stride = is_leaf ? rec : 2;
-    const yhd_float4* a      = is_leaf ? sc.prims + (size_t)t.prim_base + (size_t)leaf_start * rec : sc.nodes + 8 * (size_t)t.cur;
-    const yhd_float4 *a1 = a + min(1, last) * stride, *a2 = a + min(2, last) * stride, *a3 = a + min(3, last) * stride;
-    v4f A0 = ldg4(a), B0 = ldg4(a + 1), A1 = ldg4(a1), B1 = ldg4(a1 + 1);
-    v4f A2, B2, A3, B3;
-    if (YH_LEAF_STEP > 2 || !is_leaf) A2 = ldg4(a2), B2 = ldg4(a2 + 1), A3 = ldg4(a3), B3 = ldg4(a3 + 1);
+    // Eight 16-byte loads, ONE round trip, whatever the lane holds:
+    //   wide node      slot q = {A_q, B_q} at a + 2 q
+    //   line leaf      primitive i < 2 = {p0 r0, p1 r1} = {A_i, B_i} at a + 4 i   (A2, A3: not used)
+    //   triangle leaf  primitive i < 2 = {p0, p1} = {A_i, B_i} at a + 6 i, its p2 = A_(2 + i)
+    // (a leaf of one primitive re-reads it as the second; a leaf longer than two takes another step)
+    const yhd_float4* a  = is_leaf ? sc.prims + (size_t)t.prim_base + (size_t)leaf_start * rec : sc.nodes + 8 * (size_t)t.cur;
+    const int         o1 = is_leaf ? (leaf_num > 1 ? rec : 0) : 2;
+    const int         o2 = is_leaf ? (lines ? 0 : 2) : 4;
+    const int         o3 = is_leaf ? (lines ? 0 : o1 + 2) : 6;
+    const v4f A0 = ldg4(a), B0 = ldg4(a + 1), A1 = ldg4(a + o1), B1 = ldg4(a + o1 + 1);
+#ifdef YH_LANE_SPLIT_LOADS /* developer A/B switch: the second half only where it is used */
+    v4f A2 = A0, B2 = B0, A3 = A0, B3 = B0;
+    if (!is_leaf || !lines) A2 = ldg4(a + o2), B2 = ldg4(a + o2 + 1), A3 = ldg4(a + o3), B3 = ldg4(a + o3 + 1);
+#else
+    const v4f A2 = ldg4(a + o2), B2 = ldg4(a + o2 + 1), A3 = ldg4(a + o3), B3 = ldg4(a + o3 + 1);
+#endif
     if (!is_leaf) {
       // ---- wide node: the four slots {min.xyz, max.x} {max.yz, ref, axes} ----
       const unsigned int axes = __float_as_uint(B0.w);
@@ -217,38 +221,37 @@ YH_DEV bool lane_step(const trace_ctx& tc, lane_trav& t, lane_stack& s, int sp0,
       }
     } else {
       // ---- leaf: its primitives in leaf order, tmax shrinking after each accepted hit (pt.cpp:905-923) ----
-      const int n = min(leaf_num, YH_LEAF_STEP);
-      t.cur       = leaf_num > YH_LEAF_STEP ? (YH_TAG_LEAF | ((unsigned)(leaf_num - YH_LEAF_STEP) << 27) | (unsigned)(leaf_start + YH_LEAF_STEP)) : YH_NONE;
-      if (lines) {
-#define YH_LANE_LINE(I, A, B)                                                                             \
-  {                                                                                                       \
-    float uu = 0, vv = 0, dist = 0;                                                                       \
-    bool  ok = intersect_line<true>(t.lo, t.ld, ray_eps, t.tmax, xyz(A), xyz(B), A.w, B.w, uu, vv, dist); \
-    if (ok && I < n) {                                                                                    \
-      t.hit.object = t.cur_obj, t.hit.slot = leaf_start + I;                                              \
-      t.hit.u = uu, t.hit.v = vv, t.hit.distance = dist;                                                  \
-      t.tmax = dist, t.hit_lines = true;                                                                  \
-    }                                                                                                     \
+      t.cur = leaf_num > 2 ? (YH_TAG_LEAF | ((unsigned)(leaf_num - 2) << 27) | (unsigned)(leaf_start + 2)) : YH_NONE;
+#define YH_LANE_ACCEPT(I, LINES)                          \
+  if (ok && I < leaf_num) {                               \
+    t.hit.object = t.cur_obj, t.hit.slot = leaf_start + I; \
+    t.hit.u = uu, t.hit.v = vv, t.hit.distance = dist;    \
+    t.tmax = dist, t.hit_lines = LINES;                   \
   }
-        YH_LANE_LINE(0, A0, B0)
-        YH_LANE_LINE(1, A1, B1)
-        if (YH_LEAF_STEP > 2) {
-          YH_LANE_LINE(2, A2, B2)
-          YH_LANE_LINE(3, A3, B3)
-        }
-#undef YH_LANE_LINE
-      } else {
-        for (int i = 0; i < n; i++) {
-          const yhd_float4* p = a + i * 6;
-          v4f  P0 = ldg4(p), P1 = ldg4(p + 1), P2 = ldg4(p + 2);
+      if (lines) {
+        {
           float uu = 0, vv = 0, dist = 0;
-          if (intersect_triangle(t.lo, t.ld, ray_eps, t.tmax, xyz(P0), xyz(P1), xyz(P2), uu, vv, dist)) {
-            t.hit.object = t.cur_obj, t.hit.slot = leaf_start + i;
-            t.hit.u = uu, t.hit.v = vv, t.hit.distance = dist;
-            t.tmax = dist, t.hit_lines = false;
-          }
+          bool  ok = intersect_line<true>(t.lo, t.ld, ray_eps, t.tmax, xyz(A0), xyz(B0), A0.w, B0.w, uu, vv, dist);
+          YH_LANE_ACCEPT(0, true)
+        }
+        {
+          float uu = 0, vv = 0, dist = 0;
+          bool  ok = intersect_line<true>(t.lo, t.ld, ray_eps, t.tmax, xyz(A1), xyz(B1), A1.w, B1.w, uu, vv, dist);
+          YH_LANE_ACCEPT(1, true)
+        }
+      } else {
+        {
+          float uu = 0, vv = 0, dist = 0;
+          bool  ok = intersect_triangle(t.lo, t.ld, ray_eps, t.tmax, xyz(A0), xyz(B0), xyz(A2), uu, vv, dist);
+          YH_LANE_ACCEPT(0, false)
+        }
+        if (leaf_num > 1) {
+          float uu = 0, vv = 0, dist = 0;
+          bool  ok = intersect_triangle(t.lo, t.ld, ray_eps, t.tmax, xyz(A1), xyz(B1), xyz(A3), uu, vv, dist);
+          YH_LANE_ACCEPT(1, false)
         }
       }
+#undef YH_LANE_ACCEPT
     }
   }
   return t.cur == YH_NONE && s.sp == sp0;

@@ -40,11 +40,32 @@ using namespace yhd;
 #define YH_ST_WAVES 4 /* waves per SIMD the register allocator must allow */
 #endif
 #ifndef YH_REFILL_LANES
-#define YH_REFILL_LANES 8 /* idle lanes of a wave before the (divergent) refill code runs */
+#define YH_REFILL_LANES 16 /* idle lanes of a wave before the (divergent) refill code runs */
+#endif
+#ifndef YH_ST_POLICY
+#define YH_ST_POLICY 0 /* developer A/B switch: 0 = every stage in batches of 64 or flushed, trace left only when few lanes are busy */
 #endif
 #ifndef YH_SUSPEND_LANES
-#define YH_SUSPEND_LANES 32 /* ray list dry and at most this many lanes busy: go shading */
+#define YH_SUSPEND_LANES 16 /* ray list dry and at most this many lanes busy: go shading */
 #endif
+
+// Fields of a path slot (yh_device.h: yhd_path_slot, seven 16-byte fields). YH_ST_SOA = 1 lays the pool out
+// field by field instead (developer A/B switch).
+#ifndef YH_ST_SOA
+#define YH_ST_SOA 0
+#endif
+#if YH_ST_SOA
+#define SLOT_F4(pl, g, k) (((yhd_float4*)(pl).slots)[(size_t)(k) * (pl).total_slots + (g)])
+#else
+#define SLOT_F4(pl, g, k) (((yhd_float4*)&(pl).slots[g])[k])
+#endif
+#define SLOT_RAY_O(pl, g) SLOT_F4(pl, g, 0)
+#define SLOT_RAY_D(pl, g) SLOT_F4(pl, g, 1)
+#define SLOT_WEIGHT(pl, g) SLOT_F4(pl, g, 2)
+#define SLOT_RADIANCE(pl, g) SLOT_F4(pl, g, 3)
+#define SLOT_HIT(pl, g) (*(yhd_int4*)&SLOT_F4(pl, g, 4))
+#define SLOT_RNG(pl, g) (*(yhd_int4*)&SLOT_F4(pl, g, 5))
+#define SLOT_META(pl, g) (*(yhd_int4*)&SLOT_F4(pl, g, 6))
 
 enum { K_HAIR = 0, K_SURF = 1, K_MISS = 2, K_REDO = 3 };  // what a finished ray found (bits 12-13 of a done-list entry)
 enum { H_MISS = -1, H_ENDED = -2, H_NEW = -3 };            // yhd_stream::hit.x of a slot in the finish list
@@ -60,14 +81,17 @@ YH_DEV int list_push(YH_LDS unsigned short* list, int n, bool pred, int value) {
 }
 // Closest hit of a finished ray into its slot; returns what it hit.
 YH_DEV int publish(const yhd_stream& pl, size_t g, const hit_t& hit, bool hit_lines, unsigned int steps) {
-  pl.hit[g]                 = yhd_int4{hit.object, hit.slot, __float_as_int(hit.u), __float_as_int(hit.v)};
-  ((float*)&pl.ray_o[g])[3] = hit.distance;
-  atomicAdd((unsigned int*)&pl.meta[g].w, steps);  // scheduling hint of the pixel's work item (no return value: not waited for)
+  SLOT_HIT(pl, g)                 = yhd_int4{hit.object, hit.slot, __float_as_int(hit.u), __float_as_int(hit.v)};
+  ((float*)&SLOT_RAY_O(pl, g))[3] = hit.distance;
+  // steps of this ray: a scheduling hint of the pixel's work item, added to the pixel's total by the stage that
+  // takes the path next (NOT an atomic add here: device-scope atomics execute at the memory side and drop the
+  // slot's line from L2 — measured 1.6x on the whole kernel)
+  ((unsigned int*)&SLOT_F4(pl, g, 7))[0] = steps;
   return hit.object < 0 ? K_MISS : (hit_lines ? K_HAIR : K_SURF);
 }
 YH_DEV int path_flags(const path_t& ps) { return (ps.bounce & 255) | (ps.hit ? 256 : 0) | (ps.in_medium ? 512 : 0); }
 
-template <bool GENERAL, int WAVES>
+template <bool GENERAL, int WAVES, bool PROF>
 __global__ __launch_bounds__(YH_ST_BLOCK, WAVES) void k_stream(const yhd_scene sc, const yhd_scene* sc_dev, const yhd_state st, int nsamples,
     const yhd_stream pl) {
   constexpr int WPB = YH_ST_BLOCK / 64;
@@ -109,6 +133,7 @@ __global__ __launch_bounds__(YH_ST_BLOCK, WAVES) void k_stream(const yhd_scene s
   tc.ls   = &stk;
   // lists (wave-uniform counts) and the ray this lane holds
   int       n_ray = 0, n_done = 0, n_hair = 0, n_surf = 0, n_fin = 0, n_free = P;
+  int       n_hair_done = 0;  // hair hits among the entries of the done list
   bool      nomore = false;
   bool      have = false;
   int       slot = 0;
@@ -116,20 +141,34 @@ __global__ __launch_bounds__(YH_ST_BLOCK, WAVES) void k_stream(const yhd_scene s
   lane_begin(sc, t, mk3(0.0f), mk3(1.0f), -1);
 
   enum { A_ITEMS, A_SORT, A_FINISH, A_HAIR, A_SURF, A_TRACE };
-  // One stage per trip, each stage's code exactly once in the kernel. Order of preference: new pixels, sorting
-  // what the last trace stage finished, then full batches of 64 (finish, hair, surface); partial batches
-  // only when the rays at hand cannot fill the lanes; tracing when nothing else is due.
+  // One stage per trip, each stage's code exactly once in the kernel.
   while (true) {
-    const int  nact  = (int)__popcll(__ballot(have));
+    const int nact = (int)__popcll(__ballot(have));
+    // Hair shading is the expensive stage (thousands of instructions): full batches of 64, a partial one only when
+    // the rays at hand (plus the samples the finish stage is about to start) cannot fill the lanes. Surface shading
+    // and finishing are a few hundred instructions: whatever has gathered since the last trace stage, so that no
+    // path waits long for company. Finishing comes after shading (which ends paths) and runs once per round.
+    int act;
+#if YH_ST_POLICY == 0
     const bool flush = n_ray + nact < 64;
-    int        act;
     if (!nomore && n_free >= 64) act = A_ITEMS;
     else if (n_done > 0) act = A_SORT;
     else if (n_fin >= 64 || (flush && n_fin > 0)) act = A_FINISH;
     else if (n_hair >= 64 || (flush && n_hair > 0)) act = A_HAIR;
     else if (n_surf >= 64 || (flush && n_surf > 0)) act = A_SURF;
     else if (n_ray > 0 || nact > 0) act = A_TRACE;
+#else
+    const bool flush = n_ray + nact + n_fin < 64;
+    if (!nomore && n_free >= 64) act = A_ITEMS;
+    else if (n_done > 0) act = A_SORT;
+    else if (n_surf > 0) act = A_SURF;
+    else if (n_hair >= 64 || (flush && n_hair > 0)) act = A_HAIR;
+    else if (n_fin > 0) act = A_FINISH;
+    else if (n_ray > 0 || nact > 0) act = A_TRACE;
+#endif
     else break;  // every slot is free and the work items are used up
+    unsigned long long pc0 = 0, p_steps = 0, p_busy = 0, p_batch = 0;
+    if (PROF) pc0 = clock64();
 
     if (act == A_ITEMS) {
       // ---- items: free slots take the pixels of the next work items (4 items = 64 pixels) ------------------
@@ -153,9 +192,9 @@ __global__ __launch_bounds__(YH_ST_BLOCK, WAVES) void k_stream(const yhd_scene s
         sl                = l_free[n_free - 1 - lane_rank(m)];
         const size_t   g  = base + sl;
         const uint64_t rs = st.rng_state[pixel], ri = st.rng_inc[pixel];
-        pl.meta[g]        = yhd_int4{pixel, nsamples, item, 0};
-        pl.rng[g]         = yhd_int4{(int)(unsigned)rs, (int)(unsigned)(rs >> 32), (int)(unsigned)ri, (int)(unsigned)(ri >> 32)};
-        pl.hit[g]         = yhd_int4{H_NEW, 0, 0, 0};
+        SLOT_META(pl, g)        = yhd_int4{pixel, nsamples, item, 0};
+        SLOT_RNG(pl, g)         = yhd_int4{(int)(unsigned)rs, (int)(unsigned)(rs >> 32), (int)(unsigned)ri, (int)(unsigned)(ri >> 32)};
+        SLOT_HIT(pl, g)         = yhd_int4{H_NEW, 0, 0, 0};
       }
       n_free -= (int)__popcll(m);
       n_fin = list_push(l_fin, n_fin, valid, sl);
@@ -169,7 +208,7 @@ __global__ __launch_bounds__(YH_ST_BLOCK, WAVES) void k_stream(const yhd_scene s
         if (__ballot(kd == K_REDO) != 0) {
           if (kd == K_REDO) {  // axis-parallel ray: the reference's compare-and-select box test (dev_trace.h)
             const size_t g = base + sl;
-            yhd_float4 o = pl.ray_o[g], d = pl.ray_d[g];
+            yhd_float4 o = SLOT_RAY_O(pl, g), d = SLOT_RAY_D(pl, g);
             lane_exact_result r = lane_trace_exact(sc_dev, tc.lds_scene, stk.lds, stk.ovf, stk.sp, stk.base, f3{o.x, o.y, o.z},
                 f3{d.x, d.y, d.z}, -1);
             stk.base = r.base;
@@ -180,32 +219,35 @@ __global__ __launch_bounds__(YH_ST_BLOCK, WAVES) void k_stream(const yhd_scene s
         n_surf = list_push(l_surf, n_surf, kd == K_SURF, sl);
         n_fin  = list_push(l_fin, n_fin, kd == K_MISS, sl);
       }
-      n_done = 0;
+      n_done = 0, n_hair_done = 0;
     } else if (act == A_FINISH) {
       // ---- finish: account the sample that ended, start the pixel's next one ---------------------------------
       const int  cnt = min(n_fin, 64);
       const bool on  = lane < cnt;
       const int  sl  = on ? l_fin[n_fin - cnt + lane] : 0;
       n_fin -= cnt;
+      if (PROF) p_batch = (unsigned long long)cnt;
       bool next = false, freed = false;
       if (on) {
         const size_t   g  = base + sl;
-        const yhd_int4 mt = pl.meta[g];
-        const int      h  = pl.hit[g].x, p = mt.x, left = mt.y;
+        const yhd_int4 mt = SLOT_META(pl, g);
+        const int      h  = SLOT_HIT(pl, g).x, p = mt.x, left = mt.y;
+        unsigned int   work = (unsigned int)mt.w;
+        if (h == H_MISS) work += ((const unsigned int*)&SLOT_F4(pl, g, 7))[0];  // the ray that missed (see publish)
         if (h != H_NEW) {  // trace_sample's tail (pt.cpp:1683-1688)
-          yhd_float4 rad = pl.radiance[g], d = pl.ray_d[g];
+          yhd_float4 rad = SLOT_RADIANCE(pl, g), d = SLOT_RAY_D(pl, g);
           path_t     ps;
           ps.radiance = f3{rad.x, rad.y, rad.z};
           ps.hit      = (__float_as_int(d.w) & 256) != 0;
           if (h == H_MISS) {  // pt.cpp:1397-1400
-            yhd_float4 w = pl.weight[g];
+            yhd_float4 w = SLOT_WEIGHT(pl, g);
             ps.radiance  = ps.radiance + f3{w.x, w.y, w.z} * eval_environment<false>(tc, f3{d.x, d.y, d.z});
           }
           yhd_float4 acc = st.accum[p];
           path_end(ps, st.clamp, acc);
           st.accum[p] = acc;
         }
-        const yhd_int4 r4 = pl.rng[g];
+        const yhd_int4 r4 = SLOT_RNG(pl, g);
         rng_t          rng;
         rng.state = (uint64_t)(unsigned)r4.x | ((uint64_t)(unsigned)r4.y << 32);
         rng.inc   = (uint64_t)(unsigned)r4.z | ((uint64_t)(unsigned)r4.w << 32);
@@ -216,16 +258,17 @@ __global__ __launch_bounds__(YH_ST_BLOCK, WAVES) void k_stream(const yhd_scene s
           for (int k = 0; k < 12; k++) cam.frame[k] = lds_cam[k];
           cam.lens = lds_cam[12], cam.film_x = lds_cam[13], cam.film_y = lds_cam[14], cam.focus = lds_cam[15], cam.aperture = lds_cam[16];
           ray_t r = sample_camera_lane(cam, p % st.width, p / st.width, st.width, st.height, pu, pv, lu, lv);
-          pl.ray_o[g]    = yhd_float4{r.o.x, r.o.y, r.o.z, 0.0f};
-          pl.ray_d[g]    = yhd_float4{r.d.x, r.d.y, r.d.z, __int_as_float(0)};
-          pl.weight[g]   = yhd_float4{1.0f, 1.0f, 1.0f, 0.0f};
-          pl.radiance[g] = yhd_float4{0.0f, 0.0f, 0.0f, 0.0f};
-          pl.rng[g]      = yhd_int4{(int)(unsigned)rng.state, (int)(unsigned)(rng.state >> 32), r4.z, r4.w};
-          pl.meta[g].y   = left - 1;
+          SLOT_RAY_O(pl, g)    = yhd_float4{r.o.x, r.o.y, r.o.z, 0.0f};
+          SLOT_RAY_D(pl, g)    = yhd_float4{r.d.x, r.d.y, r.d.z, __int_as_float(0)};
+          SLOT_WEIGHT(pl, g)   = yhd_float4{1.0f, 1.0f, 1.0f, 0.0f};
+          SLOT_RADIANCE(pl, g) = yhd_float4{0.0f, 0.0f, 0.0f, 0.0f};
+          SLOT_RNG(pl, g)      = yhd_int4{(int)(unsigned)rng.state, (int)(unsigned)(rng.state >> 32), r4.z, r4.w};
+          SLOT_META(pl, g).y   = left - 1;
+          SLOT_META(pl, g).w   = (int)work;
           next           = true;
         } else {  // the pixel has all its samples: hand its stream back, report its work, free the slot
           st.rng_state[p] = rng.state;
-          if (mt.w) atomicAdd(&st.tile_cost[mt.z], (unsigned int)mt.w);
+          if (work) atomicAdd(&st.tile_cost[mt.z], work);
           freed = true;
         }
       }
@@ -240,11 +283,12 @@ __global__ __launch_bounds__(YH_ST_BLOCK, WAVES) void k_stream(const yhd_scene s
       const int  sl  = on ? list[n - cnt + lane] : 0;
       if (act == A_HAIR) n_hair -= cnt;
       else n_surf -= cnt;
+      if (PROF) p_batch = (unsigned long long)cnt;
       bool alive = false;
       if (on) {
         const size_t g = base + sl;
-        yhd_float4 o = pl.ray_o[g], d = pl.ray_d[g], w = pl.weight[g], rad = pl.radiance[g];
-        yhd_int4   h = pl.hit[g], r4 = pl.rng[g];
+        yhd_float4 o = SLOT_RAY_O(pl, g), d = SLOT_RAY_D(pl, g), w = SLOT_WEIGHT(pl, g), rad = SLOT_RADIANCE(pl, g);
+        yhd_int4   h = SLOT_HIT(pl, g), r4 = SLOT_RNG(pl, g);
         path_t     ps;
         ps.ray      = ray_t{f3{o.x, o.y, o.z}, f3{d.x, d.y, d.z}, ray_eps, flt_max};
         ps.weight   = f3{w.x, w.y, w.z}, ps.radiance = f3{rad.x, rad.y, rad.z};
@@ -260,18 +304,19 @@ __global__ __launch_bounds__(YH_ST_BLOCK, WAVES) void k_stream(const yhd_scene s
         rng.state = (uint64_t)(unsigned)r4.x | ((uint64_t)(unsigned)r4.y << 32);
         rng.inc   = (uint64_t)(unsigned)r4.z | ((uint64_t)(unsigned)r4.w << 32);
         alive     = path_step<false, 64, GENERAL>(tc, ps, isec, rng, st.bounces);
-        pl.rng[g]      = yhd_int4{(int)(unsigned)rng.state, (int)(unsigned)(rng.state >> 32), r4.z, r4.w};
-        pl.radiance[g] = yhd_float4{ps.radiance.x, ps.radiance.y, ps.radiance.z, 0.0f};
-        pl.ray_d[g]    = yhd_float4{ps.ray.d.x, ps.ray.d.y, ps.ray.d.z, __int_as_float(path_flags(ps))};
+        SLOT_META(pl, g).w += (int)((const unsigned int*)&SLOT_F4(pl, g, 7))[0];  // the steps of the ray just shaded
+        SLOT_RNG(pl, g)      = yhd_int4{(int)(unsigned)rng.state, (int)(unsigned)(rng.state >> 32), r4.z, r4.w};
+        SLOT_RADIANCE(pl, g) = yhd_float4{ps.radiance.x, ps.radiance.y, ps.radiance.z, 0.0f};
+        SLOT_RAY_D(pl, g)    = yhd_float4{ps.ray.d.x, ps.ray.d.y, ps.ray.d.z, __int_as_float(path_flags(ps))};
         if (alive) {
-          pl.ray_o[g]  = yhd_float4{ps.ray.o.x, ps.ray.o.y, ps.ray.o.z, 0.0f};
-          pl.weight[g] = yhd_float4{ps.weight.x, ps.weight.y, ps.weight.z, 0.0f};
+          SLOT_RAY_O(pl, g)  = yhd_float4{ps.ray.o.x, ps.ray.o.y, ps.ray.o.z, 0.0f};
+          SLOT_WEIGHT(pl, g) = yhd_float4{ps.weight.x, ps.weight.y, ps.weight.z, 0.0f};
           if (GENERAL && ps.in_medium) {
             pl.medium[2 * g]     = yhd_float4{ps.medium.density.x, ps.medium.density.y, ps.medium.density.z, ps.medium.anisotropy};
             pl.medium[2 * g + 1] = yhd_float4{ps.medium.scatter.x, ps.medium.scatter.y, ps.medium.scatter.z, 0.0f};
           }
         } else {
-          pl.hit[g].x = H_ENDED;
+          SLOT_HIT(pl, g).x = H_ENDED;
         }
       }
       n_ray = list_push(l_ray, n_ray, on && alive, sl);
@@ -286,7 +331,7 @@ __global__ __launch_bounds__(YH_ST_BLOCK, WAVES) void k_stream(const yhd_scene s
             if (!have && lane_rank(idle) < n_ray) {
               slot           = l_ray[n_ray - 1 - lane_rank(idle)];
               const size_t g = base + slot;
-              yhd_float4 o = pl.ray_o[g], d = pl.ray_d[g];
+              yhd_float4 o = SLOT_RAY_O(pl, g), d = SLOT_RAY_D(pl, g);
               lane_begin(sc, t, f3{o.x, o.y, o.z}, f3{d.x, d.y, d.z}, -1);
               have = true;
             }
@@ -295,7 +340,10 @@ __global__ __launch_bounds__(YH_ST_BLOCK, WAVES) void k_stream(const yhd_scene s
         }
         const int busy = (int)__popcll(__ballot(have));
         if (busy == 0) break;
-        if (n_ray == 0 && busy <= YH_SUSPEND_LANES && (n_done | n_hair | n_surf | n_fin) != 0) break;
+        // Leave for the shading stages when the ray list is dry and either a full batch of hair hits has gathered
+        // or few lanes are busy; the unfinished rays stay in their lanes.
+        if (n_ray == 0 && ((YH_ST_POLICY != 0 && n_hair + n_hair_done >= 64) || (busy <= YH_SUSPEND_LANES && (n_done | n_hair | n_surf | n_fin) != 0))) break;
+        if (PROF) p_steps++, p_busy += (unsigned long long)busy;
         bool fin  = false;
         int  kind = 0;
         if (have) {
@@ -310,8 +358,17 @@ __global__ __launch_bounds__(YH_ST_BLOCK, WAVES) void k_stream(const yhd_scene s
             }
           }
         }
-        if (__ballot(fin) != 0) n_done = list_push(l_done, n_done, fin, slot | (kind << 12));
+        if (__ballot(fin) != 0) {
+          n_done = list_push(l_done, n_done, fin, slot | (kind << 12));
+          n_hair_done += (int)__popcll(__ballot(fin && kind == K_HAIR));
+        }
       }
+    }
+    if (PROF && lane == 0) {  // developer build: where the wave's time goes (tools/stream_prof.py)
+      atomicAdd(&pl.prof[act], (unsigned long long)(clock64() - pc0));
+      atomicAdd(&pl.prof[8 + act], 1ull);
+      atomicAdd(&pl.prof[16 + act], p_batch);
+      if (act == A_TRACE) atomicAdd(&pl.prof[24], p_steps), atomicAdd(&pl.prof[25], p_busy);
     }
   }
 }
@@ -319,7 +376,10 @@ __global__ __launch_bounds__(YH_ST_BLOCK, WAVES) void k_stream(const yhd_scene s
 extern "C" {
 
 typedef void (*stream_kernel_t)(const yhd_scene, const yhd_scene*, const yhd_state, int, const yhd_stream);
-static stream_kernel_t stream_kernel(bool general) { return general ? k_stream<true, YH_ST_WAVES> : k_stream<false, YH_ST_WAVES>; }
+static stream_kernel_t stream_kernel(bool general, bool prof = false) {
+  if (prof && !general) return k_stream<false, YH_ST_WAVES, true>;
+  return general ? k_stream<true, YH_ST_WAVES, false> : k_stream<false, YH_ST_WAVES, false>;
+}
 int yhk_stream_block_threads(void) { return YH_ST_BLOCK; }
 int yhk_stream_lds_bytes(int lds_scene_f4, int slots_per_wave) {
   return lds_scene_f4 * 16 + 80 + (YH_ST_BLOCK / 64) * (64 * YH_LSTACK * 4 + 6 * slots_per_wave * 2);
@@ -335,7 +395,7 @@ int yhk_stream_occupancy(int lds_bytes, int general) {
 int yhk_stream(const yhd_scene* sc, const yhd_scene* sc_dev, const yhd_state* st, int nsamples, const yhd_stream* pl, int grid_blocks,
     hipStream_t stream) {
   int             lds  = yhk_stream_lds_bytes(sc->lds_scene_f4, pl->slots_per_wave);
-  stream_kernel_t kern = stream_kernel(sc->general_materials != 0);
+  stream_kernel_t kern = stream_kernel(sc->general_materials != 0, pl->prof != nullptr);
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;

@@ -190,18 +190,25 @@ typedef struct yhd_pool {
 
 // Path pool of the streaming integrator (csrc/stream.hip): one lane per path, `slots_per_wave` slots owned by
 // each WAVEFRONT (no workgroup-level synchronisation), SoA over the slots.
+// One path slot = one 128-byte cache line: a stage touches one line per path, not one per field.
+typedef struct yhd_path_slot {
+  yhd_float4 ray_o;     // origin.xyz; w = distance of the closest hit
+  yhd_float4 ray_d;     // direction.xyz; w = int bits: bounce | hit << 8 | in_medium << 9
+  yhd_float4 weight;    // path weight.xyz
+  yhd_float4 radiance;  // radiance collected so far .xyz
+  yhd_int4   hit;       // object (-1 miss, -2 path ended in shading, -3 new pixel), leaf slot, u bits, v bits
+  yhd_int4   rng;       // the pixel's PCG32 stream while it owns the slot: state lo, hi, inc lo, hi
+  yhd_int4   meta;      // pixel, samples left to start, work item, traversal steps so far
+  yhd_int4   pad;
+} yhd_path_slot;
 typedef struct yhd_stream {
-  yhd_float4* ray_o;     // origin.xyz; w = distance of the closest hit
-  yhd_float4* ray_d;     // direction.xyz; w = int bits: bounce | hit << 8 | in_medium << 9
-  yhd_float4* weight;    // path weight.xyz
-  yhd_float4* radiance;  // radiance collected so far .xyz
-  yhd_int4*   hit;       // object (-1 miss, -2 path ended in shading, -3 new pixel), leaf slot, u bits, v bits
-  yhd_int4*   meta;      // pixel, samples left to start, work item, traversal steps so far
-  yhd_int4*   rng;       // the pixel's PCG32 stream while it owns the slot: state lo, hi, inc lo, hi
+  yhd_path_slot* slots;
   yhd_float4* medium;    // scenes with volumes only, 2 per slot
   unsigned int* stack_ovf;  // per wave: ovf_entries x 64 lanes, what the LDS stack window spills (dev_lane.h)
+  unsigned long long* prof;    // developer build (YHAIR_ST_PROF): 32 counters, see stream.hip; else NULL
   int         slots_per_wave;  // multiple of 64, <= 4096
   int         ovf_entries;
+  long long   total_slots;     // slots in the pool (all waves)
 } yhd_stream;
 
 // Work counters (one 64-bit slot each), accumulated with atomics by the

@@ -276,7 +276,7 @@ struct yh_context {
   // path pool of the wavefront integrator (csrc/wavefront.hip), allocated at its first launch
   DevBuf           d_pool_ray_o, d_pool_ray_d, d_pool_weight, d_pool_radiance, d_pool_hit, d_pool_medium;
   // path pool of the streaming integrator (csrc/stream.hip): per-wave slots, allocated at its first launch
-  DevBuf           d_st_ray_o, d_st_ray_d, d_st_weight, d_st_radiance, d_st_hit, d_st_meta, d_st_rng, d_st_medium, d_st_ovf, d_scene_copy;
+  DevBuf           d_st_slots, d_st_medium, d_st_ovf, d_st_prof, d_scene_copy;
   size_t           st_slots = 0, st_medium_slots = 0, st_ovf_words = 0;
   yhd_stream       stream_pool{};
   size_t           pool_slots = 0, pool_medium_slots = 0;  // capacity of the per-slot arrays / of the medium array (general scenes only)
@@ -391,6 +391,8 @@ void build_work_items(const yh_context* ctx, std::vector<int>& items) {
 }  // namespace
 
 extern "C" {
+
+static void deal_items_for_stream(const yh_context* ctx, std::vector<int>& items);
 
 const char* yh_version(void) { return "yhair 0.1 (gfx950, HIP)"; }
 
@@ -829,6 +831,8 @@ int yh_init_state(yh_context* ctx, const yh_trace_params* params) {
     ctx->item_cost.assign((size_t)ctx->num_tiles_total * 4, 0);
   std::vector<int> tiles;
   build_work_items(ctx, tiles);
+  const int first_shape = getenv("YHAIR_SHAPE") ? choose_launch_shape(ctx) : ctx->launch_shape;
+  if (params->shader == YH_SHADER_PATH && first_shape == 3) deal_items_for_stream(ctx, tiles);
   int rc;
   if ((rc = upload(ctx, ctx->d_rng_state, st.data(), npix * 8))) return rc;
   if ((rc = upload(ctx, ctx->d_rng_inc, inc.data(), npix * 8))) return rc;
@@ -842,7 +846,7 @@ int yh_init_state(yh_context* ctx, const yh_trace_params* params) {
   s.tile_cursor = (int*)ctx->d_tile_cursor.p, s.tile_cost = (unsigned int*)ctx->d_tile_cost.p;
   s.rng_state = (uint64_t*)ctx->d_rng_state.p, s.rng_inc = (uint64_t*)ctx->d_rng_inc.p;
   s.accum = (yhd_float4*)ctx->d_accum.p, s.tiles = (const int*)ctx->d_tiles.p;
-  s.launch_shape = getenv("YHAIR_SHAPE") ? choose_launch_shape(ctx) : ctx->launch_shape;
+  s.launch_shape = first_shape;
   s.num_tiles = (int)tiles.size(), s.width = w, s.height = h, s.tiles_x = tx;
   ctx->launches_of_state = 0;
   s.samples_done = 0, s.bounces = params->bounces, s.clamp = params->clamp, s.shader = params->shader;
@@ -868,11 +872,12 @@ static int replan_after_launch(yh_context* ctx, int nsamples) {
   const unsigned li = ++ctx->launches_of_state;
   if ((li & (li - 1)) != 0) return YH_OK;
   HIPCHK(ctx, hipMemcpy(ctx->item_cost.data(), ctx->d_tile_cost.p, ctx->item_cost.size() * 4, hipMemcpyDeviceToHost));
-  std::vector<int> tiles;
-  build_work_items(ctx, tiles);
-  HIPCHK(ctx, hipMemcpy(ctx->d_tiles.p, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice));
   if (ctx->state.shader == YH_SHADER_PATH && (nsamples >= 16 || getenv("YHAIR_SHAPE"))) ctx->launch_shape = choose_launch_shape(ctx);
   ctx->state.launch_shape = ctx->launch_shape;
+  std::vector<int> tiles;
+  build_work_items(ctx, tiles);
+  if (ctx->state.shader == YH_SHADER_PATH && ctx->state.launch_shape == 3) deal_items_for_stream(ctx, tiles);
+  HIPCHK(ctx, hipMemcpy(ctx->d_tiles.p, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice));
   return YH_OK;
 }
 
@@ -924,36 +929,69 @@ static int wavefront_impl(yh_context* ctx, int nsamples, bool sync) {
   return YH_OK;
 }
 
-// One launch of the streaming integrator (csrc/stream.hip): persistent wavefronts, one path pool each, one lane per path.
-static int stream_impl(yh_context* ctx, int nsamples, bool sync) {
-  // Slots per wave and waves per CU: the pixels of the launch spread over the waves so that every wave has
-  // a few paths per lane to keep its lanes full between stages (YHAIR_ST_SLOTS / YHAIR_ST_WAVES: developer switches).
-  int P = 256;
+// Launch geometry of the streaming integrator: path slots per wave and workgroups. The pixels of the launch are
+// spread over as many waves as the CUs hold, each wave with a few paths per lane so that its lanes stay full
+// between stages: 128 .. 384 slots (YHAIR_ST_SLOTS / YHAIR_ST_WAVES: developer switches). Returns 0 when the
+// kernel cannot run.
+static int stream_geometry(const yh_context* ctx, int num_items, int* slots_per_wave, int* grid_blocks, int* lds_out) {
+  const int     wpb    = yhk_stream_block_threads() / 64;
+  const int64_t pixels = (int64_t)num_items * 16;  // work items are 4x4 pixel quadrants
+  int           P      = (int)std::max<int64_t>(128, std::min<int64_t>(384, (pixels / ((int64_t)ctx->num_cus * 16) + 63) / 64 * 64));
   if (const char* env = getenv("YHAIR_ST_SLOTS")) P = std::max(64, std::min(4096, atoi(env) / 64 * 64));
-  const int wpb       = yhk_stream_block_threads() / 64;
   const int lds_bytes = yhk_stream_lds_bytes(ctx->scene.lds_scene_f4, P);
   int       occupancy = yhk_stream_occupancy(lds_bytes, ctx->scene.general_materials);
-  if (occupancy < 1) return fail(ctx, YH_E_DEVICE, "k_stream cannot run with %d bytes of LDS per block", lds_bytes);
+  if (occupancy < 1) return 0;
   if (const char* env = getenv("YHAIR_ST_WAVES")) occupancy = std::max(1, std::min(occupancy, (atoi(env) + wpb - 1) / wpb));  // waves per CU
-  const int64_t pixels = (int64_t)ctx->state.num_tiles * 16;  // work items are 4x4 pixel quadrants
-  const int64_t want   = (pixels + (int64_t)P * wpb - 1) / ((int64_t)P * wpb);
-  const int     grid   = (int)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)ctx->num_cus * occupancy));
+  const int64_t want = (pixels + (int64_t)P * wpb - 1) / ((int64_t)P * wpb);
+  *slots_per_wave    = P;
+  *grid_blocks       = (int)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)ctx->num_cus * occupancy));
+  if (lds_out) *lds_out = lds_bytes;
+  return 1;
+}
+
+// Hand-out order of the work items for the streaming integrator. Its waves take items four at a time (64 pixels)
+// and keep them until all their samples are done, and the first R takes (R = what the path pools hold) are
+// resident together: dealt from the cost-sorted list in order, the first waves would get all the expensive pixels
+// and bound the launch (sparse hair: C1, C4). So each block of R takes is dealt like cards: take c holds one item
+// of each quarter of the block, and consecutive takes are spread over the block by a golden-ratio stride — every
+// wave gets a uniform sample of the costs, expensive blocks still come first.
+static void deal_items_for_stream(const yh_context* ctx, std::vector<int>& items) {
+  int P = 0, grid = 0;
+  if (items.empty() || !stream_geometry(ctx, (int)items.size(), &P, &grid, nullptr)) return;
+  const size_t R = (size_t)grid * (yhk_stream_block_threads() / 64) * (size_t)(P / 64);  // takes resident together
+  std::vector<int> out;
+  out.reserve(items.size());
+  for (size_t b0 = 0; b0 < items.size(); b0 += 4 * R) {
+    const size_t M  = std::min(items.size() - b0, 4 * R);
+    const size_t Rb = (M + 3) / 4;  // takes in this block
+    size_t       A  = std::max<size_t>(1, (size_t)(0.6180339887 * (double)Rb));
+    auto gcd = [](size_t a, size_t b) { while (b) { size_t t = a % b; a = b, b = t; } return a; };
+    while (gcd(A, Rb) != 1) A++;
+    for (size_t c = 0; c < Rb; c++) {
+      const size_t cp = (c * A) % Rb;
+      for (size_t k = 0; k < 4; k++)
+        if (cp + k * Rb < M) out.push_back(items[b0 + cp + k * Rb]);
+    }
+  }
+  items.swap(out);
+}
+
+// One launch of the streaming integrator (csrc/stream.hip): persistent wavefronts, one path pool each, one lane per path.
+static int stream_impl(yh_context* ctx, int nsamples, bool sync) {
+  int P = 0, grid = 0, lds_bytes = 0;
+  if (!stream_geometry(ctx, ctx->state.num_tiles, &P, &grid, &lds_bytes))
+    return fail(ctx, YH_E_DEVICE, "k_stream cannot run with its LDS layout on this device");
+  const int     wpb    = yhk_stream_block_threads() / 64;
   const size_t  waves  = (size_t)grid * wpb, slots = waves * P;
   // overflow of the per-lane LDS stack windows (dev_lane.h): a main ray plus a light-pdf ray above it
   const int    ovf_entries = 2 * std::max(8, ctx->stack_need);
   const size_t ovf_words   = waves * (size_t)ovf_entries * 64;
   int rc;
   if (slots > ctx->st_slots) {
-    if ((rc = alloc_zero(ctx, ctx->d_st_ray_o, slots * 16)) || (rc = alloc_zero(ctx, ctx->d_st_ray_d, slots * 16)) ||
-        (rc = alloc_zero(ctx, ctx->d_st_weight, slots * 16)) || (rc = alloc_zero(ctx, ctx->d_st_radiance, slots * 16)) ||
-        (rc = alloc_zero(ctx, ctx->d_st_hit, slots * 16)) || (rc = alloc_zero(ctx, ctx->d_st_meta, slots * 16)) ||
-        (rc = alloc_zero(ctx, ctx->d_st_rng, slots * 16)))
-      return rc;
-    ctx->st_slots = slots;
-    auto& pl = ctx->stream_pool;
-    pl.ray_o = (yhd_float4*)ctx->d_st_ray_o.p, pl.ray_d = (yhd_float4*)ctx->d_st_ray_d.p, pl.weight = (yhd_float4*)ctx->d_st_weight.p;
-    pl.radiance = (yhd_float4*)ctx->d_st_radiance.p, pl.hit = (yhd_int4*)ctx->d_st_hit.p, pl.meta = (yhd_int4*)ctx->d_st_meta.p;
-    pl.rng = (yhd_int4*)ctx->d_st_rng.p;
+    static_assert(sizeof(yhd_path_slot) == 128, "a path slot is one cache line");
+    if ((rc = alloc_zero(ctx, ctx->d_st_slots, slots * sizeof(yhd_path_slot)))) return rc;
+    ctx->st_slots          = slots;
+    ctx->stream_pool.slots = (yhd_path_slot*)ctx->d_st_slots.p;
   }
   if (ctx->scene.general_materials && slots > ctx->st_medium_slots) {
     if ((rc = alloc_zero(ctx, ctx->d_st_medium, slots * 32))) return rc;
@@ -963,7 +1001,14 @@ static int stream_impl(yh_context* ctx, int nsamples, bool sync) {
     if ((rc = alloc_zero(ctx, ctx->d_st_ovf, ovf_words * 4))) return rc;
     ctx->st_ovf_words = ovf_words, ctx->stream_pool.stack_ovf = (unsigned int*)ctx->d_st_ovf.p;
   }
-  ctx->stream_pool.slots_per_wave = P, ctx->stream_pool.ovf_entries = ovf_entries;
+  ctx->stream_pool.slots_per_wave = P, ctx->stream_pool.ovf_entries = ovf_entries, ctx->stream_pool.total_slots = (long long)ctx->st_slots;
+  const bool prof = getenv("YHAIR_ST_PROF") && atoi(getenv("YHAIR_ST_PROF")) != 0;  // developer switch: per-stage counters on stderr
+  if (prof) {
+    if ((rc = alloc_zero(ctx, ctx->d_st_prof, 32 * 8))) return rc;
+    ctx->stream_pool.prof = (unsigned long long*)ctx->d_st_prof.p;
+  } else {
+    ctx->stream_pool.prof = nullptr;
+  }
   if (!ctx->d_scene_copy.p) {  // the scene table in device memory, for the kernel's out-of-line callees
     if ((rc = upload(ctx, ctx->d_scene_copy, &ctx->scene, sizeof(yhd_scene)))) return rc;
   }
@@ -978,6 +1023,19 @@ static int stream_impl(yh_context* ctx, int nsamples, bool sync) {
   if (sync) {
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     HIPCHK(ctx, hipEventElapsedTime(&ctx->last_ms, ctx->ev0, ctx->ev1));
+    if (prof) {
+      unsigned long long c[32];
+      HIPCHK(ctx, hipMemcpy(c, ctx->d_st_prof.p, sizeof(c), hipMemcpyDeviceToHost));
+      const char* names[6] = {"items", "sort", "finish", "hair", "surf", "trace"};
+      double total = 0;
+      for (int k = 0; k < 6; k++) total += (double)c[k];
+      fprintf(stderr, "[yhair] k_stream %.2f ms, grid %d x %d waves, %d slots per wave\n", ctx->last_ms, grid, wpb, P);
+      for (int k = 0; k < 6; k++)
+        fprintf(stderr, "[yhair]   %-7s %5.1f %% of wave time, %9llu trips, mean batch %.1f lanes\n", names[k], 100.0 * (double)c[k] / total,
+            c[8 + k], c[8 + k] ? (double)c[16 + k] / (double)c[8 + k] : 0.0);
+      fprintf(stderr, "[yhair]   trace: %llu wave steps, %.1f lanes busy on average, %.0f cycles per step\n", c[24],
+          c[24] ? (double)c[25] / (double)c[24] : 0.0, c[24] ? (double)c[5] / (double)c[24] : 0.0);
+    }
     return replan_after_launch(ctx, nsamples);
   }
   return YH_OK;
