@@ -3,34 +3,37 @@
 
 Metric: Msamples/sec (whole node) on tests/sphere-hairblock, 720x720, 1536 spp, eumelanin 1.3
 (configs[1], "C1"), with the synthetic 1.6 M-segment hair block of tools/make_scenes.py (the
-reference's hair-block.ply is not distributed). samples = width * height * spp; the timed region
-is the sample loop only (apps/yscenetrace/yscenetrace.cpp:256-268), scene already resident in
-HBM.
+reference's hair-block.ply is not distributed); per-pixel L2 against the CPU reference.
+samples = width * height * spp; the timed region is the sample loop only
+(apps/yscenetrace/yscenetrace.cpp:256-268), scene already resident in HBM.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config C1|C2|C3|C4]
 
-A "step" is ONE pass of the hot path: yh_trace_samples(spp_per_step) over the whole image, i.e.
-one k_trace launch adding `spp_per_step` samples to every pixel. The defaults (24 steps of 64
-spp) are exactly the 1536 spp the metric is quoted on. For N > 1 the image's 8x8 tiles are dealt
-round-robin to the ranks (one process per GPU, launched by torch.distributed.run), every rank
-renders all samples of its own tiles with no data-path collective, and ONE RCCL gather of the
-packed float4 tiles follows the timed loop (reported as gather_ms).
+A "step" is ONE pass of the hot path: yh_trace_samples(spp) over the whole image = one launch of
+the sample-loop kernel. The K steps of a run add up to EXACTLY the config's sample count (1536 spp
+for C1 / C2, 4096 for C3 / C4): K does not divide it in general, so the first steps carry one
+sample more than the last ones (K = 24: 24 x 64; K = 20: 16 x 77 + 4 x 76).
 
-Scaling is WEAK by default: the units that shard are pixel tiles, and N GPUs render the same scene
-with N times the tiles (image side 720 * sqrt(N), rounded to a multiple of 8; 518 400 pixels per
-GPU as at N = 1), the way BASELINE.json pairs its 8-GPU configs with larger images. `--strong`
-keeps the 720x720 image instead; because a pixel's samples are sequential (one PCG32 stream per
-pixel, pt.cpp:1942-1945) the 1536-sample chain of the most expensive pixel bounds that run at any
-N.
+N > 1 (one process per GPU, launched by torch.distributed.run): the image's 8x8 tiles are dealt
+round-robin to the ranks, every rank renders all samples of its own tiles with no data-path
+collective, and ONE RCCL gather of the packed float4 tiles follows the timed loop (gather_ms).
+The run is on the CONFIG'S OWN IMAGE (strong scaling, "scaling": "strong") — that is what
+BASELINE.json asks to be reported at 1 / 2 / 4 / 8 GPUs; a second, shorter run on an image with N
+times the pixels (side x sqrt(N): pixels per GPU as at N = 1) is reported next to it as
+config.weak_scaling. `--weak` makes the weak run the reported one.
 
 The JSON line also carries
-  roofline:     the dominant kernel (k_trace) against the HBM roofline. achieved = algorithmic
-                bytes per launch / average launch duration (HIP events on the kernel's own
-                stream); algorithmic bytes per sample = SURVEY.md 8(d)'s formula with the work
-                counts N_* measured by the instrumented kernel variant on this scene.
-  cpu_baseline: the CPU oracle (oracle/libyh_oracle.so, kind "port", bit-identical to the
-                reference in the build container) timed on this host's cores on a bounded
-                number of spp of the same scene.
+  roofline      the sample-loop kernel against the HBM roofline (the contract's bound) — achieved =
+                algorithmic bytes per launch / average launch duration (HIP events on the kernel's
+                own stream) — and, in `valu`, the bound that actually binds: vector-instruction
+                issue x active lanes from the committed counter passes (profiles/).
+  parity        the metric's second half: per-pixel L2 and relRMSE of the GPU image against the CPU
+                image at equal spp and seed, the seed-to-seed floor of the CPU path, and the share
+                of pixels within 4 sigma (variance pooled over both seeds of both sides).
+  cpu_baseline  the reference itself (oracle/_ref/libyh_ref.so, kind "reference") where it has been
+                built (the container that holds /root/reference builds it and the .so travels with
+                the repository), else the CPU oracle (kind "port", bit-identical to the reference);
+                timed on this host's cores on a bounded number of spp of the same scene.
 """
 import argparse
 import ctypes as C
@@ -44,36 +47,85 @@ sys.path.insert(0, os.path.join(ROOT, "yocto-hair_amd", "python"))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+K_SIGMA = 4.0
+
+# BASELINE.json configs[1..4]
+CONFIGS = {
+    "C1": dict(scene="sphere-hairblock", resolution=720, spp=1536, kw={}),
+    "C2": dict(scene="straight-hair", resolution=720, spp=1536, kw={}),  # --beta-m 0.1 | 0.25 | 0.6 for the sweep
+    "C3": dict(scene="curly-hair", resolution=1280, spp=4096, kw={}),
+    "C4": dict(scene="hair-curls", resolution=1280, spp=4096, kw={}),
+}
+KERNELS = {0: "k_trace<512 x 4>", 1: "k_trace<256 x 6>", 2: "k_wavefront", 3: "k_stream"}
 
 
-def cpu_baseline(scene_json, resolution, budget_s=15.0):
-    """Times the CPU oracle (test infrastructure, used here only as the reported baseline)."""
+def cpu_leg(scene_json, resolution, budget_s):
+    """The CPU path on this host (test infrastructure, used here only as the reported baseline and as
+    the checker of the `parity` field): two renders of the same scene at equal spp, seeds A and B.
+    Returns (cpu_baseline dict, image A, image B, spp, seed B, work counts of the reference algorithm)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_capi as oc
     import yhair_capi as yh
+    threads = os.cpu_count() or 1
     o = oc.Oracle()
     sf = yh.SceneFile(scene_json)
     t0 = time.time()
-    sc = o.scene(sf.desc)
+    osc = o.scene(sf.desc)
     build_s = time.time() - t0
-    p = yh.TraceParams.default(resolution=resolution)
-    threads = os.cpu_count() or 1
+    pa = yh.TraceParams.default(resolution=resolution)
+    seed_b = 12345
+    pb = yh.TraceParams.default(resolution=resolution, seed=seed_b)
+    kind, what = "port", f"oracle/libyh_oracle.so with {threads} threads"
+    rsc = None
+    if oc.have_ref():
+        try:
+            rsc = oc.Ref().scene(scene_json)
+            kind, what = "reference", f"the reference itself (oracle/_ref/libyh_ref.so, its own std::async row stealing over {threads} hardware threads)"
+        except Exception:  # a reference build from another image: fall back to the port
+            rsc = None
+    render = (lambda p, n: rsc.render(p, n)) if rsc is not None else (lambda p, n: osc.render(p, n, nthreads=threads))
     t0 = time.time()
-    img = sc.render(p, 1, nthreads=threads)
+    render(pa, 1)
     t1 = time.time() - t0
-    spp = int(max(1, min(1024, budget_s / max(t1, 1e-3))))
+    spp = int(max(1, min(256, budget_s / max(t1, 1e-3))))
     t0 = time.time()
-    img = sc.render(p, spp, nthreads=threads)
+    img_a = render(pa, spp)
     dt = time.time() - t0
-    n = img.shape[0] * img.shape[1] * spp
+    img_b = render(pb, spp)  # the seed-to-seed floor of the CPU path
+    n = img_a.shape[0] * img_a.shape[1] * spp
     # work counts of the REFERENCE algorithm (binary BVH, <= 4 primitives per leaf) on this scene:
     # the N_* of SURVEY.md 8(d)'s algorithmic-bytes formula
-    _, wc = sc.render(p, 2, nthreads=threads, want_counts=True)
-    sc.close()
+    _, wc = osc.render(pa, 2, nthreads=threads, want_counts=True)
+    osc.close()
+    if rsc is not None:
+        rsc.close()
     sf.close()
-    return {"value": round(n / dt / 1e6, 3), "unit": "Msamples/s", "cores": threads, "kind": "port",
-            "sample": f"{img.shape[1]}x{img.shape[0]} x {spp} spp of the same scene, {dt:.1f} s, "
-                      f"oracle/libyh_oracle.so with {threads} threads (BVH build {build_s:.1f} s not counted)"}, wc
+    base = {"value": round(n / dt / 1e6, 3), "unit": "Msamples/s", "cores": threads, "kind": kind,
+            "sample": f"{img_a.shape[1]}x{img_a.shape[0]} x {spp} spp of the same scene, {dt:.1f} s, {what} "
+                      f"(scene load and BVH build {build_s:.1f} s not counted)"}
+    return base, img_a, img_b, spp, seed_b, wc
+
+
+def parity_field(np, gpu_a, gpu_b, cpu_a, cpu_b, spp):
+    """Per-pixel agreement of the GPU image with the CPU image at equal spp and seed (BASELINE.json's
+    "per-pixel L2 vs CPU ref"), next to what two seeds of the CPU path differ by."""
+    ga, gb, ca, cb = (x[..., :3].astype(np.float64) for x in (gpu_a, gpu_b, cpu_a, cpu_b))
+    mean = float(ca.mean())
+    l2 = np.sqrt(((ga - ca) ** 2).sum(axis=2))
+    l2_floor = np.sqrt(((cb - ca) ** 2).sum(axis=2))
+    rel = float(np.sqrt(np.mean((ga - ca) ** 2)) / mean)
+    rel_floor = float(np.sqrt(np.mean((cb - ca) ** 2)) / mean)
+    # variance of an spp-sample pixel mean, pooled over the four renders (device paths leave the CPU's
+    # after a hair bounce or two, so these are four draws of one estimator up to the shared first bounce)
+    var = np.stack([ga, gb, ca, cb]).var(axis=0, ddof=1)
+    ok = np.abs(ga - ca) <= K_SIGMA * np.sqrt(2.0 * var) + 1e-3 * np.abs(ca) + 1e-6
+    return {"spp": spp, "per_pixel_l2_mean": round(float(l2.mean()), 6), "per_pixel_l2_max": round(float(l2.max()), 5),
+            "rel_rmse_gpu_vs_cpu": round(rel, 5), "rel_rmse_cpu_seed_floor": round(rel_floor, 5),
+            "per_pixel_l2_mean_cpu_seed_floor": round(float(l2_floor.mean()), 6),
+            "ratio_to_floor": round(rel / rel_floor, 4) if rel_floor > 0 else None,
+            "share_within_4_sigma": round(float(ok.all(axis=2).mean()), 5),
+            "alpha_identical": bool(np.array_equal(gpu_a[..., 3] > 0, cpu_a[..., 3] > 0)),
+            "note": "same seed, equal spp; tolerance: rel_rmse <= 0.5 x floor and >= 99 % of pixels within 4 sigma (tests/test_gpu_parity.py)"}
 
 
 def main():
@@ -81,23 +133,43 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=24)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--spp-per-step", type=int, default=64)
-    ap.add_argument("--resolution", type=int, default=720)
-    ap.add_argument("--scene", default="sphere-hairblock")
-    ap.add_argument("--scale", type=float, default=1.0, help="hair strand-count multiplier (1.0 = the metric's scene)")
+    ap.add_argument("--config", default="C1", choices=sorted(CONFIGS), help="BASELINE.json config (C1 = the metric's)")
+    ap.add_argument("--spp-per-step", type=int, default=0, help="override: fixed samples per step (total = steps x this)")
+    ap.add_argument("--resolution", type=int, default=0, help="override the config's resolution")
+    ap.add_argument("--scene", default="", help="override the config's scene")
+    ap.add_argument("--beta-m", type=float, default=None, help="C2: straight-hair beta_m sweep value")
+    ap.add_argument("--scale", type=float, default=1.0, help="hair strand-count multiplier (1.0 = the config's scene)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=10.0, help="seconds of CPU rendering per seed (two seeds)")
     ap.add_argument("--save", default="", help="write the final image (.pfm/.hdr) on rank 0")
-    ap.add_argument("--strong", action="store_true", help="N > 1: keep the --resolution image (strong scaling)")
+    ap.add_argument("--weak", action="store_true", help="N > 1: report the weak-scaling run (image side x sqrt(N))")
+    ap.add_argument("--strong", action="store_true", help="(default for N > 1; kept for compatibility)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo (CPU staging) lets the N > 1 flow be exercised on a one-GPU box")
     a = ap.parse_args()
 
+    import numpy as np
     import torch
     import torch.distributed as dist
 
     import make_scenes
     import yhair_capi as yh
     import yhair_dist
+
+    cfg = dict(CONFIGS[a.config])
+    scene_name = a.scene or cfg["scene"]
+    base_res = a.resolution or cfg["resolution"]
+    scene_kw = dict(cfg["kw"])
+    if a.beta_m is not None:
+        scene_kw["beta_m"] = a.beta_m
+    headline = (a.config == "C1" and not a.scene and not a.resolution and a.scale == 1.0 and not a.spp_per_step and a.beta_m is None)
+    # samples of each step: exactly the config's total over the K steps
+    if a.spp_per_step:
+        step_spp = [a.spp_per_step] * a.steps
+    else:
+        total = max(cfg["spp"], a.steps)
+        step_spp = [total // a.steps + (1 if k < total % a.steps else 0) for k in range(a.steps)]
+    spp_total = sum(step_spp)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -125,52 +197,59 @@ def main():
     # ---- scene (rank 0 writes the files, everyone loads them) ------------------------------------
     scenes_dir = os.environ.get("YHAIR_SCENES", "/tmp/yhair_scenes")
     if rank == 0:
-        scene_json = make_scenes.ensure_scene(a.scene, scenes_dir, scale=a.scale)
+        scene_json = make_scenes.ensure_scene(scene_name, scenes_dir, scale=a.scale, **scene_kw)
     if world > 1:
         dist.barrier()
-    scene_json = make_scenes.ensure_scene(a.scene, scenes_dir, scale=a.scale)
+    scene_json = make_scenes.ensure_scene(scene_name, scenes_dir, scale=a.scale, **scene_kw)
     ctx = yh.Context(local_rank)
     sf = yh.SceneFile(scene_json)
     t0 = time.time()
     ctx.upload_scene(sf.desc)
     upload_s = time.time() - t0
     segments = sum(sf.desc.contents.shapes[i].num_lines for i in range(sf.desc.contents.num_shapes))
-    resolution = a.resolution
-    if world > 1 and not a.strong:  # weak scaling: pixels per GPU fixed
-        resolution = int(round(a.resolution * world ** 0.5 / 8.0)) * 8
-    p = yh.TraceParams.default(resolution=resolution)
     ctx.set_shard(rank, world)
-    width, height = ctx.init_state(p)
+    weak_res = int(round(base_res * world ** 0.5 / 8.0)) * 8
 
-    # ---- work counts (outside the timed region) ---------------------------------------------------
-    # The roofline's algorithmic bytes use the work counts of the REFERENCE algorithm, measured by
-    # the CPU oracle on this scene (rank 0; 2 spp). The instrumented kernel's own counts are
-    # reported next to them: its 4-wide BVH visits fewer, fatter nodes.
+    def timed_run(resolution, spps, warmup):
+        """W untimed steps, then the steps of `spps` between barriers; returns the max over ranks."""
+        p = yh.TraceParams.default(resolution=resolution)
+        width, height = ctx.init_state(p)
+        for k in range(warmup):
+            ctx.trace_samples(spps[k % len(spps)])
+        ctx.init_state(p)
+        kernel_ms = 0.0
+        barrier()
+        t0 = time.perf_counter()
+        for n in spps:
+            ctx.trace_samples(n)  # one launch of the sample-loop kernel, blocking
+            kernel_ms += ctx.last_trace_ms()[0]
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=cdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed, kernel_ms = t.tolist()
+        return width, height, elapsed, kernel_ms, p
+
+    # ---- work counts and the CPU leg (outside the timed region, rank 0 at N = 1 only) --------------
     ALGO = ("samples", "rays", "nodes", "seg_tests", "tri_tests", "hair_shades", "surf_shades", "env_lookups", "env_samples")
+    ctx.init_state(yh.TraceParams.default(resolution=base_res))
     gpu_counts = ctx.trace_samples_counted(2).as_dict()
-    ctx.init_state(p)  # start the measured render from a fresh state
-    cpu = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:  # the CPU leg runs at N = 1 only
-        cpu, ref_wc = cpu_baseline(scene_json, resolution)
-    elif rank == 0:
-        ref_wc = None
+    cpu = ref_wc = parity = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu, cpu_a, cpu_b, cpu_spp, seed_b, ref_wc = cpu_leg(scene_json, base_res, a.cpu_budget)
+        imgs = []
+        for sd in (None, seed_b):  # the device at the CPU leg's spp, both seeds (untimed)
+            p = yh.TraceParams.default(resolution=base_res) if sd is None else yh.TraceParams.default(resolution=base_res, seed=sd)
+            ctx.init_state(p)
+            ctx.trace_samples(cpu_spp)
+            imgs.append(ctx.download())
+        parity = parity_field(np, imgs[0], imgs[1], cpu_a, cpu_b, cpu_spp)
 
-    # ---- warmup + timed steps ------------------------------------------------------------------
-    for _ in range(a.warmup):
-        ctx.trace_samples(a.spp_per_step)
-    ctx.init_state(p)
-    kernel_ms = 0.0
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        ctx.trace_samples(a.spp_per_step)  # one k_trace launch, blocking
-        kernel_ms += ctx.last_trace_ms()[0]
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=cdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, kernel_ms = t.tolist()
+    # ---- the reported run (strong: the config's own image; --weak: N times the pixels) ---------------
+    res_main = weak_res if (a.weak and world > 1) else base_res
+    width, height, elapsed, kernel_ms, p = timed_run(res_main, step_spp, a.warmup)
+    shape_used = ctx.launch_shape() if hasattr(ctx, "launch_shape") else None
 
     # ---- the one collective: gather the float4 framebuffer on rank 0 -----------------------------
     t0 = time.perf_counter()
@@ -184,18 +263,27 @@ def main():
     torch.cuda.synchronize()
     gather_ms = (time.perf_counter() - t0) * 1e3
 
+    # ---- N > 1: the other scaling mode, a shorter run, reported next to the main one -------------------
+    other = None
+    if world > 1:
+        res_other = base_res if a.weak else weak_res
+        k_other = max(1, min(4, a.steps))
+        ow, oh, oel, _, _ = timed_run(res_other, step_spp[:k_other], 1)
+        other = {"mode": "strong" if a.weak else "weak", "image": f"{ow}x{oh}", "steps": k_other,
+                 "value": round(ow * oh * sum(step_spp[:k_other]) / oel / 1e6, 2), "unit": "Msamples/s"}
+
     if rank == 0:
         img = image.cpu().numpy()
         if a.save:
             err = C.create_string_buffer(256)
             yh.load().yh_save_image(a.save.encode(), width, height, yh.fptr(img), err, 256)
-        spp_total = a.steps * a.spp_per_step
         samples = width * height * spp_total
         value = samples / elapsed / 1e6
-        launch_s = kernel_ms / 1e3 / max(1, a.steps)               # average k_trace duration (per rank)
+        launch_s = kernel_ms / 1e3 / max(1, a.steps)               # average launch duration (per rank)
+        spp_launch = spp_total / max(1, a.steps)                   # average samples per launch
         if ref_wc is not None:
             counts, counts_from = ref_wc.as_dict(), "reference algorithm (CPU oracle, 2 spp)"
-            bytes_per_sample = ref_wc.bytes_per_sample(a.spp_per_step)
+            bytes_per_sample = ref_wc.bytes_per_sample(spp_launch)
         else:
             # no oracle run here (N > 1 or --no-cpu-baseline): the committed counts of the reference
             # algorithm for this scene (tests/golden/workcounts.json, oracle/make_workcounts.py; the
@@ -204,8 +292,8 @@ def main():
             fixture = None
             try:
                 fx = json.load(open(os.path.join(ROOT, "tests", "golden", "workcounts.json")))
-                cands = [c for c in fx.values() if c["scene"] == a.scene and not c["overrides"] and a.scale == 1.0]
-                fixture = min(cands, key=lambda c: abs(c["resolution"] - a.resolution)) if cands else None
+                cands = [c for c in fx.values() if c["scene"] == scene_name and not c["overrides"] and a.scale == 1.0 and not scene_kw]
+                fixture = min(cands, key=lambda c: abs(c["resolution"] - base_res)) if cands else None
             except Exception:
                 pass
             if fixture is not None:
@@ -214,50 +302,73 @@ def main():
                 counts["samples"] = 1
                 counts_from = "reference algorithm (committed fixture tests/golden/workcounts.json)"
                 bytes_per_sample = (32 * p_["nodes"] + 44 * p_["seg_tests"] + 52 * p_["tri_tests"] + 104 * p_["hair_shades"] +
-                                    48 * p_["env_lookups"] + 88 * p_["env_samples"]) + 32.0 / a.spp_per_step
+                                    48 * p_["env_lookups"] + 88 * p_["env_samples"]) + 32.0 / spp_launch
             else:
                 counts, counts_from = gpu_counts, "instrumented kernel (4-wide BVH; no oracle run, no fixture for this scene)"
                 g = gpu_counts
                 bytes_per_sample = (128 * g["nodes"] + 44 * g["seg_tests"] + 52 * g["tri_tests"] + 104 * g["hair_shades"] +
-                                    48 * g["env_lookups"] + 88 * g["env_samples"]) / max(1, g["samples"]) + 32.0 / a.spp_per_step
-        bytes_per_launch = bytes_per_sample * width * height * a.spp_per_step / world
+                                    48 * g["env_lookups"] + 88 * g["env_samples"]) / max(1, g["samples"]) + 32.0 / spp_launch
+        bytes_per_launch = bytes_per_sample * width * height * spp_launch / world
         achieved = bytes_per_launch / launch_s / 1e9
-        # HBM traffic of k_trace from the committed PMC passes (profiles/), valid for the default config only
+        # counters of the sample-loop kernel from the committed PMC passes (profiles/), valid for the config they were taken on
         traffic, traffic_src, pmc = None, None, {}
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "k_trace_traffic.json")))
-            if (pmc["scene"], pmc["resolution"], pmc["spp_per_launch"], pmc["scale"]) == (a.scene, resolution, a.spp_per_step, a.scale) and world == 1:
-                traffic = round((pmc["hbm_fetch_bytes_per_launch"] + pmc["hbm_write_bytes_per_launch"]) / 1e9, 3)
+            allp = json.load(open(os.path.join(ROOT, "profiles", "k_trace_traffic.json")))
+            allp = allp if isinstance(allp, list) else [allp]
+            for cand in allp:
+                if (cand["scene"], cand["resolution"], cand["scale"]) == (scene_name, res_main, a.scale) and world == 1 and not scene_kw:
+                    pmc = cand
+            if pmc:
+                scale_spp = spp_launch / pmc["spp_per_launch"]  # traffic is proportional to the samples of a launch
+                traffic = round((pmc["hbm_fetch_bytes_per_launch"] + pmc["hbm_write_bytes_per_launch"]) * scale_spp / 1e9, 3)
                 traffic_src = pmc["source"]
         except Exception:
             pass
+        valu = None
+        if pmc:
+            issue, lanes = pmc.get("valu_issue_fraction"), pmc.get("valu_lane_utilisation")
+            valu = {"bound": "valu", "issue_fraction": issue, "lane_utilisation": lanes,
+                    "achieved": round(issue * lanes, 4) if issue and lanes else None, "peak": 1.0, "unit": "share of vector lane-cycles doing work",
+                    "wait_fraction": pmc.get("wait_any_fraction"), "l2_hit_rate": pmc.get("l2_hit_rate"), "source": pmc.get("source")}
+        scaling = "weak" if (a.weak or world == 1) else "strong"
+        if headline:
+            metric = "Msamples/sec (whole node), 720x720x1536spp sphere-hairblock; per-pixel L2 vs CPU ref"
+        else:
+            metric = f"Msamples/sec (whole node), {width}x{height}x{spp_total}spp {scene_name}; per-pixel L2 vs CPU ref"
         out = {
-            "metric": "Msamples/sec (whole node), 720x720x1536spp sphere-hairblock; per-pixel L2 vs CPU ref",
+            "metric": metric,
             "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed * 1e3 / max(1, a.steps), 3), "higher_is_better": True,
-            "scaling": "strong" if (a.strong and world > 1) else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{a.scene} {width}x{height} x {spp_total} spp (C1: eumelanin 1.3, aspect 1.0), "
-                                   f"synthetic hair block {segments} segments x scale {a.scale:g}",
-                       "spp_per_step": a.spp_per_step, "bounces": 8, "seed": 961748941,
+            "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "is_headline_config": bool(headline and res_main == base_res),
+            "config": {"workload": f"{a.config}: {scene_name} {width}x{height} x {spp_total} spp"
+                                   + (" (eumelanin 1.3, aspect 1.0)" if scene_name == "sphere-hairblock" else "")
+                                   + (f" beta_m {a.beta_m:g}" if a.beta_m is not None else "")
+                                   + f", synthetic hair {segments} segments x scale {a.scale:g}",
+                       "spp_per_step": sorted(set(step_spp), reverse=True), "spp_total": spp_total, "bounces": 8, "seed": 961748941,
                        "sharding": f"8x8 tiles round-robin over {world} GPU(s), one RCCL gather after the loop"
-                                   + ("" if world == 1 else (" (strong: fixed image)" if a.strong else
-                                      f" (weak: image side {a.resolution} * sqrt({world}) -> {width}, {width * height // world} pixels per GPU)")),
+                                   + ("" if world == 1 else (f" (weak: image side {base_res} * sqrt({world}) -> {width}, {width * height // world} pixels per GPU)"
+                                                             if a.weak else " (strong: the config's own image)")),
                        "upload_s": round(upload_s, 2), "gather_ms": round(gather_ms, 2),
                        "image_mean_rgb": [round(float(x), 5) for x in img[..., :3].mean(axis=(0, 1))]},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_unit": "GB per launch",
                          "traffic_source": traffic_src, "algorithmic_gb_per_launch": round(bytes_per_launch / 1e9, 3),
-                         "valu_issue_fraction": pmc.get("valu_issue_fraction") if traffic is not None else None,
-                         "wait_fraction": pmc.get("wait_any_fraction") if traffic is not None else None,
-                         "valu_lane_utilisation": pmc.get("valu_lane_utilisation") if traffic is not None else None,
-                         "kernel": "k_trace",
-                         "avg_launch_ms": round(launch_s * 1e3, 3),
+                         "binds": "valu" if valu else None,
+                         "note": "hbm is the contract's designated roofline; the scene lives in L2 / Infinity Cache and the kernel is bound by "
+                                 "vector-instruction issue (see valu)",
+                         "valu": valu,
+                         "kernel": KERNELS.get(shape_used, "k_trace"), "launch_shape": shape_used,
+                         "avg_launch_ms": round(launch_s * 1e3, 3), "avg_spp_per_launch": round(spp_launch, 2),
                          "algorithmic_bytes_per_sample": round(bytes_per_sample, 1),
                          "work_counts_from": counts_from,
                          "work_counts_per_sample": {k: round(counts[k] / max(1, counts["samples"]), 3) for k in ALGO[1:]},
-                         "kernel_counts_per_sample": {k: round(gpu_counts[k] * world / max(1, gpu_counts["samples"] * world), 3)
-                                                      for k in ALGO[1:]}},
+                         "kernel_counts_per_sample": {k: round(gpu_counts[k] / max(1, gpu_counts["samples"]), 3) for k in ALGO[1:]}},
         }
+        if other is not None:
+            out["config"]["weak_scaling" if other["mode"] == "weak" else "strong_scaling"] = other
+        if parity is not None:
+            out["parity"] = parity
         if cpu is not None and world == 1:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)

@@ -273,6 +273,13 @@ struct yh_context {
   int              last_launches = 0;
   unsigned         launches_of_state = 0;  // synchronous launches since yh_init_state (re-planning schedule)
   int              launch_shape = 0;  // decided from launches of at least 16 spp (shorter ones have flat, noisy item costs)
+  int              last_shape = -1;   // the kernel the most recent launch ran (yh_launch_shape)
+  // kernel selection by measurement (next_launch_shape): ms per sample of a planned launch with each kernel
+  // (0 = not measured yet), whether item costs exist (the first launch of a scene runs unplanned and is not a
+  // measurement), and whether the scene is dense (more expensive items than resident waves; from k_trace's costs)
+  double           shape_ms[4] = {0, 0, 0, 0};
+  bool             have_costs = false;
+  int              dense = -1;
   // path pool of the wavefront integrator (csrc/wavefront.hip), allocated at its first launch
   DevBuf           d_pool_ray_o, d_pool_ray_d, d_pool_weight, d_pool_radiance, d_pool_hit, d_pool_medium;
   // path pool of the streaming integrator (csrc/stream.hip): per-wave slots, allocated at its first launch
@@ -340,6 +347,7 @@ int tiles_of(int n) { return (n + YH_TILE - 1) / YH_TILE; }
 // current split modes, most expensive first.
 void build_work_items(const yh_context* ctx, std::vector<int>& items);
 int  choose_launch_shape(const yh_context* ctx);
+int  next_launch_shape(yh_context* ctx, int nsamples);
 
 }  // namespace
 
@@ -351,19 +359,53 @@ namespace {
 // max-cost work items the last launch was worth (sum of item costs over the largest) against the
 // resident wave slots — measured 3 066 (C1), 4 777 (C4), 8 989 (C2), 24 970 (C3) against 4 096: with
 // fewer expensive items than slots every wave that can run already does. YHAIR_SHAPE=0|1 overrides.
-int choose_launch_shape(const yh_context* ctx) {
-  if (const char* env = getenv("YHAIR_SHAPE")) return std::max(0, std::min(3, atoi(env)));
+// Is the launch worth more max-cost work items than there are resident waves? (item costs of a k_trace launch)
+bool dense_by_costs(const yh_context* ctx, bool* known) {
   uint64_t sum = 0, mx = 0;
   for (int t : ctx->owned)
     for (int p = 0; p < 4; p++) {
       uint64_t c = ctx->item_cost[(size_t)t * 4 + p];
       sum += c, mx = std::max(mx, c);
     }
-  if (mx == 0) return 0;  // nothing measured yet
+  *known = mx != 0;
+  if (mx == 0) return false;
   int    lds      = yhk_trace_lds_bytes(ctx->scene.lds_node_count, ctx->scene.lds_scene_f4, 0);
   double resident = (double)ctx->num_cus * std::max(1, yhk_trace_occupancy(lds, ctx->scene.general_materials, 0)) * (yhk_block_threads(0) / 64);
   if (getenv("YHAIR_TIMING")) fprintf(stderr, "[yhair] launch shape: worth %.0f items, resident waves %.0f\n", (double)sum / (double)mx, resident);
-  return (double)sum / (double)mx >= resident ? 1 : 0;
+  return (double)sum / (double)mx >= resident;
+}
+int choose_launch_shape(const yh_context* ctx) {
+  if (const char* env = getenv("YHAIR_SHAPE")) return std::max(0, std::min(3, atoi(env)));
+  bool known = false;
+  return dense_by_costs(ctx, &known) ? 1 : 0;
+}
+// Kernel for the next launch, chosen by MEASUREMENT (every kernel renders the same bits, so trying one costs
+// time only). k_trace at 512 x 4 suits launches bound by a few expensive pixels (C1), k_trace at 256 x 6 and the
+// one-lane-per-path k_stream suit dense scenes, and which of those two wins depends on how many expensive pixels
+// there are per wave (straight-hair 720^2: a tie; curly-hair 1280^2: k_stream +39 %; hair-curls: k_trace 2.3x).
+// Each candidate runs one planned launch of at least 16 spp, then the fastest per sample stays. Sparse scenes
+// never try k_stream: it would cost them several times a launch.
+int next_launch_shape(yh_context* ctx, int nsamples) {
+  if (const char* env = getenv("YHAIR_SHAPE")) return std::max(0, std::min(3, atoi(env)));
+  if (nsamples < 16) return ctx->launch_shape;  // short launches have flat, noisy costs: keep what is known
+  const int last = ctx->last_shape;
+  if (ctx->have_costs && last >= 0 && last < 4 && ctx->last_ms > 0) ctx->shape_ms[last] = (double)ctx->last_ms / nsamples;
+  if (last == 0 || last == 1 || ctx->dense < 0) {
+    bool known = false, d = dense_by_costs(ctx, &known);
+    if (known && (last == 0 || last == 1)) ctx->dense = d ? 1 : 0;
+  }
+  ctx->have_costs = true;
+  if (ctx->dense < 0) return 0;
+  const int  sparse_c[2] = {0, 1}, dense_c[2] = {1, 3};
+  const int* cand = ctx->dense ? dense_c : sparse_c;
+  static const bool no_trials = getenv("YHAIR_NO_TRIALS") != nullptr;  // developer switch: the cost heuristic only
+  if (no_trials) return cand[0];
+  for (int k = 0; k < 2; k++)
+    if (ctx->shape_ms[cand[k]] == 0) return cand[k];
+  const int best = ctx->shape_ms[cand[0]] <= ctx->shape_ms[cand[1]] ? cand[0] : cand[1];
+  if (getenv("YHAIR_TIMING"))
+    fprintf(stderr, "[yhair] kernel times (ms per spp): %d: %.4f, %d: %.4f -> %d\n", cand[0], ctx->shape_ms[cand[0]], cand[1], ctx->shape_ms[cand[1]], best);
+  return best;
 }
 void build_work_items(const yh_context* ctx, std::vector<int>& items) {
   // Expensive items first, in decreasing cost (they bound the launch); the cheap
@@ -782,6 +824,8 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
   ctx->have_state = false;
   ctx->launch_shape = 0;  // a new scene: no measured costs yet
   ctx->item_cost.clear();
+  ctx->have_costs = false, ctx->dense = -1;
+  for (double& t : ctx->shape_ms) t = 0;
   return YH_OK;
 }
 
@@ -827,8 +871,11 @@ int yh_init_state(yh_context* ctx, const yh_trace_params* params) {
   auto& owned = ctx->owned;
   owned.clear();
   for (int t = ctx->rank; t < ctx->num_tiles_total; t += ctx->world) owned.push_back(t);
-  if ((int)ctx->item_cost.size() != ctx->num_tiles_total * 4)  // scheduling hints survive a re-init of the same image
+  if ((int)ctx->item_cost.size() != ctx->num_tiles_total * 4) {  // scheduling hints survive a re-init of the same image
     ctx->item_cost.assign((size_t)ctx->num_tiles_total * 4, 0);
+    ctx->have_costs = false, ctx->dense = -1, ctx->launch_shape = 0;
+    for (double& t : ctx->shape_ms) t = 0;
+  }
   std::vector<int> tiles;
   build_work_items(ctx, tiles);
   const int first_shape = getenv("YHAIR_SHAPE") ? choose_launch_shape(ctx) : ctx->launch_shape;
@@ -869,12 +916,14 @@ static int replan_after_launch(yh_context* ctx, int nsamples) {
   // cost 10-100x background ones. Re-planned after launches 1, 2, 4, 8, ... of a state: the relative
   // costs of the items settle after the first launches (they are a property of the image), and the
   // read-back, sort and upload are a few hundred microseconds of a 16 ms launch.
-  const unsigned li = ++ctx->launches_of_state;
-  if ((li & (li - 1)) != 0) return YH_OK;
-  HIPCHK(ctx, hipMemcpy(ctx->item_cost.data(), ctx->d_tile_cost.p, ctx->item_cost.size() * 4, hipMemcpyDeviceToHost));
-  if (ctx->state.shader == YH_SHADER_PATH && (nsamples >= 16 || getenv("YHAIR_SHAPE"))) ctx->launch_shape = choose_launch_shape(ctx);
+  const unsigned li      = ++ctx->launches_of_state;
+  const bool     refresh = (li & (li - 1)) == 0;
+  const int      before  = ctx->state.launch_shape;
+  if (refresh) HIPCHK(ctx, hipMemcpy(ctx->item_cost.data(), ctx->d_tile_cost.p, ctx->item_cost.size() * 4, hipMemcpyDeviceToHost));
+  if (ctx->state.shader == YH_SHADER_PATH && (refresh || ctx->have_costs)) ctx->launch_shape = next_launch_shape(ctx, nsamples);
   ctx->state.launch_shape = ctx->launch_shape;
-  std::vector<int> tiles;
+  if (!refresh && ctx->state.launch_shape == before) return YH_OK;
+  std::vector<int> tiles;  // (the hand-out order depends on the kernel: k_stream's items are dealt, not queued)
   build_work_items(ctx, tiles);
   if (ctx->state.shader == YH_SHADER_PATH && ctx->state.launch_shape == 3) deal_items_for_stream(ctx, tiles);
   HIPCHK(ctx, hipMemcpy(ctx->d_tiles.p, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice));
@@ -931,12 +980,12 @@ static int wavefront_impl(yh_context* ctx, int nsamples, bool sync) {
 
 // Launch geometry of the streaming integrator: path slots per wave and workgroups. The pixels of the launch are
 // spread over as many waves as the CUs hold, each wave with a few paths per lane so that its lanes stay full
-// between stages: 128 .. 384 slots (YHAIR_ST_SLOTS / YHAIR_ST_WAVES: developer switches). Returns 0 when the
-// kernel cannot run.
+// between stages: 128 .. 192 slots (more waves beat fuller batches: measured on C2 / C3, profiles/r02;
+// YHAIR_ST_SLOTS / YHAIR_ST_WAVES: developer switches). Returns 0 when the kernel cannot run.
 static int stream_geometry(const yh_context* ctx, int num_items, int* slots_per_wave, int* grid_blocks, int* lds_out) {
   const int     wpb    = yhk_stream_block_threads() / 64;
   const int64_t pixels = (int64_t)num_items * 16;  // work items are 4x4 pixel quadrants
-  int           P      = (int)std::max<int64_t>(128, std::min<int64_t>(384, (pixels / ((int64_t)ctx->num_cus * 16) + 63) / 64 * 64));
+  int           P      = (int)std::max<int64_t>(128, std::min<int64_t>(192, (pixels / ((int64_t)ctx->num_cus * 16) + 63) / 64 * 64));
   if (const char* env = getenv("YHAIR_ST_SLOTS")) P = std::max(64, std::min(4096, atoi(env) / 64 * 64));
   const int lds_bytes = yhk_stream_lds_bytes(ctx->scene.lds_scene_f4, P);
   int       occupancy = yhk_stream_occupancy(lds_bytes, ctx->scene.general_materials);
@@ -1055,6 +1104,7 @@ static int trace_impl(yh_context* ctx, int nsamples, bool counted, bool sync) {
   if (counted && !path) return fail(ctx, YH_E_INVALID, "work counters exist for the path shader only");
   int shape = path ? ctx->state.launch_shape : 0;  // the preview shaders have one launch shape
   if (shape >= 2 && counted) shape = 1;            // the instrumented build exists for k_trace only
+  ctx->last_shape = shape;
   if (shape == 2) return wavefront_impl(ctx, nsamples, sync);
   if (shape == 3) return stream_impl(ctx, nsamples, sync);
   int waves_per_block = yhk_block_threads(shape) / 64;  // one work item per wave at a time
@@ -1089,6 +1139,7 @@ int yh_synchronize(yh_context* ctx) {
   if (ctx->last_launches) (void)hipEventElapsedTime(&ctx->last_ms, ctx->ev0, ctx->ev1);
   return YH_OK;
 }
+int yh_launch_shape(const yh_context* ctx) { return ctx ? ctx->last_shape : YH_E_INVALID; }
 int yh_last_trace_ms(const yh_context* ctx, float* ms, int* launches) {
   if (!ctx) return YH_E_INVALID;
   if (ms) *ms = ctx->last_ms;

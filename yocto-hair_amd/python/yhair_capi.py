@@ -143,6 +143,7 @@ _SIGS = {
     "yh_download_rng": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "yh_trace_samples_counted": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(WorkCounts)]),
     "yh_last_trace_ms": (C.c_int, [C.c_void_p, c_float_p, c_int_p]),
+    "yh_launch_shape": (C.c_int, [C.c_void_p]),
     "yh_tile_costs": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_int]),
     "yh_hair_brdf_batch": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Material), c_float_p,
                                      c_float_p, c_float_p, c_float_p]),
@@ -266,6 +267,10 @@ class Context:
         wc = WorkCounts()
         self._chk(self.lib.yh_trace_samples_counted(self.h, n, C.byref(wc)))
         return wc
+
+    def launch_shape(self):
+        """The sample-loop kernel of the most recent launch (include/yhair.h: yh_launch_shape)."""
+        return int(self.lib.yh_launch_shape(self.h))
 
     def last_trace_ms(self):
         ms, n = C.c_float(), C.c_int()
