@@ -237,6 +237,15 @@ int yh_unpack_tiles_device(yh_context* ctx, const void* device_packed,
 /* Number of float4 pixels yh_pack_tiles_device writes for (rank, world).     */
 int64_t yh_shard_pixels(const yh_context* ctx, int rank, int world);
 
+/* Multi-GPU inside ONE process (yscenetrace --gpus N; the reference renders on one device and has
+ * no counterpart, the seam is save_image's input, apps/yscenetrace/yscenetrace.cpp:270): `n`
+ * contexts, context i holding shard (i, n) of the same image (yh_set_shard) and the same number of
+ * samples. Every context packs its tiles; ONE ncclGather over RCCL / xGMI (grouped, one call per
+ * communicator; librccl is opened on first use) brings them to contexts[0], which un-interleaves
+ * them and copies the full W*H float4 image to `rgba`. Contexts that share a device (tests on a
+ * one-GPU box) or YHAIR_GATHER=peer use device-to-device copies instead of the collective.        */
+int yh_gather_framebuffer(yh_context** contexts, int n, float* rgba);
+
 /* Per-pixel state (yocto_pathtrace.h:419-423) for checkpoint / parity tests:
  * rng state words (2 x u64 per pixel) and sample count.                      */
 int yh_download_rng(yh_context* ctx, uint64_t* state_inc);

@@ -534,6 +534,102 @@ def test_cli_matches_the_library(ctx, yh, tmp_path, name):
     sf.close()
 
 
+def test_async_launch_equals_the_blocking_call(ctx, yh):
+    """yh_trace_samples_async + yh_synchronize (what a caller overlapping the render with its own work uses,
+    e.g. the preview of apps/ysceneitraces/ysceneitraces.cpp:255-300) leaves the same pixels and RNG states as
+    the blocking yh_trace_samples, launch for launch."""
+    sf = yh.SceneFile(scene_path("straight-hair", scale=0.05))
+    ctx.upload_scene(sf.desc)
+    p = yh.TraceParams.default(resolution=72)
+    ctx.init_state(p)
+    ctx.trace_samples(3), ctx.trace_samples(5)
+    ref = (ctx.download(), ctx.download_rng())
+    ctx.init_state(p)
+    ctx.trace_samples_async(3)
+    ctx.trace_samples_async(5)  # queued behind the first on the context's stream
+    ctx.synchronize()
+    assert ctx.last_trace_ms()[0] > 0
+    assert np.array_equal(ctx.download(), ref[0]) and np.array_equal(ctx.download_rng(), ref[1])
+    sf.close()
+
+
+@pytest.mark.parametrize("n", [2, 3, 4])
+def test_single_process_gather_over_contexts(yh, n):
+    """yscenetrace --gpus N in one process: N contexts, context i renders shard (i, N), yh_gather_framebuffer
+    brings the packed tiles to context 0 and un-interleaves them. On this one-GPU box the contexts share the
+    device, so the payload moves by device-to-device copies instead of the RCCL gather; sharding, packing,
+    the padded shard capacity and the un-interleave are the same code. Bit-identical to one context."""
+    sf = yh.SceneFile(scene_path("hair-curls", scale=0.05))
+    p = yh.TraceParams.default(resolution=100)  # 13 x 13 tiles: ragged edge, shards of unequal size
+    one = yh.Context(0)
+    one.upload_scene(sf.desc)
+    one.init_state(p)
+    one.trace_samples(4)
+    ref = one.download()
+    ctxs = [one] + [yh.Context(0) for _ in range(n - 1)]
+    for i, c in enumerate(ctxs):
+        if i:
+            c.upload_scene(sf.desc)
+        c.set_shard(i, n)
+        c.init_state(p)
+        c.trace_samples(4)
+    img = yh.gather_framebuffer(ctxs)
+    assert np.array_equal(img, ref)
+    # a context that holds the wrong shard is refused
+    ctxs[1].set_shard(0, n)
+    ctxs[1].init_state(p)
+    with pytest.raises(yh.YhError):
+        yh.gather_framebuffer(ctxs)
+    for c in ctxs:
+        c.close()
+    sf.close()
+
+
+def test_cli_gpus_and_preview(ctx, yh, tmp_path):
+    """yscenetrace --devices 0,0,0 (three contexts, tile-sharded, gathered) writes the pixels of the one-GPU run;
+    ysceneitraces (the reference's progressive caller, headless) renders the resolution / pratio preview, then
+    its samples through the stop-flag overload, and stops early when the flag is set."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    scene = scene_path("straight-hair", scale=0.05)
+    head = b"PF\n60 60\n-1\n"
+
+    def pfm(path, w=60):
+        raw = open(path, "rb").read()
+        hd = f"PF\n{w} {w}\n-1\n".encode()
+        assert raw.startswith(hd)
+        return np.frombuffer(raw[len(hd):], np.float32).reshape(w, w, 3)
+
+    exe = os.path.join(root, "yocto-hair_amd", "yscenetrace")
+    a, b = str(tmp_path / "one.pfm"), str(tmp_path / "three.pfm")
+    for out, extra in ((a, []), (b, ["--devices", "0,0,0"])):
+        r = subprocess.run([exe, scene, "-r", "60", "-s", "5", "-o", out] + extra, capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+    assert "on 3 GPU(s)" in r.stdout
+    assert np.array_equal(pfm(a), pfm(b))
+    # the progressive caller
+    exe = os.path.join(root, "yocto-hair_amd", "ysceneitraces")
+    out, prev = str(tmp_path / "it.pfm"), str(tmp_path / "prev.pfm")
+    r = subprocess.run([exe, scene, "-r", "60", "-s", "5", "--pratio", "4", "-o", out, "--preview-image", prev], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "preview: 15x15 at 1 spp upscaled to 60x60" in r.stdout and "render: 5 of 5 samples" in r.stdout
+    assert np.array_equal(pfm(out), pfm(a))  # five one-sample launches = one five-sample launch
+    sf = yh.SceneFile(scene)
+    ctx.upload_scene(sf.desc)
+    ctx.set_shard(0, 1)
+    ctx.init_state(yh.TraceParams.default(resolution=15))
+    ctx.trace_samples(1)
+    small = ctx.download()[..., :3]
+    assert np.array_equal(pfm(prev), np.repeat(np.repeat(small, 4, axis=0), 4, axis=1))
+    # a flag set at once stops the render within a launch: far fewer samples than asked for, exit code 0
+    r = subprocess.run([exe, scene, "-r", "60", "-s", "100000", "-o", out, "--stop-after-ms", "0"], capture_output=True, text=True)
+    assert r.returncode == 0 and "(stopped)" in r.stdout, r.stdout + r.stderr
+    done = int(r.stdout.split("render: ")[1].split(" of ")[0])
+    assert done < 1000
+    sf.close()
+
+
 def test_full_size_properties(ctx, yh):
     """BASELINE.json's full C1 size (720x720, 1.6 M segments): properties that do not need the
     oracle — determinism, finiteness, energy bounds, background pixels = environment."""

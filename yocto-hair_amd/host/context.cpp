@@ -12,6 +12,8 @@
 //     timed.
 // There is no CPU fallback: without a GPU yh_create returns NULL.
 #include <hip/hip_runtime_api.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types only: the library is opened on first use (yh_gather_framebuffer)
 
 #include <algorithm>
 #include <chrono>
@@ -274,6 +276,11 @@ struct yh_context {
   unsigned         launches_of_state = 0;  // synchronous launches since yh_init_state (re-planning schedule)
   int              launch_shape = 0;  // decided from launches of at least 16 spp (shorter ones have flat, noisy item costs)
   int              last_shape = -1;   // the kernel the most recent launch ran (yh_launch_shape)
+  // single-process multi-GPU gather (yh_gather_framebuffer): this context's packed tiles; on the root also the
+  // receive buffer and the communicators of the device set they were made for
+  DevBuf                  d_gather_send, d_gather_recv;
+  std::vector<ncclComm_t> comms;
+  std::vector<int>        comm_devices;
   // kernel selection by measurement (next_launch_shape): ms per sample of a planned launch with each kernel
   // (0 = not measured yet), whether item costs exist (the first launch of a scene runs unplanned and is not a
   // measurement), and whether the scene is dense (more expensive items than resident waves; from k_trace's costs)
@@ -435,6 +442,7 @@ void build_work_items(const yh_context* ctx, std::vector<int>& items) {
 extern "C" {
 
 static void deal_items_for_stream(const yh_context* ctx, std::vector<int>& items);
+static int  trace_impl(yh_context* ctx, int nsamples, bool counted, bool sync);
 
 const char* yh_version(void) { return "yhair 0.1 (gfx950, HIP)"; }
 
@@ -464,8 +472,10 @@ yh_context* yh_create(int device) {
   return ctx;
 }
 
+static void destroy_communicators(yh_context* ctx);
 void yh_destroy(yh_context* ctx) {
   if (!ctx) return;
+  destroy_communicators(ctx);
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -899,6 +909,23 @@ int yh_init_state(yh_context* ctx, const yh_trace_params* params) {
   s.samples_done = 0, s.bounces = params->bounces, s.clamp = params->clamp, s.shader = params->shader;
   s.shard_rank = ctx->rank, s.shard_world = ctx->world;
   ctx->have_state = true;
+  // Probe: the first launch of a new image has no item costs and would hand its work items out in image order,
+  // 25-60 % slower than a planned launch (hair quadrants cost 10-100x background ones and bound the launch when
+  // they start last). One sample of every pixel measures them; the state is then put back as it was, so the
+  // render starts planned and from the reference's RNG states. (YHAIR_NO_PROBE: developer switch.)
+  bool measured = false;
+  for (int t : owned)
+    for (int q = 0; q < 4 && !measured; q++) measured = ctx->item_cost[(size_t)t * 4 + q] != 0;
+  if (!measured && !owned.empty() && params->shader == YH_SHADER_PATH && !getenv("YHAIR_NO_PROBE")) {
+    ctx->state.launch_shape = 0;
+    int prc = trace_impl(ctx, 1, false, true);  // blocking; re-plans the hand-out order from the measured costs
+    if (prc) return prc;
+    HIPCHK(ctx, hipMemcpy(ctx->d_rng_state.p, st.data(), npix * 8, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_accum.p, 0, npix * 16, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->state.samples_done = 0, ctx->launches_of_state = 0, ctx->last_shape = -1, ctx->last_ms = 0, ctx->last_launches = 0;
+    ctx->have_costs = true;  // the launches that follow are planned: their times rank the kernels
+  }
   return YH_OK;
 }
 
@@ -1204,6 +1231,136 @@ int yh_unpack_tiles_device(yh_context* ctx, const void* device_packed, int src_r
       ctx->state.height, device_image, ctx->stream);
   if (e) return fail(ctx, YH_E_DEVICE, "k_unpack launch: %s", hipGetErrorString((hipError_t)e));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return YH_OK;
+}
+
+namespace {
+// librccl, opened on first use: libyhair.so itself does not link it (a one-GPU user never needs it, and under
+// PyTorch the process already holds a librccl of its own that a second copy must not shadow)
+struct RcclApi {
+  void* lib = nullptr;
+  ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  ncclResult_t (*Gather)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+RcclApi* rccl_api() {
+  static RcclApi api;
+  static bool    tried = false;
+  if (!tried) {
+    tried = true;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (api.lib) break;
+    }
+    if (api.lib) {
+      api.CommInitAll    = (decltype(api.CommInitAll))dlsym(api.lib, "ncclCommInitAll");
+      api.CommDestroy    = (decltype(api.CommDestroy))dlsym(api.lib, "ncclCommDestroy");
+      api.GroupStart     = (decltype(api.GroupStart))dlsym(api.lib, "ncclGroupStart");
+      api.GroupEnd       = (decltype(api.GroupEnd))dlsym(api.lib, "ncclGroupEnd");
+      api.Gather         = (decltype(api.Gather))dlsym(api.lib, "ncclGather");
+      api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.lib, "ncclGetErrorString");
+      if (!api.CommInitAll || !api.CommDestroy || !api.GroupStart || !api.GroupEnd || !api.Gather || !api.GetErrorString) api.lib = nullptr;
+    }
+  }
+  return api.lib ? &api : nullptr;
+}
+}  // namespace
+
+static void destroy_communicators(yh_context* ctx) {
+  if (ctx->comms.empty()) return;
+  if (RcclApi* api = rccl_api())
+    for (ncclComm_t c : ctx->comms)
+      if (c) (void)api->CommDestroy(c);
+  ctx->comms.clear(), ctx->comm_devices.clear();
+}
+
+int yh_gather_framebuffer(yh_context** ctxs, int n, float* rgba) {
+  if (!ctxs || n < 1 || !rgba || !ctxs[0]) return YH_E_INVALID;
+  yh_context* root = ctxs[0];
+  for (int i = 0; i < n; i++) {
+    yh_context* c = ctxs[i];
+    if (!c) return fail(root, YH_E_INVALID, "context %d is NULL", i);
+    if (!c->have_state) return fail(root, YH_E_STATE, "yh_gather_framebuffer: context %d has no state", i);
+    if (c->rank != i || c->world != n) return fail(root, YH_E_INVALID, "context %d holds shard %d of %d, expected %d of %d", i, c->rank, c->world, i, n);
+    if (c->state.width != root->state.width || c->state.height != root->state.height || c->state.samples_done != root->state.samples_done)
+      return fail(root, YH_E_INVALID, "context %d renders a different image or sample count than context 0", i);
+  }
+  int64_t cap = 0;  // float4 pixels of the largest shard: ncclGather moves equal counts
+  for (int i = 0; i < n; i++) cap = std::max<int64_t>(cap, yh_shard_pixels(root, i, n));
+  const size_t cap_bytes = (size_t)std::max<int64_t>(cap, 1) * 16;
+  bool distinct = true;
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < i; j++) distinct = distinct && ctxs[i]->device != ctxs[j]->device;
+  const char* mode_env = getenv("YHAIR_GATHER");
+  const bool  use_rccl = n > 1 && distinct && !(mode_env && !strcmp(mode_env, "peer"));
+  // every context packs its own tiles on its own stream
+  for (int i = 0; i < n; i++) {
+    yh_context* c = ctxs[i];
+    HIPCHK(root, hipSetDevice(c->device));
+    if (c->d_gather_send.bytes < cap_bytes) {
+      int rc = alloc_zero(c, c->d_gather_send, cap_bytes);
+      if (rc) return fail(root, rc, "context %d: %s", i, c->error.c_str());
+    }
+    int e = yhk_pack(&c->state, (int)c->owned.size(), c->state.samples_done, c->d_gather_send.p, c->stream);
+    if (e) return fail(root, YH_E_DEVICE, "k_pack launch on context %d: %s", i, hipGetErrorString((hipError_t)e));
+  }
+  HIPCHK(root, hipSetDevice(root->device));
+  if (root->d_gather_recv.bytes < cap_bytes * n) {
+    int rc = alloc_zero(root, root->d_gather_recv, cap_bytes * n);
+    if (rc) return rc;
+  }
+  if (use_rccl) {
+    RcclApi* api = rccl_api();
+    if (!api) return fail(root, YH_E_DEVICE, "yh_gather_framebuffer: librccl could not be opened (%s)", dlerror() ? dlerror() : "missing symbols");
+    std::vector<int> devs(n);
+    for (int i = 0; i < n; i++) devs[i] = ctxs[i]->device;
+    if (root->comm_devices != devs) {  // communicators are made once per device set
+      for (ncclComm_t c : root->comms) (void)api->CommDestroy(c);
+      root->comms.assign(n, nullptr), root->comm_devices.clear();
+      ncclResult_t r = api->CommInitAll(root->comms.data(), n, devs.data());
+      if (r != ncclSuccess) {
+        root->comms.clear();
+        return fail(root, YH_E_DEVICE, "ncclCommInitAll: %s", api->GetErrorString(r));
+      }
+      root->comm_devices = devs;
+    }
+    ncclResult_t r = api->GroupStart();
+    for (int i = 0; i < n && r == ncclSuccess; i++) {
+      HIPCHK(root, hipSetDevice(ctxs[i]->device));
+      r = api->Gather(ctxs[i]->d_gather_send.p, i == 0 ? root->d_gather_recv.p : nullptr, (size_t)cap * 4, ncclFloat, 0, root->comms[i], ctxs[i]->stream);
+    }
+    ncclResult_t r2 = api->GroupEnd();
+    if (r != ncclSuccess || r2 != ncclSuccess) return fail(root, YH_E_DEVICE, "ncclGather: %s", api->GetErrorString(r != ncclSuccess ? r : r2));
+    for (int i = 0; i < n; i++) {
+      HIPCHK(root, hipSetDevice(ctxs[i]->device));
+      HIPCHK(root, hipStreamSynchronize(ctxs[i]->stream));
+    }
+  } else {
+    for (int i = 0; i < n; i++) {  // device-to-device copies (contexts sharing a device, or YHAIR_GATHER=peer)
+      yh_context* c = ctxs[i];
+      HIPCHK(root, hipSetDevice(c->device));
+      HIPCHK(root, hipStreamSynchronize(c->stream));
+      HIPCHK(root, hipSetDevice(root->device));
+      void* dst = (char*)root->d_gather_recv.p + (size_t)i * cap_bytes;
+      if (c->device == root->device) HIPCHK(root, hipMemcpyAsync(dst, c->d_gather_send.p, cap_bytes, hipMemcpyDeviceToDevice, root->stream));
+      else HIPCHK(root, hipMemcpyPeerAsync(dst, root->device, c->d_gather_send.p, c->device, cap_bytes, root->stream));
+    }
+  }
+  // the root un-interleaves every shard into the full image
+  HIPCHK(root, hipSetDevice(root->device));
+  const size_t bytes = (size_t)root->state.width * root->state.height * 16;
+  HIPCHK(root, hipMemsetAsync(root->d_image.p, 0, bytes, root->stream));
+  for (int i = 0; i < n; i++) {
+    int tiles = (int)(yh_shard_pixels(root, i, n) / 64);
+    int e = yhk_unpack((char*)root->d_gather_recv.p + (size_t)i * cap_bytes, i, n, tiles, root->num_tiles_total, root->state.tiles_x, root->state.width,
+        root->state.height, root->d_image.p, root->stream);
+    if (e) return fail(root, YH_E_DEVICE, "k_unpack launch: %s", hipGetErrorString((hipError_t)e));
+  }
+  HIPCHK(root, hipMemcpyAsync(rgba, root->d_image.p, bytes, hipMemcpyDeviceToHost, root->stream));
+  HIPCHK(root, hipStreamSynchronize(root->stream));
   return YH_OK;
 }
 

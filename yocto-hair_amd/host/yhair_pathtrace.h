@@ -25,6 +25,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "yhair.h"
@@ -41,24 +42,53 @@ struct frame3f {
 }  // namespace yhair::math
 
 namespace yhair::detail {
-inline yh_context*& context() {
-  static yh_context* ctx = nullptr;
-  return ctx;
+// The devices the path runs on: one context per entry (default: device 0). With more than one, the image's
+// 8x8 tiles are dealt round-robin to the contexts (yh_set_shard), every context renders all samples of its own
+// tiles from its own host thread, and the framebuffer is gathered over RCCL (yh_gather_framebuffer). Pixel
+// results do not depend on the number of GPUs. Set before the first call that needs a context.
+inline std::vector<int>& devices() {
+  static std::vector<int> devs = {0};
+  return devs;
 }
-inline int& device() {
-  static int dev = 0;
-  return dev;
+inline int& device() { return devices()[0]; }
+inline std::vector<yh_context*>& contexts() {
+  static std::vector<yh_context*> ctxs;
+  return ctxs;
 }
-inline yh_context* require_context() {
-  auto& ctx = context();
-  if (!ctx) {
-    ctx = yh_create(device());
-    if (!ctx) throw std::runtime_error(std::string("yhair: ") + yh_last_error(nullptr));
+inline std::vector<yh_context*>& require_contexts() {
+  auto& ctxs = contexts();
+  if (ctxs.empty()) {
+    for (int dev : devices()) {
+      auto ctx = yh_create(dev);
+      if (!ctx) throw std::runtime_error(std::string("yhair: ") + yh_last_error(nullptr));
+      ctxs.push_back(ctx);
+    }
   }
-  return ctx;
+  return ctxs;
 }
-inline void check(int rc) {
-  if (rc != YH_OK) throw std::runtime_error(std::string("yhair: ") + yh_last_error(context()));
+inline yh_context* require_context() { return require_contexts()[0]; }
+inline yh_context* context() { return contexts().empty() ? nullptr : contexts()[0]; }
+inline void check(int rc, yh_context* ctx = nullptr) {
+  if (rc != YH_OK) throw std::runtime_error(std::string("yhair: ") + yh_last_error(ctx ? ctx : context()));
+}
+// fn(context, index) on every context, each from its own host thread (calls of the C ABI block)
+template <typename F>
+inline void for_each_context(F&& fn) {
+  auto& ctxs = require_contexts();
+  if (ctxs.size() == 1) {
+    check(fn(ctxs[0], 0), ctxs[0]);
+    return;
+  }
+  std::vector<int>         rcs(ctxs.size(), YH_OK);
+  std::vector<std::thread> pool;
+  for (size_t i = 0; i < ctxs.size(); i++) pool.emplace_back([&, i]() { rcs[i] = fn(ctxs[i], (int)i); });
+  for (auto& t : pool) t.join();
+  for (size_t i = 0; i < ctxs.size(); i++) check(rcs[i], ctxs[i]);
+}
+// the state whose pixels the contexts hold (see init_state / trace_samples)
+inline const void*& bound_state() {
+  static const void* st = nullptr;
+  return st;
 }
 }  // namespace yhair::detail
 
@@ -203,6 +233,7 @@ struct scene {
 struct state {  // pt.h:426-429; `render` is refreshed by trace_samples
   int                width = 0, height = 0, samples = 0;
   std::vector<vec4f> render;
+  yh_trace_params    device_params{};  // what init_state asked for (see trace_samples: re-binding)
 };
 enum struct shader_type { naive, path, eyelight, normal };
 const auto default_seed = 961748941ull;
@@ -357,7 +388,7 @@ inline void upload_scene(const scene* sc, const camera* cam) {
   memcpy(d.camera.frame, &cam->frame, 48);
   d.camera.lens = cam->lens, d.camera.film[0] = cam->film.x, d.camera.film[1] = cam->film.y;
   d.camera.focus = cam->focus, d.camera.aperture = cam->aperture;
-  detail::check(yh_upload_scene(detail::require_context(), &d));
+  detail::for_each_context([&](yh_context* ctx, int) { return yh_upload_scene(ctx, &d); });  // the scene is replicated
   sc->uploaded_for = cam;
 }
 // init_bvh / init_lights: same signatures as pt.h:207-217. They mark the scene;
@@ -377,27 +408,48 @@ inline void init_state(state* st, const scene* sc, const camera* cam, const trac
   if (!sc->bvh_requested || !sc->lights_requested)
     throw std::runtime_error("yhair: init_state before init_bvh / init_lights");
   if (sc->uploaded_for != cam) upload_scene(sc, cam);
-  yh_trace_params p{params.resolution, params.bounces, params.clamp, params.seed, (int)params.shader};
-  auto            ctx = detail::require_context();
-  detail::check(yh_init_state(ctx, &p));
-  detail::check(yh_image_size(ctx, &st->width, &st->height));
+  st->device_params = yh_trace_params{params.resolution, params.bounces, params.clamp, params.seed, (int)params.shader};
+  detail::for_each_context([&](yh_context* ctx, int i) {
+    int rc = yh_set_shard(ctx, i, (int)detail::contexts().size());
+    return rc ? rc : yh_init_state(ctx, &st->device_params);
+  });
+  detail::check(yh_image_size(detail::require_context(), &st->width, &st->height));
   st->samples = 0;
   st->render.assign((size_t)st->width * st->height, vec4f{});
+  detail::bound_state() = st;
+}
+// The contexts hold the pixels of ONE state. The reference's interactive caller initialises its render state,
+// then initialises and traces a low-resolution preview state, then traces the render state
+// (apps/ysceneitraces/ysceneitraces.cpp:255-300): a state that was displaced by another init_state before it
+// accumulated any sample is simply initialised again on the device; one that had samples cannot be.
+inline void bind_state(state* st) {
+  if (detail::bound_state() == st) return;
+  if (st->samples != 0) throw std::runtime_error("yhair: this state's pixels were displaced by another init_state");
+  detail::for_each_context([&](yh_context* ctx, int) { return yh_init_state(ctx, &st->device_params); });
+  detail::bound_state() = st;
+}
+inline void download(state* st) {
+  auto& ctxs = detail::require_contexts();
+  if (ctxs.size() == 1) detail::check(yh_download(ctxs[0], (float*)st->render.data()));
+  else detail::check(yh_gather_framebuffer(ctxs.data(), (int)ctxs.size(), (float*)st->render.data()));
 }
 // trace_samples (pt.cpp:1992-2007): `nsamples` calls of the reference's
-// function in one launch; state->render is refreshed when `download` is set.
+// function in one launch per GPU; state->render is refreshed when `download` is set.
 inline void trace_samples(state* st, const scene*, const camera*, const trace_params&, int nsamples = 1,
-    bool download = true) {
-  auto ctx = detail::require_context();
-  detail::check(yh_trace_samples(ctx, nsamples));
+    bool download_image = true) {
+  bind_state(st);
+  detail::for_each_context([&](yh_context* ctx, int) { return yh_trace_samples(ctx, nsamples); });
   st->samples += nsamples;
-  if (download) detail::check(yh_download(ctx, (float*)st->render.data()));
+  if (download_image) download(st);
 }
-// the stop-flag overload (pt.cpp:2009-2026): checked between launches
+// the stop-flag overload (pt.cpp:2009-2026): one sample per call like the reference's; the flag is looked at
+// before the launch and again before the image is copied back, so a set flag costs at most one launch.
 inline void trace_samples(state* st, const scene* sc, const camera* cam, const trace_params& params,
     std::atomic<bool>* stop) {
   if (stop && *stop) return;
-  trace_samples(st, sc, cam, params, 1, true);
+  trace_samples(st, sc, cam, params, 1, false);
+  if (stop && *stop) return;
+  download(st);
 }
 }  // namespace yhair::pathtrace
 #endif

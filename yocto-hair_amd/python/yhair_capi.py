@@ -139,6 +139,7 @@ _SIGS = {
     "yh_download": (C.c_int, [C.c_void_p, c_float_p]),
     "yh_pack_tiles_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
     "yh_unpack_tiles_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "yh_gather_framebuffer": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, c_float_p]),
     "yh_shard_pixels": (C.c_int64, [C.c_void_p, C.c_int, C.c_int]),
     "yh_download_rng": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "yh_trace_samples_counted": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(WorkCounts)]),
@@ -214,6 +215,17 @@ class SceneFile:
             self.close()
         except Exception:  # interpreter shutdown
             pass
+
+
+def gather_framebuffer(contexts):
+    """yh_gather_framebuffer: the full (H, W, 4) image of `contexts`, context i holding shard (i, len(contexts))."""
+    lib = load()
+    w, h = C.c_int(), C.c_int()
+    contexts[0]._chk(lib.yh_image_size(contexts[0].h, C.byref(w), C.byref(h)))
+    img = np.zeros((h.value, w.value, 4), np.float32)
+    arr = (C.c_void_p * len(contexts))(*[c.h for c in contexts])
+    contexts[0]._chk(lib.yh_gather_framebuffer(arr, len(contexts), fptr(img)))
+    return img
 
 
 class Context:
