@@ -56,7 +56,7 @@ CONFIGS = {
     "C3": dict(scene="curly-hair", resolution=1280, spp=4096, kw={}),
     "C4": dict(scene="hair-curls", resolution=1280, spp=4096, kw={}),
 }
-KERNELS = {0: "k_trace<512 x 4>", 1: "k_trace<256 x 6>", 2: "k_wavefront", 3: "k_stream"}
+KERNELS = {0: "k_trace<512 x 4>", 1: "k_trace<256 x 5>", 2: "k_wavefront", 3: "k_stream"}
 
 
 def cpu_leg(scene_json, resolution, budget_s):

@@ -260,7 +260,7 @@ int yh_last_trace_ms(const yh_context* ctx, float* ms, int* launches);
 
 /* Which sample-loop kernel the most recent yh_trace_samples launch ran (the host picks per launch from
  * measured times; every choice renders the same bits): 0 = k_trace 512 threads x 4 waves per SIMD,
- * 1 = k_trace 256 x 6, 2 = k_wavefront, 3 = k_stream; < 0 = nothing launched yet (or an error code).    */
+ * 1 = k_trace 256 x 5, 2 = k_wavefront, 3 = k_stream; < 0 = nothing launched yet (or an error code).    */
 int yh_launch_shape(const yh_context* ctx);
 
 /* Load-balance telemetry: for every tile id (row-major over ceil(W/8) x

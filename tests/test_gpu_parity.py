@@ -694,14 +694,14 @@ def test_per_pixel_error_within_k_sigma(ctx, oracle, yh, name, kw):
                                      ("hair-curls", dict(scale=0.05)), ("lobes", dict(scale=0.05))],
                          ids=["sphere-hairblock", "straight-hair", "hair-curls", "lobes"])
 def test_launch_shapes_and_kernels_render_identical_pixels(ctx, yh, name, kw, monkeypatch):
-    """The host picks the integrator kernel — k_trace at 512 x 4 or at 256 x 6 (single-predicate line test),
+    """The host picks the integrator kernel — k_trace at 512 x 4 or at 256 x 5 (single-predicate line test),
     the staged k_wavefront (csrc/wavefront.hip) or the one-lane-per-path k_stream (csrc/stream.hip) — from the previous launch's item costs, so which kernel
     a render runs depends on history. Every choice must give the same bits: YHAIR_SHAPE forces each."""
     sf = yh.SceneFile(scene_path(name, **kw))
     ctx.upload_scene(sf.desc)
     p = yh.TraceParams.default(resolution=88)
     images = {}
-    for shape in ("0", "1", "2", "3"):  # k_trace 512 x 4, k_trace 256 x 6, k_wavefront, k_stream
+    for shape in ("0", "1", "2", "3"):  # k_trace 512 x 4, k_trace 256 x 5, k_wavefront, k_stream
         monkeypatch.setenv("YHAIR_SHAPE", shape)
         ctx.init_state(p)
         ctx.trace_samples(3), ctx.trace_samples(5)

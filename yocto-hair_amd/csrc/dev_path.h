@@ -152,12 +152,10 @@ YH_DEV f3 eval_environment(const trace_ctx& tc, f3 dir) {
   return emission;
 }
 
-// sample_discrete_cdf (math.h:4957-4962): std::upper_bound over the cdf
-YH_DEV int sample_discrete_cdf(const float* cdf, int n, float r) {
-  float back = cdf[n - 1];
-  r          = fclamp(r * back, 0.0f, back - 0.00001f);
-  int lo = 0, len = n;
-  while (len > 0) {  // first element > r
+// std::upper_bound (math.h:4960): first index in [lo, lo + len) whose entry is greater than r, lo + len if none
+template <typename P>
+YH_DEV int cdf_upper_bound(P cdf, int lo, int len, float r) {
+  while (len > 0) {
     int half = len >> 1;
     if (!(r < cdf[lo + half])) {
       lo += half + 1;
@@ -166,18 +164,84 @@ YH_DEV int sample_discrete_cdf(const float* cdf, int n, float r) {
       len = half;
     }
   }
-  return iclamp(lo, 0, n - 1);
+  return lo;
+}
+// sample_discrete_cdf (math.h:4957-4962): std::upper_bound over the cdf
+template <typename P>
+YH_DEV int sample_discrete_cdf(P cdf, int n, float r) {
+  float back = cdf[n - 1];
+  r          = fclamp(r * back, 0.0f, back - 0.00001f);
+  return iclamp(cdf_upper_bound(cdf, 0, n, r), 0, n - 1);
+}
+// The same through a coarse index in LDS (yhd_scene::env_tab: tab[k] = cdf[min(n, (k + 1) * S) - 1], K entries): the
+// block of S entries that holds the answer is found in LDS, only the search inside it reads memory. Entries before
+// the block are <= r and the block's last entry is > r, so the result is upper_bound's over the whole array.
+YH_DEV int sample_discrete_cdf_indexed(const float* cdf, int n, const YH_LDS float* tab, int K, int S, float r) {
+  float back = tab[K - 1];  // = cdf[n - 1]
+  r          = fclamp(r * back, 0.0f, back - 0.00001f);
+  int k      = cdf_upper_bound(tab, 0, K, r);
+  if (k >= K) return n - 1;  // no entry is greater than r: upper_bound = n, clamped
+  int lo = k * S;
+  return iclamp(cdf_upper_bound(cdf, lo, min(S, n - lo), r), 0, n - 1);
+}
+
+// ---- small area lights (yh_device.h: YH_SMALL_LIGHT_F4 record in LDS) ----------------------------------------
+// object -> world frame and its inverse, from the LDS copy of the object table when there is one
+YH_DEV void object_frames(const trace_ctx& tc, int object, frame& fr, frame& inv) {
+  if (tc.lds_scene) {
+    const YH_LDS v4f* ob = tc.lds_scene + YH_OBJECT_F4 * object;
+    v4f a = ob[0], b = ob[1], c = ob[2], d = ob[3], e = ob[4], g = ob[5];
+    fr.x = {a.x, a.y, a.z}, fr.y = {a.w, b.x, b.y}, fr.z = {b.z, b.w, c.x}, fr.o = {c.y, c.z, c.w};
+    inv.x = {d.x, d.y, d.z}, inv.y = {d.w, e.x, e.y}, inv.z = {e.z, e.w, g.x}, inv.o = {g.y, g.z, g.w};
+  } else {
+    const yhd_object& o = tc.sc->objects[object];
+    fr = ldframe(o.frame), inv = ldframe(o.inv_frame);
+  }
+}
+// Closest hit of a ray with a small light: what intersect_instance_bvh (pt.cpp:1031-1037) computes for a shape
+// whose tree is one leaf — the ray taken to object space (pt.cpp:1012-1013), the root box, then the leaf's
+// triangles in order with tmax shrinking after each accepted hit (pt.cpp:905-923) — on the record in LDS: the
+// same arithmetic as the traversal (dev_trace.h), no memory access.
+YH_DEV bool small_light_hit(const YH_LDS v4f* L, const frame& inv, f3 ro, f3 rd, int& slot, float& uu, float& vv) {
+  f3  lo = transform_point(inv, ro), ld = transform_vector(inv, rd);
+  f3  ldinv = quad_rcp(ld);
+  v4f b0 = L[0], b1 = L[1];
+  if (!intersect_bbox(lo, ldinv, ray_eps, flt_max, xyz(b0), xyz(b1))) return false;
+  const int num  = __float_as_int(b0.w);
+  float     tmax = flt_max;
+  bool      hit  = false;
+  for (int i = 0; i < num; i++) {
+    float u = 0, v = 0, d = 0;
+    if (intersect_triangle(lo, ld, ray_eps, tmax, xyz(L[2 + 3 * i]), xyz(L[3 + 3 * i]), xyz(L[4 + 3 * i]), u, v, d)) hit = true, slot = i, uu = u, vv = v, tmax = d;
+  }
+  return hit;
 }
 
 // sample_lights (pt.cpp:1283-1308)
-template <bool COUNT>
+// BIG_LIGHTS = false: every area light of the scene is a small one with its record in LDS (the host says so:
+// yhd_scene::general_materials is set otherwise), and the code that samples / intersects a light through memory —
+// with a whole traversal loop inlined into the shading code — is not compiled in.
+template <bool COUNT, bool BIG_LIGHTS>
 YH_DEV f3 sample_lights(const trace_ctx& tc, f3 position, float rl, float rel, float ruvx,
     float ruvy) {
   const yhd_scene& sc = *tc.sc;
   int n        = sc.num_lights;
   int light_id = iclamp((int)(rl * n), 0, n - 1);
   const yhd_light& light = sc.lights[light_id];
-  if (light.object >= 0) {
+  if (light.object >= 0 && (!BIG_LIGHTS || (light.small_base >= 0 && tc.lds_lights))) {  // a small light: its record is in LDS
+    const YH_LDS v4f* L = tc.lds_lights + light.small_base;
+    int   element = sample_discrete_cdf((const YH_LDS float*)(L + 14), light.cdf_count, rel);
+    int   rec     = 0;
+    for (int i = 1; i < __float_as_int(L[0].w); i++)
+      if (__float_as_int(L[2 + 3 * i].w) == element) rec = i;
+    float su = sqrtf(ruvx);
+    float u = 1 - su, v = ruvy * su;  // sample_triangle, math.h:4910-4912
+    frame fr, inv;
+    object_frames(tc, light.object, fr, inv);
+    f3 p0 = xyz(L[2 + 3 * rec]), p1 = xyz(L[3 + 3 * rec]), p2 = xyz(L[4 + 3 * rec]);
+    f3 lposition = transform_point(fr, p0 * (1 - u - v) + p1 * u + p2 * v);  // eval_position (pt.cpp:232-250)
+    return normalize(lposition - position);
+  } else if (BIG_LIGHTS && light.object >= 0) {
     int   element = sample_discrete_cdf(sc.light_cdf + light.cdf_base, light.cdf_count, rel);
     float su      = sqrtf(ruvx);
     float u = 1 - su, v = ruvy * su;  // sample_triangle, math.h:4910-4912
@@ -187,7 +251,9 @@ YH_DEV f3 sample_lights(const trace_ctx& tc, f3 position, float rl, float rel, f
     const yhd_environment& env = sc.environments[light.environment];
     if (env.tex_w) {
       if (COUNT) count_quad<COUNT>(tc.stats->envs);
-      int   idx = sample_discrete_cdf(sc.light_cdf + light.cdf_base, light.cdf_count, rel);
+      int   idx = (tc.lds_envtab && light_id == sc.env_tab_light)
+                      ? sample_discrete_cdf_indexed(sc.light_cdf + light.cdf_base, light.cdf_count, tc.lds_envtab, sc.env_tab_k, sc.env_tab_stride, rel)
+                      : sample_discrete_cdf(sc.light_cdf + light.cdf_base, light.cdf_count, rel);
       float ux  = (idx % env.tex_w + 0.5f) / env.tex_w;
       float uy  = (idx / env.tex_w + 0.5f) / env.tex_h;
       return transform_direction(ldframe(env.frame),
@@ -204,13 +270,32 @@ YH_DEV f3 sample_lights(const trace_ctx& tc, f3 position, float rl, float rel, f
 }
 
 // sample_lights_pdf (pt.cpp:1311-1358)
-template <bool COUNT, int STRIDE>
+template <bool COUNT, int STRIDE, bool BIG_LIGHTS>
 YH_DEV float sample_lights_pdf(const trace_ctx& tc, f3 position, f3 direction) {
   const yhd_scene& sc = *tc.sc;
   float pdf = 0.0f;
   for (int k = 0; k < sc.num_lights; k++) {
     const yhd_light& light = sc.lights[k];
-    if (light.object >= 0) {
+    if (light.object >= 0 && (!BIG_LIGHTS || (light.small_base >= 0 && tc.lds_lights))) {  // a small light: no memory access
+      const YH_LDS v4f* L = tc.lds_lights + light.small_base;
+      frame fr, inv;
+      object_frames(tc, light.object, fr, inv);
+      const float area = L[1].w;
+      float lpdf = 0.0f;
+      f3    next_position = position;
+      for (int bounce = 0; bounce < 100; bounce++) {
+        int   slot = 0;
+        float uu = 0, vv = 0;
+        if (!small_light_hit(L, inv, next_position, direction, slot, uu, vv)) break;
+        f3 p0 = xyz(L[2 + 3 * slot]), p1 = xyz(L[3 + 3 * slot]), p2 = xyz(L[4 + 3 * slot]);
+        f3 lposition = transform_point(fr, p0 * (1 - uu - vv) + p1 * uu + p2 * vv);              // eval_hit: position
+        f3 lnormal   = quad_transform_normal(fr, quad_normalize(cross(p1 - p0, p2 - p0)));        // eval_hit: element normal
+        f3 dp        = lposition - position;
+        lpdf += dot(dp, dp) / (fabs_(dot(lnormal, direction)) * area);
+        next_position = lposition + direction * 1e-3f;
+      }
+      pdf += lpdf;
+    } else if (BIG_LIGHTS && light.object >= 0) {
       const yhd_object& o = sc.objects[light.object];
       float lpdf = 0.0f;
       f3    next_position = position;
@@ -355,11 +440,11 @@ YH_DEV bool path_step(const trace_ctx& tc, path_t& ps, const hit_t& isec, rng_t&
         float ruvx = rand1f(rng), ruvy = rand1f(rng);
         float rel = rand1f(rng);
         float rl2 = rand1f(rng);
-        incoming  = sample_lights<COUNT>(tc, position, rl2, rel, ruvx, ruvy);
+        incoming  = sample_lights<COUNT, GENERAL>(tc, position, rl2, rel, ruvx, ruvy);
       }
       f3    f         = eval_scattering(ps.medium, outgoing, incoming);
       float pdf       = sample_scattering_pdf(ps.medium, outgoing, incoming);
-      float light_pdf = sample_lights_pdf<COUNT, STRIDE>(tc, position, incoming);
+      float light_pdf = sample_lights_pdf<COUNT, STRIDE, GENERAL>(tc, position, incoming);
       ps.weight = ps.weight * (f / (0.5f * pdf + 0.5f * light_pdf));
       ps.ray    = mkray(position, incoming);
       if (COUNT) tc.stats->c_rest += clock64() - k0;
@@ -440,7 +525,7 @@ YH_DEV bool path_step(const trace_ctx& tc, path_t& ps, const hit_t& isec, rng_t&
     float ruvx = rand1f(rng), ruvy = rand1f(rng);
     float rel = rand1f(rng);
     float rl  = rand1f(rng);
-    incoming  = sample_lights<COUNT>(tc, position, rl, rel, ruvx, ruvy);
+    incoming  = sample_lights<COUNT, GENERAL>(tc, position, rl, rel, ruvx, ruvy);
   }
   if (COUNT) k2 = clock64(), tc.stats->c_sample += k2 - k1;
   f3    brdfcos;
@@ -472,7 +557,7 @@ YH_DEV bool path_step(const trace_ctx& tc, path_t& ps, const hit_t& isec, rng_t&
     }
   }
   if (COUNT) k3 = clock64(), tc.stats->c_eval += k3 - k2;
-  float light_pdf = sample_lights_pdf<COUNT, STRIDE>(tc, position, incoming);
+  float light_pdf = sample_lights_pdf<COUNT, STRIDE, GENERAL>(tc, position, incoming);
   ps.weight = ps.weight * (brdfcos / (0.5f * brdf_pdf + 0.5f * light_pdf));
   if (general) medium_crossing(sc, ps, mat, normal, outgoing, incoming, ctex, etex_x, tu, tv);
   ps.ray    = mkray(position, incoming);

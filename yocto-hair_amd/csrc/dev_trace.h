@@ -192,10 +192,41 @@ struct trace_ctx {
   // [objects: 8 float4 each][scene BVH nodes: 2 float4 each][scene BVH primitives]
   const YH_LDS v4f*     lds_scene;
   struct stats_t*       stats;      // per-lane work counters of the instrumented build, else NULL
+  const YH_LDS v4f*     lds_lights; // LDS copy of sc.light_table (small area lights), or nullptr
+  const YH_LDS float*   lds_envtab; // LDS copy of sc.env_tab (coarse index of an environment's texel cdf), or nullptr
   lane_stack*           ls;         // one lane per path (YH_LANE, dev_lane.h): this lane's stack, else unused
   const yhd_scene*      sc_dev;     // YH_LANE: a copy of *sc in device memory, for out-of-line callees (the kernel
                                     // argument itself must not have its address escape: it would be copied to scratch)
 };
+// Stages the tables every kernel keeps in LDS — the scene level (objects, scene BVH nodes and primitives; when it
+// fits), the camera, the small area lights and the environment cdf index — at `at` (YHD_LDS_TABLES_F4 float4) and
+// points `tc` at them. All threads of the block call it; a __syncthreads() must follow.
+YH_DEV void stage_tables(const yhd_scene& sc, YH_LDS v4f* at, int tid, int nthreads, trace_ctx& tc, YH_LDS float*& lds_cam) {
+  tc.lds_scene = nullptr, tc.lds_lights = nullptr, tc.lds_envtab = nullptr;
+  if (sc.lds_scene_f4 > 0) {
+    const int  nobj = YH_OBJECT_F4 * sc.num_objects, nnod = 2 * sc.num_scene_nodes, npri = (sc.num_objects + 3) / 4;
+    const v4f* gobj = (const v4f*)sc.objects;
+    const v4f* gpri = (const v4f*)sc.scene_prims;  // padded to a multiple of 4 ints by the host
+    for (int i = tid; i < nobj; i += nthreads) at[i] = gobj[i];
+    for (int i = tid; i < nnod; i += nthreads) at[nobj + i] = *(const v4f*)(sc.scene_nodes + i);
+    for (int i = tid; i < npri; i += nthreads) at[nobj + nnod + i] = gpri[i];
+    tc.lds_scene = at;
+  }
+  // the camera too: as kernel arguments its 17 floats end up in spilled SGPRs reloaded one v_readlane at a time
+  lds_cam = (YH_LDS float*)(at + sc.lds_scene_f4);
+  if (tid < 17) lds_cam[tid] = ((const float*)&sc.camera)[tid];
+  YH_LDS v4f* lights = at + sc.lds_scene_f4 + 5;
+  if (sc.light_table_f4 > 0) {
+    for (int i = tid; i < sc.light_table_f4; i += nthreads) lights[i] = *(const v4f*)(sc.light_table + i);
+    tc.lds_lights = lights;
+  }
+  YH_LDS float* envtab = (YH_LDS float*)(lights + sc.light_table_f4);
+  if (sc.env_tab_k > 0) {
+    for (int i = tid; i < sc.env_tab_k; i += nthreads) envtab[i] = sc.env_tab[i];
+    tc.lds_envtab = envtab;
+  }
+}
+
 // Per-lane counters of the instrumented build (COUNT = true): kept in registers
 // for a whole work item and flushed once, so that the instrumented kernel runs
 // at nearly the speed of the production one and its cycle stamps mean something.

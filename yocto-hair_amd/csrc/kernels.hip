@@ -53,32 +53,20 @@ using namespace yhd;
 template <bool COUNT, bool GENERAL, int BLOCK, int SHADER>
 YH_DEV void trace_items(const yhd_scene& sc, const yhd_state& st, int nsamples, yhd_counters* counters) {
   extern __shared__ v4f lds_dyn[];
-  // LDS carve-out: [nodelets: 8 * lds_node_count float4][stacks: YH_QSTACK x (BLOCK / 4) uint]
-  //                [scene table: objects | scene BVH nodes | scene BVH primitives] (lds_scene_f4 float4)
+  // LDS carve-out: [nodelets: 8 * lds_node_count float4][stacks: stack_entries x (BLOCK / 4) uint]
+  //                [tables: scene level | camera | small area lights | environment cdf index] (dev_trace.h: stage_tables)
   YH_LDS v4f*          lds_nodes = (YH_LDS v4f*)lds_dyn;
   YH_LDS unsigned int* lds_stack = (YH_LDS unsigned int*)(lds_nodes + 8 * sc.lds_node_count);
-  YH_LDS v4f*          lds_scene = (YH_LDS v4f*)(lds_stack + YH_QSTACK * (BLOCK / 4));
+  YH_LDS v4f*          lds_tabs  = (YH_LDS v4f*)(lds_stack + sc.stack_entries * (BLOCK / 4));
   // stage the nodelets: the first lds_node_count wide nodes (breadth-first =
   // top levels) of the dominant hair shape, 128 B each, coalesced dwordx4 loads
   for (int i = threadIdx.x; i < 8 * sc.lds_node_count; i += blockDim.x)
     lds_nodes[i] = ldg4(sc.nodes + 8 * (size_t)sc.lds_node_base + i);
   trace_ctx tc;
   tc.sc = &sc;
-  tc.lds_scene = nullptr, tc.ls = nullptr, tc.sc_dev = nullptr;
-  if (sc.lds_scene_f4 > 0) {
-    // the scene level (a handful of objects and BVH nodes) lives in LDS: its steps need no memory round trip
-    const int nobj = YH_OBJECT_F4 * sc.num_objects, nnod = 2 * sc.num_scene_nodes, npri = (sc.num_objects + 3) / 4;
-    const v4f* gobj = (const v4f*)sc.objects;
-    const v4f* gpri = (const v4f*)sc.scene_prims;  // padded to a multiple of 4 ints by the host
-    for (int i = threadIdx.x; i < nobj; i += blockDim.x) lds_scene[i] = gobj[i];
-    for (int i = threadIdx.x; i < nnod; i += blockDim.x) lds_scene[nobj + i] = ldg4(sc.scene_nodes + i);
-    for (int i = threadIdx.x; i < npri; i += blockDim.x) lds_scene[nobj + nnod + i] = gpri[i];
-    tc.lds_scene = lds_scene;
-  }
-  // the camera too: as kernel arguments its 17 floats end up in spilled SGPRs that path_begin
-  // reloads one v_readlane at a time
-  YH_LDS float* lds_cam = (YH_LDS float*)(lds_scene + sc.lds_scene_f4);
-  if (threadIdx.x < 17) lds_cam[threadIdx.x] = ((const float*)&sc.camera)[threadIdx.x];
+  tc.ls = nullptr, tc.sc_dev = nullptr;
+  YH_LDS float* lds_cam;
+  stage_tables(sc, lds_tabs, threadIdx.x, blockDim.x, tc, lds_cam);
   __syncthreads();
 
   tc.lds_nodes = sc.lds_node_count ? lds_nodes : nullptr;
@@ -343,7 +331,7 @@ __global__ __launch_bounds__(256) void k_intersect(const yhd_scene sc, int n, co
   bool valid = i < n;
   if (!valid) i = n - 1;  // whole quads stay converged; surplus quads redo the last ray
   trace_ctx tc;
-  tc.sc = &sc, tc.lds_nodes = nullptr, tc.stats = nullptr, tc.lds_scene = nullptr, tc.ls = nullptr, tc.sc_dev = nullptr;
+  tc.sc = &sc, tc.lds_nodes = nullptr, tc.stats = nullptr, tc.lds_scene = nullptr, tc.ls = nullptr, tc.sc_dev = nullptr, tc.lds_lights = nullptr, tc.lds_envtab = nullptr;
   tc.lds_stack   = (YH_LDS unsigned int*)stacks + (threadIdx.x >> 2);
   const float* r = rays + 8 * (size_t)i;
   ray_t ray      = ray_t{ld3(r), ld3(r + 3), r[6], r[7]};
@@ -581,9 +569,9 @@ extern "C" {
 
 typedef void (*trace_kernel_t)(const yhd_scene, const yhd_state, int, yhd_counters*);
 #ifndef YH_DENSE_WAVES
-#define YH_DENSE_WAVES 6
+#define YH_DENSE_WAVES 5 /* 96 VGPRs: at 6 (80 VGPRs) the traversal loop itself spills and the kernel is at the mercy of the register allocator (measured 0.6-0.75x after an unrelated change of the shading code, profiles/r02) */
 #endif
-// shape 0 = 512 threads x 4 waves per SIMD, shape 1 = 256 threads x YH_DENSE_WAVES (6) waves per SIMD
+// shape 0 = 512 threads x 4 waves per SIMD, shape 1 = 256 threads x YH_DENSE_WAVES (5) waves per SIMD
 static int shape_block(int shape) { return shape ? 256 : YH_BLOCK; }
 static trace_kernel_t trace_kernel(bool counted, bool general, int shape, int shader = YH_SHADER_PATH) {
   if (shader == YH_SHADER_NAIVE) return k_trace_shader<YH_SHADER_NAIVE>;
@@ -595,15 +583,15 @@ static trace_kernel_t trace_kernel(bool counted, bool general, int shape, int sh
   return counted ? (general ? k_trace<true, true, YH_BLOCK, YH_MIN_WAVES> : k_trace<true, false, YH_BLOCK, YH_MIN_WAVES>)
                  : (general ? k_trace<false, true, YH_BLOCK, YH_MIN_WAVES> : k_trace<false, false, YH_BLOCK, YH_MIN_WAVES>);
 }
-static size_t trace_lds(int lds_node_count, int lds_scene_f4, int shape) {
-  return (size_t)lds_node_count * 128 + (size_t)YH_QSTACK * (shape_block(shape) / 4) * 4 + (size_t)lds_scene_f4 * 16 + 80;
+static size_t trace_lds(const yhd_scene* sc, int shape) {
+  return (size_t)sc->lds_node_count * 128 + (size_t)sc->stack_entries * (shape_block(shape) / 4) * 4 + (size_t)YHD_LDS_TABLES_F4(sc) * 16;
 }
 int yhk_trace(const yhd_scene* sc, const yhd_state* st, int nsamples, yhd_counters* counters,
     int grid_blocks, hipStream_t stream) {
   const bool path  = st->shader == YH_SHADER_PATH;
   const int  shape = path && st->launch_shape ? 1 : 0;  // the other shaders have one shape (512 x 4)
   if (!path && counters) return (int)hipErrorInvalidValue;
-  size_t    lds   = trace_lds(sc->lds_node_count, sc->lds_scene_f4, shape);
+  size_t    lds   = trace_lds(sc, shape);
   trace_kernel_t k     = trace_kernel(counters != nullptr, sc->general_materials != 0, shape, st->shader);
   if (lds > 64 * 1024) {  // above 64 KB the dynamic-LDS limit must be raised explicitly; the attribute is per
                           // device, so it is set for the current device at every such launch (no process-wide cache)
@@ -615,9 +603,7 @@ int yhk_trace(const yhd_scene* sc, const yhd_state* st, int nsamples, yhd_counte
 }
 int yhk_block_threads(int shape) { return shape_block(shape ? 1 : 0); }
 int yhk_stack_entries(void) { return YH_QSTACK; }
-int yhk_trace_lds_bytes(int lds_node_count, int lds_scene_f4, int shape) {
-  return (int)trace_lds(lds_node_count, lds_scene_f4, shape ? 1 : 0);
-}
+int yhk_trace_lds_bytes(const yhd_scene* sc, int shape) { return (int)trace_lds(sc, shape ? 1 : 0); }
 int yhk_trace_occupancy(int lds_bytes, int general, int shape) {
   int            blocks = 0;
   trace_kernel_t k      = trace_kernel(false, general != 0, shape ? 1 : 0);

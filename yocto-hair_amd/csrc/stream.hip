@@ -97,12 +97,11 @@ __global__ __launch_bounds__(YH_ST_BLOCK, WAVES) void k_stream(const yhd_scene s
   constexpr int WPB = YH_ST_BLOCK / 64;
   extern __shared__ v4f lds_dyn[];
   const int P = pl.slots_per_wave;
-  // LDS: [scene table][camera][per wave: stack window 64 x YH_LSTACK | six lists of P slot ids]
-  YH_LDS v4f*   lds_scene = (YH_LDS v4f*)lds_dyn;
-  YH_LDS float* lds_cam   = (YH_LDS float*)(lds_scene + sc.lds_scene_f4);
+  // LDS: [tables: scene level | camera | small lights | env cdf index][per wave: stack window 64 x YH_LSTACK | six lists of P slot ids]
+  YH_LDS v4f*   lds_tabs  = (YH_LDS v4f*)lds_dyn;  // dev_trace.h: stage_tables
   const int     wave_lds  = 64 * YH_LSTACK * 4 + 6 * P * 2;
   const int     lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
-  YH_LDS unsigned char*  wbase   = (YH_LDS unsigned char*)(lds_cam + 20) + wib * wave_lds;
+  YH_LDS unsigned char*  wbase   = (YH_LDS unsigned char*)(lds_tabs + YHD_LDS_TABLES_F4(&sc)) + wib * wave_lds;
   YH_LDS unsigned int*   w_stack = (YH_LDS unsigned int*)wbase;
   YH_LDS unsigned short* l_ray   = (YH_LDS unsigned short*)(w_stack + 64 * YH_LSTACK);
   YH_LDS unsigned short* l_done  = l_ray + P;
@@ -114,17 +113,9 @@ __global__ __launch_bounds__(YH_ST_BLOCK, WAVES) void k_stream(const yhd_scene s
   const size_t base    = wave_id * (size_t)P;  // this wave's first slot
 
   trace_ctx tc;
-  tc.sc = &sc, tc.sc_dev = sc_dev, tc.lds_nodes = nullptr, tc.lds_stack = nullptr, tc.stats = nullptr, tc.lds_scene = nullptr;
-  if (sc.lds_scene_f4 > 0) {  // the scene level in LDS (as in k_trace), shared by the block's waves
-    const int nobj = YH_OBJECT_F4 * sc.num_objects, nnod = 2 * sc.num_scene_nodes, npri = (sc.num_objects + 3) / 4;
-    const v4f* gobj = (const v4f*)sc.objects;
-    const v4f* gpri = (const v4f*)sc.scene_prims;
-    for (int i = threadIdx.x; i < nobj; i += YH_ST_BLOCK) lds_scene[i] = gobj[i];
-    for (int i = threadIdx.x; i < nnod; i += YH_ST_BLOCK) lds_scene[nobj + i] = ldg4(sc.scene_nodes + i);
-    for (int i = threadIdx.x; i < npri; i += YH_ST_BLOCK) lds_scene[nobj + nnod + i] = gpri[i];
-    tc.lds_scene = lds_scene;
-  }
-  if (threadIdx.x < 17) lds_cam[threadIdx.x] = ((const float*)&sc.camera)[threadIdx.x];
+  tc.sc = &sc, tc.sc_dev = sc_dev, tc.lds_nodes = nullptr, tc.lds_stack = nullptr, tc.stats = nullptr;
+  YH_LDS float* lds_cam;
+  stage_tables(sc, lds_tabs, threadIdx.x, YH_ST_BLOCK, tc, lds_cam);  // shared by the block's waves
   for (int s = lane; s < P; s += 64) l_free[s] = (unsigned short)s;
   __syncthreads();  // the only workgroup barrier: from here on every wave runs on its own
 
@@ -381,8 +372,8 @@ static stream_kernel_t stream_kernel(bool general, bool prof = false) {
   return general ? k_stream<true, YH_ST_WAVES, false> : k_stream<false, YH_ST_WAVES, false>;
 }
 int yhk_stream_block_threads(void) { return YH_ST_BLOCK; }
-int yhk_stream_lds_bytes(int lds_scene_f4, int slots_per_wave) {
-  return lds_scene_f4 * 16 + 80 + (YH_ST_BLOCK / 64) * (64 * YH_LSTACK * 4 + 6 * slots_per_wave * 2);
+int yhk_stream_lds_bytes(int tables_f4, int slots_per_wave) {
+  return tables_f4 * 16 + (YH_ST_BLOCK / 64) * (64 * YH_LSTACK * 4 + 6 * slots_per_wave * 2);
 }
 int yhk_stream_occupancy(int lds_bytes, int general) {
   int             blocks = 0;
@@ -394,7 +385,7 @@ int yhk_stream_occupancy(int lds_bytes, int general) {
 }
 int yhk_stream(const yhd_scene* sc, const yhd_scene* sc_dev, const yhd_state* st, int nsamples, const yhd_stream* pl, int grid_blocks,
     hipStream_t stream) {
-  int             lds  = yhk_stream_lds_bytes(sc->lds_scene_f4, pl->slots_per_wave);
+  int             lds  = yhk_stream_lds_bytes(YHD_LDS_TABLES_F4(sc), pl->slots_per_wave);
   stream_kernel_t kern = stream_kernel(sc->general_materials != 0, pl->prof != nullptr);
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);

@@ -44,9 +44,8 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_wavefront(const yhd_scene sc, 
   extern __shared__ v4f lds_dyn[];
   // LDS: [stacks][scene table][camera][pix left item work][six slot lists][slot state][counters]
   YH_LDS unsigned int*   lds_stack = (YH_LDS unsigned int*)lds_dyn;
-  YH_LDS v4f*            lds_scene = (YH_LDS v4f*)(lds_stack + pl.stack_entries * QUADS);
-  YH_LDS float*          lds_cam   = (YH_LDS float*)(lds_scene + sc.lds_scene_f4);
-  YH_LDS int*            s_pix     = (YH_LDS int*)(lds_cam + 20);
+  YH_LDS v4f*            lds_tabs  = (YH_LDS v4f*)(lds_stack + pl.stack_entries * QUADS);  // dev_trace.h: stage_tables
+  YH_LDS int*            s_pix     = (YH_LDS int*)(lds_tabs + YHD_LDS_TABLES_F4(&sc));
   YH_LDS int*            s_left    = s_pix + P;
   YH_LDS int*            s_item    = s_left + P;
   YH_LDS unsigned int*   s_work    = (YH_LDS unsigned int*)(s_item + P);
@@ -64,17 +63,9 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_wavefront(const yhd_scene sc, 
   for (int s = tid; s < P; s += BLOCK) s_state[s] = YH_SLOT_FREE, l_free[s] = (unsigned short)s, s_work[s] = 0;
   if (tid < C_COUNT) ctr[tid] = tid == C_NFREE ? P : 0;
   trace_ctx tc;
-  tc.sc = &sc, tc.lds_nodes = nullptr, tc.stats = nullptr, tc.lds_scene = nullptr, tc.ls = nullptr, tc.sc_dev = nullptr;
-  if (sc.lds_scene_f4 > 0) {  // the scene level in LDS (as in k_trace)
-    const int nobj = YH_OBJECT_F4 * sc.num_objects, nnod = 2 * sc.num_scene_nodes, npri = (sc.num_objects + 3) / 4;
-    const v4f* gobj = (const v4f*)sc.objects;
-    const v4f* gpri = (const v4f*)sc.scene_prims;
-    for (int i = tid; i < nobj; i += BLOCK) lds_scene[i] = gobj[i];
-    for (int i = tid; i < nnod; i += BLOCK) lds_scene[nobj + i] = ldg4(sc.scene_nodes + i);
-    for (int i = tid; i < npri; i += BLOCK) lds_scene[nobj + nnod + i] = gpri[i];
-    tc.lds_scene = lds_scene;
-  }
-  if (tid < 17) lds_cam[tid] = ((const float*)&sc.camera)[tid];
+  tc.sc = &sc, tc.lds_nodes = nullptr, tc.stats = nullptr, tc.ls = nullptr, tc.sc_dev = nullptr;
+  YH_LDS float* lds_cam;
+  stage_tables(sc, lds_tabs, tid, BLOCK, tc, lds_cam);
   tc.lds_stack = lds_stack + quad;
   __syncthreads();
 
@@ -250,9 +241,9 @@ static wavefront_kernel_t wavefront_kernel(bool general, int k) {
 }
 int yhk_wavefront_block_threads(void) { return YH_WF_BLOCK; }
 int yhk_wavefront_slots(int k) { return YH_WF_BLOCK * (k >= 2 ? 2 : 1); }
-int yhk_wavefront_lds_bytes(int stack_entries, int lds_scene_f4, int k) {
+int yhk_wavefront_lds_bytes(int stack_entries, int tables_f4, int k) {
   int P = yhk_wavefront_slots(k);
-  return stack_entries * (YH_WF_BLOCK / 4) * 4 + lds_scene_f4 * 16 + 80 + P * (4 * 4 + 6 * 2 + 1) + C_COUNT * 4;
+  return stack_entries * (YH_WF_BLOCK / 4) * 4 + tables_f4 * 16 + P * (4 * 4 + 6 * 2 + 1) + C_COUNT * 4;
 }
 int yhk_wavefront_occupancy(int lds_bytes, int general, int k) {
   int                blocks = 0;
@@ -264,7 +255,7 @@ int yhk_wavefront_occupancy(int lds_bytes, int general, int k) {
 }
 int yhk_wavefront(const yhd_scene* sc, const yhd_state* st, int nsamples, const yhd_pool* pl, int k, int grid_blocks,
     hipStream_t stream) {
-  int                lds  = yhk_wavefront_lds_bytes(pl->stack_entries, sc->lds_scene_f4, k);
+  int                lds  = yhk_wavefront_lds_bytes(pl->stack_entries, YHD_LDS_TABLES_F4(sc), k);
   wavefront_kernel_t kern = wavefront_kernel(sc->general_materials != 0, k);
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);

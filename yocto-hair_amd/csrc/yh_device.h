@@ -102,7 +102,17 @@ typedef struct yhd_light {
   int environment;  // >= 0: environment light
   int cdf_base;     // offset into light_cdf
   int cdf_count;    // triangles / texels (0 for a constant environment)
+  int small_base;   // >= 0: an area light of at most YH_SMALL_LIGHT_TRIS triangles, its record at this float4 of
+                    // yhd_scene::light_table (staged in LDS by the kernels); -1: sampled / intersected through memory
 } yhd_light;
+// Record of a small area light (yhd_scene::light_table): the shading code samples it and intersects the light-pdf
+// rays with it (sample_lights / sample_lights_pdf, pt.cpp:1283-1358) without a memory access — through the BVH
+// that is six dependent fetches per bounce for a two-triangle light.
+//   [0] = {root box min.xyz, number of triangles (int)}   [1] = {root box max.xyz, total area}
+//   [2 + 3 i ..] = triangle i in LEAF order: {p0.xyz, element (int)} {p1.xyz, 0} {p2.xyz, 0}
+//   [14] = area cdf by ELEMENT (light_cdf's entries)
+#define YH_SMALL_LIGHT_TRIS 4
+#define YH_SMALL_LIGHT_F4 15
 
 typedef struct yhd_environment {
   float frame[12];
@@ -146,10 +156,22 @@ typedef struct yhd_scene {
   int               num_nodes_total; // wide nodes in `nodes` (bounds checks of the debug build)
   int               num_prim_f4;     // float4 in `prims`
   int               lds_scene_f4;       // float4 count of the scene-level LDS table (0: scene too big, read from memory)
-  int               general_materials;  // some material has lobes beyond diffuse / hair: k_trace<.., true>
+  int               general_materials;  // some material has lobes beyond diffuse / hair, or some area light is not a small one: the GENERAL kernel variants
   int               lds_node_base;   // global index of that shape's root
   int               lds_node_count;
+  int               stack_entries;   // traversal stack depth per ray the kernels reserve in LDS (>= the trees' need)
+  // tables the kernels stage in LDS next to the scene-level table (dev_trace.h: stage_tables)
+  const yhd_float4* light_table;     // small area lights, YH_SMALL_LIGHT_F4 float4 each
+  int               light_table_f4;
+  // coarse index of ONE environment light's texel cdf: env_tab[k] = cdf[min(n, (k + 1) * env_tab_stride) - 1], so that
+  // the first log2(env_tab_k) steps of the binary search of sample_lights (math.h:4957-4962, 21 dependent
+  // fetches for sky.hdr) read LDS
+  const float*      env_tab;
+  int               env_tab_light;   // index into lights[], -1: none
+  int               env_tab_k, env_tab_stride;
 } yhd_scene;
+// float4 the kernels reserve in LDS for the tables: scene level | camera (5) | small lights | env cdf index
+#define YHD_LDS_TABLES_F4(sc) ((sc)->lds_scene_f4 + 5 + (sc)->light_table_f4 + ((sc)->env_tab_k + 3) / 4)
 
 // Render state (pt.h:419-429) in SoA form.
 typedef struct yhd_state {
@@ -163,7 +185,7 @@ typedef struct yhd_state {
   unsigned int* tile_cost;  // per item: wall-clock ticks (100 MHz) its last launch took
   int         num_tiles;  // number of work items in `tiles`
   int         shader;        // YH_SHADER_* (yhair.h): path is the product path, the others preview / debug
-  int         launch_shape;  // 0: k_trace 512 threads x 4 waves per SIMD; 1: k_trace 256 x 6 (dense scenes); 2: k_wavefront; 3: k_stream
+  int         launch_shape;  // 0: k_trace 512 threads x 4 waves per SIMD; 1: k_trace 256 x 5 (dense scenes); 2: k_wavefront; 3: k_stream
   int         width, height;
   int         tiles_x;
   int         samples_done;

@@ -36,15 +36,15 @@ extern "C" {
 int yhk_trace(const yhd_scene*, const yhd_state*, int, yhd_counters*, int, hipStream_t);
 int yhk_block_threads(int shape);
 int yhk_trace_occupancy(int lds_bytes, int general, int shape);
-int yhk_trace_lds_bytes(int lds_node_count, int lds_scene_f4, int shape);
+int yhk_trace_lds_bytes(const yhd_scene* sc, int shape);
 int yhk_stack_entries(void);
 int yhk_wavefront(const yhd_scene*, const yhd_state*, int, const yhd_pool*, int k, int grid_blocks, hipStream_t);
 int yhk_wavefront_slots(int k);
-int yhk_wavefront_lds_bytes(int stack_entries, int lds_scene_f4, int k);
+int yhk_wavefront_lds_bytes(int stack_entries, int tables_f4, int k);
 int yhk_wavefront_occupancy(int lds_bytes, int general, int k);
 int yhk_stream(const yhd_scene*, const yhd_scene* sc_dev, const yhd_state*, int, const yhd_stream*, int grid_blocks, hipStream_t);
 int yhk_stream_block_threads(void);
-int yhk_stream_lds_bytes(int lds_scene_f4, int slots_per_wave);
+int yhk_stream_lds_bytes(int tables_f4, int slots_per_wave);
 int yhk_stream_occupancy(int lds_bytes, int general);
 int yhk_resolve(const yhd_state*, int, int, void*, hipStream_t);
 int yhk_pack(const yhd_state*, int, int, void*, hipStream_t);
@@ -259,7 +259,7 @@ struct yh_context {
   bool      have_scene = false;
   yhd_scene scene{};
   DevBuf    d_nodes, d_prims, d_vpos, d_elems, d_objects, d_materials, d_scene_nodes,
-      d_scene_prims, d_light_cdf, d_env_texels;
+      d_scene_prims, d_light_cdf, d_env_texels, d_light_table, d_env_tab;
   int       stack_need = 0;
   // state
   bool             have_state = false;
@@ -376,7 +376,7 @@ bool dense_by_costs(const yh_context* ctx, bool* known) {
     }
   *known = mx != 0;
   if (mx == 0) return false;
-  int    lds      = yhk_trace_lds_bytes(ctx->scene.lds_node_count, ctx->scene.lds_scene_f4, 0);
+  int    lds      = yhk_trace_lds_bytes(&ctx->scene, 0);
   double resident = (double)ctx->num_cus * std::max(1, yhk_trace_occupancy(lds, ctx->scene.general_materials, 0)) * (yhk_block_threads(0) / 64);
   if (getenv("YHAIR_TIMING")) fprintf(stderr, "[yhair] launch shape: worth %.0f items, resident waves %.0f\n", (double)sum / (double)mx, resident);
   return (double)sum / (double)mx >= resident;
@@ -387,7 +387,7 @@ int choose_launch_shape(const yh_context* ctx) {
   return dense_by_costs(ctx, &known) ? 1 : 0;
 }
 // Kernel for the next launch, chosen by MEASUREMENT (every kernel renders the same bits, so trying one costs
-// time only). k_trace at 512 x 4 suits launches bound by a few expensive pixels (C1), k_trace at 256 x 6 and the
+// time only). k_trace at 512 x 4 suits launches bound by a few expensive pixels (C1), k_trace at 256 x 5 and the
 // one-lane-per-path k_stream suit dense scenes, and which of those two wins depends on how many expensive pixels
 // there are per wave (straight-hair 720^2: a tie; curly-hair 1280^2: k_stream +39 %; hair-curls: k_trace 2.3x).
 // Each candidate runs one planned launch of at least 16 spp, then the fastest per sample stays. Sparse scenes
@@ -691,6 +691,7 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
   yhd_scene sc{};
   std::vector<float>      light_cdf;
   std::vector<yhd_float4> env_texels;
+  std::vector<int>        small_lights;  // lights whose record goes into the LDS light table
   for (int oi = 0; oi < sd->num_objects; oi++) {
     auto& o = sd->objects[oi];
     auto& m = sd->materials[o.material];
@@ -699,7 +700,9 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
     if (s.num_lines > 0 || s.num_triangles <= 0) continue;
     if (sc.num_lights >= YH_MAX_LIGHTS) return fail(ctx, YH_E_INVALID, "more than %d lights", YH_MAX_LIGHTS);
     auto& L = sc.lights[sc.num_lights++];
-    L.object = oi, L.environment = -1, L.cdf_base = (int)light_cdf.size(), L.cdf_count = s.num_triangles;
+    L.object = oi, L.environment = -1, L.cdf_base = (int)light_cdf.size(), L.cdf_count = s.num_triangles, L.small_base = -1;
+    if (s.num_triangles <= YH_SMALL_LIGHT_TRIS) small_lights.push_back(sc.num_lights - 1);  // its record is made below, once the cdf exists
+    else general_materials = 1;  // a light sampled and intersected through memory: the general kernel variant (dev_path.h: BIG_LIGHTS)
     for (int t = 0; t < s.num_triangles; t++) {
       F3 p0 = ld3(s.positions + 3 * (size_t)s.triangles[3 * t]), p1 = ld3(s.positions + 3 * (size_t)s.triangles[3 * t + 1]),
          p2 = ld3(s.positions + 3 * (size_t)s.triangles[3 * t + 2]);
@@ -724,7 +727,7 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
     if (e.emission[0] == 0 && e.emission[1] == 0 && e.emission[2] == 0) continue;
     if (sc.num_lights >= YH_MAX_LIGHTS) return fail(ctx, YH_E_INVALID, "more than %d lights", YH_MAX_LIGHTS);
     auto& L = sc.lights[sc.num_lights++];
-    L.object = -1, L.environment = ei, L.cdf_base = (int)light_cdf.size(), L.cdf_count = 0;
+    L.object = -1, L.environment = ei, L.cdf_base = (int)light_cdf.size(), L.cdf_count = 0, L.small_base = -1;
     if (e.texels) {
       size_t n    = (size_t)e.tex_width * e.tex_height;
       L.cdf_count = (int)n;
@@ -739,6 +742,35 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
     }
   }
   if (sc.num_lights == 0) return fail(ctx, YH_E_INVALID, "scene has no lights (the path sampler needs at least one)");
+  // ---- tables the kernels keep in LDS (yh_device.h) -----------------------------------------------------
+  // small area lights: root box, leaf-ordered triangles, area cdf — everything sample_lights / sample_lights_pdf read
+  std::vector<yhd_float4> light_table;
+  for (int li : small_lights) {
+    auto& L  = sc.lights[li];
+    auto& I  = info[sd->objects[L.object].shape];
+    const yhd_float4* rec = prims.data() + I.prim_base;
+    L.small_base = (int)light_table.size();
+    yhd_float4 b0{I.root.min[0], I.root.min[1], I.root.min[2], 0}, b1{I.root.max[0], I.root.max[1], I.root.max[2], light_cdf[(size_t)L.cdf_base + L.cdf_count - 1]};
+    memcpy(&b0.w, &L.cdf_count, 4);
+    light_table.push_back(b0), light_table.push_back(b1);
+    for (int t = 0; t < YH_SMALL_LIGHT_TRIS; t++)
+      for (int k = 0; k < 3; k++) light_table.push_back(t < L.cdf_count ? rec[6 * t + k] : yhd_float4{0, 0, 0, 0});
+    yhd_float4 cdf{0, 0, 0, 0};
+    for (int t = 0; t < L.cdf_count; t++) (&cdf.x)[t] = light_cdf[(size_t)L.cdf_base + t];
+    light_table.push_back(cdf);
+  }
+  // coarse index of the first textured environment light's cdf: 2048 entries (8 KB) halve the dependent fetches of
+  // its 21-step binary search
+  std::vector<float> env_tab;
+  sc.env_tab_light = -1, sc.env_tab_k = 0, sc.env_tab_stride = 0;
+  for (int li = 0; li < sc.num_lights && sc.env_tab_light < 0; li++) {
+    auto& L = sc.lights[li];
+    if (L.environment < 0 || L.cdf_count < 4096) continue;
+    const int n = L.cdf_count, S = (n + 2047) / 2048, K = (n + S - 1) / S;
+    env_tab.resize((size_t)K);
+    for (int k = 0; k < K; k++) env_tab[(size_t)k] = light_cdf[(size_t)L.cdf_base + (size_t)std::min<int64_t>(n, (int64_t)(k + 1) * S) - 1];
+    sc.env_tab_light = li, sc.env_tab_k = K, sc.env_tab_stride = S;
+  }
   // ---- material colour textures (lookup_texture's per-texel conversion done once, pt.cpp:147-164) --------
   std::vector<yhd_texture> textures((size_t)std::max(0, sd->num_textures));
   std::vector<yhd_float4>  tex_texels;
@@ -794,6 +826,8 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
   scene_prims_padded.resize((scene_prims_padded.size() + 3) / 4 * 4, 0);  // staged to LDS as float4
   if ((rc = upload(ctx, ctx->d_scene_prims, scene_prims_padded.data(), scene_prims_padded.size() * 4))) return rc;
   if ((rc = upload(ctx, ctx->d_light_cdf, light_cdf.data(), light_cdf.size() * 4))) return rc;
+  if ((rc = upload(ctx, ctx->d_light_table, light_table.data(), light_table.size() * 16))) return rc;
+  if ((rc = upload(ctx, ctx->d_env_tab, env_tab.data(), env_tab.size() * 4))) return rc;
   if ((rc = upload(ctx, ctx->d_env_texels, env_texels.data(), env_texels.size() * 16))) return rc;
   if ((rc = upload(ctx, ctx->d_textures, textures.data(), textures.size() * sizeof(yhd_texture)))) return rc;
   if ((rc = upload(ctx, ctx->d_tex_texels, tex_texels.data(), tex_texels.size() * 16))) return rc;
@@ -806,6 +840,9 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
   sc.scene_nodes = (const yhd_float4*)ctx->d_scene_nodes.p, sc.scene_prims = (const int*)ctx->d_scene_prims.p;
   sc.num_scene_nodes = (int)scene_tree.nodes.size(), sc.num_objects = sd->num_objects;
   sc.light_cdf = (const float*)ctx->d_light_cdf.p, sc.env_texels = (const yhd_float4*)ctx->d_env_texels.p;
+  sc.light_table = (const yhd_float4*)ctx->d_light_table.p, sc.light_table_f4 = (int)light_table.size();
+  sc.env_tab = (const float*)ctx->d_env_tab.p;
+  sc.stack_entries = std::max(8, (ctx->stack_need + 7) / 8 * 8);
   sc.textures = (const yhd_texture*)ctx->d_textures.p, sc.tex_texels = (const yhd_float4*)ctx->d_tex_texels.p;
   sc.vtex = (const float*)ctx->d_vtex.p;
   memcpy(sc.camera.frame, sd->camera.frame, 48);
@@ -825,7 +862,8 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
     int want = 0;  // LDS nodelets are optional (YHAIR_LDS_NODES): measured no gain once a step is a single fetch, see DESIGN.md
     if (const char* env = getenv("YHAIR_LDS_NODES")) want = std::max(0, atoi(env));
     // 128 B per nodelet next to the stacks and the scene table of the larger launch shape: stay inside the CU's 160 KB
-    int room = (160 * 1024 - yhk_trace_lds_bytes(0, sc.lds_scene_f4, 0)) / 128;
+    sc.lds_node_count = 0;
+    int room = (160 * 1024 - yhk_trace_lds_bytes(&sc, 0)) / 128;
     sc.lds_node_count = std::max(0, std::min({info[best_shape].num_nodes, want, room}));
   }
   ctx->scene      = sc;
@@ -963,7 +1001,7 @@ static int wavefront_impl(yh_context* ctx, int nsamples, bool sync) {
   if (const char* env = getenv("YHAIR_WF_SLOTS")) k = atoi(env) >= 2 ? 2 : 1;  // path slots per thread (developer switch)
   const int P         = yhk_wavefront_slots(k);
   const int stack     = std::max(8, (ctx->stack_need + 7) / 8 * 8);
-  const int lds_bytes = yhk_wavefront_lds_bytes(stack, ctx->scene.lds_scene_f4, k);
+  const int lds_bytes = yhk_wavefront_lds_bytes(stack, YHD_LDS_TABLES_F4(&ctx->scene), k);
   const int occupancy = yhk_wavefront_occupancy(lds_bytes, ctx->scene.general_materials, k);
   if (occupancy < 1) return fail(ctx, YH_E_DEVICE, "k_wavefront cannot run with %d bytes of LDS per block", lds_bytes);
   const int64_t pixels = (int64_t)ctx->state.num_tiles * 16;  // work items are 4x4 pixel quadrants
@@ -1014,7 +1052,7 @@ static int stream_geometry(const yh_context* ctx, int num_items, int* slots_per_
   const int64_t pixels = (int64_t)num_items * 16;  // work items are 4x4 pixel quadrants
   int           P      = (int)std::max<int64_t>(128, std::min<int64_t>(192, (pixels / ((int64_t)ctx->num_cus * 16) + 63) / 64 * 64));
   if (const char* env = getenv("YHAIR_ST_SLOTS")) P = std::max(64, std::min(4096, atoi(env) / 64 * 64));
-  const int lds_bytes = yhk_stream_lds_bytes(ctx->scene.lds_scene_f4, P);
+  const int lds_bytes = yhk_stream_lds_bytes(YHD_LDS_TABLES_F4(&ctx->scene), P);
   int       occupancy = yhk_stream_occupancy(lds_bytes, ctx->scene.general_materials);
   if (occupancy < 1) return 0;
   if (const char* env = getenv("YHAIR_ST_WAVES")) occupancy = std::max(1, std::min(occupancy, (atoi(env) + wpb - 1) / wpb));  // waves per CU
@@ -1135,7 +1173,7 @@ static int trace_impl(yh_context* ctx, int nsamples, bool counted, bool sync) {
   if (shape == 2) return wavefront_impl(ctx, nsamples, sync);
   if (shape == 3) return stream_impl(ctx, nsamples, sync);
   int waves_per_block = yhk_block_threads(shape) / 64;  // one work item per wave at a time
-  int lds_bytes       = yhk_trace_lds_bytes(ctx->scene.lds_node_count, ctx->scene.lds_scene_f4, shape);
+  int lds_bytes       = yhk_trace_lds_bytes(&ctx->scene, shape);
   int occupancy       = yhk_trace_occupancy(lds_bytes, ctx->scene.general_materials, shape);
   if (occupancy < 1) return fail(ctx, YH_E_DEVICE, "k_trace cannot run with %d bytes of LDS per block", lds_bytes);
   int resident        = ctx->num_cus * occupancy;
