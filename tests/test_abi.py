@@ -153,3 +153,17 @@ def test_host_bvh_is_the_reference_tree(yh, oracle, name, kw):
         lib.yh_bvh_build(len(boxes), yh.fptr(boxes), yh.fptr(nodes2), None)
         assert np.array_equal(nodes.view(np.uint32), nodes2.view(np.uint32))
     osc.close(), sf.close()
+
+
+def test_traversal_loops_do_not_spill():
+    """The traversal loop of the product kernels (plain k_trace in both launch shapes, plain k_stream) must not contain
+    scratch instructions: a spill reload there stalls every step of every ray (0.75-0.8x on the dense configs), and
+    whether the register allocator puts one there flips with unrelated edits of the shading code (profiles/r02).
+    tools/check_codegen.py compiles the kernels to gfx950 assembly (no GPU needed) and looks."""
+    import shutil
+    import subprocess
+    import sys
+    if not (os.path.exists("/opt/rocm/bin/hipcc") or shutil.which("hipcc")):
+        pytest.skip("no hipcc")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_codegen.py"), "--strict"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr

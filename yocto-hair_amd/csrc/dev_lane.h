@@ -269,7 +269,7 @@ __device__ __attribute__((noinline)) lane_exact_result lane_trace_exact(const yh
     YH_LDS unsigned int* lds, unsigned int* ovf, int sp, int base, f3 ro, f3 rd, int first_object) {
   trace_ctx tc;
   tc.sc = sc, tc.lds_nodes = nullptr, tc.lds_stack = nullptr, tc.lds_scene = lds_scene, tc.stats = nullptr, tc.ls = nullptr, tc.sc_dev = sc;
-  tc.lds_lights = nullptr, tc.lds_envtab = nullptr;
+  tc.lds_lights = nullptr, tc.lds_envtab = nullptr, tc.lds_mats = nullptr;
   lane_stack s;
   s.lds = lds, s.ovf = ovf, s.sp = sp, s.base = base;
   lane_trav t;

@@ -194,6 +194,7 @@ struct trace_ctx {
   struct stats_t*       stats;      // per-lane work counters of the instrumented build, else NULL
   const YH_LDS v4f*     lds_lights; // LDS copy of sc.light_table (small area lights), or nullptr
   const YH_LDS float*   lds_envtab; // LDS copy of sc.env_tab (coarse index of an environment's texel cdf), or nullptr
+  const YH_LDS v4f*     lds_mats;   // LDS copy of sc.materials (YH_MATERIAL_F4 float4 each), or nullptr
   lane_stack*           ls;         // one lane per path (YH_LANE, dev_lane.h): this lane's stack, else unused
   const yhd_scene*      sc_dev;     // YH_LANE: a copy of *sc in device memory, for out-of-line callees (the kernel
                                     // argument itself must not have its address escape: it would be copied to scratch)
@@ -202,7 +203,7 @@ struct trace_ctx {
 // fits), the camera, the small area lights and the environment cdf index — at `at` (YHD_LDS_TABLES_F4 float4) and
 // points `tc` at them. All threads of the block call it; a __syncthreads() must follow.
 YH_DEV void stage_tables(const yhd_scene& sc, YH_LDS v4f* at, int tid, int nthreads, trace_ctx& tc, YH_LDS float*& lds_cam) {
-  tc.lds_scene = nullptr, tc.lds_lights = nullptr, tc.lds_envtab = nullptr;
+  tc.lds_scene = nullptr, tc.lds_lights = nullptr, tc.lds_envtab = nullptr, tc.lds_mats = nullptr;
   if (sc.lds_scene_f4 > 0) {
     const int  nobj = YH_OBJECT_F4 * sc.num_objects, nnod = 2 * sc.num_scene_nodes, npri = (sc.num_objects + 3) / 4;
     const v4f* gobj = (const v4f*)sc.objects;
@@ -224,6 +225,13 @@ YH_DEV void stage_tables(const yhd_scene& sc, YH_LDS v4f* at, int tid, int nthre
   if (sc.env_tab_k > 0) {
     for (int i = tid; i < sc.env_tab_k; i += nthreads) envtab[i] = sc.env_tab[i];
     tc.lds_envtab = envtab;
+  }
+  // the material table: per-material hair constants and surface parameters, read by every shaded hit
+  YH_LDS v4f* mats = (YH_LDS v4f*)(envtab + (sc.env_tab_k + 3) / 4 * 4);
+  if (sc.lds_materials > 0) {
+    const v4f* gm = (const v4f*)sc.materials;
+    for (int i = tid; i < YH_MATERIAL_F4 * sc.lds_materials; i += nthreads) mats[i] = gm[i];
+    tc.lds_mats = mats;
   }
 }
 

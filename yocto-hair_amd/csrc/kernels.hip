@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256) void k_intersect(const yhd_scene sc, int n, co
   bool valid = i < n;
   if (!valid) i = n - 1;  // whole quads stay converged; surplus quads redo the last ray
   trace_ctx tc;
-  tc.sc = &sc, tc.lds_nodes = nullptr, tc.stats = nullptr, tc.lds_scene = nullptr, tc.ls = nullptr, tc.sc_dev = nullptr, tc.lds_lights = nullptr, tc.lds_envtab = nullptr;
+  tc.sc = &sc, tc.lds_nodes = nullptr, tc.stats = nullptr, tc.lds_scene = nullptr, tc.ls = nullptr, tc.sc_dev = nullptr, tc.lds_lights = nullptr, tc.lds_envtab = nullptr, tc.lds_mats = nullptr;
   tc.lds_stack   = (YH_LDS unsigned int*)stacks + (threadIdx.x >> 2);
   const float* r = rays + 8 * (size_t)i;
   ray_t ray      = ray_t{ld3(r), ld3(r + 3), r[6], r[7]};

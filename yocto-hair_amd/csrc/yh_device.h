@@ -169,9 +169,11 @@ typedef struct yhd_scene {
   const float*      env_tab;
   int               env_tab_light;   // index into lights[], -1: none
   int               env_tab_k, env_tab_stride;
+  int               lds_materials;   // materials staged in LDS (all of them, or 0 when they are too many)
 } yhd_scene;
-// float4 the kernels reserve in LDS for the tables: scene level | camera (5) | small lights | env cdf index
-#define YHD_LDS_TABLES_F4(sc) ((sc)->lds_scene_f4 + 5 + (sc)->light_table_f4 + ((sc)->env_tab_k + 3) / 4)
+#define YH_MATERIAL_F4 17 /* sizeof(yhd_material) / 16 */
+// float4 the kernels reserve in LDS for the tables: scene level | camera (5) | small lights | env cdf index | materials
+#define YHD_LDS_TABLES_F4(sc) ((sc)->lds_scene_f4 + 5 + (sc)->light_table_f4 + ((sc)->env_tab_k + 3) / 4 + YH_MATERIAL_F4 * (sc)->lds_materials)
 
 // Render state (pt.h:419-429) in SoA form.
 typedef struct yhd_state {

@@ -856,6 +856,11 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
     int f4 = YH_OBJECT_F4 * sd->num_objects + 2 * (int)scene_tree.nodes.size() + (sd->num_objects + 3) / 4;
     sc.lds_scene_f4 = f4 * 16 <= 8192 ? f4 : 0;
   }
+  {  // the material table in LDS; the plain kernel variants rely on it and on the scene-level table (dev_path.h)
+    static_assert(sizeof(yhd_material) == 16 * YH_MATERIAL_F4, "yhd_material is staged to LDS as float4");
+    sc.lds_materials = sd->num_materials <= 24 ? sd->num_materials : 0;
+    if (sc.lds_materials == 0 || sc.lds_scene_f4 == 0) sc.general_materials = 1;
+  }
   sc.lds_node_base = 0, sc.lds_node_count = 0;
   if (best_shape >= 0) {
     sc.lds_node_base  = info[best_shape].node_base;
