@@ -80,6 +80,10 @@ YH_DEV void trace_items(const yhd_scene& sc, const yhd_state& st, int nsamples, 
     if (lane == 0) t = atomicAdd(st.tile_cursor, 1);
     t = __builtin_amdgcn_readfirstlane(t);
     if (t >= st.num_tiles) break;
+#ifdef YH_PRIO /* developer A/B switch: issue priority for the waves that hold the most expensive items (the head of the cost-sorted list) */
+    if (t < st.num_tiles / YH_PRIO) __builtin_amdgcn_s_setprio(3);
+    else __builtin_amdgcn_s_setprio(0);
+#endif
     unsigned long long t0 = wall_clock64();
     int  item  = st.tiles[t];
     int  tile  = item >> 2, part = item & 3;
