@@ -1,11 +1,14 @@
 // kernels.hip — gfx950 kernels of the hair path and their launchers.
 //
-//   k_trace          the sample loop (trace_samples, pt.cpp:1992-2007): persistent
-//                    wavefronts pull 4x4-pixel work items (most expensive first);
-//                    a QUAD of four lanes owns one pixel / one path (its PCG32
-//                    stream is sequential) and splits BVH steps and hair lobes
-//                    over its lanes; traversal stacks, the scene-level tables and
-//                    the camera live in LDS (nodelets optional, YHAIR_LDS_NODES).
+//   k_trace          the sample loop (trace_samples, pt.cpp:1992-2007) with a QUAD per path: persistent
+//                    wavefronts pull 4x4-pixel work items (most expensive first); four adjacent lanes own one
+//                    pixel / one path (its PCG32 stream is sequential) and split BVH steps and hair lobes over
+//                    their lanes. In LDS: the traversal stacks (one column per quad, sized by the scene's
+//                    need) and the tables of dev_trace.h: stage_tables — scene level, camera, small area
+//                    lights, the index of the environment cdf, the material table (nodelets optional,
+//                    YHAIR_LDS_NODES). Two launch shapes: 512 threads x 4 waves per SIMD, 256 x 5.
+//                    The other sample-loop kernels: csrc/stream.hip (k_stream, one lane per path),
+//                    csrc/wavefront.hip (k_wavefront, staged per workgroup); the host picks per launch.
 //   k_hair_*         unit-level batches of the four yocto::extension functions
 //   k_intersect      unit-level closest-hit batch
 //   k_selftest       the four Monte-Carlo self-tests (ext.cpp:555-693), made
@@ -46,8 +49,8 @@ using namespace yhd;
 // GENERAL = the scene has materials with lobes beyond diffuse / hair (dev_surface.h); scenes
 // without them (all BASELINE configs) run the variant that does not carry that code.
 // BLOCK x WAVES = the launch shape: 512 threads at 4 waves per SIMD (128 VGPRs) when the launch is
-// bound by a few expensive pixels (C1), 256 threads at 6 waves per SIMD (80 VGPRs, more spills but
-// more latency hiding) when every pixel is expensive (dense hair: +5-10 %, profiles/r01); the host picks.
+// bound by a few expensive pixels (C1), 256 threads at 5 waves per SIMD (96 VGPRs, more latency hiding)
+// when many pixels are expensive (dense hair: +5-10 %, profiles/r01, r02); the host picks by measurement.
 // SHADER = the reference's shader_type (YH_SHADER_*): trace_path is the product path (k_trace), the
 // preview / debug shaders (naive, eyelight, normal) share everything but the bounce step (k_trace_shader).
 template <bool COUNT, bool GENERAL, int BLOCK, int SHADER>
