@@ -315,8 +315,10 @@ def main():
         try:
             allp = json.load(open(os.path.join(ROOT, "profiles", "k_trace_traffic.json")))
             allp = allp if isinstance(allp, list) else [allp]
-            for cand in allp:
-                if (cand["scene"], cand["resolution"], cand["scale"]) == (scene_name, res_main, a.scale) and world == 1 and not scene_kw:
+            pmc_kernel = {0: "k_trace<false, false, 512, 4>", 1: "k_trace<false, false, 256, 5>", 3: "k_stream"}.get(shape_used, "?")
+            for cand in allp:  # the passes were taken on one kernel: they describe this run only if it chose the same one
+                if (cand["scene"], cand["resolution"], cand["scale"]) == (scene_name, res_main, a.scale) and world == 1 and not scene_kw \
+                        and cand.get("kernel", pmc_kernel) == pmc_kernel:
                     pmc = cand
             if pmc:
                 scale_spp = spp_launch / pmc["spp_per_launch"]  # traffic is proportional to the samples of a launch
@@ -329,6 +331,7 @@ def main():
             issue, lanes = pmc.get("valu_issue_fraction"), pmc.get("valu_lane_utilisation")
             valu = {"bound": "valu", "issue_fraction": issue, "lane_utilisation": lanes,
                     "achieved": round(issue * lanes, 4) if issue and lanes else None, "peak": 1.0, "unit": "share of vector lane-cycles doing work",
+                    "simd_busy": pmc.get("valu_simd_busy_at_2GHz"),
                     "wait_fraction": pmc.get("wait_any_fraction"), "l2_hit_rate": pmc.get("l2_hit_rate"), "source": pmc.get("source")}
         scaling = "weak" if (a.weak or world == 1) else "strong"
         if headline:

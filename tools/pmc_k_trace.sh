@@ -21,14 +21,16 @@ out = sys.argv[1]
 res = {}
 for d in sorted(glob.glob(out + "/p*/")):
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
-        acc, cnt = collections.defaultdict(float), collections.defaultdict(set)
+        per = collections.defaultdict(lambda: collections.defaultdict(float))  # counter -> dispatch -> value
         for r in csv.DictReader(open(f)):
             if sys.argv[2] not in r["Kernel_Name"]:  # the launch shape of the config under test only
                 continue
-            acc[r["Counter_Name"]] += float(r["Counter_Value"])
-            cnt[r["Counter_Name"]].add(r["Dispatch_Id"])
-        for k in acc:
-            res[k] = acc[k] / max(1, len(cnt[k]))
+            per[r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
+        for k, d in per.items():
+            vals = sorted(d.values())
+            med = vals[len(vals) // 2]
+            full = [v for v in vals if v >= 0.2 * med]  # without the 1-spp probe launch of yh_init_state
+            res[k] = sum(full) / max(1, len(full))
 json.dump(res, open(out + "/k_trace_pmc.json", "w"), indent=1)
 print(json.dumps(res, indent=1))
 PY
