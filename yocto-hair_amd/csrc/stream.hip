@@ -125,6 +125,7 @@ __global__ __launch_bounds__(YH_ST_BLOCK, WAVES) void k_stream(const yhd_scene s
   // lists (wave-uniform counts) and the ray this lane holds
   int       n_ray = 0, n_done = 0, n_hair = 0, n_surf = 0, n_fin = 0, n_free = P;
   int       n_hair_done = 0;  // hair hits among the entries of the done list
+  int       my_group = (int)(blockIdx.x % (unsigned)st.num_groups), groups_done = 0;  // item group being taken from (yh_device.h)
   bool      nomore = false;
   bool      have = false;
   int       slot = 0;
@@ -163,11 +164,18 @@ __global__ __launch_bounds__(YH_ST_BLOCK, WAVES) void k_stream(const yhd_scene s
 
     if (act == A_ITEMS) {
       // ---- items: free slots take the pixels of the next work items (4 items = 64 pixels) ------------------
-      int t0 = 0;
-      if (lane == 0) t0 = atomicAdd(st.tile_cursor, 4);
-      t0            = __builtin_amdgcn_readfirstlane(t0);
-      const int got = max(0, min(4, st.num_tiles - t0));
-      if (got < 4) nomore = true;
+      // the next items of this workgroup's group (its XCD's image region); a group that is used up hands over to the next
+      int t0 = 0, got = 0;
+      while (true) {
+        int c = 0;
+        if (lane == 0) c = atomicAdd(st.tile_cursor + 16 * my_group, 4);
+        c   = __builtin_amdgcn_readfirstlane(c);
+        t0  = st.group_begin[my_group] + c;
+        got = max(0, min(4, st.group_begin[my_group + 1] - t0));
+        if (got > 0 || ++groups_done >= st.num_groups) break;
+        my_group = (my_group + 1) % st.num_groups;
+      }
+      if (got == 0) nomore = true;
       int pixel = -1, item = 0;
       if (lane < 16 * got) {
         item     = st.tiles[t0 + (lane >> 4)];

@@ -183,7 +183,14 @@ typedef struct yhd_state {
   // Work items of a launch, in hand-out order: item = tile id * 4 + quadrant
   // (one 4x4-pixel quadrant of an 8x8 tile = 16 quads = one wavefront).
   const int*  tiles;
-  int*        tile_cursor;  // next position in `tiles` (zeroed before every launch)
+  int*        tile_cursor;  // next position in `tiles` (zeroed before every launch); k_stream: one cursor per item
+                            // group, 16 ints apart
+  // k_stream: the hand-out list in `num_groups` groups, group g = tiles[group_begin[g] .. group_begin[g + 1]).
+  // Workgroups are placed round-robin over the 8 XCDs, each with an L2 of its own: the workgroups of one XCD
+  // (blockIdx % 8) take the items of ONE compact image region, so that what an XCD's L2 holds is the part of the
+  // scene behind that region and not an eighth of everything; a group that runs dry takes from the next.
+  int         num_groups;
+  int         group_begin[9];
   unsigned int* tile_cost;  // per item: wall-clock ticks (100 MHz) its last launch took
   int         num_tiles;  // number of work items in `tiles`
   int         shader;        // YH_SHADER_* (yhair.h): path is the product path, the others preview / debug

@@ -441,7 +441,7 @@ void build_work_items(const yh_context* ctx, std::vector<int>& items) {
 
 extern "C" {
 
-static void deal_items_for_stream(const yh_context* ctx, std::vector<int>& items);
+static void deal_items_for_stream(yh_context* ctx, std::vector<int>& items);
 static int  trace_impl(yh_context* ctx, int nsamples, bool counted, bool sync);
 
 const char* yh_version(void) { return "yhair 0.1 (gfx950, HIP)"; }
@@ -932,6 +932,7 @@ int yh_init_state(yh_context* ctx, const yh_trace_params* params) {
   std::vector<int> tiles;
   build_work_items(ctx, tiles);
   const int first_shape = getenv("YHAIR_SHAPE") ? choose_launch_shape(ctx) : ctx->launch_shape;
+  ctx->state.tiles_x = tx, ctx->state.num_groups = 1, ctx->state.group_begin[0] = 0, ctx->state.group_begin[1] = (int)tiles.size();
   if (params->shader == YH_SHADER_PATH && first_shape == 3) deal_items_for_stream(ctx, tiles);
   int rc;
   if ((rc = upload(ctx, ctx->d_rng_state, st.data(), npix * 8))) return rc;
@@ -940,7 +941,7 @@ int yh_init_state(yh_context* ctx, const yh_trace_params* params) {
   if ((rc = alloc_zero(ctx, ctx->d_image, npix * 16))) return rc;
   if ((rc = upload(ctx, ctx->d_tiles, tiles.data(), tiles.size() * 4))) return rc;
   if ((rc = alloc_zero(ctx, ctx->d_counters, sizeof(yhd_counters)))) return rc;
-  if ((rc = alloc_zero(ctx, ctx->d_tile_cursor, 4))) return rc;
+  if ((rc = alloc_zero(ctx, ctx->d_tile_cursor, 8 * 16 * 4))) return rc;  // one cursor, or k_stream's one per item group 64 bytes apart
   if ((rc = alloc_zero(ctx, ctx->d_tile_cost, (size_t)ctx->num_tiles_total * 16))) return rc;
   auto& s = ctx->state;
   s.tile_cursor = (int*)ctx->d_tile_cursor.p, s.tile_cost = (unsigned int*)ctx->d_tile_cost.p;
@@ -995,6 +996,7 @@ static int replan_after_launch(yh_context* ctx, int nsamples) {
   if (!refresh && ctx->state.launch_shape == before) return YH_OK;
   std::vector<int> tiles;  // (the hand-out order depends on the kernel: k_stream's items are dealt, not queued)
   build_work_items(ctx, tiles);
+  ctx->state.num_groups = 1, ctx->state.group_begin[0] = 0, ctx->state.group_begin[1] = (int)tiles.size();
   if (ctx->state.shader == YH_SHADER_PATH && ctx->state.launch_shape == 3) deal_items_for_stream(ctx, tiles);
   HIPCHK(ctx, hipMemcpy(ctx->d_tiles.p, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice));
   return YH_OK;
@@ -1032,7 +1034,7 @@ static int wavefront_impl(yh_context* ctx, int nsamples, bool sync) {
     ctx->pool.medium       = (yhd_float4*)ctx->d_pool_medium.p;
   }
   ctx->pool.slots_per_block = P, ctx->pool.stack_entries = stack;
-  HIPCHK(ctx, hipMemsetAsync(ctx->d_tile_cursor.p, 0, 4, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(ctx->d_tile_cursor.p, 0, 8 * 16 * 4, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(ctx->d_tile_cost.p, 0, (size_t)ctx->num_tiles_total * 16, ctx->stream));
   HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   int e = yhk_wavefront(&ctx->scene, &ctx->state, nsamples, &ctx->pool, k, grid, ctx->stream);
@@ -1074,14 +1076,9 @@ static int stream_geometry(const yh_context* ctx, int num_items, int* slots_per_
 // and bound the launch (sparse hair: C1, C4). So each block of R takes is dealt like cards: take c holds one item
 // of each quarter of the block, and consecutive takes are spread over the block by a golden-ratio stride — every
 // wave gets a uniform sample of the costs, expensive blocks still come first.
-static void deal_items_for_stream(const yh_context* ctx, std::vector<int>& items) {
-  int P = 0, grid = 0;
-  if (items.empty() || !stream_geometry(ctx, (int)items.size(), &P, &grid, nullptr)) return;
-  const size_t R = (size_t)grid * (yhk_stream_block_threads() / 64) * (size_t)(P / 64);  // takes resident together
-  std::vector<int> out;
-  out.reserve(items.size());
-  for (size_t b0 = 0; b0 < items.size(); b0 += 4 * R) {
-    const size_t M  = std::min(items.size() - b0, 4 * R);
+static void deal_block(std::vector<int>& out, const int* items, size_t n, size_t R) {
+  for (size_t b0 = 0; b0 < n; b0 += 4 * R) {
+    const size_t M  = std::min(n - b0, 4 * R);
     const size_t Rb = (M + 3) / 4;  // takes in this block
     size_t       A  = std::max<size_t>(1, (size_t)(0.6180339887 * (double)Rb));
     auto gcd = [](size_t a, size_t b) { while (b) { size_t t = a % b; a = b, b = t; } return a; };
@@ -1091,6 +1088,57 @@ static void deal_items_for_stream(const yh_context* ctx, std::vector<int>& items
       for (size_t k = 0; k < 4; k++)
         if (cp + k * Rb < M) out.push_back(items[b0 + cp + k * Rb]);
     }
+  }
+}
+static void deal_items_for_stream(yh_context* ctx, std::vector<int>& items) {
+  int P = 0, grid = 0;
+  ctx->state.num_groups = 1, ctx->state.group_begin[0] = 0, ctx->state.group_begin[1] = (int)items.size();
+  if (items.empty() || !stream_geometry(ctx, (int)items.size(), &P, &grid, nullptr)) return;
+  const size_t R = (size_t)grid * (yhk_stream_block_threads() / 64) * (size_t)(P / 64);  // takes resident together
+  // Groups: one compact image region per XCD (yh_device.h: yhd_state::group_begin). The items in Morton order of
+  // their tiles, cut into G runs of equal cost; inside a run the dealing above. MEASURED WITHOUT GAIN, so off by
+  // default (G = 1; YHAIR_ST_GROUPS=8 turns it on): C3 296 -> 300 Msamples/s, C2 237 -> 222 (the regions' costs drift
+  // apart during a launch), C4 unchanged (profiles/r02/k_stream_xcd_groups.txt) — after the first bounce the rays of
+  // a region wander through the hair, and 4 MB of L2 hold little of a region's 40 MB anyway.
+  int G = 1;
+  if (const char* env = getenv("YHAIR_ST_GROUPS")) G = std::max(1, std::min(8, atoi(env)));
+  if ((size_t)G * 64 > items.size()) G = 1;
+  std::vector<int> out;
+  out.reserve(items.size());
+  if (G == 1) {
+    deal_block(out, items.data(), items.size(), R);
+  } else {
+    auto morton = [&](int item) -> uint64_t {
+      const int tile = item >> 2, tx = tile % ctx->state.tiles_x, ty = tile / ctx->state.tiles_x;
+      const unsigned x = (unsigned)(2 * tx + (item & 1)), y = (unsigned)(2 * ty + ((item >> 1) & 1));  // 4x4-pixel quadrant coordinates
+      uint64_t m = 0;
+      for (int b = 0; b < 16; b++) m |= ((uint64_t)((x >> b) & 1) << (2 * b)) | ((uint64_t)((y >> b) & 1) << (2 * b + 1));
+      return m;
+    };
+    std::vector<std::pair<uint64_t, int>> order;  // (morton, rank in the cost-sorted list)
+    order.reserve(items.size());
+    for (size_t i = 0; i < items.size(); i++) order.push_back({morton(items[i]), (int)i});
+    std::sort(order.begin(), order.end());
+    double total = 0;
+    for (int it : items) total += 1.0 + (double)ctx->item_cost[(size_t)it];
+    size_t at = 0;
+    double acc = 0;
+    for (int g = 0; g < G; g++) {
+      std::vector<int> ranks;  // this group's items, by rank in the cost-sorted list (= most expensive first)
+      const double upto = total * (g + 1) / G;
+      while (at < order.size() && (g == G - 1 || acc < upto)) {
+        acc += 1.0 + (double)ctx->item_cost[(size_t)items[(size_t)order[at].second]];
+        ranks.push_back(order[at].second);
+        at++;
+      }
+      std::sort(ranks.begin(), ranks.end());
+      std::vector<int> grp;
+      grp.reserve(ranks.size());
+      for (int r : ranks) grp.push_back(items[(size_t)r]);
+      ctx->state.group_begin[g] = (int)out.size();
+      deal_block(out, grp.data(), grp.size(), std::max<size_t>(1, R / G));
+    }
+    ctx->state.num_groups = G, ctx->state.group_begin[G] = (int)out.size();
   }
   items.swap(out);
 }
@@ -1131,7 +1179,7 @@ static int stream_impl(yh_context* ctx, int nsamples, bool sync) {
   if (!ctx->d_scene_copy.p) {  // the scene table in device memory, for the kernel's out-of-line callees
     if ((rc = upload(ctx, ctx->d_scene_copy, &ctx->scene, sizeof(yhd_scene)))) return rc;
   }
-  HIPCHK(ctx, hipMemsetAsync(ctx->d_tile_cursor.p, 0, 4, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(ctx->d_tile_cursor.p, 0, 8 * 16 * 4, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(ctx->d_tile_cost.p, 0, (size_t)ctx->num_tiles_total * 16, ctx->stream));
   HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   int e = yhk_stream(&ctx->scene, (const yhd_scene*)ctx->d_scene_copy.p, &ctx->state, nsamples, &ctx->stream_pool, grid, ctx->stream);
@@ -1184,7 +1232,7 @@ static int trace_impl(yh_context* ctx, int nsamples, bool counted, bool sync) {
   int resident        = ctx->num_cus * occupancy;
   int want            = (ctx->state.num_tiles + waves_per_block - 1) / waves_per_block;
   int grid            = std::max(1, std::min(want, resident));
-  HIPCHK(ctx, hipMemsetAsync(ctx->d_tile_cursor.p, 0, 4, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(ctx->d_tile_cursor.p, 0, 8 * 16 * 4, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(ctx->d_tile_cost.p, 0, (size_t)ctx->num_tiles_total * 16, ctx->stream));
   HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   int e = yhk_trace(&ctx->scene, &ctx->state, nsamples, counted ? (yhd_counters*)ctx->d_counters.p : nullptr, grid,
