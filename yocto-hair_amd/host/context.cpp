@@ -354,7 +354,7 @@ int tiles_of(int n) { return (n + YH_TILE - 1) / YH_TILE; }
 // current split modes, most expensive first.
 void build_work_items(const yh_context* ctx, std::vector<int>& items);
 int  choose_launch_shape(const yh_context* ctx);
-int  next_launch_shape(yh_context* ctx, int nsamples);
+int  next_launch_shape(yh_context* ctx, int nsamples, bool fresh_costs);
 
 }  // namespace
 
@@ -392,12 +392,12 @@ int choose_launch_shape(const yh_context* ctx) {
 // there are per wave (straight-hair 720^2: a tie; curly-hair 1280^2: k_stream +39 %; hair-curls: k_trace 2.3x).
 // Each candidate runs one planned launch of at least 16 spp, then the fastest per sample stays. Sparse scenes
 // never try k_stream: it would cost them several times a launch.
-int next_launch_shape(yh_context* ctx, int nsamples) {
+int next_launch_shape(yh_context* ctx, int nsamples, bool fresh_costs) {
   if (const char* env = getenv("YHAIR_SHAPE")) return std::max(0, std::min(3, atoi(env)));
   if (nsamples < 16) return ctx->launch_shape;  // short launches have flat, noisy costs: keep what is known
   const int last = ctx->last_shape;
   if (ctx->have_costs && last >= 0 && last < 4 && ctx->last_ms > 0) ctx->shape_ms[last] = (double)ctx->last_ms / nsamples;
-  if (last == 0 || last == 1 || ctx->dense < 0) {
+  if (fresh_costs && (last == 0 || last == 1 || ctx->dense < 0)) {  // (only when the item costs have just been read back)
     bool known = false, d = dense_by_costs(ctx, &known);
     if (known && (last == 0 || last == 1)) ctx->dense = d ? 1 : 0;
   }
@@ -991,7 +991,7 @@ static int replan_after_launch(yh_context* ctx, int nsamples) {
   const bool     refresh = (li & (li - 1)) == 0;
   const int      before  = ctx->state.launch_shape;
   if (refresh) HIPCHK(ctx, hipMemcpy(ctx->item_cost.data(), ctx->d_tile_cost.p, ctx->item_cost.size() * 4, hipMemcpyDeviceToHost));
-  if (ctx->state.shader == YH_SHADER_PATH && (refresh || ctx->have_costs)) ctx->launch_shape = next_launch_shape(ctx, nsamples);
+  if (ctx->state.shader == YH_SHADER_PATH && (refresh || ctx->have_costs)) ctx->launch_shape = next_launch_shape(ctx, nsamples, refresh);
   ctx->state.launch_shape = ctx->launch_shape;
   if (!refresh && ctx->state.launch_shape == before) return YH_OK;
   std::vector<int> tiles;  // (the hand-out order depends on the kernel: k_stream's items are dealt, not queued)
