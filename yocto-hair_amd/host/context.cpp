@@ -359,13 +359,13 @@ int  next_launch_shape(yh_context* ctx, int nsamples, bool fresh_costs);
 }  // namespace
 
 namespace {
-// Launch shape for the next launch (kernels.hip: k_trace's BLOCK x WAVES). When every pixel is
-// expensive the kernel is latency-bound and six waves per SIMD pay for their extra spills
-// (C2 +19 %, C3 +7-20 %, C4 +2-5 % over four); when a few expensive pixels bound the launch (C1: the hair covers
-// 11 % of the frame and barely fills the resident waves) it costs 11 %. Measure: the number of
+// Dense or sparse? When every pixel is expensive the quad kernel is latency-bound and more waves per SIMD pay
+// (k_trace 256 x 5: C2 +19 %, C4 +10 % over 512 x 4); when a few expensive pixels bound the launch (C1: the hair covers
+// 11 % of the frame and barely fills the resident waves) they cost 11 %. Measure: the number of
 // max-cost work items the last launch was worth (sum of item costs over the largest) against the
 // resident wave slots — measured 3 066 (C1), 4 777 (C4), 8 989 (C2), 24 970 (C3) against 4 096: with
-// fewer expensive items than slots every wave that can run already does. YHAIR_SHAPE=0|1 overrides.
+// fewer expensive items than slots every wave that can run already does. This only picks the CANDIDATES; which
+// kernel runs is measured (next_launch_shape). YHAIR_SHAPE=0..3 overrides.
 // Is the launch worth more max-cost work items than there are resident waves? (item costs of a k_trace launch)
 bool dense_by_costs(const yh_context* ctx, bool* known) {
   uint64_t sum = 0, mx = 0;
