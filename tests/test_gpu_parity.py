@@ -691,8 +691,9 @@ def test_per_pixel_error_within_k_sigma(ctx, oracle, yh, name, kw):
 
 
 @pytest.mark.parametrize("name,kw", [("sphere-hairblock", dict(scale=0.05, zoom=True)), ("straight-hair", dict(scale=0.05)),
-                                     ("hair-curls", dict(scale=0.05)), ("lobes", dict(scale=0.05))],
-                         ids=["sphere-hairblock", "straight-hair", "hair-curls", "lobes"])
+                                     ("hair-curls", dict(scale=0.05)), ("lobes", dict(scale=0.05)),
+                                     ("lights-unit", dict(scale=0.05, biglight=True))],
+                         ids=["sphere-hairblock", "straight-hair", "hair-curls", "lobes", "big-light"])
 def test_launch_shapes_and_kernels_render_identical_pixels(ctx, yh, name, kw, monkeypatch):
     """The host picks the integrator kernel — k_trace at 512 x 4 or at 256 x 5 (single-predicate line test),
     the staged k_wavefront (csrc/wavefront.hip) or the one-lane-per-path k_stream (csrc/stream.hip) — from the previous launch's item costs, so which kernel
@@ -771,12 +772,15 @@ def test_baseline_configs_at_full_size(ctx, oracle, yh, tag, name, kw, res):
     osc.close(), sf.close()
 
 
-def test_light_sampling_matches_oracle_at_unit_level(ctx, oracle, yh):
+@pytest.mark.parametrize("biglight", [False, True], ids=["small-lights-in-lds", "big-light-through-the-bvh"])
+def test_light_sampling_matches_oracle_at_unit_level(ctx, oracle, yh, biglight):
     """a20 (sample_lights / sample_lights_pdf, pt.cpp:1283-1358) isolated from the BSDF: a scene whose
     only surfaces are diffuse (no hair, so no libm-driven divergence before the light code runs) under
     two area lights and the textured sky, at 1 bounce: every radiance value is emission + one
-    MIS-weighted light / BRDF sample, i.e. sample_lights, the env-CDF upper_bound and both pdf branches."""
-    sf = yh.SceneFile(scene_path("lights-unit", scale=0.05))
+    MIS-weighted light / BRDF sample, i.e. sample_lights, the env-CDF upper_bound and both pdf branches.
+    Both light paths of the kernels: quads of two triangles (their records staged in LDS, no traversal) and,
+    with `biglight`, an 18-triangle light that is sampled and intersected through memory (GENERAL variants)."""
+    sf = yh.SceneFile(scene_path("lights-unit", scale=0.05, biglight=biglight))
     ctx.upload_scene(sf.desc)
     osc = oracle.scene(sf.desc)
     for bounces, spp in ((2, 4), (8, 4)):

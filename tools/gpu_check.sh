@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU tests, then bench.py on the four BASELINE configs (kernel chosen by measurement)
+# Developer tool (GPU box): the GPU tests, then bench.py on the four BASELINE configs (kernel chosen by measurement). usage: tools/gpu_check.sh [outdir-name]
 cd $GRAFT_REPO_ROOT
 out=gpurun_out/${1:-s6}; mkdir -p $out
 (time timeout -k 10 900 python -m pytest tests -m gpu -q -x --durations=8) > $out/pytest.log 2>&1; tail -14 $out/pytest.log

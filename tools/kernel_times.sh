@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU tests, then the four configs with each kernel forced (wf_check: bitwise comparison + timing)
+# Developer tool (GPU box): the GPU tests, then the four configs with each kernel forced (tools/wf_check.py: bitwise comparison + timing). usage: tools/kernel_times.sh [outdir-name]
 cd $GRAFT_REPO_ROOT
 out=gpurun_out/${1:-s8}; mkdir -p $out
 (time timeout -k 10 900 python -m pytest tests -m gpu -q -x --durations=5) > $out/pytest.log 2>&1; tail -9 $out/pytest.log

@@ -476,7 +476,25 @@ def _ref_maker(which):
     return lambda outdir, scale=1.0, name=None: make_reference_scene(outdir, scale, name or ("ref-" + which), which)
 
 
-def make_lights_unit(outdir, scale=1.0, name="lights-unit"):
+def _write_grid_light(path, n=3):
+    """The reference's arealight quad (-2..2 in x and y, z = 0, facing +z) as an n x n grid: 2 n^2 triangles — an area
+    light too big for the kernels' LDS light table (> 4 triangles), i.e. one sampled and intersected through memory."""
+    verts = [(-2 + 4 * i / n, -2 + 4 * j / n, 0.0) for j in range(n + 1) for i in range(n + 1)]
+    faces = []
+    for j in range(n):
+        for i in range(n):
+            a, b, c, d = j * (n + 1) + i, j * (n + 1) + i + 1, (j + 1) * (n + 1) + i, (j + 1) * (n + 1) + i + 1
+            faces += [(a, b, c), (d, c, b)]
+    with open(path, "w") as f:
+        f.write(f"ply\nformat ascii 1.0\nelement vertex {len(verts)}\nproperty float x\nproperty float y\nproperty float z\n"
+                f"property float nx\nproperty float ny\nproperty float nz\nelement face {len(faces)}\nproperty list uchar int vertex_indices\nend_header\n")
+        for v in verts:
+            f.write(f"{v[0]:.9g} {v[1]:.9g} {v[2]:.9g} 0 0 1\n")
+        for t in faces:
+            f.write(f"3 {t[0]} {t[1]} {t[2]}\n")
+
+
+def make_lights_unit(outdir, scale=1.0, name="lights-unit", biglight=False):
     """Light sampling in isolation (pt.cpp:1283-1358): diffuse spheres and a floor — no hair, so no
     libm-driven path divergence ahead of the light code — under two area lights (the uniform light
     pick, triangle CDF, the 100-step area pdf walk through both quads) and the textured sky (texel CDF
@@ -491,8 +509,10 @@ def make_lights_unit(outdir, scale=1.0, name="lights-unit"):
         "ball1": {"frame": [0.6, 0, 0, 0, 0.6, 0, 0, 0, 0.6, 0.8, 0.0, 0.6], "shape": "sphere", "material": "white"},
         # one light behind the other as seen from the floor: the area pdf walk crosses both quads
         "light1": {"lookat": [0.5, 4, 1.5, 0.0, 0.5, 0, 0, 1, 0], "shape": "arealight", "material": "arealight"},
-        "light2": {"lookat": [1.0, 8, 3.0, 0.0, 0.5, 0, 0, 1, 0], "shape": "arealight", "material": "arealight2"},
+        "light2": {"lookat": [1.0, 8, 3.0, 0.0, 0.5, 0, 0, 1, 0], "shape": "gridlight" if biglight else "arealight", "material": "arealight2"},
     }
+    if biglight:  # the second light as an 18-triangle mesh: the light code that goes through the BVH (GENERAL kernel variants)
+        _write_grid_light(os.path.join(d, "shapes", "gridlight.ply"))
     scene = {
         "asset": {"copyright": "synthetic; sphere, quad and sky.hdr from the reference's test assets"},
         "cameras": {"default": {"lens": 0.05, "aperture": 0.0, "aspect": 1.0, "lookat": [0.0, 2.4, 5.5, 0.0, 0.5, 0, 0, 1, 0]}},
