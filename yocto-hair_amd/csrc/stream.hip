@@ -67,6 +67,10 @@ using namespace yhd;
 #define SLOT_RNG(pl, g) (*(yhd_int4*)&SLOT_F4(pl, g, 5))
 #define SLOT_META(pl, g) (*(yhd_int4*)&SLOT_F4(pl, g, 6))
 
+// Progress: a trace stage that leaves with rays suspended (<= YH_SUSPEND_LANES busy lanes, something pending) must be
+// followed by a stage that consumes what is pending — the scheduler flushes partial batches when fewer than 64 rays are at
+// hand — or the two would hand the wave back and forth forever.
+static_assert(YH_SUSPEND_LANES < 64, "the trace stage's exit condition must imply the scheduler's flush condition");
 enum { K_HAIR = 0, K_SURF = 1, K_MISS = 2, K_REDO = 3 };  // what a finished ray found (bits 12-13 of a done-list entry)
 enum { H_MISS = -1, H_ENDED = -2, H_NEW = -3 };            // yhd_stream::hit.x of a slot in the finish list
 
