@@ -8,6 +8,7 @@ import os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "yocto-hair_amd", "csrc")
 FLAGS = "-O3 --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -fno-vectorize -std=c++17 --cuda-device-only -S".split()
+FLAGS += os.environ.get("YH_EXTRA_FLAGS", "").split()  # e.g. YH_EXTRA_FLAGS=-DYH_SUSPEND=8 to look at a developer variant
 
 
 def kernels(src):

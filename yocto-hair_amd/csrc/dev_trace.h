@@ -280,8 +280,19 @@ YH_DEV void count_quad(unsigned int& slot) {
 // reports `redo`, and trace_ray repeats that ray with EXACT = true, the reference's compare +
 // select form throughout. Results are identical either way; only axis-parallel rays take the
 // second pass.
-template <bool COUNT, int STRIDE, bool EXACT>
-YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_object, unsigned int* steps_out, bool& redo) {
+// PHASE = true (developer experiment YH_SUSPEND, kernels.hip): the traversal is resumable. `rs` holds what cannot be
+// recomputed from the ray (current entry, stack depth, entered object, closest hit so far); the wave leaves the loop
+// as soon as no more than `leave_at` lanes are still running, the quads still running keep their state in `rs` and
+// their LDS stack, and the next call picks them up where they stopped (instance-space ray data recomputed: same
+// operations, same bits).
+struct trav_state {
+  unsigned int cur;
+  int          sp, cur_obj;
+  hit_t        hit;
+};
+template <bool COUNT, int STRIDE, bool EXACT, bool PHASE = false>
+YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_object, unsigned int* steps_out, bool& redo,
+    trav_state* rs = nullptr, int leave_at = 0) {
   const yhd_scene&     sc   = *tc.sc;
   const unsigned int   q    = __lane_id() & 3u;
   int                  sp   = 0;
@@ -314,7 +325,26 @@ YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_obj
     return sc.scene_prims[i];
   };
   unsigned int cur;
-  if (first_object >= 0) {
+  if (PHASE) {
+    cur = rs->cur, sp = rs->sp, cur_obj = rs->cur_obj, hit = rs->hit;
+    if (hit.object >= 0) tmax = hit.distance;
+    if (cur_obj >= 0) {  // resumed inside an object: the ENTER arithmetic again
+      frame inv;
+      if (tc.lds_scene) {
+        const YH_LDS v4f* ob = tc.lds_scene + YH_OBJECT_F4 * cur_obj;
+        v4f a = ob[3], b = ob[4], c = ob[5], d = ob[6];
+        inv.x = {a.x, a.y, a.z}, inv.y = {a.w, b.x, b.y}, inv.z = {b.z, b.w, c.x}, inv.o = {c.y, c.z, c.w};
+        kind = __float_as_int(d.x), node_base = __float_as_int(d.y), prim_base = __float_as_int(d.z);
+      } else {
+        const yhd_object& o = sc.objects[cur_obj];
+        inv  = ldframe(o.inv_frame);
+        kind = o.kind, node_base = o.node_base, prim_base = o.prim_base;
+      }
+      lo = transform_point(inv, ray.o), ld = transform_vector(inv, ray.d);
+      ldinv = quad_rcp(ld);
+      lsign = (ldinv.x < 0 ? 1 : 0) | (ldinv.y < 0 ? 2 : 0) | (ldinv.z < 0 ? 4 : 0);
+    }
+  } else if (first_object >= 0) {
     cur = YH_TAG_ENTER | (unsigned)first_object;
   } else {
     if (sc.num_scene_nodes == 0) return hit;
@@ -331,6 +361,7 @@ YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_obj
       if (sp == 0) break;
       cur = pop();
     }
+    if (PHASE && __popcll(__ballot(1)) <= leave_at) break;  // few enough quads left: the wave goes shading, these resume later
     unsigned int tag = cur & YH_TAG_MASK;
     // The scene level costs no trip of its own: a scene node (read from the LDS copy
     // of the tiny scene BVH), the ENTER it leads to and the root fetch of the entered
@@ -509,6 +540,7 @@ YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_obj
     if (steps_out) *steps_out = n_steps;
     tc.stats->nodes += (unsigned int)n_nodes, tc.stats->seg += (unsigned int)n_seg, tc.stats->tri += (unsigned int)n_tri;
   }
+  if (PHASE) rs->cur = cur, rs->sp = sp, rs->cur_obj = cur_obj, rs->hit = hit;
   return hit;
 }
 

@@ -103,6 +103,9 @@ YH_DEV void trace_items(const yhd_scene& sc, const yhd_state& st, int nsamples, 
     bool   alive   = false;
     path_t ps;
     ps.bounce = 0, ps.hit = false;
+    bool       running = false;  // YH_SUSPEND: this quad's ray is suspended mid-traversal
+    trav_state rs;
+    rs.cur = YH_NONE, rs.sp = 0, rs.cur_obj = -1, rs.hit = hit_t{};
     unsigned long long cyc_trace = 0, cyc_shade = 0;
     unsigned int       w_iters = 0, w_steps = 0, l_steps = 0, l_iters = 0;
     while (true) {
@@ -119,6 +122,27 @@ YH_DEV void trace_items(const yhd_scene& sc, const yhd_state& st, int nsamples, 
       unsigned int       steps = 0;
       if (COUNT) c0 = clock64(), l_iters += (alive && (lane & 3) == 0) ? 1 : 0, w_iters++;
       hit_t isec;
+#ifdef YH_SUSPEND /* developer experiment: resumable traversal, the wave shades once YH_SUSPEND / 16 of its live quads are left running */
+      if constexpr (!COUNT && SHADER == YH_SHADER_PATH) {
+        if (alive && !running) {
+          rs.cur = sc.num_scene_nodes ? (YH_TAG_SCENE | 0u) : YH_NONE, rs.sp = 0, rs.cur_obj = -1;
+          rs.hit.object = -1, rs.hit.slot = -1, rs.hit.u = 0, rs.hit.v = 0, rs.hit.distance = 0;
+        }
+        if (alive) {
+          int  live = __popcll(__ballot(1)) >> 2;
+          bool redo = false;
+          trace_ray_loop<false, (BLOCK / 4), false, true>(tc, ps.ray, -1, nullptr, redo, &rs, ((live * YH_SUSPEND) >> 4) << 2);
+          if (__any(redo)) {
+            if (redo) {
+              rs.hit = trace_ray_loop<false, (BLOCK / 4), true>(tc, ps.ray, -1, nullptr, redo);
+              rs.cur = YH_NONE, rs.sp = 0;
+            }
+          }
+          running = !(rs.cur == YH_NONE && rs.sp == 0);
+          isec    = rs.hit;
+        }
+      } else
+#endif
       if (alive) {
         if (COUNT) count_quad<COUNT>(stats.rays);
         isec = trace_ray<COUNT, (BLOCK / 4)>(tc, ps.ray, -1, &steps);
@@ -129,7 +153,7 @@ YH_DEV void trace_items(const yhd_scene& sc, const yhd_state& st, int nsamples, 
         for (int off = 32; off > 0; off >>= 1) smax = max(smax, (unsigned int)__shfl_xor((int)smax, off, 64));
         w_steps += smax, l_steps += (lane & 3) == 0 ? steps : 0;
       }
-      if (alive) {
+      if (alive && !running) {
         if constexpr (SHADER == YH_SHADER_PATH) alive = path_step<COUNT, (BLOCK / 4), GENERAL>(tc, ps, isec, rng, st.bounces);
         else alive = shade_step<COUNT, (BLOCK / 4), SHADER>(tc, ps, isec, rng, st.bounces);
         if (!alive) {
