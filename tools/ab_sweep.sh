@@ -20,8 +20,8 @@ done
 wait
 for v in "${variants[@]}"; do
   name=${v%%:*}
-  [ -f /tmp/yh_sweep/libyhair_$name.so ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o /tmp/yh_sweep/libyhair_$name.so /tmp/yh_sweep/k_$name.o $R/yocto-hair_amd/csrc/bvh_gpu.o \
-      $R/yocto-hair_amd/host/context.o $R/yocto-hair_amd/host/bvh_build.o $R/yocto-hair_amd/host/scene_io.o -lpthread -lz
+  [ -f /tmp/yh_sweep/libyhair_$name.so ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o /tmp/yh_sweep/libyhair_$name.so /tmp/yh_sweep/k_$name.o $R/yocto-hair_amd/csrc/wavefront.o $R/yocto-hair_amd/csrc/stream.o $R/yocto-hair_amd/csrc/bvh_gpu.o \
+      $R/yocto-hair_amd/host/context.o $R/yocto-hair_amd/host/bvh_build.o $R/yocto-hair_amd/host/scene_io.o -lpthread -lz -ldl
 done
 for r in $(seq 1 $rounds); do
   for v in "${variants[@]}"; do

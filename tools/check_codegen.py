@@ -1,14 +1,69 @@
 #!/usr/bin/env python3
 """Developer tool (no GPU needed): compiles the integrator kernels to gfx950 assembly and reports, per kernel
-variant, registers, spills, and the scratch (spill) instructions INSIDE the innermost traversal loop — a spill
-reload there stalls every step on a scratch load (measured 0.75-0.8x on the dense configs), and whether the
-register allocator puts one there changes with unrelated edits of the shading code.
-usage: tools/check_codegen.py [--strict]   (--strict: exit 1 when a product kernel's traversal loop touches scratch)"""
+variant, registers, spills, and the instruction mix of its TRAVERSAL loops — with the scratch (spill) instructions
+inside them: a spill reload there stalls every step on a scratch load (measured 0.75-0.8x on the dense configs),
+and whether the register allocator puts one there changes with unrelated edits of the shading code.
+
+Loop membership comes from LLVM's own block annotations ("in Loop: Header=BBn_m Depth=d", "Parent Loop ..."), not
+from the layout: the block placement may put a loop's latch above its header.
+usage: tools/check_codegen.py [--strict] [--loops]
+  --strict: exit 1 when a traversal loop of a product kernel touches scratch
+  --loops:  list every other loop of >= 100 vector instructions too
+  env YH_EXTRA_FLAGS="-DYH_SUSPEND=8": look at a developer variant"""
 import os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "yocto-hair_amd", "csrc")
 FLAGS = "-O3 --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -fno-vectorize -std=c++17 --cuda-device-only -S".split()
-FLAGS += os.environ.get("YH_EXTRA_FLAGS", "").split()  # e.g. YH_EXTRA_FLAGS=-DYH_SUSPEND=8 to look at a developer variant
+FLAGS += os.environ.get("YH_EXTRA_FLAGS", "").split()
+
+
+def loops_of(body):
+    """body: the lines of one kernel. Returns {header: counts}, every instruction counted in its innermost loop
+    and in all the loops around it."""
+    blocks, cur, parent, depth = [], None, {}, {}
+    k = 0
+    while k < len(body):
+        l = body[k]
+        m = re.match(r"(\.LBB\d+_\d+):", l) or re.match(r"; %bb\.(\d+):", l)
+        if m:
+            ann, j = [l], k + 1
+            while j < len(body) and re.match(r"\s+;", body[j]):
+                ann.append(body[j])
+                j += 1
+            a, inner = " ".join(ann), None
+            hm = re.search(r"This (?:Inner )?Loop Header: Depth=(\d+)", a)
+            if hm:
+                inner = m.group(1).replace(".L", "")
+                depth[inner] = int(hm.group(1))
+                ps = re.findall(r"Parent Loop (BB\d+_\d+) Depth=\d+", a)
+                parent[inner] = ps[-1] if ps else None
+            else:
+                im = re.search(r"in Loop: Header=(BB\d+_\d+) Depth=\d+", a)
+                inner = im.group(1) if im else None
+            cur = dict(loop=inner, ins=[])
+            blocks.append(cur)
+        elif cur is not None and re.match(r"\s+[a-z]", l):
+            cur["ins"].append(l.strip())
+        k += 1
+    res = {}
+    for b in blocks:
+        h = b["loop"]
+        while h:
+            r = res.setdefault(h, dict(valu=0, salu=0, lds=0, vmem=0, x4=0, scratch=0, depth=depth.get(h, 0)))
+            for x in b["ins"]:
+                if x.startswith("v_"):
+                    r["valu"] += 1
+                elif x.startswith("s_"):
+                    r["salu"] += 1
+                elif x.startswith("ds_"):
+                    r["lds"] += 1
+                elif x.startswith("scratch_"):
+                    r["scratch"] += 1
+                elif x.startswith(("global_", "buffer_", "flat_")):
+                    r["vmem"] += 1
+                    r["x4"] += 1 if "dwordx4" in x else 0
+            h = parent.get(h)
+    return res
 
 
 def kernels(src):
@@ -24,32 +79,11 @@ def kernels(src):
         i = text.find("\n" + name + ":")
         if i < 0:
             continue
-        body = text[i:text.find(".end_amdhsa_kernel", i)].split("\n")
-        # loops: a header label and the last branch back to it; the traversal loop = the deepest loop of a few
-        # hundred vector instructions that loads 16-byte records (the small loops inside it push scene entries)
-        best, best_key = (0, 0, 0), (-1, -1)
-        for k, l in enumerate(body):
-            m = re.search(r"Loop Header: Depth=(\d+)", l)
-            if not m:
-                continue
-            depth = int(m.group(1))
-            lm = None
-            for up in range(0, 8):  # the label sits on the header line or a few "Parent Loop" comment lines above it
-                if k - up >= 0:
-                    lm = re.match(r"(\.LBB\d+_\d+):", body[k - up])
-                    if lm:
-                        break
-            if not lm:
-                continue
-            label = lm.group(1)
-            end = max((j for j in range(k, len(body)) if re.search(r"s_c?branch\S*\s+" + re.escape(label) + r"\b", body[j])), default=k)
-            seg = body[k:end + 1]
-            valu = sum(1 for x in seg if re.match(r"\s+v_", x))
-            if not (250 <= valu <= 2000) or sum(1 for x in seg if "global_load_dwordx4" in x) < 2:
-                continue
-            if (depth, valu) > best_key:
-                best_key, best = (depth, valu), (valu, sum(1 for x in seg if "scratch_" in x), end - k)
-        info.update(loop_valu=best[0], loop_scratch=best[1])
+        loops = loops_of(text[i:text.find(".end_amdhsa_kernel", i)].split("\n"))
+        # traversal loops = the step loops of the BVH walk: a few hundred vector instructions around the 16-byte loads
+        # of a node / leaf record (the sample and item loops around them hold thousands)
+        info["loops"] = loops
+        info["trav"] = {h: r for h, r in loops.items() if 250 <= r["valu"] <= 2500 and r["x4"] >= 2}
         out[name] = info
     return out
 
@@ -60,10 +94,21 @@ if __name__ == "__main__":
         for name, k in sorted(kernels(src).items()):
             if not re.search(pat, name):
                 continue
-            flag = ""
             product = ("k_traceILb0ELb0" in name or "k_streamILb0" in name)  # the plain variants every BASELINE config runs
-            if product and (k["loop_scratch"] or not k["loop_valu"]):
-                flag, bad = "   <-- spill traffic in the traversal loop", bad + 1
-            print(f"{name[:64]:64s} vgprs {k['vgprs']:3d} spilled {k['vgpr_spills']:3d} (sgpr {k['sgpr_spills']:3d}) scratch {k['scratch_bytes']:4d} B   "
-                  f"traversal loop: {k['loop_valu']} VALU, {k['loop_scratch']} scratch ops{flag}")
+            print(f"{name[:64]:64s} vgprs {k['vgprs']:3d} spilled {k['vgpr_spills']:3d} (sgpr {k['sgpr_spills']:3d}) scratch {k['scratch_bytes']:4d} B")
+            for h, r in k["trav"].items():
+                flag = ""
+                # k_stream's step loop also holds the refill and the retire blocks (once per ray, not per step): one reload
+                # in each is the known state; k_trace's traversal loops are pure step loops
+                allowed = 2 if "k_stream" in name else 0
+                if product and r["scratch"] > allowed:
+                    flag, bad = "   <-- spill traffic in a traversal loop", bad + 1
+                print(f"    loop {h:10s} depth {r['depth']}: {r['valu']:4d} VALU {r['salu']:4d} SALU {r['lds']:3d} LDS {r['vmem']:3d} VMEM, {r['scratch']} scratch ops{flag}")
+            if product and not k["trav"]:
+                print("    no traversal loop found   <-- the heuristic needs a look")
+                bad += 1
+            if "--loops" in sys.argv:
+                for h, r in k["loops"].items():
+                    if r["valu"] >= 100 and h not in k["trav"]:
+                        print(f"    (loop {h:10s} depth {r['depth']}: {r['valu']:5d} VALU {r['salu']:5d} SALU, {r['scratch']} scratch ops)")
     sys.exit(1 if (bad and "--strict" in sys.argv) else 0)

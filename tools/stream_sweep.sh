@@ -7,8 +7,10 @@ out=$R/gpurun_out/$1; cfg=$2; shift 2
 mkdir -p $out /tmp/yh_sweep
 for v in "$@"; do
   name=${v%%:*}; flags=${v#*:}
-  /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -fno-vectorize -fPIC -std=c++17 -I$R/include -I$R/yocto-hair_amd/csrc $flags \
-      -c $R/yocto-hair_amd/csrc/${SRC:-stream}.hip -o /tmp/yh_sweep/s_$name.o &
+  src=$R/yocto-hair_amd/csrc
+  case $name in old*) src=$R/tools/_old_csrc;; esac   # a snapshot of an earlier csrc/ placed there by hand (git-ignored)
+  /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -fno-vectorize -fPIC -std=c++17 -I$R/include -I$src $flags \
+      -c $src/${SRC:-stream}.hip -o /tmp/yh_sweep/s_$name.o &
 done
 wait
 for v in "$@"; do

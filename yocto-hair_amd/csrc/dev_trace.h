@@ -285,16 +285,24 @@ YH_DEV void count_quad(unsigned int& slot) {
 // as soon as no more than `leave_at` lanes are still running, the quads still running keep their state in `rs` and
 // their LDS stack, and the next call picks them up where they stopped (instance-space ray data recomputed: same
 // operations, same bits).
+#ifndef YH_REMAT_Q
+#define YH_REMAT_Q 1 /* dense launch shape (96 registers): lane #define YH_REMAT_Q 0 3 recomputed in the node step (two instructions) instead of reloaded from scratch */
+#endif
 struct trav_state {
   unsigned int cur;
   int          sp, cur_obj;
   hit_t        hit;
 };
-template <bool COUNT, int STRIDE, bool EXACT, bool PHASE = false>
+// LDS_SCENE = true: the caller knows the scene-level table is in LDS (the plain kernel variants: the host selects the
+// GENERAL ones when it does not fit), so the loop carries no second code path for reading it from memory.
+template <bool COUNT, int STRIDE, bool EXACT, bool PHASE = false, bool LDS_SCENE = false>
 YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_object, unsigned int* steps_out, bool& redo,
     trav_state* rs = nullptr, int leave_at = 0) {
   const yhd_scene&     sc   = *tc.sc;
   const unsigned int   q    = __lane_id() & 3u;
+#if YH_REMAT_Q
+  const unsigned int   q_   = q;
+#endif
   int                  sp   = 0;
   YH_LDS unsigned int* lstk = tc.lds_stack;
   auto push = [&](unsigned int v) { lstk[sp * STRIDE] = v, sp++; };
@@ -319,9 +327,10 @@ YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_obj
   unsigned long long n_nodes = 0, n_seg = 0, n_tri = 0;
   unsigned int       n_steps = 0;
 
-  const YH_LDS v4f* lds_snodes = tc.lds_scene ? tc.lds_scene + YH_OBJECT_F4 * sc.num_objects : nullptr;
+  const bool in_lds = LDS_SCENE || tc.lds_scene != nullptr;
+  const YH_LDS v4f* lds_snodes = in_lds ? tc.lds_scene + YH_OBJECT_F4 * sc.num_objects : nullptr;
   auto scene_prim = [&](int i) -> int {
-    if (tc.lds_scene) return ((const YH_LDS int*)(lds_snodes + 2 * sc.num_scene_nodes))[i];
+    if (in_lds) return ((const YH_LDS int*)(lds_snodes + 2 * sc.num_scene_nodes))[i];
     return sc.scene_prims[i];
   };
   unsigned int cur;
@@ -330,7 +339,7 @@ YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_obj
     if (hit.object >= 0) tmax = hit.distance;
     if (cur_obj >= 0) {  // resumed inside an object: the ENTER arithmetic again
       frame inv;
-      if (tc.lds_scene) {
+      if (in_lds) {
         const YH_LDS v4f* ob = tc.lds_scene + YH_OBJECT_F4 * cur_obj;
         v4f a = ob[3], b = ob[4], c = ob[5], d = ob[6];
         inv.x = {a.x, a.y, a.z}, inv.y = {a.w, b.x, b.y}, inv.z = {b.z, b.w, c.x}, inv.o = {c.y, c.z, c.w};
@@ -372,7 +381,7 @@ YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_obj
       if (COUNT) count_branch<COUNT>(tc.stats->t_scene, tc.stats->l_scene);
       int idx = (int)(cur & ~YH_TAG_MASK);
       v4f n0, n1;
-      if (lds_snodes) n0 = lds_snodes[2 * idx], n1 = lds_snodes[2 * idx + 1];
+      if (in_lds) n0 = lds_snodes[2 * idx], n1 = lds_snodes[2 * idx + 1];
       else n0 = ldg4(sc.scene_nodes + 2 * idx), n1 = ldg4(sc.scene_nodes + 2 * idx + 1);
       if (q == 0) n_nodes++;
       cur = YH_NONE;
@@ -402,7 +411,7 @@ YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_obj
       // Skipped for axis-parallel rays (a 0 * inf slab would make the test inconclusive).
       if (wnonan) {
         v4f bmin, bmax;
-        if (tc.lds_scene) {
+        if (in_lds) {
           const YH_LDS v4f* ob = tc.lds_scene + YH_OBJECT_F4 * cur_obj;
           bmin = ob[8], bmax = ob[9];
         } else {
@@ -415,7 +424,7 @@ YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_obj
         }
       }
       frame inv;
-      if (tc.lds_scene) {  // yhd_object: frame[12] inv_frame[12] kind node_base prim_base ... (10 float4)
+      if (in_lds) {  // yhd_object: frame[12] inv_frame[12] kind node_base prim_base ... (10 float4)
         const YH_LDS v4f* ob = tc.lds_scene + YH_OBJECT_F4 * cur_obj;
         v4f a = ob[3], b = ob[4], c = ob[5], d = ob[6];
         inv.x = {a.x, a.y, a.z}, inv.y = {a.w, b.x, b.y}, inv.z = {b.z, b.w, c.x}, inv.o = {c.y, c.z, c.w};
@@ -457,7 +466,7 @@ YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_obj
                                        : sc.nodes + 8 * (size_t)cur + 2 * q;
       v4f s0, s1;
       int rel = (int)cur - sc.lds_node_base;
-      if (tc.lds_nodes && !is_leaf && rel >= 0 && rel < sc.lds_node_count) {
+      if (YH_LDS_NODELETS && tc.lds_nodes && !is_leaf && rel >= 0 && rel < sc.lds_node_count) {
         const YH_LDS v4f* n = tc.lds_nodes + 8 * rel + 2 * q;  // optional nodelets (YHAIR_LDS_NODES), off by default
         s0 = n[0], s1 = n[1];
       } else {
@@ -478,6 +487,14 @@ YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_obj
         // Each lane computes the RANK of its own slot in that order; the hit lanes
         // then push themselves in one parallel step: the first hit in visiting order
         // becomes `cur`, the others go on the stack so that they pop in visiting order.
+#if YH_REMAT_Q
+        unsigned int q = q_;
+        if (STRIDE == 64) {  // dense shape, 96 registers: two instructions here instead of a lane constant that the allocator reloads from scratch
+          unsigned int x;
+          asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(x));
+          q = x & 3u;
+        }
+#endif
         unsigned int pair = q >> 1;
         unsigned int sgn  = (lsign >> ((axes >> (2 + 2 * pair)) & 3)) & 1;   // near side of this pair's own axis
         unsigned int s0_  = (lsign >> (axes & 3)) & 1;                      // near side of the node's axis
@@ -522,8 +539,8 @@ YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_obj
   {                                                                                        \
     int   oi = dpp_i<CTRL>(key_i);                                                         \
     float ot = dpp_f<CTRL>(key_t), ou = dpp_f<CTRL>(uu), ov = dpp_f<CTRL>(vv);             \
-    bool  take = oi >= 0 && (key_i < 0 || ot < key_t || (ot == key_t && oi > key_i));      \
-    if (take) key_i = oi, key_t = ot, uu = ou, vv = ov;                                    \
+    bool  take = (oi >= 0) & ((key_i < 0) | (ot < key_t) | ((ot == key_t) & (oi > key_i))); /* no short circuits: selects, not branches */ \
+    key_i = take ? oi : key_i, key_t = take ? ot : key_t, uu = take ? ou : uu, vv = take ? ov : vv; \
   }
         YH_QUAD_MERGE(YH_QUAD_XOR1)
         YH_QUAD_MERGE(YH_QUAD_XOR2)
@@ -544,12 +561,12 @@ YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_obj
   return hit;
 }
 
-template <bool COUNT, int STRIDE>
+template <bool COUNT, int STRIDE, bool LDS_SCENE = false>
 YH_DEV hit_t trace_ray(const trace_ctx& tc, const ray_t& ray, int first_object, unsigned int* steps_out = nullptr) {
   bool  redo = false;
-  hit_t hit  = trace_ray_loop<COUNT, STRIDE, false>(tc, ray, first_object, steps_out, redo);
+  hit_t hit  = trace_ray_loop<COUNT, STRIDE, false, false, LDS_SCENE>(tc, ray, first_object, steps_out, redo);
   if (__any(redo)) {
-    if (redo) hit = trace_ray_loop<COUNT, STRIDE, true>(tc, ray, first_object, steps_out, redo);
+    if (redo) hit = trace_ray_loop<COUNT, STRIDE, true, false, LDS_SCENE>(tc, ray, first_object, steps_out, redo);
   }
   return hit;
 }

@@ -63,8 +63,8 @@ YH_DEV void trace_items(const yhd_scene& sc, const yhd_state& st, int nsamples, 
   YH_LDS v4f*          lds_tabs  = (YH_LDS v4f*)(lds_stack + sc.stack_entries * (BLOCK / 4));
   // stage the nodelets: the first lds_node_count wide nodes (breadth-first =
   // top levels) of the dominant hair shape, 128 B each, coalesced dwordx4 loads
-  for (int i = threadIdx.x; i < 8 * sc.lds_node_count; i += blockDim.x)
-    lds_nodes[i] = ldg4(sc.nodes + 8 * (size_t)sc.lds_node_base + i);
+  if (YH_LDS_NODELETS)
+    for (int i = threadIdx.x; i < 8 * sc.lds_node_count; i += blockDim.x) lds_nodes[i] = ldg4(sc.nodes + 8 * (size_t)sc.lds_node_base + i);
   trace_ctx tc;
   tc.sc = &sc;
   tc.ls = nullptr, tc.sc_dev = nullptr;
@@ -131,7 +131,7 @@ YH_DEV void trace_items(const yhd_scene& sc, const yhd_state& st, int nsamples, 
         if (alive) {
           int  live = __popcll(__ballot(1)) >> 2;
           bool redo = false;
-          trace_ray_loop<false, (BLOCK / 4), false, true>(tc, ps.ray, -1, nullptr, redo, &rs, ((live * YH_SUSPEND) >> 4) << 2);
+          trace_ray_loop<false, (BLOCK / 4), false, true, !GENERAL>(tc, ps.ray, -1, nullptr, redo, &rs, ((live * YH_SUSPEND) >> 4) << 2);
           if (__any(redo)) {
             if (redo) {
               rs.hit = trace_ray_loop<false, (BLOCK / 4), true>(tc, ps.ray, -1, nullptr, redo);
@@ -145,7 +145,7 @@ YH_DEV void trace_items(const yhd_scene& sc, const yhd_state& st, int nsamples, 
 #endif
       if (alive) {
         if (COUNT) count_quad<COUNT>(stats.rays);
-        isec = trace_ray<COUNT, (BLOCK / 4)>(tc, ps.ray, -1, &steps);
+        isec = trace_ray<COUNT, (BLOCK / 4), !GENERAL>(tc, ps.ray, -1, &steps);
       }
       if (COUNT) {
         c1 = clock64(), cyc_trace += c1 - c0;

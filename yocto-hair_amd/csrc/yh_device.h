@@ -157,7 +157,7 @@ typedef struct yhd_scene {
   int               num_prim_f4;     // float4 in `prims`
   int               lds_scene_f4;       // float4 count of the scene-level LDS table (0: scene too big, read from memory)
   int               general_materials;  // some material has lobes beyond diffuse / hair, or some area light is not a small one: the GENERAL kernel variants
-  int               lds_node_base;   // global index of that shape's root
+  int               lds_node_base;   // global index of that shape's root (nodelets: builds with -DYH_LDS_NODELETS=1 only)
   int               lds_node_count;
   int               stack_entries;   // traversal stack depth per ray the kernels reserve in LDS (>= the trees' need)
   // tables the kernels stage in LDS next to the scene-level table (dev_trace.h: stage_tables)
@@ -171,6 +171,9 @@ typedef struct yhd_scene {
   int               env_tab_k, env_tab_stride;
   int               lds_materials;   // materials staged in LDS (all of them, or 0 when they are too many)
 } yhd_scene;
+#ifndef YH_LDS_NODELETS
+#define YH_LDS_NODELETS 0 /* developer switch: stage the top wide nodes of the dominant hair shape in LDS (YHAIR_LDS_NODES=n); measured twice without gain */
+#endif
 #define YH_MATERIAL_F4 17 /* sizeof(yhd_material) / 16 */
 // float4 the kernels reserve in LDS for the tables: scene level | camera (5) | small lights | env cdf index | materials
 #define YHD_LDS_TABLES_F4(sc) ((sc)->lds_scene_f4 + 5 + (sc)->light_table_f4 + ((sc)->env_tab_k + 3) / 4 + YH_MATERIAL_F4 * (sc)->lds_materials)

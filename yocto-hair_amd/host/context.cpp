@@ -276,12 +276,13 @@ struct yh_context {
   unsigned         launches_of_state = 0;  // synchronous launches since yh_init_state (re-planning schedule)
   int              launch_shape = 0;  // decided from launches of at least 16 spp (shorter ones have flat, noisy item costs)
   int              last_shape = -1;   // the kernel the most recent launch ran (yh_launch_shape)
+  bool             last_counted = false;  // ... and whether it was the instrumented build (its time ranks nothing)
   // single-process multi-GPU gather (yh_gather_framebuffer): this context's packed tiles; on the root also the
   // receive buffer and the communicators of the device set they were made for
   DevBuf                  d_gather_send, d_gather_recv;
   std::vector<ncclComm_t> comms;
   std::vector<int>        comm_devices;
-  // kernel selection by measurement (next_launch_shape): ms per sample of a planned launch with each kernel
+  // kernel selection by measurement (pick_launch_shape): ms per sample of a planned launch with each kernel
   // (0 = not measured yet), whether item costs exist (the first launch of a scene runs unplanned and is not a
   // measurement), and whether the scene is dense (more expensive items than resident waves; from k_trace's costs)
   double           shape_ms[4] = {0, 0, 0, 0};
@@ -354,7 +355,9 @@ int tiles_of(int n) { return (n + YH_TILE - 1) / YH_TILE; }
 // current split modes, most expensive first.
 void build_work_items(const yh_context* ctx, std::vector<int>& items);
 int  choose_launch_shape(const yh_context* ctx);
-int  next_launch_shape(yh_context* ctx, int nsamples, bool fresh_costs);
+void record_launch(yh_context* ctx, int nsamples, bool fresh_costs);
+int  pick_launch_shape(const yh_context* ctx, int nsamples);
+bool trial_pending(const yh_context* ctx);
 
 }  // namespace
 
@@ -365,7 +368,7 @@ namespace {
 // max-cost work items the last launch was worth (sum of item costs over the largest) against the
 // resident wave slots — measured 3 066 (C1), 4 777 (C4), 8 989 (C2), 24 970 (C3) against 4 096: with
 // fewer expensive items than slots every wave that can run already does. This only picks the CANDIDATES; which
-// kernel runs is measured (next_launch_shape). YHAIR_SHAPE=0..3 overrides.
+// kernel runs is measured (pick_launch_shape). YHAIR_SHAPE=0..3 overrides.
 // Is the launch worth more max-cost work items than there are resident waves? (item costs of a k_trace launch)
 bool dense_by_costs(const yh_context* ctx, bool* known) {
   uint64_t sum = 0, mx = 0;
@@ -386,33 +389,51 @@ int choose_launch_shape(const yh_context* ctx) {
   bool known = false;
   return dense_by_costs(ctx, &known) ? 1 : 0;
 }
-// Kernel for the next launch, chosen by MEASUREMENT (every kernel renders the same bits, so trying one costs
-// time only). k_trace at 512 x 4 suits launches bound by a few expensive pixels (C1), k_trace at 256 x 5 and the
-// one-lane-per-path k_stream suit dense scenes, and which of those two wins depends on how many expensive pixels
-// there are per wave (straight-hair 720^2: a tie; curly-hair 1280^2: k_stream +39 %; hair-curls: k_trace 2.3x).
-// Each candidate runs one planned launch of at least 16 spp, then the fastest per sample stays. Sparse scenes
-// never try k_stream: it would cost them several times a launch.
-int next_launch_shape(yh_context* ctx, int nsamples, bool fresh_costs) {
-  if (const char* env = getenv("YHAIR_SHAPE")) return std::max(0, std::min(3, atoi(env)));
-  if (nsamples < 16) return ctx->launch_shape;  // short launches have flat, noisy costs: keep what is known
+// Kernel selection by MEASUREMENT (every kernel renders the same bits, so trying one costs time only). k_trace at
+// 512 x 4 suits launches bound by a few expensive pixels (C1), k_trace at 256 x 5 and the one-lane-per-path k_stream
+// suit dense scenes, and which of those two wins depends on how many expensive pixels there are per wave
+// (straight-hair 720^2: a tie; curly-hair 1280^2: k_stream +39 %; hair-curls: k_trace 2.3x). Every candidate is timed
+// once per image on a SHORT planned launch (YH_TRIAL_SPP samples: yh_trace_samples cuts them off the front of a long
+// request, so all samples count and a trial of the wrong kernel costs milliseconds — a whole 512-spp launch of it cost
+// hair-curls 14 % of an 8-launch render), then the fastest per sample stays; its time keeps being updated.
+constexpr int YH_TRIAL_SPP   = 16;  // shorter launches have flat, noisy costs: they neither rank kernels nor try new ones
+constexpr int kCandidates[3] = {0, 1, 3};
+bool trials_off() {
+  static const bool off = getenv("YHAIR_NO_TRIALS") != nullptr;  // developer switch: the cost heuristic only
+  return off || getenv("YHAIR_SHAPE") != nullptr;
+}
+// After a synchronous launch: its time, and dense / sparse from fresh item costs of a k_trace launch.
+void record_launch(yh_context* ctx, int nsamples, bool fresh_costs) {
   const int last = ctx->last_shape;
-  if (ctx->have_costs && last >= 0 && last < 4 && ctx->last_ms > 0) ctx->shape_ms[last] = (double)ctx->last_ms / nsamples;
+  if (nsamples >= YH_TRIAL_SPP && ctx->have_costs && !ctx->last_counted && last >= 0 && last < 4 && ctx->last_ms > 0) ctx->shape_ms[last] = (double)ctx->last_ms / nsamples;
   if (fresh_costs && (last == 0 || last == 1 || ctx->dense < 0)) {  // (only when the item costs have just been read back)
     bool known = false, d = dense_by_costs(ctx, &known);
     if (known && (last == 0 || last == 1)) ctx->dense = d ? 1 : 0;
   }
   ctx->have_costs = true;
-  if (ctx->dense < 0) return 0;
-  const int  sparse_c[2] = {0, 1}, dense_c[2] = {1, 3};
-  const int* cand = ctx->dense ? dense_c : sparse_c;
-  static const bool no_trials = getenv("YHAIR_NO_TRIALS") != nullptr;  // developer switch: the cost heuristic only
-  if (no_trials) return cand[0];
-  for (int k = 0; k < 2; k++)
-    if (ctx->shape_ms[cand[k]] == 0) return cand[k];
-  const int best = ctx->shape_ms[cand[0]] <= ctx->shape_ms[cand[1]] ? cand[0] : cand[1];
-  if (getenv("YHAIR_TIMING"))
-    fprintf(stderr, "[yhair] kernel times (ms per spp): %d: %.4f, %d: %.4f -> %d\n", cand[0], ctx->shape_ms[cand[0]], cand[1], ctx->shape_ms[cand[1]], best);
-  return best;
+}
+// Is a candidate kernel still untimed on this image (so that a long request should start with a short trial)?
+bool trial_pending(const yh_context* ctx) {
+  if (!ctx->have_state || !ctx->have_costs || ctx->state.shader != YH_SHADER_PATH || trials_off()) return false;
+  for (int c : kCandidates)
+    if (ctx->shape_ms[c] == 0) return true;
+  return false;
+}
+// The kernel for a launch of `nsamples`.
+int pick_launch_shape(const yh_context* ctx, int nsamples) {
+  if (const char* env = getenv("YHAIR_SHAPE")) return std::max(0, std::min(3, atoi(env)));
+  if (!ctx->have_costs) return ctx->launch_shape;  // the first launch of an image: unplanned, not a measurement
+  const int by_costs = ctx->dense > 0 ? 1 : 0;
+  if (trials_off()) return by_costs;
+  int best = -1;
+  for (int c : kCandidates) {
+    if (ctx->shape_ms[c] == 0) {
+      if (nsamples >= YH_TRIAL_SPP) return c;  // a trial
+      continue;
+    }
+    if (best < 0 || ctx->shape_ms[c] < ctx->shape_ms[best]) best = c;
+  }
+  return best >= 0 ? best : by_costs;
 }
 void build_work_items(const yh_context* ctx, std::vector<int>& items) {
   // Expensive items first, in decreasing cost (they bound the launch); the cheap
@@ -865,7 +886,9 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
   if (best_shape >= 0) {
     sc.lds_node_base  = info[best_shape].node_base;
     int want = 0;  // LDS nodelets are optional (YHAIR_LDS_NODES): measured no gain once a step is a single fetch, see DESIGN.md
+#if YH_LDS_NODELETS
     if (const char* env = getenv("YHAIR_LDS_NODES")) want = std::max(0, atoi(env));
+#endif
     // 128 B per nodelet next to the stacks and the scene table of the larger launch shape: stay inside the CU's 160 KB
     sc.lds_node_count = 0;
     int room = (160 * 1024 - yhk_trace_lds_bytes(&sc, 0)) / 128;
@@ -980,8 +1003,19 @@ int yh_image_size(const yh_context* ctx, int* width, int* height) {
   return YH_OK;
 }
 
-// Bookkeeping after a synchronous launch: longest-processing-time-first order and launch shape
-// for the next one (the pixel results do not depend on either).
+// The hand-out order of the work items for the kernel in ctx->state.launch_shape, from the item costs the host holds
+// (it depends on the kernel: k_stream's items are dealt, not queued).
+static int upload_work_items(yh_context* ctx) {
+  std::vector<int> tiles;
+  build_work_items(ctx, tiles);
+  ctx->state.num_groups = 1, ctx->state.group_begin[0] = 0, ctx->state.group_begin[1] = (int)tiles.size();
+  if (ctx->state.shader == YH_SHADER_PATH && ctx->state.launch_shape == 3) deal_items_for_stream(ctx, tiles);
+  HIPCHK(ctx, hipMemcpy(ctx->d_tiles.p, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice));
+  return YH_OK;
+}
+
+// Bookkeeping after a synchronous launch: its time (kernel selection) and, after launches 1, 2, 4, 8, ... of a state,
+// the longest-processing-time-first order for the next ones (the pixel results do not depend on either).
 static int replan_after_launch(yh_context* ctx, int nsamples) {
   // A pixel's samples are sequential, so the items that start last bound the launch; hair quadrants
   // cost 10-100x background ones. Re-planned after launches 1, 2, 4, 8, ... of a state: the relative
@@ -989,17 +1023,10 @@ static int replan_after_launch(yh_context* ctx, int nsamples) {
   // read-back, sort and upload are a few hundred microseconds of a 16 ms launch.
   const unsigned li      = ++ctx->launches_of_state;
   const bool     refresh = (li & (li - 1)) == 0;
-  const int      before  = ctx->state.launch_shape;
   if (refresh) HIPCHK(ctx, hipMemcpy(ctx->item_cost.data(), ctx->d_tile_cost.p, ctx->item_cost.size() * 4, hipMemcpyDeviceToHost));
-  if (ctx->state.shader == YH_SHADER_PATH && (refresh || ctx->have_costs)) ctx->launch_shape = next_launch_shape(ctx, nsamples, refresh);
-  ctx->state.launch_shape = ctx->launch_shape;
-  if (!refresh && ctx->state.launch_shape == before) return YH_OK;
-  std::vector<int> tiles;  // (the hand-out order depends on the kernel: k_stream's items are dealt, not queued)
-  build_work_items(ctx, tiles);
-  ctx->state.num_groups = 1, ctx->state.group_begin[0] = 0, ctx->state.group_begin[1] = (int)tiles.size();
-  if (ctx->state.shader == YH_SHADER_PATH && ctx->state.launch_shape == 3) deal_items_for_stream(ctx, tiles);
-  HIPCHK(ctx, hipMemcpy(ctx->d_tiles.p, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice));
-  return YH_OK;
+  if (ctx->state.shader == YH_SHADER_PATH && (refresh || ctx->have_costs)) record_launch(ctx, nsamples, refresh);
+  if (!refresh) return YH_OK;
+  return upload_work_items(ctx);
 }
 
 // One launch of the wavefront integrator (csrc/wavefront.hip): persistent workgroups, one path pool each.
@@ -1220,9 +1247,18 @@ static int trace_impl(yh_context* ctx, int nsamples, bool counted, bool sync) {
   }
   const bool path = ctx->state.shader == YH_SHADER_PATH;
   if (counted && !path) return fail(ctx, YH_E_INVALID, "work counters exist for the path shader only");
+  if (path && !counted) {  // the kernel for this launch; the hand-out order follows it
+    const int want = pick_launch_shape(ctx, sync ? nsamples : 0);  // (an asynchronous launch is not timed: never a trial)
+    if (want != ctx->state.launch_shape) {
+      if (getenv("YHAIR_TIMING"))
+        fprintf(stderr, "[yhair] kernel times (ms per spp): 0: %.4f, 1: %.4f, 3: %.4f -> %d (%d spp)\n", ctx->shape_ms[0], ctx->shape_ms[1], ctx->shape_ms[3], want, nsamples);
+      ctx->launch_shape = ctx->state.launch_shape = want;
+      if (int rc = upload_work_items(ctx)) return rc;
+    }
+  }
   int shape = path ? ctx->state.launch_shape : 0;  // the preview shaders have one launch shape
   if (shape >= 2 && counted) shape = 1;            // the instrumented build exists for k_trace only
-  ctx->last_shape = shape;
+  ctx->last_shape = shape, ctx->last_counted = counted;
   if (shape == 2) return wavefront_impl(ctx, nsamples, sync);
   if (shape == 3) return stream_impl(ctx, nsamples, sync);
   int waves_per_block = yhk_block_threads(shape) / 64;  // one work item per wave at a time
@@ -1248,7 +1284,20 @@ static int trace_impl(yh_context* ctx, int nsamples, bool counted, bool sync) {
   }
   return YH_OK;
 }
-int yh_trace_samples(yh_context* ctx, int nsamples) { return trace_impl(ctx, nsamples, false, true); }
+int yh_trace_samples(yh_context* ctx, int nsamples) {
+  if (!ctx) return YH_E_INVALID;
+  // a long request starts with the short trial launches of the kernels this image has not timed yet (pick_launch_shape)
+  float ms = 0;
+  int   launches = 0, remaining = nsamples;
+  do {
+    const int n  = (remaining >= 2 * YH_TRIAL_SPP && trial_pending(ctx)) ? YH_TRIAL_SPP : remaining;
+    const int rc = trace_impl(ctx, n, false, true);
+    if (rc) return rc;
+    ms += ctx->last_ms, launches += ctx->last_launches, remaining -= n;
+  } while (remaining > 0);
+  ctx->last_ms = ms, ctx->last_launches = launches;
+  return YH_OK;
+}
 int yh_trace_samples_async(yh_context* ctx, int nsamples) { return trace_impl(ctx, nsamples, false, false); }
 int yh_synchronize(yh_context* ctx) {
   if (!ctx) return YH_E_INVALID;
