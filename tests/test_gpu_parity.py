@@ -719,6 +719,34 @@ def test_launch_shapes_and_kernels_render_identical_pixels(ctx, yh, name, kw, mo
     sf.close()
 
 
+@pytest.mark.parametrize("name,kw", [("sphere-hairblock", dict(scale=0.05, zoom=True)), ("straight-hair", dict(scale=0.05))],
+                         ids=["sphere-hairblock", "straight-hair"])
+def test_kernel_trials_are_cut_off_a_long_request(ctx, yh, name, kw, monkeypatch):
+    """yh_trace_samples starts a long request with 32-sample launches of the kernels the image has not timed yet
+    (host/context.cpp: pick_launch_shape). The samples count like any others: one 150-sample request renders the bits of
+    a single launch of one kernel, in more than one launch; once every candidate is timed a request is one launch again."""
+    sf = yh.SceneFile(scene_path(name, **kw))
+    ctx.upload_scene(sf.desc)
+    p = yh.TraceParams.default(resolution=90)  # (a size no other test uses: no timings kept from an earlier image)
+    monkeypatch.setenv("YHAIR_SHAPE", "0")
+    ctx.init_state(p)
+    ctx.trace_samples(150)
+    assert ctx.last_trace_ms()[1] == 1
+    base = (ctx.download(), ctx.download_rng())
+    monkeypatch.delenv("YHAIR_SHAPE")
+    ctx.init_state(p)
+    ctx.trace_samples(150)
+    ms, launches = ctx.last_trace_ms()
+    assert 3 <= launches <= 4 and ms > 0, launches  # two or three trials, then the rest
+    assert np.array_equal(ctx.download(), base[0]) and np.array_equal(ctx.download_rng(), base[1])
+    ctx.trace_samples(150)
+    assert ctx.last_trace_ms()[1] <= 2  # (fresh item costs may still turn a sparse reading into a dense one: one more trial)
+    ctx.trace_samples(150)
+    assert ctx.last_trace_ms()[1] == 1
+    assert ctx.launch_shape() in (0, 1, 3)
+    sf.close()
+
+
 FULL_CONFIGS = [
     ("C2-beta_m0.1", "straight-hair", dict(scale=1.0, beta_m=0.1), 720),
     ("C2-beta_m0.25", "straight-hair", dict(scale=1.0, beta_m=0.25), 720),

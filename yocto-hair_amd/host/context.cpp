@@ -276,6 +276,7 @@ struct yh_context {
   unsigned         launches_of_state = 0;  // synchronous launches since yh_init_state (re-planning schedule)
   int              launch_shape = 0;  // decided from launches of at least 16 spp (shorter ones have flat, noisy item costs)
   int              last_shape = -1;   // the kernel the most recent launch ran (yh_launch_shape)
+  bool             async_pending = false;  // an asynchronous launch whose time yh_synchronize has still to read
   bool             last_counted = false;  // ... and whether it was the instrumented build (its time ranks nothing)
   // single-process multi-GPU gather (yh_gather_framebuffer): this context's packed tiles; on the root also the
   // receive buffer and the communicators of the device set they were made for
@@ -395,17 +396,25 @@ int choose_launch_shape(const yh_context* ctx) {
 // (straight-hair 720^2: a tie; curly-hair 1280^2: k_stream +39 %; hair-curls: k_trace 2.3x). Every candidate is timed
 // once per image on a SHORT planned launch (YH_TRIAL_SPP samples: yh_trace_samples cuts them off the front of a long
 // request, so all samples count and a trial of the wrong kernel costs milliseconds — a whole 512-spp launch of it cost
-// hair-curls 14 % of an 8-launch render), then the fastest per sample stays; its time keeps being updated.
-constexpr int YH_TRIAL_SPP   = 16;  // shorter launches have flat, noisy costs: they neither rank kernels nor try new ones
-constexpr int kCandidates[3] = {0, 1, 3};
+// hair-curls 14 % of an 8-launch render), then the fastest per sample stays. Only launches of that length class rank
+// kernels: a short launch costs more per sample than a long one (C1, 512 x 4: 0.25 against 0.23 ms), so a long launch
+// of the running kernel must not be compared with the trials of the others. Sparse scenes never try k_stream: it costs
+// them a fixed 20 ms per launch for the cheap pixels.
+constexpr int YH_TRIAL_SPP = 32;  // shorter launches have flat, noisy costs: they neither rank kernels nor try new ones
 bool trials_off() {
   static const bool off = getenv("YHAIR_NO_TRIALS") != nullptr;  // developer switch: the cost heuristic only
   return off || getenv("YHAIR_SHAPE") != nullptr;
 }
-// After a synchronous launch: its time, and dense / sparse from fresh item costs of a k_trace launch.
+int candidates(const yh_context* ctx, int cand[3]) {
+  cand[0] = 0, cand[1] = 1, cand[2] = 3;
+  return ctx->dense > 0 ? 3 : 2;
+}
+// After a synchronous launch: its time if it was a trial-length one, and dense / sparse from fresh item costs of a
+// k_trace launch.
 void record_launch(yh_context* ctx, int nsamples, bool fresh_costs) {
   const int last = ctx->last_shape;
-  if (nsamples >= YH_TRIAL_SPP && ctx->have_costs && !ctx->last_counted && last >= 0 && last < 4 && ctx->last_ms > 0) ctx->shape_ms[last] = (double)ctx->last_ms / nsamples;
+  if (nsamples >= YH_TRIAL_SPP && nsamples < 2 * YH_TRIAL_SPP && ctx->have_costs && !ctx->last_counted && last >= 0 && last < 4 && ctx->last_ms > 0)
+    ctx->shape_ms[last] = (double)ctx->last_ms / nsamples;
   if (fresh_costs && (last == 0 || last == 1 || ctx->dense < 0)) {  // (only when the item costs have just been read back)
     bool known = false, d = dense_by_costs(ctx, &known);
     if (known && (last == 0 || last == 1)) ctx->dense = d ? 1 : 0;
@@ -415,8 +424,9 @@ void record_launch(yh_context* ctx, int nsamples, bool fresh_costs) {
 // Is a candidate kernel still untimed on this image (so that a long request should start with a short trial)?
 bool trial_pending(const yh_context* ctx) {
   if (!ctx->have_state || !ctx->have_costs || ctx->state.shader != YH_SHADER_PATH || trials_off()) return false;
-  for (int c : kCandidates)
-    if (ctx->shape_ms[c] == 0) return true;
+  int cand[3], n = candidates(ctx, cand);
+  for (int k = 0; k < n; k++)
+    if (ctx->shape_ms[cand[k]] == 0) return true;
   return false;
 }
 // The kernel for a launch of `nsamples`.
@@ -425,10 +435,11 @@ int pick_launch_shape(const yh_context* ctx, int nsamples) {
   if (!ctx->have_costs) return ctx->launch_shape;  // the first launch of an image: unplanned, not a measurement
   const int by_costs = ctx->dense > 0 ? 1 : 0;
   if (trials_off()) return by_costs;
-  int best = -1;
-  for (int c : kCandidates) {
+  int cand[3], n = candidates(ctx, cand), best = -1;
+  for (int k = 0; k < n; k++) {
+    const int c = cand[k];
     if (ctx->shape_ms[c] == 0) {
-      if (nsamples >= YH_TRIAL_SPP) return c;  // a trial
+      if (nsamples >= YH_TRIAL_SPP && nsamples < 2 * YH_TRIAL_SPP) return c;  // a trial
       continue;
     }
     if (best < 0 || ctx->shape_ms[c] < ctx->shape_ms[best]) best = c;
@@ -1298,12 +1309,17 @@ int yh_trace_samples(yh_context* ctx, int nsamples) {
   ctx->last_ms = ms, ctx->last_launches = launches;
   return YH_OK;
 }
-int yh_trace_samples_async(yh_context* ctx, int nsamples) { return trace_impl(ctx, nsamples, false, false); }
+int yh_trace_samples_async(yh_context* ctx, int nsamples) {
+  const int rc = trace_impl(ctx, nsamples, false, false);
+  if (ctx && rc == YH_OK) ctx->async_pending = ctx->last_launches > 0;
+  return rc;
+}
 int yh_synchronize(yh_context* ctx) {
   if (!ctx) return YH_E_INVALID;
   HIPCHK(ctx, hipSetDevice(ctx->device));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  if (ctx->last_launches) (void)hipEventElapsedTime(&ctx->last_ms, ctx->ev0, ctx->ev1);
+  if (ctx->async_pending) (void)hipEventElapsedTime(&ctx->last_ms, ctx->ev0, ctx->ev1);  // (a blocking call has its own sum)
+  ctx->async_pending = false;
   return YH_OK;
 }
 int yh_launch_shape(const yh_context* ctx) { return ctx ? ctx->last_shape : YH_E_INVALID; }
