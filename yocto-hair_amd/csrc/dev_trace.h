@@ -286,7 +286,7 @@ YH_DEV void count_quad(unsigned int& slot) {
 // their LDS stack, and the next call picks them up where they stopped (instance-space ray data recomputed: same
 // operations, same bits).
 #ifndef YH_REMAT_Q
-#define YH_REMAT_Q 1 /* dense launch shape (96 registers): lane #define YH_REMAT_Q 0 3 recomputed in the node step (two instructions) instead of reloaded from scratch */
+#define YH_REMAT_Q 1 /* dense launch shape (96 registers): lane & 3 recomputed in the node step (two instructions) instead of reloaded from scratch */
 #endif
 struct trav_state {
   unsigned int cur;
