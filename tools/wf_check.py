@@ -43,7 +43,7 @@ else:
     for rnd in range(2):
         for shape in shapes:
             img, _, ms = render(sf, res, (spp, spp, spp), shape)
-            same = "" if ref is None else f" same image as first: {np.array_equal(img, ref)}"
+            same = f" image md5 {__import__('hashlib').md5(img.tobytes()).hexdigest()[:8]}" if ref is None else f" same image as first: {np.array_equal(img, ref)}"
             ref = img if ref is None else ref
             print(f"{name} {res}^2 x {spp} spp shape {shape} (YHAIR_WF_SLOTS={os.environ.get('YHAIR_WF_SLOTS', '1')}): ms {np.round(ms, 2)} -> "
                   f"{res * res * spp / ms[-1] / 1e3:.1f} Msamples/s{same}", flush=True)
