@@ -288,6 +288,8 @@ struct yh_context {
   // measurement), and whether the scene is dense (more expensive items than resident waves; from k_trace's costs)
   double           shape_ms[4] = {0, 0, 0, 0};
   bool             have_costs = false;
+  bool             costs_settled = false;   // the item costs come from a launch of at least YH_TRIAL_SPP samples (not from the 1-spp probe)
+  bool             planned_settled = false; // ... and the most recent launch was planned from such costs (only then does its time rank a kernel)
   int              dense = -1;
   // path pool of the wavefront integrator (csrc/wavefront.hip), allocated at its first launch
   DevBuf           d_pool_ray_o, d_pool_ray_d, d_pool_weight, d_pool_radiance, d_pool_hit, d_pool_medium;
@@ -398,8 +400,10 @@ int choose_launch_shape(const yh_context* ctx) {
 // request, so all samples count and a trial of the wrong kernel costs milliseconds — a whole 512-spp launch of it cost
 // hair-curls 14 % of an 8-launch render), then the fastest per sample stays. Only launches of that length class rank
 // kernels: a short launch costs more per sample than a long one (C1, 512 x 4: 0.25 against 0.23 ms), so a long launch
-// of the running kernel must not be compared with the trials of the others. Sparse scenes never try k_stream: it costs
-// them a fixed 20 ms per launch for the cheap pixels.
+// of the running kernel must not be compared with the trials of the others; and only launches planned from the item
+// costs of a launch of that length or more: the hand-out order planned from the 1-spp probe costs 15 % of a launch
+// (C1: 0.269 against 0.234 ms per sample), so on a new image a first short launch settles the costs and the trials
+// follow it. Sparse scenes never try k_stream: it costs them a fixed 20 ms per launch for the cheap pixels.
 constexpr int YH_TRIAL_SPP = 32;  // shorter launches have flat, noisy costs: they neither rank kernels nor try new ones
 bool trials_off() {
   static const bool off = getenv("YHAIR_NO_TRIALS") != nullptr;  // developer switch: the cost heuristic only
@@ -413,8 +417,9 @@ int candidates(const yh_context* ctx, int cand[3]) {
 // k_trace launch.
 void record_launch(yh_context* ctx, int nsamples, bool fresh_costs) {
   const int last = ctx->last_shape;
-  if (nsamples >= YH_TRIAL_SPP && nsamples < 2 * YH_TRIAL_SPP && ctx->have_costs && !ctx->last_counted && last >= 0 && last < 4 && ctx->last_ms > 0)
+  if (nsamples >= YH_TRIAL_SPP && nsamples < 2 * YH_TRIAL_SPP && ctx->planned_settled && !ctx->last_counted && last >= 0 && last < 4 && ctx->last_ms > 0)
     ctx->shape_ms[last] = (double)ctx->last_ms / nsamples;
+  if (fresh_costs && nsamples >= YH_TRIAL_SPP) ctx->costs_settled = true;
   if (fresh_costs && (last == 0 || last == 1 || ctx->dense < 0)) {  // (only when the item costs have just been read back)
     bool known = false, d = dense_by_costs(ctx, &known);
     if (known && (last == 0 || last == 1)) ctx->dense = d ? 1 : 0;
@@ -424,6 +429,7 @@ void record_launch(yh_context* ctx, int nsamples, bool fresh_costs) {
 // Is a candidate kernel still untimed on this image (so that a long request should start with a short trial)?
 bool trial_pending(const yh_context* ctx) {
   if (!ctx->have_state || !ctx->have_costs || ctx->state.shader != YH_SHADER_PATH || trials_off()) return false;
+  if (!ctx->costs_settled) return true;  // (the first short launch settles the item costs; the trials follow it)
   int cand[3], n = candidates(ctx, cand);
   for (int k = 0; k < n; k++)
     if (ctx->shape_ms[cand[k]] == 0) return true;
@@ -439,7 +445,7 @@ int pick_launch_shape(const yh_context* ctx, int nsamples) {
   for (int k = 0; k < n; k++) {
     const int c = cand[k];
     if (ctx->shape_ms[c] == 0) {
-      if (nsamples >= YH_TRIAL_SPP && nsamples < 2 * YH_TRIAL_SPP) return c;  // a trial
+      if (ctx->costs_settled && nsamples >= YH_TRIAL_SPP && nsamples < 2 * YH_TRIAL_SPP) return c;  // a trial
       continue;
     }
     if (best < 0 || ctx->shape_ms[c] < ctx->shape_ms[best]) best = c;
@@ -911,7 +917,7 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
   ctx->have_state = false;
   ctx->launch_shape = 0;  // a new scene: no measured costs yet
   ctx->item_cost.clear();
-  ctx->have_costs = false, ctx->dense = -1;
+  ctx->have_costs = false, ctx->costs_settled = false, ctx->dense = -1;
   for (double& t : ctx->shape_ms) t = 0;
   return YH_OK;
 }
@@ -960,7 +966,7 @@ int yh_init_state(yh_context* ctx, const yh_trace_params* params) {
   for (int t = ctx->rank; t < ctx->num_tiles_total; t += ctx->world) owned.push_back(t);
   if ((int)ctx->item_cost.size() != ctx->num_tiles_total * 4) {  // scheduling hints survive a re-init of the same image
     ctx->item_cost.assign((size_t)ctx->num_tiles_total * 4, 0);
-    ctx->have_costs = false, ctx->dense = -1, ctx->launch_shape = 0;
+    ctx->have_costs = false, ctx->costs_settled = false, ctx->dense = -1, ctx->launch_shape = 0;
     for (double& t : ctx->shape_ms) t = 0;
   }
   std::vector<int> tiles;
@@ -1269,7 +1275,7 @@ static int trace_impl(yh_context* ctx, int nsamples, bool counted, bool sync) {
   }
   int shape = path ? ctx->state.launch_shape : 0;  // the preview shaders have one launch shape
   if (shape >= 2 && counted) shape = 1;            // the instrumented build exists for k_trace only
-  ctx->last_shape = shape, ctx->last_counted = counted;
+  ctx->last_shape = shape, ctx->last_counted = counted, ctx->planned_settled = ctx->costs_settled;
   if (shape == 2) return wavefront_impl(ctx, nsamples, sync);
   if (shape == 3) return stream_impl(ctx, nsamples, sync);
   int waves_per_block = yhk_block_threads(shape) / 64;  // one work item per wave at a time
