@@ -213,7 +213,10 @@ int yh_set_shard(yh_context* ctx, int rank, int world);
 
 /* trace_samples called `nsamples` times (yocto_pathtrace.cpp:1992-2007, call
  * site apps/yscenetrace/yscenetrace.cpp:256-258): adds nsamples samples to
- * every owned pixel. Blocking.                                               */
+ * every owned pixel. Blocking. Normally one kernel launch; a request of 64
+ * samples or more on an image whose kernels have not been timed yet starts
+ * with 32-sample launches of the candidates (same samples, same bits:
+ * yh_last_trace_ms reports the sum and the number of launches).              */
 int yh_trace_samples(yh_context* ctx, int nsamples);
 /* Same, but only enqueues the work on the context's stream.                  */
 int yh_trace_samples_async(yh_context* ctx, int nsamples);
