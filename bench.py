@@ -59,7 +59,7 @@ CONFIGS = {
 KERNELS = {0: "k_trace<512 x 4>", 1: "k_trace<256 x 5>", 2: "k_wavefront", 3: "k_stream"}
 
 
-def cpu_leg(scene_json, resolution, budget_s):
+def cpu_leg(scene_json, resolution, budget_s, force_spp=0):
     """The CPU path on this host (test infrastructure, used here only as the reported baseline and as
     the checker of the `parity` field): two renders of the same scene at equal spp, seeds A and B.
     Returns (cpu_baseline dict, image A, image B, spp, seed B, work counts of the reference algorithm)."""
@@ -87,7 +87,7 @@ def cpu_leg(scene_json, resolution, budget_s):
     t0 = time.time()
     render(pa, 1)
     t1 = time.time() - t0
-    spp = int(max(1, min(256, budget_s / max(t1, 1e-3))))
+    spp = force_spp if force_spp > 0 else int(max(1, min(256, budget_s / max(t1, 1e-3))))
     t0 = time.time()
     img_a = render(pa, spp)
     dt = time.time() - t0
@@ -141,6 +141,8 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0, help="hair strand-count multiplier (1.0 = the config's scene)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=10.0, help="seconds of CPU rendering per seed (two seeds)")
+    ap.add_argument("--cpu-spp", type=int, default=0, help="samples of the CPU leg and of the parity field (default: what --cpu-budget allows, at most 256); "
+                                                           "1536 = the metric's own sample count on C1, about 40 s per seed on 256 threads")
     ap.add_argument("--save", default="", help="write the final image (.pfm/.hdr) on rank 0")
     ap.add_argument("--weak", action="store_true", help="N > 1: report the weak-scaling run (image side x sqrt(N))")
     ap.add_argument("--strong", action="store_true", help="(default for N > 1; kept for compatibility)")
@@ -237,7 +239,7 @@ def main():
     gpu_counts = ctx.trace_samples_counted(2).as_dict()
     cpu = ref_wc = parity = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        cpu, cpu_a, cpu_b, cpu_spp, seed_b, ref_wc = cpu_leg(scene_json, base_res, a.cpu_budget)
+        cpu, cpu_a, cpu_b, cpu_spp, seed_b, ref_wc = cpu_leg(scene_json, base_res, a.cpu_budget, a.cpu_spp)
         imgs = []
         for sd in (None, seed_b):  # the device at the CPU leg's spp, both seeds (untimed)
             p = yh.TraceParams.default(resolution=base_res) if sd is None else yh.TraceParams.default(resolution=base_res, seed=sd)
