@@ -1039,7 +1039,8 @@ static int replan_after_launch(yh_context* ctx, int nsamples) {
   // costs of the items settle after the first launches (they are a property of the image), and the
   // read-back, sort and upload are a few hundred microseconds of a 16 ms launch.
   const unsigned li      = ++ctx->launches_of_state;
-  const bool     refresh = (li & (li - 1)) == 0;
+  // (... and after the first launch long enough to settle the costs, whenever it comes: the kernel trials wait for it)
+  const bool     refresh = (li & (li - 1)) == 0 || (!ctx->costs_settled && nsamples >= YH_TRIAL_SPP && ctx->state.shader == YH_SHADER_PATH);
   if (refresh) HIPCHK(ctx, hipMemcpy(ctx->item_cost.data(), ctx->d_tile_cost.p, ctx->item_cost.size() * 4, hipMemcpyDeviceToHost));
   if (ctx->state.shader == YH_SHADER_PATH && (refresh || ctx->have_costs)) record_launch(ctx, nsamples, refresh);
   if (!refresh) return YH_OK;
