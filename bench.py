@@ -14,9 +14,13 @@ the sample-loop kernel. The K steps of a run add up to EXACTLY the config's samp
 for C1 / C2, 4096 for C3 / C4): K does not divide it in general, so the first steps carry one
 sample more than the last ones (K = 24: 24 x 64; K = 20: 16 x 77 + 4 x 76).
 
-N > 1 (one process per GPU, launched by torch.distributed.run): the image's 8x8 tiles are dealt
-round-robin to the ranks, every rank renders all samples of its own tiles with no data-path
-collective, and ONE RCCL gather of the packed float4 tiles follows the timed loop (gather_ms).
+N > 1 (one process per GPU): under torch.distributed.run the ranks are the launcher's; as a bare
+`python bench.py --gpus N` this process starts the N ranks itself (plain child processes, before it
+touches the GPU, 127.0.0.1 rendezvous) and exits with the first failing rank's code. The image's 8x8
+tiles are dealt round-robin to the ranks, every rank renders all samples of its own tiles with no
+data-path collective, and ONE RCCL gather of the packed float4 tiles follows the timed loop
+(gather_ms). With fewer devices than ranks (a one-GPU box) the ranks share devices and the gather
+goes through gloo (RCCL refuses two ranks on one device); config.collective says which ran.
 The run is on the CONFIG'S OWN IMAGE (strong scaling, "scaling": "strong") — that is what
 BASELINE.json asks to be reported at 1 / 2 / 4 / 8 GPUs; a second, shorter run on an image with N
 times the pixels (side x sqrt(N): pixels per GPU as at N = 1) is reported next to it as
@@ -56,7 +60,7 @@ CONFIGS = {
     "C3": dict(scene="curly-hair", resolution=1280, spp=4096, kw={}),
     "C4": dict(scene="hair-curls", resolution=1280, spp=4096, kw={}),
 }
-KERNELS = {0: "k_trace<512 x 4>", 1: "k_trace<256 x 5>", 2: "k_wavefront", 3: "k_stream"}
+KERNELS = {0: "k_trace<512 x 4>", 1: "k_trace<256 x 5>", 3: "k_stream"}
 
 
 def cpu_leg(scene_json, resolution, budget_s, force_spp=0):
@@ -128,6 +132,49 @@ def parity_field(np, gpu_a, gpu_b, cpu_a, cpu_b, spp):
             "note": "same seed, equal spp; tolerance: rel_rmse <= 0.5 x floor and >= 99 % of pixels within 4 sigma (tests/test_gpu_parity.py)"}
 
 
+def csrc_sha16():
+    """Fingerprint of the device code (csrc/*.hip, *.h): a committed counter pass describes this run only if it was
+    taken on the same kernels (tools/traffic_from_pmc.py stores it)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    base = os.path.join(ROOT, "yocto-hair_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(base, "*.hip")) + glob.glob(os.path.join(base, "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def spawn_ranks(n):
+    """Bare `bench.py --gpus N`: N rank processes of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as the
+    launcher would set them). The parent never touches the GPU; it waits, ends the others when one fails, and
+    returns the first non-zero exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    pending = set(range(n))
+    while pending:
+        for r in sorted(pending):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            pending.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in pending:  # a failed rank leaves the others waiting in a collective: end them (exact PIDs)
+                    procs[q].terminate()
+        time.sleep(0.05)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -148,7 +195,12 @@ def main():
     ap.add_argument("--strong", action="store_true", help="(default for N > 1; kept for compatibility)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo (CPU staging) lets the N > 1 flow be exercised on a one-GPU box")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="N = 1: still create the process group and run the framebuffer gather through the collective "
+                         "(a one-rank RCCL communicator: how a one-GPU box executes the nccl branch)")
     a = ap.parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(a.gpus))
 
     import numpy as np
     import torch
@@ -179,20 +231,28 @@ def main():
     if world != a.gpus and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if a.gpus > 1 and world == 1:
-        raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
-    if a.backend == "gloo":  # functional test of the N > 1 flow: ranks may share a GPU
-        local_rank %= max(1, torch.cuda.device_count())
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE=1")
+    ndev = max(1, torch.cuda.device_count())  # (counting devices does not initialise the GPU)
+    backend = a.backend
+    if backend == "nccl" and world > ndev:  # ranks share a device: RCCL refuses duplicate GPUs, stage through gloo
+        backend = "gloo"
+    if backend == "gloo":
+        local_rank %= ndev
+    collective = (f"{backend}" + (f" ({world} ranks on {ndev} device(s): CPU staging)" if backend == "gloo" and world > 1 else
+                                  " = RCCL" if backend == "nccl" else ""))
     torch.cuda.set_device(local_rank)
-    cdev = "cuda" if a.backend == "nccl" else "cpu"  # where collective payloads live
-    if world > 1:
+    cdev = "cuda" if backend == "nccl" else "cpu"  # where collective payloads live
+    grouped = world > 1 or a.force_collective
+    if grouped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if a.backend == "nccl":
+        os.environ.setdefault("MASTER_PORT", "29531")
+        if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
     def barrier():
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -261,7 +321,7 @@ def main():
     ctx.pack_tiles_device(packed.data_ptr(), n)
     if cdev == "cpu":
         packed = packed.cpu()
-    image = yhair_dist.gather_framebuffer(packed, width, height, rank, world, ctx=ctx)
+    image = yhair_dist.gather_framebuffer(packed, width, height, rank, world, ctx=ctx, force_collective=a.force_collective)
     torch.cuda.synchronize()
     gather_ms = (time.perf_counter() - t0) * 1e3
 
@@ -321,8 +381,12 @@ def main():
             for cand in allp:  # the passes were taken on one kernel: they describe this run only if it chose the same one
                 if (cand["scene"], cand["resolution"], cand["scale"]) == (scene_name, res_main, a.scale) and world == 1 and not scene_kw \
                         and cand.get("kernel", pmc_kernel) == pmc_kernel:
+                    if cand.get("csrc_sha16") != csrc_sha16():  # taken on other device code: not a statement about this run
+                        traffic_src = f"stale: {cand['source'].split(' ')[0]} was taken on other kernels (csrc fingerprint differs); retake with tools/profile_configs.sh"
+                        continue
                     pmc = cand
             if pmc:
+                traffic_src = None
                 scale_spp = spp_launch / pmc["spp_per_launch"]  # traffic is proportional to the samples of a launch
                 traffic = round((pmc["hbm_fetch_bytes_per_launch"] + pmc["hbm_write_bytes_per_launch"]) * scale_spp / 1e9, 3)
                 traffic_src = pmc["source"]
@@ -354,6 +418,7 @@ def main():
                        "sharding": f"8x8 tiles round-robin over {world} GPU(s), one RCCL gather after the loop"
                                    + ("" if world == 1 else (f" (weak: image side {base_res} * sqrt({world}) -> {width}, {width * height // world} pixels per GPU)"
                                                              if a.weak else " (strong: the config's own image)")),
+                       "collective": collective if grouped else "none (one rank: the packed tiles are un-interleaved in place)",
                        "upload_s": round(upload_s, 2), "gather_ms": round(gather_ms, 2),
                        "image_mean_rgb": [round(float(x), 5) for x in img[..., :3].mean(axis=(0, 1))]},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -377,7 +442,7 @@ def main():
         if cpu is not None and world == 1:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
 

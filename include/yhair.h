@@ -147,6 +147,11 @@ typedef struct yh_trace_params {
   float    clamp;      /* 100                                               */
   uint64_t seed;       /* 961748941                                         */
   int      shader;     /* YH_SHADER_PATH; others: "sampler unknown" error   */
+  int      hair_exact; /* extension (0 = default). The hair BSDF is evaluated within 1e-4 relative of the
+                        * reference with hardware reciprocal / sqrt / log2 / sin / cos and float asinf; 1 selects
+                        * the exact forms (IEEE divisions, library log / sin / cos, the reference's DOUBLE asin,
+                        * yocto_extension.cpp:111,148-151): paths follow the reference's for more bounces at about
+                        * 0.88 x the speed. Path shader only; runs the 512 x 4 quad kernel (csrc/exact.hip).        */
 } yh_trace_params;
 
 /* Per-sample work counters of the reference algorithm: what
@@ -203,6 +208,10 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* scene);
 /* init_state (yocto_pathtrace.cpp:1931-1946): image size from the camera film
  * and params->resolution, zeroed accumulators, per-pixel PCG32 streams
  * make_rng(seed, rand1i(master, 1<<31)/2+1) with master = make_rng(1301081). */
+/* On an image this context has not rendered yet it also launches a 1-sample
+ * PROBE of the path shader (the per-tile costs that plan the first real launch)
+ * and puts accumulators and RNG streams back as they were: blocking, one
+ * kernel launch, no effect on the pixels.                                     */
 int yh_init_state(yh_context* ctx, const yh_trace_params* params);
 int yh_image_size(const yh_context* ctx, int* width, int* height);
 
@@ -216,7 +225,8 @@ int yh_set_shard(yh_context* ctx, int rank, int world);
  * every owned pixel. Blocking. Normally one kernel launch; a request of 64
  * samples or more on an image whose kernels have not been timed yet starts
  * with 32-sample launches of the candidates (same samples, same bits:
- * yh_last_trace_ms reports the sum and the number of launches).              */
+ * yh_last_trace_ms reports the sum and the number of launches): up to three
+ * kernels, each tried once, twice when two of them tie within 15 %.          */
 int yh_trace_samples(yh_context* ctx, int nsamples);
 /* Same, but only enqueues the work on the context's stream.                  */
 int yh_trace_samples_async(yh_context* ctx, int nsamples);
@@ -263,13 +273,17 @@ int yh_last_trace_ms(const yh_context* ctx, float* ms, int* launches);
 
 /* Which sample-loop kernel the most recent yh_trace_samples launch ran (the host picks per launch from
  * measured times; every choice renders the same bits): 0 = k_trace 512 threads x 4 waves per SIMD,
- * 1 = k_trace 256 x 5, 2 = k_wavefront, 3 = k_stream; < 0 = nothing launched yet (or an error code).    */
+ * 1 = k_trace 256 x 5, 3 = k_stream (2 is a developer kernel that product builds do not contain);
+ * < 0 = nothing launched yet (or an error code). With yh_trace_params::hair_exact it is always 0.        */
 int yh_launch_shape(const yh_context* ctx);
 
 /* Load-balance telemetry: for every tile id (row-major over ceil(W/8) x
  * ceil(H/8) tiles) the time its wavefront spent on it in the most recent
- * launch, in ticks of the 100 MHz device wall clock (0 for tiles of other
- * shards). `count` = number of tiles the caller's buffer holds.               */
+ * launch (0 for tiles of other shards). The UNIT depends on the kernel that
+ * ran (yh_launch_shape): k_trace (0, 1) reports ticks of the 100 MHz device
+ * wall clock, k_stream (3) the BVH steps of the tile's rays — both are
+ * relative costs for scheduling, comparable within one launch only.
+ * `count` = number of tiles the caller's buffer holds.                       */
 int yh_tile_costs(yh_context* ctx, uint32_t* ticks, int count);
 
 /* ------------------------------------------------------------------------ */

@@ -65,3 +65,18 @@ def test_pack_unpack_roundtrip_host():
     for r in range(3):
         yhair_dist.unpack_tiles_host(yhair_dist.pack_tiles_host(img, r, 3), r, 3, out)
     assert np.array_equal(out, img)
+
+
+def test_bare_bench_gpus_2_starts_its_own_ranks_and_reports_their_failure():
+    """`python bench.py --gpus 2` without a launcher: the script starts the two ranks itself. Here (no GPU) both
+    ranks fail at yh_create — there is no CPU fallback — and the parent must exit non-zero without printing a line."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                          "--scale", "0.02", "--resolution", "32", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the ranks run (tests/test_gpu_parity.py covers that)")
+    assert out.returncode != 0
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert "no HIP device" in out.stderr or "HIP" in out.stderr

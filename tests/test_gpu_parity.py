@@ -12,10 +12,13 @@ Bars (SURVEY.md 7 "parity definition"):
     at 16 spp image relRMSE(gpu, ref) <= 0.5 x relRMSE(ref seed A, ref seed B);
   * the reference's four Monte-Carlo self-tests pass on the device with their own thresholds.
 """
+import os
+import sys
+
 import numpy as np
 import pytest
 
-from conftest import GOLDEN_SCENES, golden, scene_path, scene_tag
+from conftest import GOLDEN_SCENES, ROOT, SCENES, golden, scene_path, scene_tag
 
 pytestmark = pytest.mark.gpu
 
@@ -378,15 +381,18 @@ def test_other_shaders_match_reference(ctx, oracle, yh, name, kw, shader):
     sf.close()
 
 
+@pytest.mark.parametrize("exact", [False, True], ids=["fast-bsdf", "exact-bsdf"])
 @pytest.mark.parametrize("which", ["sloth", "bold-man", "straight-hair", "curly-hair", "hair-curls", "sphere-hairblock"])
-def test_reference_scene_files_render_like_the_reference(ctx, yh, which):
+def test_reference_scene_files_render_like_the_reference(ctx, yh, which, exact):
     """The reference's own scene files (verbatim JSON, stand-in geometry) through loader, upload and
-    k_trace, against the reference's images of the same files (tests/golden/refscenes.npz)."""
+    k_trace, against the reference's images of the same files (tests/golden/refscenes.npz) — with the
+    default BSDF arithmetic (inside 1e-4 of the reference's values) and with yh_trace_params::hair_exact
+    (IEEE divisions, library log / sin / cos, the reference's double asin: csrc/exact.hip)."""
     g = golden("refscenes.npz")
     ref1, ref8, other = g[f"{which}|1"], g[f"{which}|8"], g[f"{which}|8_seed777"]
     sf = yh.SceneFile(scene_path("ref-" + which, scale=0.05))
     ctx.upload_scene(sf.desc)
-    p = yh.TraceParams.default(resolution=48)
+    p = yh.TraceParams.default(resolution=48, hair_exact=exact)
     assert ctx.init_state(p) == (ref1.shape[1], ref1.shape[0])
     ctx.trace_samples(1)
     img = ctx.download()
@@ -394,13 +400,17 @@ def test_reference_scene_files_render_like_the_reference(ctx, yh, which):
     assert np.mean(img[..., 3] == ref1[..., 3]) > 0.995
     close = _rel(img[..., :3], ref1[..., :3]).max(axis=2) < 1e-3
     assert close.mean() >= BAR_1SPP, f"only {close.mean():.3f} of pixels within rel 1e-3 at 1 spp"
-    # 8 spp against the seed-to-seed floor. Bar 0.75 instead of the golden scenes' 0.5: the
-    # reference's sphere-hairblock material is light hair (colour 0.8: eight-bounce paths, each bounce
-    # a chance to leave the reference's path), measured 0.52-0.62 there and 0.00-0.43 on the others
-    # (oracle/divergence_report.py)
+    # 8 spp against the seed-to-seed floor (0.5 x floor). The exact arithmetic meets it on every
+    # file (measured 0.00-0.23). The default arithmetic has the STATED bar 0.75 here: the reference's sphere-hairblock
+    # material is light hair (colour 0.8: eight-bounce paths, each bounce a chance to leave the reference's path),
+    # measured 0.52-0.62 there and 0.00-0.43 on the others (oracle/divergence_report.py,
+    # profiles/r02/bsdf_arithmetic_variants.txt)
     ctx.init_state(p)
     ctx.trace_samples(8)
-    assert _relrmse(ctx.download(), ref8) <= 0.75 * _relrmse(other, ref8)
+    assert ctx.launch_shape() == 0 or not exact
+    bar = 0.5 if exact else 0.75
+    err, floor = _relrmse(ctx.download(), ref8), _relrmse(other, ref8)
+    assert err <= bar * floor, f"{which}: relRMSE {err:.4f} vs {bar} x seed floor {floor:.4f}"
     sf.close()
 
 
@@ -695,14 +705,14 @@ def test_per_pixel_error_within_k_sigma(ctx, oracle, yh, name, kw):
                                      ("lights-unit", dict(scale=0.05, biglight=True))],
                          ids=["sphere-hairblock", "straight-hair", "hair-curls", "lobes", "big-light"])
 def test_launch_shapes_and_kernels_render_identical_pixels(ctx, yh, name, kw, monkeypatch):
-    """The host picks the integrator kernel — k_trace at 512 x 4 or at 256 x 5 (single-predicate line test),
-    the staged k_wavefront (csrc/wavefront.hip) or the one-lane-per-path k_stream (csrc/stream.hip) — from the previous launch's item costs, so which kernel
-    a render runs depends on history. Every choice must give the same bits: YHAIR_SHAPE forces each."""
+    """The host picks the integrator kernel — k_trace at 512 x 4 or at 256 x 5 (single-predicate line test) or the
+    one-lane-per-path k_stream (csrc/stream.hip) — by measurement, so which kernel a render runs depends on
+    history. Every choice must give the same bits: YHAIR_SHAPE forces each."""
     sf = yh.SceneFile(scene_path(name, **kw))
     ctx.upload_scene(sf.desc)
     p = yh.TraceParams.default(resolution=88)
     images = {}
-    for shape in ("0", "1", "2", "3"):  # k_trace 512 x 4, k_trace 256 x 5, k_wavefront, k_stream
+    for shape in ("0", "1", "3"):  # k_trace 512 x 4, k_trace 256 x 5, k_stream (2 = a developer kernel, not in the product build)
         monkeypatch.setenv("YHAIR_SHAPE", shape)
         ctx.init_state(p)
         ctx.trace_samples(3), ctx.trace_samples(5)
@@ -737,10 +747,11 @@ def test_kernel_trials_are_cut_off_a_long_request(ctx, yh, name, kw, monkeypatch
     ctx.init_state(p)
     ctx.trace_samples(150)
     ms, launches = ctx.last_trace_ms()
-    assert 3 <= launches <= 4 and ms > 0, launches  # two or three trials, then the rest
+    assert 3 <= launches <= 5 and ms > 0, launches  # the settling launch, two or three trials (a tie: one more each), then the rest
     assert np.array_equal(ctx.download(), base[0]) and np.array_equal(ctx.download_rng(), base[1])
-    ctx.trace_samples(150)
-    assert ctx.last_trace_ms()[1] <= 2  # (fresh item costs may still turn a sparse reading into a dense one: one more trial)
+    for _ in range(3):  # (a tie between two kernels is tried again, fresh item costs may turn a sparse reading into a dense one)
+        ctx.trace_samples(150)
+        assert ctx.last_trace_ms()[1] <= 3
     ctx.trace_samples(150)
     assert ctx.last_trace_ms()[1] == 1
     assert ctx.launch_shape() in (0, 1, 3)
@@ -748,6 +759,7 @@ def test_kernel_trials_are_cut_off_a_long_request(ctx, yh, name, kw, monkeypatch
 
 
 FULL_CONFIGS = [
+    ("C1", "sphere-hairblock", dict(scale=1.0), 720),
     ("C2-beta_m0.1", "straight-hair", dict(scale=1.0, beta_m=0.1), 720),
     ("C2-beta_m0.25", "straight-hair", dict(scale=1.0, beta_m=0.25), 720),
     ("C2-beta_m0.6", "straight-hair", dict(scale=1.0, beta_m=0.6), 720),
@@ -758,9 +770,10 @@ FULL_CONFIGS = [
 
 @pytest.mark.parametrize("tag,name,kw,res", FULL_CONFIGS, ids=[c[0] for c in FULL_CONFIGS])
 def test_baseline_configs_at_full_size(ctx, oracle, yh, tag, name, kw, res):
-    """BASELINE.json configs[2..4] with their full geometry (1.6 M / 3.2 M / 4 x 1.0 M segments): (1) at the
+    """BASELINE.json configs[1..4] with their full geometry (1.6 M / 3.2 M / 4 x 1.0 M segments): (1) at the
     config's resolution, the size-independent properties of test_full_size_properties; (2) the same
-    geometry at 96 x 96 against the oracle with the image bars of the golden scenes."""
+    geometry at 96 x 96 against the oracle with ALL THREE image bars of the golden scenes: 1 spp within 1e-3,
+    16 spp relRMSE <= 0.5 x the seed-to-seed floor, 16 spp per-pixel error within K_SIGMA standard errors."""
     sf = yh.SceneFile(scene_path(name, **kw))
     d = sf.desc.contents
     segments = sum(d.shapes[i].num_lines for i in range(d.num_shapes))
@@ -775,12 +788,13 @@ def test_baseline_configs_at_full_size(ctx, oracle, yh, tag, name, kw, res):
     assert np.array_equal(ctx.download(), a)                       # determinism; 1 + 2 spp == 3 spp
     assert np.isfinite(a).all() and a.min() >= 0 and a[..., :3].max() <= 100.0 * (1 + 1e-6)
     hit = a[..., 3] > 0
-    assert 0.2 < hit.mean() < 0.98
-    # camera rays that escape see the sky texture times the environment's emission: bounded by its
-    # brightest texel, and never black
+    assert 0.05 < hit.mean() < 0.98
+    # camera rays that escape see the sky texture times the environment's emission (C1: a constant environment):
+    # bounded by its brightest texel, and never black
     env = d.environments[0]
     n_tex = env.tex_width * env.tex_height
-    texmax = np.ctypeslib.as_array(env.texels, (n_tex, 3)).max(axis=0) * np.array(list(env.emission), np.float32)
+    emission = np.array(list(env.emission), np.float32)
+    texmax = (np.ctypeslib.as_array(env.texels, (n_tex, 3)).max(axis=0) if n_tex else np.ones(3, np.float32)) * emission
     assert (a[~hit][:, :3] <= texmax * (1 + 1e-5)).all() and a[~hit][:, :3].max(axis=1).min() > 0
     # (2) full geometry, 96 x 96, against the oracle
     osc = oracle.scene(sf.desc)
@@ -797,6 +811,8 @@ def test_baseline_configs_at_full_size(ctx, oracle, yh, tag, name, kw, res):
     other = osc.render(yh.TraceParams.default(resolution=96, seed=12345), 16)
     err, floor = _relrmse(g16, r16), _relrmse(other, r16)
     assert err <= 0.5 * floor, f"{tag}: relRMSE {err:.4f} vs seed floor {floor:.4f}"
+    share, _ = _k_sigma_share(ctx, osc, yh, 96, 16, r16, seeds=(961748941, 12345, 777, 31337))
+    assert share >= 0.99, f"{tag}: {share:.4f} of pixels within {K_SIGMA} sigma at 16 spp"
     osc.close(), sf.close()
 
 
@@ -823,3 +839,125 @@ def test_light_sampling_matches_oracle_at_unit_level(ctx, oracle, yh, biglight):
         assert close.mean() > 0.99, f"bounces {bounces}: {close.mean():.4f}"
         assert (ref[..., 3] > 0).mean() > 0.3
     osc.close(), sf.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# round 3: the collective executed for real (a world of one), the bare `bench.py --gpus N`, the kernel choice pinned
+# ---------------------------------------------------------------------------------------------
+def _small_render(ctx, yh, res=100, spp=4):
+    sf = yh.SceneFile(scene_path("sphere-hairblock", scale=0.05, zoom=True))
+    ctx.upload_scene(sf.desc)
+    ctx.set_shard(0, 1)
+    w, h = ctx.init_state(yh.TraceParams.default(resolution=res))  # 100 is not a multiple of 8: ragged edge tiles
+    ctx.trace_samples(spp)
+    return sf, w, h, ctx.download()
+
+
+def test_rccl_gather_executes_on_a_world_of_one(ctx, yh, monkeypatch):
+    """yh_gather_framebuffer's RCCL branch (librccl dlopen + dlsym signatures, ncclCommInitAll, the grouped
+    ncclGather on the context's stream, k_unpack behind it) on the one GPU a test box has: YHAIR_GATHER=rccl
+    makes a communicator of one rank. The image must be the bits of yh_download."""
+    sf, w, h, want = _small_render(ctx, yh)
+    monkeypatch.setenv("YHAIR_GATHER", "rccl")
+    got = yh.gather_framebuffer([ctx])
+    assert got.shape == want.shape and np.array_equal(got, want)
+    got2 = yh.gather_framebuffer([ctx])  # the communicator is reused
+    assert np.array_equal(got2, want)
+    monkeypatch.delenv("YHAIR_GATHER")
+    assert np.array_equal(yh.gather_framebuffer([ctx]), want)  # (the copy branch, for comparison)
+    sf.close()
+
+
+def test_torch_nccl_gather_executes_on_a_world_of_one(ctx, yh):
+    """bench.py's collective path — init_process_group("nccl") = RCCL, dist.gather of the packed tiles, the
+    un-interleave on the context's stream — with one rank: yhair_dist.gather_framebuffer(force_collective=True)."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    import yhair_dist
+    sf, w, h, want = _small_render(ctx, yh)
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        n = ctx.shard_pixels(0, 1)
+        packed = torch.zeros((n, 4), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        ctx.pack_tiles_device(packed.data_ptr(), n)
+        image = yhair_dist.gather_framebuffer(packed, w, h, 0, 1, ctx=ctx, force_collective=True)
+        torch.cuda.synchronize()
+        assert np.array_equal(image.cpu().numpy(), want)
+    finally:
+        dist.destroy_process_group()
+    sf.close()
+
+
+def _bench(args, timeout=600):
+    import json
+    import subprocess
+    env = dict(os.environ, YHAIR_SCENES=SCENES)
+    env.pop("YHAIR_SHAPE", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]  # rank 0 prints ONE JSON line
+    return json.loads(lines[0])
+
+
+def test_bench_runs_as_a_bare_command_with_two_ranks():
+    """`python bench.py --gpus 2` with no launcher around it: the script starts its two ranks itself (they share
+    device 0 on a one-GPU box, so the gather goes through gloo), renders the same image as one rank, and prints one line."""
+    common = ["--scale", "0.05", "--resolution", "96", "--steps", "2", "--warmup", "1", "--spp-per-step", "4", "--no-cpu-baseline"]
+    one = _bench(["--gpus", "1"] + common)
+    two = _bench(["--gpus", "2"] + common)
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["scaling"] == "strong"
+    assert two["config"]["image_mean_rgb"] == one["config"]["image_mean_rgb"]  # pixels do not depend on the shard
+    assert "weak_scaling" in two["config"] and two["value"] > 0
+    forced = _bench(["--gpus", "1", "--force-collective"] + common)  # the nccl process group with one rank
+    assert forced["config"]["collective"].startswith("nccl") and forced["config"]["image_mean_rgb"] == one["config"]["image_mean_rgb"]
+
+
+PINNED = {"C1": (0,), "C2-beta_m0.25": (1, 3), "C3": (3,), "C4": (1,)}
+
+
+@pytest.mark.parametrize("tag,name,kw,res", [c for c in FULL_CONFIGS if c[0] in PINNED], ids=list(PINNED))
+def test_kernel_choice_is_stable_on_the_baseline_configs(yh, tag, name, kw, res, monkeypatch):
+    """Which kernel the timing trials settle on, three times over from a fresh context (no trial record carried
+    over: YHAIR_NO_TRIAL_CACHE): the same kernel every time, and the one the round's profiles were taken on."""
+    monkeypatch.setenv("YHAIR_NO_TRIAL_CACHE", "1")
+    monkeypatch.delenv("YHAIR_SHAPE", raising=False)
+    sf = yh.SceneFile(scene_path(name, **kw))
+    chosen = []
+    for _ in range(3):
+        c = yh.Context(0)
+        c.upload_scene(sf.desc)
+        c.init_state(yh.TraceParams.default(resolution=res))
+        c.trace_samples(32 * 8)  # settling launch, trials (twice on a tie), then the chosen kernel
+        c.trace_samples(64)
+        chosen.append(c.launch_shape())
+        c.close()
+    assert len(set(chosen)) == 1 and chosen[0] in PINNED[tag], f"{tag}: kernels chosen {chosen}, expected {PINNED[tag]}"
+    sf.close()
+
+
+def test_blocking_launch_after_an_async_one_across_a_kernel_switch(ctx, yh, monkeypatch):
+    """A blocking yh_trace_samples right behind yh_trace_samples_async without yh_synchronize, with a kernel switch
+    in between (the hand-out list is rewritten for the new kernel): the queued launch must not see the new list."""
+    sf = yh.SceneFile(scene_path("straight-hair", scale=0.05))
+    ctx.upload_scene(sf.desc)
+    p = yh.TraceParams.default(resolution=120)
+    monkeypatch.setenv("YHAIR_SHAPE", "0")
+    ctx.init_state(p)
+    ctx.trace_samples(40)
+    want = (ctx.download(), ctx.download_rng())
+    for first, second in (("0", "3"), ("3", "1"), ("1", "0")):
+        monkeypatch.setenv("YHAIR_SHAPE", first)
+        ctx.init_state(p)
+        ctx.trace_samples_async(30)
+        monkeypatch.setenv("YHAIR_SHAPE", second)  # the next launch runs another kernel: work items re-dealt
+        ctx.trace_samples(10)
+        ctx.synchronize()
+        assert np.array_equal(ctx.download(), want[0]) and np.array_equal(ctx.download_rng(), want[1]), (first, second)
+    sf.close()

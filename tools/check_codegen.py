@@ -13,7 +13,24 @@ usage: tools/check_codegen.py [--strict] [--loops]
 import os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "yocto-hair_amd", "csrc")
-FLAGS = "-O3 --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -fno-vectorize -std=c++17 --cuda-device-only -S".split()
+import shutil
+
+
+def hipcc():
+    return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def makefile_flags():
+    """The device flags of the product build (yocto-hair_amd/Makefile: HIPFLAGS), so that the code looked at is the code shipped."""
+    for line in open(os.path.join(ROOT, "yocto-hair_amd", "Makefile")):
+        m = re.match(r"HIPFLAGS\s*:=\s*(.*)", line)
+        if m:
+            flags = [f.replace("$(ARCH)", "gfx950") for f in m.group(1).split()]
+            return [f for f in flags if f != "-fPIC" and not f.startswith("-I")]
+    raise SystemExit("HIPFLAGS not found in yocto-hair_amd/Makefile")
+
+
+FLAGS = makefile_flags() + ["--cuda-device-only", "-S"]
 FLAGS += os.environ.get("YH_EXTRA_FLAGS", "").split()
 
 
@@ -68,7 +85,7 @@ def loops_of(body):
 
 def kernels(src):
     with tempfile.NamedTemporaryFile(suffix=".s") as f:
-        subprocess.run(["/opt/rocm/bin/hipcc", *FLAGS, "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, os.path.join(CSRC, src), "-o", f.name],
+        subprocess.run([hipcc(), *FLAGS, "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, os.path.join(CSRC, src), "-o", f.name],
                        check=True, stderr=subprocess.DEVNULL)
         text = open(f.name).read()
     meta = {}
@@ -90,11 +107,11 @@ def kernels(src):
 
 if __name__ == "__main__":
     bad = 0
-    for src, pat in (("kernels.hip", r"k_traceILb0ELb[01]E"), ("stream.hip", r"k_streamILb[01]ELi\dELb0"), ("wavefront.hip", r"k_wavefront")):
+    for src, pat in (("kernels.hip", r"k_traceILb0ELb[01]E"), ("exact.hip", r"k_trace_exact"), ("stream.hip", r"k_streamILb[01]ELi\dELb0")):
         for name, k in sorted(kernels(src).items()):
             if not re.search(pat, name):
                 continue
-            product = ("k_traceILb0ELb0" in name or "k_streamILb0" in name)  # the plain variants every BASELINE config runs
+            product = ("k_traceILb0ELb0" in name or "k_streamILb0" in name or "k_trace_exactILb0" in name)  # the plain variants every BASELINE config runs
             print(f"{name[:64]:64s} vgprs {k['vgprs']:3d} spilled {k['vgpr_spills']:3d} (sgpr {k['sgpr_spills']:3d}) scratch {k['scratch_bytes']:4d} B")
             for h, r in k["trav"].items():
                 flag = ""

@@ -20,189 +20,8 @@
 #include <hip/hip_runtime.h>
 
 #include "yhair.h"
-#include "dev_path.h"
+#include "dev_items.h"
 
-using namespace yhd;
-
-#ifndef YH_BLOCK
-#define YH_BLOCK 512
-#endif
-#ifndef YH_MIN_WAVES
-#define YH_MIN_WAVES 4 /* waves per SIMD the register allocator must allow */
-#endif
-
-// ---------------------------------------------------------------------------
-// The sample loop
-// ---------------------------------------------------------------------------
-// Persistent wavefronts, quads and path regeneration. A wave pulls a work item
-// — one 4x4-pixel quadrant of an 8x8 tile — from the launch's queue (items are
-// queued most-expensive-first using the cost each reported in the previous
-// launch). Each QUAD (four adjacent lanes) owns one pixel and keeps ONE path in
-// flight: the four lanes run the same path redundantly and split the work
-// inside BVH steps (one box / one primitive per lane) and inside the hair BSDF
-// (one lobe per lane). Every iteration traces the current segment of all live
-// quads and shades it; a quad whose path ended starts its pixel's next sample
-// in the same iteration (a pixel's PCG32 stream is sequential, pt.cpp:1942-1945,
-// so its samples cannot run side by side) — quads never wait for the longest
-// path of a sample, only for the item's last quad.
-#define YH_QUADS (YH_BLOCK / 4)
-// GENERAL = the scene has materials with lobes beyond diffuse / hair (dev_surface.h); scenes
-// without them (all BASELINE configs) run the variant that does not carry that code.
-// BLOCK x WAVES = the launch shape: 512 threads at 4 waves per SIMD (128 VGPRs) when the launch is
-// bound by a few expensive pixels (C1), 256 threads at 5 waves per SIMD (96 VGPRs, more latency hiding)
-// when many pixels are expensive (dense hair: +5-10 %, profiles/r01, r02); the host picks by measurement.
-// SHADER = the reference's shader_type (YH_SHADER_*): trace_path is the product path (k_trace), the
-// preview / debug shaders (naive, eyelight, normal) share everything but the bounce step (k_trace_shader).
-template <bool COUNT, bool GENERAL, int BLOCK, int SHADER>
-YH_DEV void trace_items(const yhd_scene& sc, const yhd_state& st, int nsamples, yhd_counters* counters) {
-  extern __shared__ v4f lds_dyn[];
-  // LDS carve-out: [nodelets: 8 * lds_node_count float4][stacks: stack_entries x (BLOCK / 4) uint]
-  //                [tables: scene level | camera | small area lights | environment cdf index] (dev_trace.h: stage_tables)
-  YH_LDS v4f*          lds_nodes = (YH_LDS v4f*)lds_dyn;
-  YH_LDS unsigned int* lds_stack = (YH_LDS unsigned int*)(lds_nodes + 8 * sc.lds_node_count);
-  YH_LDS v4f*          lds_tabs  = (YH_LDS v4f*)(lds_stack + sc.stack_entries * (BLOCK / 4));
-  // stage the nodelets: the first lds_node_count wide nodes (breadth-first =
-  // top levels) of the dominant hair shape, 128 B each, coalesced dwordx4 loads
-  if (YH_LDS_NODELETS)
-    for (int i = threadIdx.x; i < 8 * sc.lds_node_count; i += blockDim.x) lds_nodes[i] = ldg4(sc.nodes + 8 * (size_t)sc.lds_node_base + i);
-  trace_ctx tc;
-  tc.sc = &sc;
-  tc.ls = nullptr, tc.sc_dev = nullptr;
-  YH_LDS float* lds_cam;
-  stage_tables(sc, lds_tabs, threadIdx.x, blockDim.x, tc, lds_cam);
-  __syncthreads();
-
-  tc.lds_nodes = sc.lds_node_count ? lds_nodes : nullptr;
-  tc.lds_stack = lds_stack + (threadIdx.x >> 2);
-  stats_t stats = {};
-  tc.stats = COUNT ? &stats : nullptr;
-
-  const int lane = threadIdx.x & 63;
-  while (true) {
-    int t = 0;
-    if (lane == 0) t = atomicAdd(st.tile_cursor, 1);
-    t = __builtin_amdgcn_readfirstlane(t);
-    if (t >= st.num_tiles) break;
-#ifdef YH_PRIO /* developer A/B switch: issue priority for the waves that hold the most expensive items (the head of the cost-sorted list) */
-    if (t < st.num_tiles / YH_PRIO) __builtin_amdgcn_s_setprio(3);
-    else __builtin_amdgcn_s_setprio(0);
-#endif
-    unsigned long long t0 = wall_clock64();
-    int  item  = st.tiles[t];
-    int  tile  = item >> 2, part = item & 3;
-    int  pq    = lane >> 2;  // pixel of the 4x4 quadrant owned by this lane's quad
-    int  i     = (tile % st.tiles_x) * YH_TILE + (part & 1) * 4 + (pq & 3);
-    int  j     = (tile / st.tiles_x) * YH_TILE + (part >> 1) * 4 + (pq >> 2);
-    bool owner = i < st.width && j < st.height;
-    size_t pix = owner ? (size_t)j * st.width + i : 0;
-    rng_t  rng;
-    rng.state      = st.rng_state[pix];
-    rng.inc        = st.rng_inc[pix];
-    yhd_float4 acc = st.accum[pix];
-    int    left    = owner ? nsamples : 0;  // samples this quad still has to start
-    bool   alive   = false;
-    path_t ps;
-    ps.bounce = 0, ps.hit = false;
-    bool       running = false;  // YH_SUSPEND: this quad's ray is suspended mid-traversal
-    trav_state rs;
-    rs.cur = YH_NONE, rs.sp = 0, rs.cur_obj = -1, rs.hit = hit_t{};
-    unsigned long long cyc_trace = 0, cyc_shade = 0;
-    unsigned int       w_iters = 0, w_steps = 0, l_steps = 0, l_iters = 0;
-    while (true) {
-      if (!alive && left > 0) {
-        yhd_camera cam;
-        for (int k = 0; k < 12; k++) cam.frame[k] = lds_cam[k];
-        cam.lens = lds_cam[12], cam.film_x = lds_cam[13], cam.film_y = lds_cam[14], cam.focus = lds_cam[15], cam.aperture = lds_cam[16];
-        path_begin(cam, ps, rng, i, j, st.width, st.height);
-        left--;
-        alive = true;
-      }
-      if (!__any(alive)) break;
-      unsigned long long c0 = 0, c1 = 0;
-      unsigned int       steps = 0;
-      if (COUNT) c0 = clock64(), l_iters += (alive && (lane & 3) == 0) ? 1 : 0, w_iters++;
-      hit_t isec;
-#ifdef YH_SUSPEND /* developer experiment: resumable traversal, the wave shades once YH_SUSPEND / 16 of its live quads are left running */
-      if constexpr (!COUNT && SHADER == YH_SHADER_PATH) {
-        if (alive && !running) {
-          rs.cur = sc.num_scene_nodes ? (YH_TAG_SCENE | 0u) : YH_NONE, rs.sp = 0, rs.cur_obj = -1;
-          rs.hit.object = -1, rs.hit.slot = -1, rs.hit.u = 0, rs.hit.v = 0, rs.hit.distance = 0;
-        }
-        if (alive) {
-          int  live = __popcll(__ballot(1)) >> 2;
-          bool redo = false;
-          trace_ray_loop<false, (BLOCK / 4), false, true, !GENERAL>(tc, ps.ray, -1, nullptr, redo, &rs, ((live * YH_SUSPEND) >> 4) << 2);
-          if (__any(redo)) {
-            if (redo) {
-              rs.hit = trace_ray_loop<false, (BLOCK / 4), true>(tc, ps.ray, -1, nullptr, redo);
-              rs.cur = YH_NONE, rs.sp = 0;
-            }
-          }
-          running = !(rs.cur == YH_NONE && rs.sp == 0);
-          isec    = rs.hit;
-        }
-      } else
-#endif
-      if (alive) {
-        if (COUNT) count_quad<COUNT>(stats.rays);
-        isec = trace_ray<COUNT, (BLOCK / 4), !GENERAL>(tc, ps.ray, -1, &steps);
-      }
-      if (COUNT) {
-        c1 = clock64(), cyc_trace += c1 - c0;
-        unsigned int smax = steps;
-        for (int off = 32; off > 0; off >>= 1) smax = max(smax, (unsigned int)__shfl_xor((int)smax, off, 64));
-        w_steps += smax, l_steps += (lane & 3) == 0 ? steps : 0;
-      }
-      if (alive && !running) {
-        if constexpr (SHADER == YH_SHADER_PATH) alive = path_step<COUNT, (BLOCK / 4), GENERAL>(tc, ps, isec, rng, st.bounces);
-        else alive = shade_step<COUNT, (BLOCK / 4), SHADER>(tc, ps, isec, rng, st.bounces);
-        if (!alive) {
-          path_end(ps, st.clamp, acc);
-          if (COUNT) count_quad<COUNT>(stats.samples);
-        }
-      }
-      if (COUNT) cyc_shade += clock64() - c1;
-    }
-    if (COUNT) {  // flush this item's counters: one wave reduction, one atomic per counter
-      unsigned int v[11] = {stats.samples, stats.rays, stats.nodes, stats.seg, stats.tri, stats.hair, stats.surf,
-          stats.envl, stats.envs, l_steps, l_iters};
-      for (int k = 0; k < 11; k++)
-        for (int off = 32; off > 0; off >>= 1) v[k] += (unsigned int)__shfl_xor((int)v[k], off, 64);
-      if (lane == 0) {
-        atomicAdd(&counters->samples, (unsigned long long)v[0]), atomicAdd(&counters->rays, (unsigned long long)v[1]);
-        atomicAdd(&counters->nodes, (unsigned long long)v[2]), atomicAdd(&counters->seg, (unsigned long long)v[3]);
-        atomicAdd(&counters->tri, (unsigned long long)v[4]), atomicAdd(&counters->hair, (unsigned long long)v[5]);
-        atomicAdd(&counters->surf, (unsigned long long)v[6]), atomicAdd(&counters->envl, (unsigned long long)v[7]);
-        atomicAdd(&counters->envs, (unsigned long long)v[8]);
-        atomicAdd(&counters->lane_steps, (unsigned long long)v[9]), atomicAdd(&counters->lane_iters, (unsigned long long)v[10]);
-        atomicAdd(&counters->cyc_trace, cyc_trace), atomicAdd(&counters->cyc_shade, cyc_shade);
-        atomicAdd(&counters->wave_iters, (unsigned long long)w_iters), atomicAdd(&counters->wave_steps, (unsigned long long)w_steps);
-      }
-      if (lane == 0) {
-        atomicAdd(&counters->c_geom, stats.c_geom), atomicAdd(&counters->c_sample, stats.c_sample);
-        atomicAdd(&counters->c_eval, stats.c_eval), atomicAdd(&counters->c_rest, stats.c_rest);
-      }
-      {
-        unsigned int b[10] = {stats.t_node, stats.l_node, stats.t_line, stats.l_line, stats.t_tri, stats.l_tri, stats.t_enter,
-            stats.l_enter, stats.t_scene, stats.l_scene};
-        for (int k = 0; k < 10; k++) {
-          for (int off = 32; off > 0; off >>= 1) b[k] += (unsigned int)__shfl_xor((int)b[k], off, 64);
-          if (lane == 0) atomicAdd(&counters->branch[k], (unsigned long long)b[k]);
-        }
-      }
-      stats = stats_t{};
-    }
-    if (owner && (lane & 3) == 0) {
-      st.rng_state[pix] = rng.state;
-      st.accum[pix]     = acc;
-    }
-    if (lane == 0) {
-      unsigned int dt = (unsigned int)(wall_clock64() - t0);
-      st.tile_cost[item] = dt;
-      if (COUNT) atomicAdd(&counters->cyc_tile, (unsigned long long)dt);
-    }
-  }
-}
 template <bool COUNT, bool GENERAL, int BLOCK, int WAVES>
 __global__ __launch_bounds__(BLOCK, WAVES) void k_trace(const yhd_scene sc, const yhd_state st,
     int nsamples, yhd_counters* counters) {

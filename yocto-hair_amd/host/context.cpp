@@ -19,10 +19,14 @@
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <map>
+#include <mutex>
+#include <tuple>
 #include <string>
 #include <thread>
 #include <vector>
@@ -34,14 +38,18 @@
 // launchers in csrc/kernels.hip
 extern "C" {
 int yhk_trace(const yhd_scene*, const yhd_state*, int, yhd_counters*, int, hipStream_t);
+int yhk_trace_exact(const yhd_scene*, const yhd_state*, int nsamples, int lds_bytes, int grid_blocks, hipStream_t);  // csrc/exact.hip
+int yhk_trace_exact_occupancy(int lds_bytes, int general);
 int yhk_block_threads(int shape);
 int yhk_trace_occupancy(int lds_bytes, int general, int shape);
 int yhk_trace_lds_bytes(const yhd_scene* sc, int shape);
 int yhk_stack_entries(void);
+#ifdef YH_LAB_WAVEFRONT  // developer build (make WAVEFRONT=1): the workgroup-staged kernel of csrc/lab/, YHAIR_SHAPE=2
 int yhk_wavefront(const yhd_scene*, const yhd_state*, int, const yhd_pool*, int k, int grid_blocks, hipStream_t);
 int yhk_wavefront_slots(int k);
 int yhk_wavefront_lds_bytes(int stack_entries, int tables_f4, int k);
 int yhk_wavefront_occupancy(int lds_bytes, int general, int k);
+#endif
 int yhk_stream(const yhd_scene*, const yhd_scene* sc_dev, const yhd_state*, int, const yhd_stream*, int grid_blocks, hipStream_t);
 int yhk_stream_block_threads(void);
 int yhk_stream_lds_bytes(int tables_f4, int slots_per_wave);
@@ -287,6 +295,8 @@ struct yh_context {
   // (0 = not measured yet), whether item costs exist (the first launch of a scene runs unplanned and is not a
   // measurement), and whether the scene is dense (more expensive items than resident waves; from k_trace's costs)
   double           shape_ms[4] = {0, 0, 0, 0};
+  int              shape_trials[4] = {0, 0, 0, 0};  // trial launches behind each shape_ms (the minimum over them counts)
+  uint64_t         scene_key = 0;                   // fingerprint of the uploaded scene (key of the process-wide trial record)
   bool             have_costs = false;
   bool             costs_settled = false;   // the item costs come from a launch of at least YH_TRIAL_SPP samples (not from the 1-spp probe)
   bool             planned_settled = false; // ... and the most recent launch was planned from such costs (only then does its time rank a kernel)
@@ -405,6 +415,45 @@ int choose_launch_shape(const yh_context* ctx) {
 // (C1: 0.269 against 0.234 ms per sample), so on a new image a first short launch settles the costs and the trials
 // follow it. Sparse scenes never try k_stream: it costs them a fixed 20 ms per launch for the cheap pixels.
 constexpr int YH_TRIAL_SPP = 32;  // shorter launches have flat, noisy costs: they neither rank kernels nor try new ones
+// One 32-sample trial is a noisy measurement (± 5 % launch to launch): when the runner-up is within YH_TRIAL_TIE of the
+// best, both are tried a second time and the minimum of a kernel's trials counts, so that two ranks rendering halves of
+// one image, or two renders of one image, do not settle on different kernels by chance.
+constexpr double YH_TRIAL_TIE  = 1.15;
+constexpr int    YH_TRIALS_MAX = 2;
+// The trial results of an image are kept per process under (scene fingerprint, image size, shard, bounces): a new
+// context on the same scene and image (a re-render, the next frame of a caller that re-creates its context) starts
+// from them instead of re-deciding.
+struct TrialKey {
+  uint64_t scene;
+  int      w, h, rank, world, bounces;
+  bool operator<(const TrialKey& o) const {
+    return std::tie(scene, w, h, rank, world, bounces) < std::tie(o.scene, o.w, o.h, o.rank, o.world, o.bounces);
+  }
+};
+struct TrialRecord {
+  double ms[4];
+  int    trials[4], dense;
+};
+std::mutex                      g_trials_mutex;
+std::map<TrialKey, TrialRecord> g_trials;
+TrialKey trial_key(const yh_context* ctx) {
+  return TrialKey{ctx->scene_key, ctx->state.width, ctx->state.height, ctx->rank, ctx->world, ctx->state.bounces};
+}
+void trials_store(const yh_context* ctx) {
+  TrialRecord r;
+  for (int k = 0; k < 4; k++) r.ms[k] = ctx->shape_ms[k], r.trials[k] = ctx->shape_trials[k];
+  r.dense = ctx->dense;
+  std::lock_guard<std::mutex> lock(g_trials_mutex);
+  g_trials[trial_key(ctx)] = r;
+}
+void trials_load(yh_context* ctx) {
+  if (getenv("YHAIR_NO_TRIAL_CACHE")) return;  // developer switch
+  std::lock_guard<std::mutex> lock(g_trials_mutex);
+  auto it = g_trials.find(trial_key(ctx));
+  if (it == g_trials.end()) return;
+  for (int k = 0; k < 4; k++) ctx->shape_ms[k] = it->second.ms[k], ctx->shape_trials[k] = it->second.trials[k];
+  ctx->dense = it->second.dense;
+}
 bool trials_off() {
   static const bool off = getenv("YHAIR_NO_TRIALS") != nullptr;  // developer switch: the cost heuristic only
   return off || getenv("YHAIR_SHAPE") != nullptr;
@@ -417,37 +466,59 @@ int candidates(const yh_context* ctx, int cand[3]) {
 // k_trace launch.
 void record_launch(yh_context* ctx, int nsamples, bool fresh_costs) {
   const int last = ctx->last_shape;
-  if (nsamples >= YH_TRIAL_SPP && nsamples < 2 * YH_TRIAL_SPP && ctx->planned_settled && !ctx->last_counted && last >= 0 && last < 4 && ctx->last_ms > 0)
-    ctx->shape_ms[last] = (double)ctx->last_ms / nsamples;
+  bool trial = false;
+  if (nsamples >= YH_TRIAL_SPP && nsamples < 2 * YH_TRIAL_SPP && ctx->planned_settled && !ctx->last_counted && !ctx->params.hair_exact && last >= 0 && last < 4 && ctx->last_ms > 0) {
+    const double ms = (double)ctx->last_ms / nsamples;
+    ctx->shape_ms[last] = ctx->shape_trials[last] > 0 ? std::min(ctx->shape_ms[last], ms) : ms;
+    ctx->shape_trials[last]++;
+    trial = true;
+  }
   if (fresh_costs && nsamples >= YH_TRIAL_SPP) ctx->costs_settled = true;
-  if (fresh_costs && (last == 0 || last == 1 || ctx->dense < 0)) {  // (only when the item costs have just been read back)
+  // dense / sparse from the item costs of a k_trace launch long enough to mean something: a trial-length launch, or —
+  // while nothing is known yet — one of a few samples (the 1-spp probe's costs are too flat to decide on)
+  if (fresh_costs && (last == 0 || last == 1) && (nsamples >= YH_TRIAL_SPP || (ctx->dense < 0 && nsamples >= 4))) {
     bool known = false, d = dense_by_costs(ctx, &known);
-    if (known && (last == 0 || last == 1)) ctx->dense = d ? 1 : 0;
+    if (known) ctx->dense = d ? 1 : 0;
   }
   ctx->have_costs = true;
+  if (trial) trials_store(ctx);
+}
+// Does candidate c want a (further) trial? Untimed: yes. Timed once: when it is one of at least two candidates within
+// YH_TRIAL_TIE of the best (a tie at the noise of one trial).
+bool wants_trial(const yh_context* ctx, const int* cand, int n, int c) {
+  if (ctx->shape_ms[c] == 0) return true;
+  if (ctx->shape_trials[c] >= YH_TRIALS_MAX) return false;
+  double best = 0;
+  for (int k = 0; k < n; k++) {
+    if (ctx->shape_ms[cand[k]] == 0) return false;  // (first trials first)
+    if (best == 0 || ctx->shape_ms[cand[k]] < best) best = ctx->shape_ms[cand[k]];
+  }
+  int close = 0;
+  for (int k = 0; k < n; k++) close += ctx->shape_ms[cand[k]] <= YH_TRIAL_TIE * best;
+  return close >= 2 && ctx->shape_ms[c] <= YH_TRIAL_TIE * best;
 }
 // Is a candidate kernel still untimed on this image (so that a long request should start with a short trial)?
 bool trial_pending(const yh_context* ctx) {
-  if (!ctx->have_state || !ctx->have_costs || ctx->state.shader != YH_SHADER_PATH || trials_off()) return false;
+  if (!ctx->have_state || !ctx->have_costs || ctx->state.shader != YH_SHADER_PATH || trials_off() || ctx->params.hair_exact) return false;
   if (!ctx->costs_settled) return true;  // (the first short launch settles the item costs; the trials follow it)
   int cand[3], n = candidates(ctx, cand);
   for (int k = 0; k < n; k++)
-    if (ctx->shape_ms[cand[k]] == 0) return true;
+    if (wants_trial(ctx, cand, n, cand[k])) return true;
   return false;
 }
 // The kernel for a launch of `nsamples`.
 int pick_launch_shape(const yh_context* ctx, int nsamples) {
+  if (ctx->params.hair_exact) return 0;  // the exact arithmetic exists as the 512 x 4 quad kernel only (csrc/exact.hip)
   if (const char* env = getenv("YHAIR_SHAPE")) return std::max(0, std::min(3, atoi(env)));
   if (!ctx->have_costs) return ctx->launch_shape;  // the first launch of an image: unplanned, not a measurement
   const int by_costs = ctx->dense > 0 ? 1 : 0;
   if (trials_off()) return by_costs;
   int cand[3], n = candidates(ctx, cand), best = -1;
+  const bool trial_length = ctx->costs_settled && nsamples >= YH_TRIAL_SPP && nsamples < 2 * YH_TRIAL_SPP;
   for (int k = 0; k < n; k++) {
     const int c = cand[k];
-    if (ctx->shape_ms[c] == 0) {
-      if (ctx->costs_settled && nsamples >= YH_TRIAL_SPP && nsamples < 2 * YH_TRIAL_SPP) return c;  // a trial
-      continue;
-    }
+    if (trial_length && wants_trial(ctx, cand, n, c)) return c;  // a trial
+    if (ctx->shape_ms[c] == 0) continue;
     if (best < 0 || ctx->shape_ms[c] < ctx->shape_ms[best]) best = c;
   }
   return best >= 0 ? best : by_costs;
@@ -912,6 +983,27 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
     sc.lds_node_count = std::max(0, std::min({info[best_shape].num_nodes, want, room}));
   }
   ctx->scene      = sc;
+  {  // fingerprint of the scene for the process-wide trial record: counts, camera, materials, objects, a sample of the geometry
+    uint64_t h = 1469598103934665603ULL;
+    auto mix = [&](const void* p, size_t n) {
+      const unsigned char* b = (const unsigned char*)p;
+      for (size_t i = 0; i < n; i++) h = (h ^ b[i]) * 1099511628211ULL;
+    };
+    mix(&sd->camera, sizeof(sd->camera));
+    mix(sd->materials, sizeof(yh_material) * (size_t)sd->num_materials);
+    mix(sd->objects, sizeof(yh_object) * (size_t)sd->num_objects);
+    for (int i = 0; i < sd->num_shapes; i++) {
+      const yh_shape& sh = sd->shapes[i];
+      int counts[3] = {sh.num_vertices, sh.num_lines, sh.num_triangles};
+      mix(counts, sizeof(counts));
+      if (sh.positions && sh.num_vertices > 0) {
+        const size_t n = (size_t)sh.num_vertices, take = std::min<size_t>(n, 256);
+        mix(sh.positions, take * 12), mix(sh.positions + 3 * (n - take), take * 12);
+      }
+    }
+    for (int i = 0; i < sd->num_environments; i++) mix(&sd->environments[i], offsetof(yh_environment, texels));
+    ctx->scene_key = h;
+  }
   ctx->d_scene_copy.reset();  // (stream_impl uploads the new table at its first launch)
   ctx->have_scene = true;
   ctx->have_state = false;
@@ -919,6 +1011,7 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
   ctx->item_cost.clear();
   ctx->have_costs = false, ctx->costs_settled = false, ctx->dense = -1;
   for (double& t : ctx->shape_ms) t = 0;
+  for (int& t : ctx->shape_trials) t = 0;
   return YH_OK;
 }
 
@@ -937,6 +1030,7 @@ int yh_init_state(yh_context* ctx, const yh_trace_params* params) {
     return fail(ctx, YH_E_INVALID, "bad trace params");
   if (params->shader < 0 || params->shader >= YH_SHADER_COUNT)
     return fail(ctx, YH_E_INVALID, "sampler unknown");  // get_trace_shader_func's throw (pt.cpp:1669)
+  if (params->hair_exact && params->shader != YH_SHADER_PATH) return fail(ctx, YH_E_INVALID, "hair_exact exists for the path shader only");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   ctx->params = *params;
   // image size (pt.cpp:1933-1939)
@@ -964,10 +1058,13 @@ int yh_init_state(yh_context* ctx, const yh_trace_params* params) {
   auto& owned = ctx->owned;
   owned.clear();
   for (int t = ctx->rank; t < ctx->num_tiles_total; t += ctx->world) owned.push_back(t);
+  bool new_image = false;
   if ((int)ctx->item_cost.size() != ctx->num_tiles_total * 4) {  // scheduling hints survive a re-init of the same image
     ctx->item_cost.assign((size_t)ctx->num_tiles_total * 4, 0);
     ctx->have_costs = false, ctx->costs_settled = false, ctx->dense = -1, ctx->launch_shape = 0;
     for (double& t : ctx->shape_ms) t = 0;
+    for (int& t : ctx->shape_trials) t = 0;
+    new_image = true;
   }
   std::vector<int> tiles;
   build_work_items(ctx, tiles);
@@ -993,6 +1090,7 @@ int yh_init_state(yh_context* ctx, const yh_trace_params* params) {
   s.samples_done = 0, s.bounces = params->bounces, s.clamp = params->clamp, s.shader = params->shader;
   s.shard_rank = ctx->rank, s.shard_world = ctx->world;
   ctx->have_state = true;
+  if (new_image) trials_load(ctx);  // what this process already measured on this scene, image and shard
   // Probe: the first launch of a new image has no item costs and would hand its work items out in image order,
   // 25-60 % slower than a planned launch (hair quadrants cost 10-100x background ones and bound the launch when
   // they start last). One sample of every pixel measures them; the state is then put back as it was, so the
@@ -1047,7 +1145,8 @@ static int replan_after_launch(yh_context* ctx, int nsamples) {
   return upload_work_items(ctx);
 }
 
-// One launch of the wavefront integrator (csrc/wavefront.hip): persistent workgroups, one path pool each.
+#ifdef YH_LAB_WAVEFRONT
+// One launch of the wavefront integrator (csrc/lab/wavefront.hip): persistent workgroups, one path pool each.
 static int wavefront_impl(yh_context* ctx, int nsamples, bool sync) {
   int k = 1;
   if (const char* env = getenv("YHAIR_WF_SLOTS")) k = atoi(env) >= 2 ? 2 : 1;  // path slots per thread (developer switch)
@@ -1094,6 +1193,7 @@ static int wavefront_impl(yh_context* ctx, int nsamples, bool sync) {
   }
   return YH_OK;
 }
+#endif
 
 // Launch geometry of the streaming integrator: path slots per wave and workgroups. The pixels of the launch are
 // spread over as many waves as the CUs hold, each wave with a few paths per lane so that its lanes stay full
@@ -1271,17 +1371,35 @@ static int trace_impl(yh_context* ctx, int nsamples, bool counted, bool sync) {
       if (getenv("YHAIR_TIMING"))
         fprintf(stderr, "[yhair] kernel times (ms per spp): 0: %.4f, 1: %.4f, 3: %.4f -> %d (%d spp)\n", ctx->shape_ms[0], ctx->shape_ms[1], ctx->shape_ms[3], want, nsamples);
       ctx->launch_shape = ctx->state.launch_shape = want;
+      // The list is rewritten by a blocking copy on the null stream; the context's stream is non-blocking, so a launch
+      // queued by yh_trace_samples_async may still be reading it: wait for it first.
+      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
       if (int rc = upload_work_items(ctx)) return rc;
     }
   }
   int shape = path ? ctx->state.launch_shape : 0;  // the preview shaders have one launch shape
   if (shape >= 2 && counted) shape = 1;            // the instrumented build exists for k_trace only
+  if (shape == 3 && !getenv("YHAIR_SHAPE")) {      // a candidate that cannot run here is dropped, not an error: k_trace renders the same bits
+    int P = 0, grid = 0;
+    if (!stream_geometry(ctx, ctx->state.num_tiles, &P, &grid, nullptr)) {
+      ctx->shape_ms[3] = std::numeric_limits<double>::infinity();
+      shape = ctx->dense > 0 ? 1 : 0;
+      ctx->launch_shape = ctx->state.launch_shape = shape;
+      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+      if (int rc = upload_work_items(ctx)) return rc;
+    }
+  }
   ctx->last_shape = shape, ctx->last_counted = counted, ctx->planned_settled = ctx->costs_settled;
+#ifdef YH_LAB_WAVEFRONT
   if (shape == 2) return wavefront_impl(ctx, nsamples, sync);
+#else
+  if (shape == 2) return fail(ctx, YH_E_INVALID, "launch shape 2 (k_wavefront) is a developer kernel: build with make WAVEFRONT=1");
+#endif
   if (shape == 3) return stream_impl(ctx, nsamples, sync);
   int waves_per_block = yhk_block_threads(shape) / 64;  // one work item per wave at a time
   int lds_bytes       = yhk_trace_lds_bytes(&ctx->scene, shape);
-  int occupancy       = yhk_trace_occupancy(lds_bytes, ctx->scene.general_materials, shape);
+  const bool exact    = path && ctx->params.hair_exact && !counted;
+  int occupancy       = exact ? yhk_trace_exact_occupancy(lds_bytes, ctx->scene.general_materials) : yhk_trace_occupancy(lds_bytes, ctx->scene.general_materials, shape);
   if (occupancy < 1) return fail(ctx, YH_E_DEVICE, "k_trace cannot run with %d bytes of LDS per block", lds_bytes);
   int resident        = ctx->num_cus * occupancy;
   int want            = (ctx->state.num_tiles + waves_per_block - 1) / waves_per_block;
@@ -1289,8 +1407,8 @@ static int trace_impl(yh_context* ctx, int nsamples, bool counted, bool sync) {
   HIPCHK(ctx, hipMemsetAsync(ctx->d_tile_cursor.p, 0, 8 * 16 * 4, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(ctx->d_tile_cost.p, 0, (size_t)ctx->num_tiles_total * 16, ctx->stream));
   HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-  int e = yhk_trace(&ctx->scene, &ctx->state, nsamples, counted ? (yhd_counters*)ctx->d_counters.p : nullptr, grid,
-      ctx->stream);
+  int e = exact ? yhk_trace_exact(&ctx->scene, &ctx->state, nsamples, lds_bytes, grid, ctx->stream)
+                : yhk_trace(&ctx->scene, &ctx->state, nsamples, counted ? (yhd_counters*)ctx->d_counters.p : nullptr, grid, ctx->stream);
   if (e) return fail(ctx, YH_E_DEVICE, "k_trace launch: %s", hipGetErrorString((hipError_t)e));
   HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   ctx->state.samples_done += nsamples;
@@ -1408,12 +1526,12 @@ struct RcclApi {
   ncclResult_t (*GroupEnd)() = nullptr;
   ncclResult_t (*Gather)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  std::string open_error = "missing symbols";  // why rccl_api() returned NULL (dlerror() read once)
 };
-RcclApi* rccl_api() {
-  static RcclApi api;
-  static bool    tried = false;
-  if (!tried) {
-    tried = true;
+RcclApi* rccl_api(const char** why = nullptr) {
+  static RcclApi        api;
+  static std::once_flag once;  // the C++ mirror drives contexts from several host threads
+  std::call_once(once, [] {
     for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
       api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
       if (api.lib) break;
@@ -1426,8 +1544,11 @@ RcclApi* rccl_api() {
       api.Gather         = (decltype(api.Gather))dlsym(api.lib, "ncclGather");
       api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.lib, "ncclGetErrorString");
       if (!api.CommInitAll || !api.CommDestroy || !api.GroupStart || !api.GroupEnd || !api.Gather || !api.GetErrorString) api.lib = nullptr;
+    } else if (const char* why = dlerror()) {
+      api.open_error = why;
     }
-  }
+  });
+  if (!api.lib && why) *why = api.open_error.c_str();
   return api.lib ? &api : nullptr;
 }
 }  // namespace
@@ -1457,8 +1578,11 @@ int yh_gather_framebuffer(yh_context** ctxs, int n, float* rgba) {
   bool distinct = true;
   for (int i = 0; i < n; i++)
     for (int j = 0; j < i; j++) distinct = distinct && ctxs[i]->device != ctxs[j]->device;
+  // YHAIR_GATHER=peer: device-to-device copies even between distinct devices; YHAIR_GATHER=rccl: the collective even
+  // for ONE context (a communicator of one rank: how a one-GPU box executes the RCCL calls, tests/test_gpu_parity.py)
   const char* mode_env = getenv("YHAIR_GATHER");
-  const bool  use_rccl = n > 1 && distinct && !(mode_env && !strcmp(mode_env, "peer"));
+  const bool  force_rccl = mode_env && !strcmp(mode_env, "rccl");
+  const bool  use_rccl = distinct && (n > 1 || force_rccl) && !(mode_env && !strcmp(mode_env, "peer"));
   // every context packs its own tiles on its own stream
   for (int i = 0; i < n; i++) {
     yh_context* c = ctxs[i];
@@ -1476,8 +1600,9 @@ int yh_gather_framebuffer(yh_context** ctxs, int n, float* rgba) {
     if (rc) return rc;
   }
   if (use_rccl) {
-    RcclApi* api = rccl_api();
-    if (!api) return fail(root, YH_E_DEVICE, "yh_gather_framebuffer: librccl could not be opened (%s)", dlerror() ? dlerror() : "missing symbols");
+    const char* why = "";
+    RcclApi*    api = rccl_api(&why);
+    if (!api) return fail(root, YH_E_DEVICE, "yh_gather_framebuffer: librccl could not be opened (%s)", why);
     std::vector<int> devs(n);
     for (int i = 0; i < n; i++) devs[i] = ctxs[i]->device;
     if (root->comm_devices != devs) {  // communicators are made once per device set
@@ -1491,12 +1616,18 @@ int yh_gather_framebuffer(yh_context** ctxs, int n, float* rgba) {
       root->comm_devices = devs;
     }
     ncclResult_t r = api->GroupStart();
-    for (int i = 0; i < n && r == ncclSuccess; i++) {
-      HIPCHK(root, hipSetDevice(ctxs[i]->device));
-      r = api->Gather(ctxs[i]->d_gather_send.p, i == 0 ? root->d_gather_recv.p : nullptr, (size_t)cap * 4, ncclFloat, 0, root->comms[i], ctxs[i]->stream);
+    hipError_t   he = hipSuccess;  // the group is closed whatever happens inside it: an open group would hang the
+                                   // process's next RCCL call (PyTorch's included)
+    if (r == ncclSuccess) {
+      for (int i = 0; i < n && r == ncclSuccess && he == hipSuccess; i++) {
+        if ((he = hipSetDevice(ctxs[i]->device)) != hipSuccess) break;
+        r = api->Gather(ctxs[i]->d_gather_send.p, i == 0 ? root->d_gather_recv.p : nullptr, (size_t)cap * 4, ncclFloat, 0, root->comms[i], ctxs[i]->stream);
+      }
+      ncclResult_t r2 = api->GroupEnd();
+      if (r == ncclSuccess) r = r2;
     }
-    ncclResult_t r2 = api->GroupEnd();
-    if (r != ncclSuccess || r2 != ncclSuccess) return fail(root, YH_E_DEVICE, "ncclGather: %s", api->GetErrorString(r != ncclSuccess ? r : r2));
+    if (he != hipSuccess) return fail(root, YH_E_DEVICE, "yh_gather_framebuffer: hipSetDevice: %s", hipGetErrorString(he));
+    if (r != ncclSuccess) return fail(root, YH_E_DEVICE, "ncclGather: %s", api->GetErrorString(r));
     for (int i = 0; i < n; i++) {
       HIPCHK(root, hipSetDevice(ctxs[i]->device));
       HIPCHK(root, hipStreamSynchronize(ctxs[i]->stream));

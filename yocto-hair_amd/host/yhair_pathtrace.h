@@ -246,6 +246,7 @@ struct trace_params {  // pt.h:188-197
   uint64_t    seed       = default_seed;
   bool        noparallel = false;
   int         pratio     = 8;
+  bool        hair_exact = false;  // extension: the hair BSDF's exact arithmetic (yh_trace_params::hair_exact)
 };
 const auto shader_names = std::vector<std::string>{"naive", "path", "eyelight", "normal"};
 using progress_callback = std::function<void(const std::string& message, int current, int total)>;
@@ -408,7 +409,7 @@ inline void init_state(state* st, const scene* sc, const camera* cam, const trac
   if (!sc->bvh_requested || !sc->lights_requested)
     throw std::runtime_error("yhair: init_state before init_bvh / init_lights");
   if (sc->uploaded_for != cam) upload_scene(sc, cam);
-  st->device_params = yh_trace_params{params.resolution, params.bounces, params.clamp, params.seed, (int)params.shader};
+  st->device_params = yh_trace_params{params.resolution, params.bounces, params.clamp, params.seed, (int)params.shader, params.hair_exact ? 1 : 0};
   detail::for_each_context([&](yh_context* ctx, int i) {
     int rc = yh_set_shard(ctx, i, (int)detail::contexts().size());
     return rc ? rc : yh_init_state(ctx, &st->device_params);

@@ -4,7 +4,7 @@
 // Same flags and defaults (cli.cpp:208-219): --camera, --resolution,-r 720,
 // --samples,-s 512, --shader,-t path, --bounces,-b 8, --clamp 100,
 // --save-batch, --output-image,-o out.hdr, positional scene. Extensions:
-// --seed, --device, --spp-per-launch, --gpus N / --devices A,B,.. (tile-sharded over
+// --seed, --exact-bsdf, --device, --spp-per-launch, --gpus N / --devices A,B,.. (tile-sharded over
 // the GPUs of one node, one RCCL gather of the float4 framebuffer at the end). Same flow: load scene -> convert through
 // the add_* / set_* API -> init_bvh -> init_lights -> init_state -> sample loop
 // -> save_image. Errors print and exit(1) like print_fatal
@@ -27,7 +27,7 @@ int main(int argc, const char* argv[]) {
   auto usage = [&]() {
     printf("usage: yscenetrace [--camera NAME] [--resolution,-r N] [--samples,-s N] [--shader,-t naive|path|eyelight|normal]\n"
            "                   [--bounces,-b N] [--clamp F] [--save-batch] [--output-image,-o FILE]\n"
-           "                   [--seed N] [--device N] [--gpus N] [--devices A,B,..] [--spp-per-launch N] scene\n"
+           "                   [--seed N] [--exact-bsdf] [--device N] [--gpus N] [--devices A,B,..] [--spp-per-launch N] scene\n"
            "Offline path tracing of hair scenes on MI355X. --gpus N: the image's 8x8 tiles are dealt round-robin to N\n"
            "GPUs of this node (devices --device .. --device + N - 1, or --devices), one RCCL gather at the end.\n");
   };
@@ -47,6 +47,7 @@ int main(int argc, const char* argv[]) {
     else if (a == "--save-batch") save_batch = true;
     else if (a == "--output-image" || a == "-o") imfilename = next();
     else if (a == "--seed") params.seed = strtoull(next().c_str(), nullptr, 10);
+    else if (a == "--exact-bsdf") params.hair_exact = true;
     else if (a == "--device") first_device = atoi(next().c_str());
     else if (a == "--gpus") gpus = std::max(1, atoi(next().c_str()));
     else if (a == "--devices") device_list = next();

@@ -72,11 +72,12 @@ SHADER_NAMES = ["naive", "path", "eyelight", "normal"]  # shader_type, yocto_pat
 
 class TraceParams(C.Structure):
     _fields_ = [("resolution", C.c_int), ("bounces", C.c_int), ("clamp", C.c_float),
-                ("seed", C.c_uint64), ("shader", C.c_int)]
+                ("seed", C.c_uint64), ("shader", C.c_int), ("hair_exact", C.c_int)]
 
     @staticmethod
-    def default(resolution=720, bounces=8, clamp=100.0, seed=961748941, shader="path"):
-        return TraceParams(resolution, bounces, clamp, seed, SHADER_NAMES.index(shader) if isinstance(shader, str) else shader)
+    def default(resolution=720, bounces=8, clamp=100.0, seed=961748941, shader="path", hair_exact=False):
+        return TraceParams(resolution, bounces, clamp, seed, SHADER_NAMES.index(shader) if isinstance(shader, str) else shader,
+                           1 if hair_exact else 0)
 
 
 class WorkCounts(C.Structure):

@@ -52,13 +52,15 @@ def unpack_tiles_host(packed, src_rank, world, image):
     return image
 
 
-def gather_framebuffer(packed, width, height, rank, world, ctx=None, dst=0):
+def gather_framebuffer(packed, width, height, rank, world, ctx=None, dst=0, force_collective=False):
     """packed: torch tensor (shard_pixels, 4) float32 on this rank's device (or CPU under gloo).
-    Returns the full (H, W, 4) torch tensor on rank `dst`, None elsewhere. One collective."""
+    Returns the full (H, W, 4) torch tensor on rank `dst`, None elsewhere. One collective.
+    force_collective: a world of one still goes through dist.gather (its process group must exist): the way a
+    one-GPU box executes the RCCL branch."""
     import torch
     import torch.distributed as dist
 
-    if world == 1:
+    if world == 1 and not force_collective:
         shards = [packed]
     else:
         cap = max(shard_pixels(width, height, r, world) for r in range(world))
