@@ -60,7 +60,7 @@ CONFIGS = {
     "C3": dict(scene="curly-hair", resolution=1280, spp=4096, kw={}),
     "C4": dict(scene="hair-curls", resolution=1280, spp=4096, kw={}),
 }
-KERNELS = {0: "k_trace<512 x 4>", 1: "k_trace<256 x 5>", 3: "k_stream"}
+KERNELS = {0: "k_trace<512 x 4>", 1: "k_trace<256 x 5>", 2: "k_trace<512 x 4, 8-wide nodes>", 3: "k_stream", 4: "k_trace<256 x 4, octets>"}
 
 
 def cpu_leg(scene_json, resolution, budget_s, force_spp=0):
@@ -195,6 +195,8 @@ def main():
     ap.add_argument("--strong", action="store_true", help="(default for N > 1; kept for compatibility)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo (CPU staging) lets the N > 1 flow be exercised on a one-GPU box")
+    ap.add_argument("--no-project-scaling", dest="project_scaling", action="store_false",
+                    help="N = 1: skip the three extra renders of shard 0 of 2 / 4 / 8 (config.projected_strong_scaling)")
     ap.add_argument("--force-collective", action="store_true",
                     help="N = 1: still create the process group and run the framebuffer gather through the collective "
                          "(a one-rank RCCL communicator: how a one-GPU box executes the nccl branch)")
@@ -312,6 +314,24 @@ def main():
     res_main = weak_res if (a.weak and world > 1) else base_res
     width, height, elapsed, kernel_ms, p = timed_run(res_main, step_spp, a.warmup)
     shape_used = ctx.launch_shape() if hasattr(ctx, "launch_shape") else None
+
+    # ---- one rank: what ONE GPU of N would take on this image (its shard rendered alone here) ----------
+    projected = None
+    if world == 1 and a.project_scaling:
+        projected = []
+        try:
+            for n_proj in (2, 4, 8):
+                ctx.set_shard(0, n_proj)
+                pw, ph, pel, _, _ = timed_run(res_main, step_spp, 1)
+                projected.append({"n_gpus": n_proj, "shard": f"0 of {n_proj}", "seconds": round(pel, 4),
+                                  "value_if_every_gpu_takes_this_long": round(pw * ph * spp_total / pel / 1e6, 1),
+                                  "kernel": KERNELS.get(ctx.launch_shape(), "?")})
+        except Exception as e:  # never at the expense of the reported line
+            projected.append({"error": str(e)})
+        ctx.set_shard(0, 1)
+        ctx.init_state(p)
+        for n in step_spp:  # the image the gather below packs is the full render again
+            ctx.trace_samples(n)
 
     # ---- the one collective: gather the float4 framebuffer on rank 0 -----------------------------
     t0 = time.perf_counter()
@@ -437,6 +457,11 @@ def main():
         }
         if other is not None:
             out["config"]["weak_scaling" if other["mode"] == "weak" else "strong_scaling"] = other
+        if projected:
+            out["config"]["projected_strong_scaling"] = {
+                "what": "shard 0 of N (tile_id % N == 0) of this image rendered ALONE on this GPU, same steps: the time one GPU of N "
+                        "would take (the shards are statistically alike: 8x8 tiles dealt round-robin); the gather is not in it. "
+                        "A projection from one GPU, not a measurement on N.", "runs": projected}
         if parity is not None:
             out["parity"] = parity
         if cpu is not None and world == 1:

@@ -272,8 +272,10 @@ int yh_trace_samples_counted(yh_context* ctx, int nsamples, yh_workcounts* out);
 int yh_last_trace_ms(const yh_context* ctx, float* ms, int* launches);
 
 /* Which sample-loop kernel the most recent yh_trace_samples launch ran (the host picks per launch from
- * measured times; every choice renders the same bits): 0 = k_trace 512 threads x 4 waves per SIMD,
- * 1 = k_trace 256 x 5, 3 = k_stream (2 is a developer kernel that product builds do not contain);
+ * measured times; every choice renders the same bits): 0 = k_trace, a quad of lanes per path, 512 threads
+ * x 4 waves per SIMD; 1 = the same at 256 x 5 (dense images); 3 = k_stream, one lane per path (dense
+ * images); 4 = k_trace with an OCTET per path over 8-wide BVH nodes (launches bound by the chain of one
+ * path: few expensive pixels per GPU); 2 = quads over 8-wide nodes, never chosen (YHAIR_SHAPE=2 forces it).
  * < 0 = nothing launched yet (or an error code). With yh_trace_params::hair_exact it is always 0.        */
 int yh_launch_shape(const yh_context* ctx);
 

@@ -705,14 +705,15 @@ def test_per_pixel_error_within_k_sigma(ctx, oracle, yh, name, kw):
                                      ("lights-unit", dict(scale=0.05, biglight=True))],
                          ids=["sphere-hairblock", "straight-hair", "hair-curls", "lobes", "big-light"])
 def test_launch_shapes_and_kernels_render_identical_pixels(ctx, yh, name, kw, monkeypatch):
-    """The host picks the integrator kernel — k_trace at 512 x 4 or at 256 x 5 (single-predicate line test) or the
-    one-lane-per-path k_stream (csrc/stream.hip) — by measurement, so which kernel a render runs depends on
-    history. Every choice must give the same bits: YHAIR_SHAPE forces each."""
+    """The host picks the integrator kernel — k_trace with a quad per path at 512 x 4 or at 256 x 5 (single-predicate
+    line test), with an OCTET per path over 8-wide nodes (chain-bound launches), or the one-lane-per-path k_stream
+    (csrc/stream.hip) — by measurement, so which kernel a render runs depends on history. Every choice must give
+    the same bits: YHAIR_SHAPE forces each (2 = quads over 8-wide nodes, a developer shape)."""
     sf = yh.SceneFile(scene_path(name, **kw))
     ctx.upload_scene(sf.desc)
     p = yh.TraceParams.default(resolution=88)
     images = {}
-    for shape in ("0", "1", "3"):  # k_trace 512 x 4, k_trace 256 x 5, k_stream (2 = a developer kernel, not in the product build)
+    for shape in ("0", "1", "2", "3", "4"):  # k_trace 512 x 4, 256 x 5, 512 x 4 over 8-wide nodes, k_stream, k_trace with octets
         monkeypatch.setenv("YHAIR_SHAPE", shape)
         ctx.init_state(p)
         ctx.trace_samples(3), ctx.trace_samples(5)
@@ -747,14 +748,14 @@ def test_kernel_trials_are_cut_off_a_long_request(ctx, yh, name, kw, monkeypatch
     ctx.init_state(p)
     ctx.trace_samples(150)
     ms, launches = ctx.last_trace_ms()
-    assert 3 <= launches <= 5 and ms > 0, launches  # the settling launch, two or three trials (a tie: one more each), then the rest
+    assert 3 <= launches <= 5 and ms > 0, launches  # the settling launch, two or three trials, then the rest (150 samples hold at most four 32-sample launches)
     assert np.array_equal(ctx.download(), base[0]) and np.array_equal(ctx.download_rng(), base[1])
     for _ in range(3):  # (a tie between two kernels is tried again, fresh item costs may turn a sparse reading into a dense one)
         ctx.trace_samples(150)
         assert ctx.last_trace_ms()[1] <= 3
     ctx.trace_samples(150)
     assert ctx.last_trace_ms()[1] == 1
-    assert ctx.launch_shape() in (0, 1, 3)
+    assert ctx.launch_shape() in (0, 1, 3, 4)
     sf.close()
 
 
@@ -961,3 +962,26 @@ def test_blocking_launch_after_an_async_one_across_a_kernel_switch(ctx, yh, monk
         ctx.synchronize()
         assert np.array_equal(ctx.download(), want[0]) and np.array_equal(ctx.download_rng(), want[1]), (first, second)
     sf.close()
+
+
+def test_octet_kernel_is_chosen_for_a_chain_bound_shard_and_renders_the_same_pixels(yh, monkeypatch):
+    """C1's geometry at 360 x 360: a few hundred expensive work items for thousands of resident waves — the launch is
+    bound by the chain of one path (what one GPU of several sees of the metric's image). The octet kernel (eight
+    lanes per path, 8-wide nodes) is then a trial candidate and must win (measured 0.75 x the quad kernel's time),
+    with the quad kernel's bits."""
+    monkeypatch.delenv("YHAIR_SHAPE", raising=False)
+    monkeypatch.setenv("YHAIR_NO_TRIAL_CACHE", "1")
+    sf = yh.SceneFile(scene_path("sphere-hairblock", scale=1.0))
+    c = yh.Context(0)
+    c.upload_scene(sf.desc)
+    p = yh.TraceParams.default(resolution=360)
+    c.init_state(p)
+    c.trace_samples(32 * 7)
+    c.trace_samples(64)
+    assert c.launch_shape() == 4, c.launch_shape()
+    got = (c.download(), c.download_rng())
+    monkeypatch.setenv("YHAIR_SHAPE", "0")
+    c.init_state(p)
+    c.trace_samples(32 * 7 + 64)
+    assert np.array_equal(c.download(), got[0]) and np.array_equal(c.download_rng(), got[1])
+    c.close(), sf.close()

@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Developer tool (GPU box): the chain of a wave, per forced launch shape — time of a 64-spp launch and the
+instrumented launch's wave-level profile (cycles in traversal / shading per wave iteration, trips per iteration,
+cycles per trip, which kinds of step ran in how many of the trips).
+usage: tools/chain_profile.py SCENE RES SHAPES   e.g. sphere-hairblock 180 0,2,4"""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "yocto-hair_amd", "python")); sys.path.insert(0, os.path.join(ROOT, "tools"))
+import torch  # noqa
+import make_scenes, yhair_capi as yh
+name, res = sys.argv[1], int(sys.argv[2])
+shapes = [int(x) for x in sys.argv[3].split(",")]
+ctx = yh.Context(0)
+sf = yh.SceneFile(make_scenes.ensure_scene(name, os.environ.get("YHAIR_SCENES", "/tmp/yhair_scenes"), scale=1.0))
+ctx.upload_scene(sf.desc)
+for shape in shapes:
+    os.environ["YHAIR_SHAPE"] = str(shape)
+    ctx.init_state(yh.TraceParams.default(resolution=res))
+    ms = []
+    for _ in range(3):
+        ctx.trace_samples(64)
+        ms.append(ctx.last_trace_ms()[0])
+    wc = ctx.trace_samples_counted(64).as_dict()
+    wi = max(1, wc["wave_iters"])
+    ws = max(1, wc["wave_steps"])
+    print(f"{name} {res}^2 shape {shape}: 64 spp {min(ms):.2f} ms (instrumented {ctx.last_trace_ms()[0]:.2f}) | per wave iteration: trace {wc['cyc_trace'] / wi:.0f} cyc, "
+          f"shade {wc['cyc_shade'] / wi:.0f} cyc, trips {ws / wi:.2f}, cycles per trip {wc['cyc_trace'] / ws:.0f}, wave iterations {wi} | steps ran in share of trips: "
+          + ", ".join(f"{nm} {wc['trips_' + nm] / ws:.2f}" for nm in ("node", "line", "tri", "enter", "scene")), flush=True)

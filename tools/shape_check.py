@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
-"""Developer tool (GPU box): k_wavefront (YHAIR_SHAPE=2) against k_trace (YHAIR_SHAPE=0) — bitwise image / RNG
-comparison on small scenes, then throughput of both on a BASELINE config."""
+"""Developer tool (GPU box): the sample-loop kernels against each other (YHAIR_SHAPE forces one: 0, 1 k_trace over
+4-wide nodes, 2 k_trace over 8-wide nodes, 3 k_stream, 4 k_trace with octets) — bitwise image / RNG comparison on
+small scenes, then throughput of each on a BASELINE config.
+usage: shape_check.py check            (WF_SHAPE=n against shape 0 on seven small scenes)
+       shape_check.py SCENE RES SPP SHAPES   e.g. sphere-hairblock 720 64 0,2,4"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -45,5 +48,5 @@ else:
             img, _, ms = render(sf, res, (spp, spp, spp), shape)
             same = f" image md5 {__import__('hashlib').md5(img.tobytes()).hexdigest()[:8]}" if ref is None else f" same image as first: {np.array_equal(img, ref)}"
             ref = img if ref is None else ref
-            print(f"{name} {res}^2 x {spp} spp shape {shape} (YHAIR_WF_SLOTS={os.environ.get('YHAIR_WF_SLOTS', '1')}): ms {np.round(ms, 2)} -> "
+            print(f"{name} {res}^2 x {spp} spp shape {shape}: ms {np.round(ms, 2)} -> "
                   f"{res * res * spp / ms[-1] / 1e3:.1f} Msamples/s{same}", flush=True)

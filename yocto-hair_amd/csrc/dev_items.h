@@ -35,14 +35,20 @@ using namespace yhd;
 // when many pixels are expensive (dense hair: +5-10 %, profiles/r01, r02); the host picks by measurement.
 // SHADER = the reference's shader_type (YH_SHADER_*): trace_path is the product path (k_trace), the
 // preview / debug shaders (naive, eyelight, normal) share everything but the bounce step (k_trace_shader).
-template <bool COUNT, bool GENERAL, int BLOCK, int SHADER>
+// MODE (dev_trace.h): YH_MODE_QUAD, YH_MODE_W8 = a quad per path as above, over 4-wide or 8-wide nodes;
+// YH_MODE_OCT = EIGHT lanes per path (two quads that run the same path and share the box tests of an 8-wide node): a
+// wave holds 8 pixels, a work-list entry is HALF a quadrant (entry = item << 1 | half: rows 2 half, 2 half + 1 of the
+// 4x4 block) — half the paths per wave, twice the waves, for launches bound by the chain of one path.
+template <bool COUNT, bool GENERAL, int BLOCK, int SHADER, int MODE = YH_MODE_QUAD>
 YH_DEV void trace_items(const yhd_scene& sc, const yhd_state& st, int nsamples, yhd_counters* counters) {
+  constexpr int LPP    = MODE == YH_MODE_OCT ? 8 : 4;  // lanes per path
+  constexpr int GROUPS = BLOCK / LPP;                   // paths per block = columns of the LDS stack
   extern __shared__ v4f lds_dyn[];
-  // LDS carve-out: [nodelets: 8 * lds_node_count float4][stacks: stack_entries x (BLOCK / 4) uint]
+  // LDS carve-out: [nodelets: 8 * lds_node_count float4][stacks: stack entries x GROUPS uint]
   //                [tables: scene level | camera | small area lights | environment cdf index] (dev_trace.h: stage_tables)
   YH_LDS v4f*          lds_nodes = (YH_LDS v4f*)lds_dyn;
   YH_LDS unsigned int* lds_stack = (YH_LDS unsigned int*)(lds_nodes + 8 * sc.lds_node_count);
-  YH_LDS v4f*          lds_tabs  = (YH_LDS v4f*)(lds_stack + sc.stack_entries * (BLOCK / 4));
+  YH_LDS v4f*          lds_tabs  = (YH_LDS v4f*)(lds_stack + (MODE == YH_MODE_QUAD ? sc.stack_entries : sc.stack_entries8) * GROUPS);
   // stage the nodelets: the first lds_node_count wide nodes (breadth-first =
   // top levels) of the dominant hair shape, 128 B each, coalesced dwordx4 loads
   if (YH_LDS_NODELETS)
@@ -55,7 +61,7 @@ YH_DEV void trace_items(const yhd_scene& sc, const yhd_state& st, int nsamples, 
   __syncthreads();
 
   tc.lds_nodes = sc.lds_node_count ? lds_nodes : nullptr;
-  tc.lds_stack = lds_stack + (threadIdx.x >> 2);
+  tc.lds_stack = lds_stack + (threadIdx.x / LPP);
   stats_t stats = {};
   tc.stats = COUNT ? &stats : nullptr;
 
@@ -71,8 +77,10 @@ YH_DEV void trace_items(const yhd_scene& sc, const yhd_state& st, int nsamples, 
 #endif
     unsigned long long t0 = wall_clock64();
     int  item  = st.tiles[t];
+    int  half  = 0;
+    if (MODE == YH_MODE_OCT) half = item & 1, item >>= 1;
     int  tile  = item >> 2, part = item & 3;
-    int  pq    = lane >> 2;  // pixel of the 4x4 quadrant owned by this lane's quad
+    int  pq    = MODE == YH_MODE_OCT ? half * 8 + (lane >> 3) : lane >> 2;  // pixel of the 4x4 quadrant owned by this lane's quad (octet)
     int  i     = (tile % st.tiles_x) * YH_TILE + (part & 1) * 4 + (pq & 3);
     int  j     = (tile / st.tiles_x) * YH_TILE + (part >> 1) * 4 + (pq >> 2);
     bool owner = i < st.width && j < st.height;
@@ -127,7 +135,7 @@ YH_DEV void trace_items(const yhd_scene& sc, const yhd_state& st, int nsamples, 
 #endif
       if (alive) {
         if (COUNT) count_quad<COUNT>(stats.rays);
-        isec = trace_ray<COUNT, (BLOCK / 4), !GENERAL>(tc, ps.ray, -1, &steps);
+        isec = trace_ray<COUNT, GROUPS, !GENERAL, MODE>(tc, ps.ray, -1, &steps);
       }
       if (COUNT) {
         c1 = clock64(), cyc_trace += c1 - c0;
@@ -136,8 +144,8 @@ YH_DEV void trace_items(const yhd_scene& sc, const yhd_state& st, int nsamples, 
         w_steps += smax, l_steps += (lane & 3) == 0 ? steps : 0;
       }
       if (alive && !running) {
-        if constexpr (SHADER == YH_SHADER_PATH) alive = path_step<COUNT, (BLOCK / 4), GENERAL>(tc, ps, isec, rng, st.bounces);
-        else alive = shade_step<COUNT, (BLOCK / 4), SHADER>(tc, ps, isec, rng, st.bounces);
+        if constexpr (SHADER == YH_SHADER_PATH) alive = path_step<COUNT, GROUPS, GENERAL>(tc, ps, isec, rng, st.bounces);
+        else alive = shade_step<COUNT, GROUPS, SHADER>(tc, ps, isec, rng, st.bounces);
         if (!alive) {
           path_end(ps, st.clamp, acc);
           if (COUNT) count_quad<COUNT>(stats.samples);
@@ -174,13 +182,14 @@ YH_DEV void trace_items(const yhd_scene& sc, const yhd_state& st, int nsamples, 
       }
       stats = stats_t{};
     }
-    if (owner && (lane & 3) == 0) {
+    if (owner && (lane & (LPP - 1)) == 0) {
       st.rng_state[pix] = rng.state;
       st.accum[pix]     = acc;
     }
     if (lane == 0) {
       unsigned int dt = (unsigned int)(wall_clock64() - t0);
-      st.tile_cost[item] = dt;
+      if (MODE == YH_MODE_OCT) atomicAdd(&st.tile_cost[item], dt);  // the two halves of a quadrant add up (zeroed before the launch)
+      else st.tile_cost[item] = dt;
       if (COUNT) atomicAdd(&counters->cyc_tile, (unsigned long long)dt);
     }
   }

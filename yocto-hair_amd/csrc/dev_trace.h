@@ -295,9 +295,26 @@ struct trav_state {
 };
 // LDS_SCENE = true: the caller knows the scene-level table is in LDS (the plain kernel variants: the host selects the
 // GENERAL ones when it does not fit), so the loop carries no second code path for reading it from memory.
-template <bool COUNT, int STRIDE, bool EXACT, bool PHASE = false, bool LDS_SCENE = false>
+// MODE: how many lanes own the ray and how many binary levels a node step covers.
+//   YH_MODE_QUAD  four lanes, 4-wide nodes (two levels): lane q tests slot q.
+//   YH_MODE_W8    four lanes, 8-wide nodes (three levels, host/bvh_build.h: WideNode8): lane q tests slots 2q and
+//                 2q + 1 — a third fewer node steps per ray for a node step that costs half as much again.
+//   YH_MODE_OCT   EIGHT lanes, 8-wide nodes: lane o tests slot o; the two quads of the octet hold the same path and run
+//                 everything else (scene level, ENTER, leaves, shading) twice over. Eight paths share a wave instead of
+//                 sixteen: for launches bound by the chain of steps of ONE path (few expensive pixels per GPU).
+// The children of a wide node are visited in the reference's order in every mode (ranks below), so closest hits,
+// `tmax` and exact-t ties are the same.
+#define YH_MODE_QUAD 0
+#define YH_MODE_W8 1
+#define YH_MODE_OCT 2
+#define YH_ROW_HALF_MIRROR 0x141 /* DPP: lane i of every eight reads lane 7 - i */
+#ifndef YH_OCT_LEAF_PAIRS
+#define YH_OCT_LEAF_PAIRS 0 /* A/B switch: the octet's two quads test two leaves in one step (below). Bit-identical, 6 % fewer trips, and 2-6 % SLOWER (profiles/r03/oct_leaf_pairs_ab.txt): the look at the stack's top and the exchange between the quads cost every leaf step more than the saved steps return. Off. */
+#endif
+template <bool COUNT, int STRIDE, bool EXACT, bool PHASE = false, bool LDS_SCENE = false, int MODE = YH_MODE_QUAD>
 YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_object, unsigned int* steps_out, bool& redo,
     trav_state* rs = nullptr, int leave_at = 0) {
+  static_assert(MODE == YH_MODE_QUAD || !PHASE, "the resumable traversal exists for the 4-wide quad form only");
   const yhd_scene&     sc   = *tc.sc;
   const unsigned int   q    = __lane_id() & 3u;
 #if YH_REMAT_Q
@@ -429,10 +446,12 @@ YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_obj
         v4f a = ob[3], b = ob[4], c = ob[5], d = ob[6];
         inv.x = {a.x, a.y, a.z}, inv.y = {a.w, b.x, b.y}, inv.z = {b.z, b.w, c.x}, inv.o = {c.y, c.z, c.w};
         kind = __float_as_int(d.x), node_base = __float_as_int(d.y), prim_base = __float_as_int(d.z);
+        if (MODE != YH_MODE_QUAD) node_base = __float_as_int(ob[8].w);  // the shape's first 8-wide node (yhd_object::wbox_min[3])
       } else {
         const yhd_object& o = sc.objects[cur_obj];
         inv  = ldframe(o.inv_frame);
         kind = o.kind, node_base = o.node_base, prim_base = o.prim_base;
+        if (MODE != YH_MODE_QUAD) node_base = __float_as_int(o.wbox_min[3]);
       }
       lo    = transform_point(inv, ray.o);
       ld    = transform_vector(inv, ray.d);
@@ -447,7 +466,20 @@ YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_obj
     }
     {
       bool is_leaf    = tag == YH_TAG_LEAF;
-      int  leaf_start = (int)(cur & 0x07FFFFFFu), leaf_num = (int)((cur >> 27) & 7u);
+      // YH_MODE_OCT, LEAF PAIRS: when the entry is a leaf and the stack's top is a leaf too (siblings that were both hit:
+      // the common case in hair), the upper quad of the octet tests the second leaf in the same step and the two
+      // results are applied in the reference's order (first leaf, then the second against the shortened ray): the
+      // primitive test depends on `tmax` only through its final `t > tmax` reject, so testing against the older,
+      // longer `tmax` and rejecting afterwards accepts exactly what the sequential order accepts.
+      bool         pair = false;
+      unsigned int peek = YH_NONE;
+      if (MODE == YH_MODE_OCT && YH_OCT_LEAF_PAIRS) {
+        peek = sp > 0 ? lstk[(sp - 1) * STRIDE] : 0u;  // (YH_NONE itself carries the leaf tag: an empty stack must not read as a leaf)
+        pair = is_leaf && sp > 0 && (peek & YH_TAG_MASK) == YH_TAG_LEAF;
+      }
+      const bool   upper = MODE == YH_MODE_OCT && YH_OCT_LEAF_PAIRS && (__lane_id() & 4u) != 0;
+      unsigned int mycur = (pair && upper) ? peek : cur;  // the leaf this lane's quad tests
+      int  leaf_start = (int)(mycur & 0x07FFFFFFu), leaf_num = (int)((mycur >> 27) & 7u);
       int  rec        = kind == YH_KIND_LINES ? 4 : 6;  // float4 per leaf record
       bool mine       = !is_leaf || (int)q < leaf_num;  // lanes beyond the leaf's count re-read its last record
 #ifdef YH_DEBUG_BOUNDS
@@ -462,17 +494,62 @@ YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_obj
       }
 #endif
       int  pq         = mine ? (int)q : leaf_num - 1;
-      const yhd_float4* addr = is_leaf ? sc.prims + (size_t)prim_base + (size_t)(leaf_start + pq) * rec
-                                       : sc.nodes + 8 * (size_t)cur + 2 * q;
-      v4f s0, s1;
+      const yhd_float4* addr;
+      if (MODE == YH_MODE_QUAD) addr = is_leaf ? sc.prims + (size_t)prim_base + (size_t)(leaf_start + pq) * rec : sc.nodes + 8 * (size_t)cur + 2 * q;
+      else if (MODE == YH_MODE_W8) addr = is_leaf ? sc.prims + (size_t)prim_base + (size_t)(leaf_start + pq) * rec : sc.nodes8 + 16 * (size_t)cur + 4 * q;
+      else addr = is_leaf ? sc.prims + (size_t)prim_base + (size_t)(leaf_start + pq) * rec : sc.nodes8 + 16 * (size_t)cur + 2 * (__lane_id() & 7u);
+      v4f s0, s1, s2w, s3w;  // (s2w, s3w: the lane's second slot in YH_MODE_W8; of a leaf record they are the rest of its 64 bytes)
       int rel = (int)cur - sc.lds_node_base;
-      if (YH_LDS_NODELETS && tc.lds_nodes && !is_leaf && rel >= 0 && rel < sc.lds_node_count) {
+      if (MODE == YH_MODE_QUAD && YH_LDS_NODELETS && tc.lds_nodes && !is_leaf && rel >= 0 && rel < sc.lds_node_count) {
         const YH_LDS v4f* n = tc.lds_nodes + 8 * rel + 2 * q;  // optional nodelets (YHAIR_LDS_NODES), off by default
         s0 = n[0], s1 = n[1];
       } else {
         s0 = ldg4(addr), s1 = ldg4(addr + 1);
+        if (MODE == YH_MODE_W8) s2w = ldg4(addr + 2), s3w = ldg4(addr + 3);
       }
-      if (!is_leaf) {
+      if (MODE != YH_MODE_QUAD && !is_leaf) {
+        // ---- 8-wide node: slot o = s1 << 2 | s2 << 1 | s3 (host/bvh_build.h). The visiting order applies pt.cpp:887-893
+        // at the three collapsed levels: rank bit 2 = side of the node's own axis, bit 1 = side of the child's, bit 0 =
+        // side of the grandchild's, each flipped when the ray runs against that axis. Every hit slot pushes itself so
+        // that the stack pops in visiting order; the first visited becomes `cur`.
+        if (q == 0) n_nodes++;
+        if (COUNT) count_branch<COUNT>(tc.stats->t_node, tc.stats->l_node);
+        const unsigned int axes = __float_as_uint(s1.w);
+        const unsigned int g    = MODE == YH_MODE_W8 ? q : ((__lane_id() & 7u) >> 1);  // this lane's grandchild: 2 * s1 + s2
+        const unsigned int n0   = (lsign >> (axes & 3)) & 1;
+        const unsigned int n1   = (lsign >> ((axes >> (2 + 2 * (g >> 1))) & 3)) & 1;
+        const unsigned int n2   = (lsign >> ((axes >> (6 + 2 * g)) & 3)) & 1;
+        const unsigned int base = ((((g >> 1) ^ n0) << 2) | (((g & 1) ^ n1) << 1));
+        unsigned int rank_a, rank_b = 0, ref_a, ref_b = YH_NONE;
+        bool         h_a, h_b = false;
+        if (MODE == YH_MODE_W8) {
+          rank_a = base | n2, rank_b = base | (1u ^ n2);  // slots 2q (s3 = 0) and 2q + 1 (s3 = 1)
+          ref_a = __float_as_uint(s1.z), ref_b = __float_as_uint(s3w.z);
+          h_a = box_test(lo, ldinv, ray.tmin, tmax, f3{s0.x, s0.y, s0.z}, f3{s0.w, s1.x, s1.y}) && ref_a != YH_NONE;
+          h_b = box_test(lo, ldinv, ray.tmin, tmax, f3{s2w.x, s2w.y, s2w.z}, f3{s2w.w, s3w.x, s3w.y}) && ref_b != YH_NONE;
+        } else {
+          rank_a = base | ((__lane_id() & 1u) ^ n2);
+          ref_a  = __float_as_uint(s1.z);
+          h_a    = box_test(lo, ldinv, ray.tmin, tmax, f3{s0.x, s0.y, s0.z}, f3{s0.w, s1.x, s1.y}) && ref_a != YH_NONE;
+        }
+        if ((ref_a & YH_TAG_MASK) == 0) ref_a += (unsigned)node_base;  // child wide nodes are shape-local indices
+        if (MODE == YH_MODE_W8 && (ref_b & YH_TAG_MASK) == 0) ref_b += (unsigned)node_base;
+        unsigned int bits = (h_a ? (1u << rank_a) : 0u) | (h_b ? (1u << rank_b) : 0u);
+        unsigned int M    = bits | (unsigned int)dpp_i<YH_QUAD_XOR1>((int)bits);
+        M |= (unsigned int)dpp_i<YH_QUAD_XOR2>((int)M);
+        if (MODE == YH_MODE_OCT) M |= (unsigned int)dpp_i<YH_ROW_HALF_MIRROR>((int)M);  // hits in visiting order, bit k = k-th visited
+        const unsigned int low     = M & (0u - M);                                      // the first visited hit slot
+        const bool         first_a = h_a && (1u << rank_a) == low, first_b = h_b && (1u << rank_b) == low;
+        if (h_a && !first_a) lstk[(sp + (int)__popc(M >> (rank_a + 1))) * STRIDE] = ref_a;
+        if (MODE == YH_MODE_W8 && h_b && !first_b) lstk[(sp + (int)__popc(M >> (rank_b + 1))) * STRIDE] = ref_b;
+        unsigned int mine = first_a ? ref_a : (first_b ? ref_b : 0u);  // child refs are never 0 (node 0 is a root)
+        mine |= (unsigned int)dpp_i<YH_QUAD_XOR1>((int)mine);
+        mine |= (unsigned int)dpp_i<YH_QUAD_XOR2>((int)mine);
+        if (MODE == YH_MODE_OCT) mine |= (unsigned int)dpp_i<YH_ROW_HALF_MIRROR>((int)mine);
+        int nh = __popc(M);
+        sp += nh > 0 ? nh - 1 : 0;
+        cur = nh > 0 ? mine : YH_NONE;
+      } else if (!is_leaf) {
         // ---- wide node: lane q tests slot q {min.xyz, max.x} {max.yz, ref, axes} ----
         if (q == 0) n_nodes++;
         if (COUNT) count_branch<COUNT>(tc.stats->t_node, tc.stats->l_node);
@@ -524,7 +601,7 @@ YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_obj
           }
         } else {
           if (COUNT) count_branch<COUNT>(tc.stats->t_tri, tc.stats->l_tri);
-          v4f s2 = ldg4(addr + 2);
+          v4f s2 = MODE == YH_MODE_W8 ? s2w : ldg4(addr + 2);
           if (mine) {
             n_tri++;
             ok = intersect_triangle(lo, ld, ray.tmin, tmax, xyz(s0), xyz(s1), xyz(s2), uu, vv, dist);
@@ -545,7 +622,25 @@ YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_obj
         YH_QUAD_MERGE(YH_QUAD_XOR1)
         YH_QUAD_MERGE(YH_QUAD_XOR2)
 #undef YH_QUAD_MERGE
-        if (key_i >= 0) {
+        if (MODE == YH_MODE_OCT && YH_OCT_LEAF_PAIRS) {
+          // every lane takes the first leaf's result (the lower quad's) and then, of a pair, the second's
+          int   o_i = dpp_i<YH_ROW_HALF_MIRROR>(key_i), o_s = dpp_i<YH_ROW_HALF_MIRROR>(leaf_start);
+          float o_t = dpp_f<YH_ROW_HALF_MIRROR>(key_t), o_u = dpp_f<YH_ROW_HALF_MIRROR>(uu), o_v = dpp_f<YH_ROW_HALF_MIRROR>(vv);
+          int   a_i = upper ? o_i : key_i, a_s = upper ? o_s : leaf_start, b_i = upper ? key_i : o_i, b_s = upper ? leaf_start : o_s;
+          float a_t = upper ? o_t : key_t, a_u = upper ? o_u : uu, a_v = upper ? o_v : vv;
+          float b_t = upper ? key_t : o_t, b_u = upper ? uu : o_u, b_v = upper ? vv : o_v;
+          if (a_i >= 0) {
+            hit.object = cur_obj, hit.slot = a_s + a_i;
+            hit.u = a_u, hit.v = a_v, hit.distance = a_t;
+            tmax = a_t;
+          }
+          if (pair && b_i >= 0 && !(b_t > tmax)) {  // math.h:3450: the later primitive is rejected only when farther
+            hit.object = cur_obj, hit.slot = b_s + b_i;
+            hit.u = b_u, hit.v = b_v, hit.distance = b_t;
+            tmax = b_t;
+          }
+          if (pair) sp--;  // the second leaf came off the stack
+        } else if (key_i >= 0) {
           hit.object = cur_obj, hit.slot = leaf_start + key_i;
           hit.u = uu, hit.v = vv, hit.distance = key_t;
           tmax = key_t;
@@ -561,12 +656,12 @@ YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_obj
   return hit;
 }
 
-template <bool COUNT, int STRIDE, bool LDS_SCENE = false>
+template <bool COUNT, int STRIDE, bool LDS_SCENE = false, int MODE = YH_MODE_QUAD>
 YH_DEV hit_t trace_ray(const trace_ctx& tc, const ray_t& ray, int first_object, unsigned int* steps_out = nullptr) {
   bool  redo = false;
-  hit_t hit  = trace_ray_loop<COUNT, STRIDE, false, false, LDS_SCENE>(tc, ray, first_object, steps_out, redo);
+  hit_t hit  = trace_ray_loop<COUNT, STRIDE, false, false, LDS_SCENE, MODE>(tc, ray, first_object, steps_out, redo);
   if (__any(redo)) {
-    if (redo) hit = trace_ray_loop<COUNT, STRIDE, true, false, LDS_SCENE>(tc, ray, first_object, steps_out, redo);
+    if (redo) hit = trace_ray_loop<COUNT, STRIDE, true, false, LDS_SCENE, MODE>(tc, ray, first_object, steps_out, redo);
   }
   return hit;
 }

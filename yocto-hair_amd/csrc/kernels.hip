@@ -22,10 +22,10 @@
 #include "yhair.h"
 #include "dev_items.h"
 
-template <bool COUNT, bool GENERAL, int BLOCK, int WAVES>
+template <bool COUNT, bool GENERAL, int BLOCK, int WAVES, int MODE = YH_MODE_QUAD>
 __global__ __launch_bounds__(BLOCK, WAVES) void k_trace(const yhd_scene sc, const yhd_state st,
     int nsamples, yhd_counters* counters) {
-  trace_items<COUNT, GENERAL, BLOCK, YH_SHADER_PATH>(sc, st, nsamples, counters);
+  trace_items<COUNT, GENERAL, BLOCK, YH_SHADER_PATH, MODE>(sc, st, nsamples, counters);
 }
 template <int SHADER>
 __global__ __launch_bounds__(YH_BLOCK, YH_MIN_WAVES) void k_trace_shader(const yhd_scene sc, const yhd_state st,
@@ -421,28 +421,42 @@ typedef void (*trace_kernel_t)(const yhd_scene, const yhd_state, int, yhd_counte
 #ifndef YH_DENSE_WAVES
 #define YH_DENSE_WAVES 5 /* 96 VGPRs: at 6 (80 VGPRs) the traversal loop itself spills and the kernel is at the mercy of the register allocator (measured 0.6-0.75x after an unrelated change of the shading code, profiles/r02) */
 #endif
-// shape 0 = 512 threads x 4 waves per SIMD, shape 1 = 256 threads x YH_DENSE_WAVES (5) waves per SIMD
-static int shape_block(int shape) { return shape ? 256 : YH_BLOCK; }
+// shape 0 = 512 threads x 4 waves per SIMD, shape 1 = 256 threads x YH_DENSE_WAVES (5) waves per SIMD: quads over 4-wide nodes;
+// shape 2 = 512 x 4, quads over 8-wide nodes (YH_MODE_W8); shape 4 = 256 x 4, octets over 8-wide nodes (YH_MODE_OCT).
+// (3 is k_stream, csrc/stream.hip.)
+#define YH_OCT_BLOCK 256
+static int shape_block(int shape) { return shape == 1 ? 256 : shape == 4 ? YH_OCT_BLOCK : YH_BLOCK; }
+static int shape_groups(int shape) { return shape_block(shape) / (shape == 4 ? 8 : 4); }
 static trace_kernel_t trace_kernel(bool counted, bool general, int shape, int shader = YH_SHADER_PATH) {
   if (shader == YH_SHADER_NAIVE) return k_trace_shader<YH_SHADER_NAIVE>;
   if (shader == YH_SHADER_EYELIGHT) return k_trace_shader<YH_SHADER_EYELIGHT>;
   if (shader == YH_SHADER_NORMAL) return k_trace_shader<YH_SHADER_NORMAL>;
-  if (shape)
+  // (instrumented builds of the 8-wide forms: plain scenes only; their per-quad counters count an octet twice, the wave-level ones hold)
+  if (shape == 2 && counted && !general) return k_trace<true, false, YH_BLOCK, YH_MIN_WAVES, YH_MODE_W8>;
+  if (shape == 4 && counted && !general) return k_trace<true, false, YH_OCT_BLOCK, YH_MIN_WAVES, YH_MODE_OCT>;
+  if (shape == 2 && !counted) return general ? k_trace<false, true, YH_BLOCK, YH_MIN_WAVES, YH_MODE_W8> : k_trace<false, false, YH_BLOCK, YH_MIN_WAVES, YH_MODE_W8>;
+  if (shape == 4 && !counted) return general ? k_trace<false, true, YH_OCT_BLOCK, YH_MIN_WAVES, YH_MODE_OCT> : k_trace<false, false, YH_OCT_BLOCK, YH_MIN_WAVES, YH_MODE_OCT>;
+  if (shape == 2 || shape == 4) return nullptr;
+  if (shape == 1)
     return counted ? (general ? k_trace<true, true, 256, YH_DENSE_WAVES> : k_trace<true, false, 256, YH_DENSE_WAVES>)
                    : (general ? k_trace<false, true, 256, YH_DENSE_WAVES> : k_trace<false, false, 256, YH_DENSE_WAVES>);
   return counted ? (general ? k_trace<true, true, YH_BLOCK, YH_MIN_WAVES> : k_trace<true, false, YH_BLOCK, YH_MIN_WAVES>)
                  : (general ? k_trace<false, true, YH_BLOCK, YH_MIN_WAVES> : k_trace<false, false, YH_BLOCK, YH_MIN_WAVES>);
 }
 static size_t trace_lds(const yhd_scene* sc, int shape) {
-  return (size_t)sc->lds_node_count * 128 + (size_t)sc->stack_entries * (shape_block(shape) / 4) * 4 + (size_t)YHD_LDS_TABLES_F4(sc) * 16;
+  const int entries = (shape == 2 || shape == 4) ? sc->stack_entries8 : sc->stack_entries;
+  return (size_t)sc->lds_node_count * 128 + (size_t)entries * shape_groups(shape) * 4 + (size_t)YHD_LDS_TABLES_F4(sc) * 16;
 }
-int yhk_trace(const yhd_scene* sc, const yhd_state* st, int nsamples, yhd_counters* counters,
+// `shape`: 0, 1, 2 or 4 (above); the caller built the work list for it (shape 4: half-quadrant entries)
+int yhk_trace(const yhd_scene* sc, const yhd_state* st, int nsamples, yhd_counters* counters, int shape,
     int grid_blocks, hipStream_t stream) {
   const bool path  = st->shader == YH_SHADER_PATH;
-  const int  shape = path && st->launch_shape ? 1 : 0;  // the other shaders have one shape (512 x 4)
+  if (!path) shape = 0;  // the other shaders have one shape (512 x 4)
   if (!path && counters) return (int)hipErrorInvalidValue;
+  if (shape == 3 || shape < 0 || shape > 4) return (int)hipErrorInvalidValue;
   size_t    lds   = trace_lds(sc, shape);
   trace_kernel_t k     = trace_kernel(counters != nullptr, sc->general_materials != 0, shape, st->shader);
+  if (!k) return (int)hipErrorInvalidValue;
   if (lds > 64 * 1024) {  // above 64 KB the dynamic-LDS limit must be raised explicitly; the attribute is per
                           // device, so it is set for the current device at every such launch (no process-wide cache)
     hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -451,16 +465,16 @@ int yhk_trace(const yhd_scene* sc, const yhd_state* st, int nsamples, yhd_counte
   hipLaunchKernelGGL(k, dim3(grid_blocks), dim3(shape_block(shape)), lds, stream, *sc, *st, nsamples, counters);
   return (int)hipGetLastError();
 }
-int yhk_block_threads(int shape) { return shape_block(shape ? 1 : 0); }
+int yhk_block_threads(int shape) { return shape_block(shape); }
 int yhk_stack_entries(void) { return YH_QSTACK; }
-int yhk_trace_lds_bytes(const yhd_scene* sc, int shape) { return (int)trace_lds(sc, shape ? 1 : 0); }
+int yhk_trace_lds_bytes(const yhd_scene* sc, int shape) { return (int)trace_lds(sc, shape); }
 int yhk_trace_occupancy(int lds_bytes, int general, int shape) {
   int            blocks = 0;
-  trace_kernel_t k      = trace_kernel(false, general != 0, shape ? 1 : 0);
+  trace_kernel_t k      = trace_kernel(false, general != 0, shape);
   if (lds_bytes > 64 * 1024 &&
       hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
     return 0;  // the kernel cannot be launched with this much LDS: the caller reports it
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k, shape_block(shape ? 1 : 0), lds_bytes) != hipSuccess) return 1;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k, shape_block(shape), lds_bytes) != hipSuccess) return 1;
   return blocks < 1 ? 0 : blocks;
 }
 int yhk_resolve(const yhd_state* st, int owned_tiles, int samples, void* image, hipStream_t stream) {

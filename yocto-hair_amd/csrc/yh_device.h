@@ -6,7 +6,7 @@
 //   * shape BVH node (128 B, one cache line): the reference's binary tree
 //     (pt.cpp:557-650) with two levels collapsed into a 4-wide node, SoA over
 //     the four slots: minx[4] miny[4] minz[4] maxx[4] maxy[4] maxz[4] ref[4]
-//     {axes,0,0,0} (host/bvh_build.h: WideNode). Wide nodes are numbered
+//     {axes,0,0,0} (host/bvh_build.h: WideNode; WideNode8 = three levels, 256 B). Wide nodes are numbered
 //     breadth-first, so the first K nodes are the top of the tree (the
 //     "nodelets" staged in LDS).
 //   * scene-level node (32 B): {min.xyz, start} {max.xyz, meta}; meta = num |
@@ -47,7 +47,7 @@ typedef struct yhd_object {
   // world-space box of the object (transform_bbox of the shape's root box, pt.cpp:806) grown by a
   // safety margin: a ray that misses it by that much cannot hit anything in the object, so ENTER
   // and the root fetch are skipped for it (dev_trace.h)
-  float wbox_min[4], wbox_max[4];
+  float wbox_min[4], wbox_max[4];  // wbox_min[3] = (int bits) first 8-wide node of the shape in yhd_scene::nodes8
 } yhd_object;
 #define YH_OBJECT_F4 10 /* sizeof(yhd_object) / 16 */
 
@@ -170,6 +170,11 @@ typedef struct yhd_scene {
   int               env_tab_light;   // index into lights[], -1: none
   int               env_tab_k, env_tab_stride;
   int               lds_materials;   // materials staged in LDS (all of them, or 0 when they are too many)
+  // the same trees with THREE binary levels per node (host/bvh_build.h: WideNode8, 16 float4 each): a node step of the
+  // kernels in YH_MODE_W8 / YH_MODE_OCT (dev_trace.h) covers three levels of the reference's tree
+  const yhd_float4* nodes8;
+  int               num_nodes8_total;
+  int               stack_entries8;  // traversal stack depth per ray over the 8-wide trees (up to seven pushes per node)
 } yhd_scene;
 #ifndef YH_LDS_NODELETS
 #define YH_LDS_NODELETS 0 /* developer switch: stage the top wide nodes of the dominant hair shape in LDS (YHAIR_LDS_NODES=n); measured twice without gain */

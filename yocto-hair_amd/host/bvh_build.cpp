@@ -162,4 +162,66 @@ int collapse_wide(const Tree& tree, std::vector<WideNode>& out) {
   return max_depth;
 }
 
+int collapse_wide8(const Tree& tree, std::vector<WideNode8>& out) {
+  out.clear();
+  const float inf = std::numeric_limits<float>::infinity();
+  auto leaf_ref = [](const Node& n) { return 0xC0000000u | ((unsigned)n.num << 27) | (unsigned)n.start; };
+  struct Item {
+    int binary, wide, depth;
+  };
+  std::deque<Item> queue;
+  auto new_wide = [&](int binary, int depth) {
+    out.emplace_back();
+    queue.push_back({binary, (int)out.size() - 1, depth});
+    return (unsigned)out.size() - 1;
+  };
+  int max_depth = 1;
+  new_wide(0, 1);
+  while (!queue.empty()) {
+    Item it = queue.front();
+    queue.pop_front();
+    max_depth = std::max(max_depth, it.depth);
+    WideNode8 w;
+    unsigned  axes = 0;
+    for (int s = 0; s < 8; s++) {
+      for (int k = 0; k < 3; k++) w.slot[s].bmin[k] = inf, w.slot[s].bmax[k] = -inf;
+      w.slot[s].ref = 0xFFFFFFFFu, w.slot[s].axes = 0;
+    }
+    auto set_slot = [&](int s, int binary) {
+      const Node& n = tree.nodes[binary];
+      for (int k = 0; k < 3; k++) w.slot[s].bmin[k] = n.bbox.min[k], w.slot[s].bmax[k] = n.bbox.max[k];
+      w.slot[s].ref = n.internal ? new_wide(binary, it.depth + 1) : leaf_ref(n);
+    };
+    const Node& b = tree.nodes[it.binary];
+    if (!b.internal) {  // a shape whose binary root is a leaf
+      set_slot(0, it.binary);
+    } else {
+      axes = b.axis;
+      for (int s1 = 0; s1 < 2; s1++) {
+        const int   child = b.start + s1;
+        const Node& c     = tree.nodes[child];
+        if (!c.internal) {
+          set_slot(s1 << 2, child);
+          continue;
+        }
+        axes |= (unsigned)c.axis << (2 + 2 * s1);
+        for (int s2 = 0; s2 < 2; s2++) {
+          const int   grand = c.start + s2;
+          const Node& g     = tree.nodes[grand];
+          if (!g.internal) {
+            set_slot((s1 << 2) | (s2 << 1), grand);
+            continue;
+          }
+          axes |= (unsigned)g.axis << (6 + 2 * (2 * s1 + s2));
+          set_slot((s1 << 2) | (s2 << 1) | 0, g.start + 0);
+          set_slot((s1 << 2) | (s2 << 1) | 1, g.start + 1);
+        }
+      }
+    }
+    for (int s = 0; s < 8; s++) w.slot[s].axes = axes;
+    out[it.wide] = w;
+  }
+  return max_depth;
+}
+
 }  // namespace yhh

@@ -55,5 +55,18 @@ static_assert(sizeof(WideNode) == 128, "wide node is 128 bytes");
 // the tree). Returns the depth of the wide tree.
 int collapse_wide(const Tree& tree, std::vector<WideNode>& out);
 
+// 8-wide node: THREE levels of the binary tree in one 256-byte record of eight slots (same slot format), for the
+// kernels whose paths are bound by the number of dependent steps of one ray (dev_trace.h, YH_MODE_W8 / YH_MODE_OCT):
+// a node step covers three binary levels instead of two. Slot o = s1 << 2 | s2 << 1 | s3 holds the great-grandchild
+// reached by sides s1, s2, s3; a child (grandchild) that is a leaf sits in the first slot of its group of four (two).
+//   axes (same in the eight slots): bits 0-1 the binary node's split axis, bits 2-3 / 4-5 its left / right child's,
+//   bits 6-13 the four grandchildren's (index 2 * s1 + s2): the seven comparisons of the reference's near-first
+//   order (pt.cpp:887-893) over three levels.
+struct WideNode8 {
+  WideSlot slot[8];
+};
+static_assert(sizeof(WideNode8) == 256, "8-wide node is 256 bytes");
+int collapse_wide8(const Tree& tree, std::vector<WideNode8>& out);
+
 }  // namespace yhh
 #endif

@@ -37,7 +37,7 @@
 
 // launchers in csrc/kernels.hip
 extern "C" {
-int yhk_trace(const yhd_scene*, const yhd_state*, int, yhd_counters*, int, hipStream_t);
+int yhk_trace(const yhd_scene*, const yhd_state*, int, yhd_counters*, int shape, int grid_blocks, hipStream_t);
 int yhk_trace_exact(const yhd_scene*, const yhd_state*, int nsamples, int lds_bytes, int grid_blocks, hipStream_t);  // csrc/exact.hip
 int yhk_trace_exact_occupancy(int lds_bytes, int general);
 int yhk_block_threads(int shape);
@@ -257,6 +257,7 @@ void parallel_for(int n, F&& fn) {
   for (auto& th : pool) th.join();
 }
 
+constexpr int YH_SHAPES = 5;  // launch shapes: 0, 1 k_trace (4-wide nodes) | 2 k_trace over 8-wide nodes | 3 k_stream | 4 k_trace with octets
 struct yh_context {
   int         device = 0;
   hipStream_t stream = nullptr;
@@ -266,9 +267,9 @@ struct yh_context {
   // scene
   bool      have_scene = false;
   yhd_scene scene{};
-  DevBuf    d_nodes, d_prims, d_vpos, d_elems, d_objects, d_materials, d_scene_nodes,
+  DevBuf    d_nodes, d_nodes8, d_prims, d_vpos, d_elems, d_objects, d_materials, d_scene_nodes,
       d_scene_prims, d_light_cdf, d_env_texels, d_light_table, d_env_tab;
-  int       stack_need = 0;
+  int       stack_need = 0, stack_need8 = 0;
   // state
   bool             have_state = false;
   yhd_state        state{};
@@ -294,13 +295,15 @@ struct yh_context {
   // kernel selection by measurement (pick_launch_shape): ms per sample of a planned launch with each kernel
   // (0 = not measured yet), whether item costs exist (the first launch of a scene runs unplanned and is not a
   // measurement), and whether the scene is dense (more expensive items than resident waves; from k_trace's costs)
-  double           shape_ms[4] = {0, 0, 0, 0};
-  int              shape_trials[4] = {0, 0, 0, 0};  // trial launches behind each shape_ms (the minimum over them counts)
+  double           shape_ms[YH_SHAPES] = {};   // (indexed by launch shape, yhd_state::launch_shape)
+  int              shape_trials[YH_SHAPES] = {};  // trial launches behind each shape_ms (the minimum over them counts)
   uint64_t         scene_key = 0;                   // fingerprint of the uploaded scene (key of the process-wide trial record)
   bool             have_costs = false;
   bool             costs_settled = false;   // the item costs come from a launch of at least YH_TRIAL_SPP samples (not from the 1-spp probe)
   bool             planned_settled = false; // ... and the most recent launch was planned from such costs (only then does its time rank a kernel)
   int              dense = -1;
+  int              chain = -1;   // 1: so few expensive items that even twice as many waves would all be resident: the launch is bound by the
+                                 // chain of steps of ONE path, and the octet kernel (half the paths per wave, shape 4) is a candidate
   // path pool of the wavefront integrator (csrc/wavefront.hip), allocated at its first launch
   DevBuf           d_pool_ray_o, d_pool_ray_d, d_pool_weight, d_pool_radiance, d_pool_hit, d_pool_medium;
   // path pool of the streaming integrator (csrc/stream.hip): per-wave slots, allocated at its first launch
@@ -383,7 +386,7 @@ namespace {
 // fewer expensive items than slots every wave that can run already does. This only picks the CANDIDATES; which
 // kernel runs is measured (pick_launch_shape). YHAIR_SHAPE=0..3 overrides.
 // Is the launch worth more max-cost work items than there are resident waves? (item costs of a k_trace launch)
-bool dense_by_costs(const yh_context* ctx, bool* known) {
+bool dense_by_costs(const yh_context* ctx, bool* known, bool* chain_bound = nullptr) {
   uint64_t sum = 0, mx = 0;
   for (int t : ctx->owned)
     for (int p = 0; p < 4; p++) {
@@ -395,10 +398,15 @@ bool dense_by_costs(const yh_context* ctx, bool* known) {
   int    lds      = yhk_trace_lds_bytes(&ctx->scene, 0);
   double resident = (double)ctx->num_cus * std::max(1, yhk_trace_occupancy(lds, ctx->scene.general_materials, 0)) * (yhk_block_threads(0) / 64);
   if (getenv("YHAIR_TIMING")) fprintf(stderr, "[yhair] launch shape: worth %.0f items, resident waves %.0f\n", (double)sum / (double)mx, resident);
+  if (chain_bound) {  // the octet kernel needs two waves per expensive item: all of them resident at once, with room to spare
+    const int    lds4 = yhk_trace_lds_bytes(&ctx->scene, 4);
+    const double res4 = (double)ctx->num_cus * std::max(1, yhk_trace_occupancy(lds4, ctx->scene.general_materials, 4)) * (yhk_block_threads(4) / 64);
+    *chain_bound      = 2.0 * (double)sum / (double)mx <= 0.9 * res4;
+  }
   return (double)sum / (double)mx >= resident;
 }
 int choose_launch_shape(const yh_context* ctx) {
-  if (const char* env = getenv("YHAIR_SHAPE")) return std::max(0, std::min(3, atoi(env)));
+  if (const char* env = getenv("YHAIR_SHAPE")) return std::max(0, std::min(YH_SHAPES - 1, atoi(env)));
   bool known = false;
   return dense_by_costs(ctx, &known) ? 1 : 0;
 }
@@ -431,8 +439,8 @@ struct TrialKey {
   }
 };
 struct TrialRecord {
-  double ms[4];
-  int    trials[4], dense;
+  double ms[YH_SHAPES];
+  int    trials[YH_SHAPES], dense, chain;
 };
 std::mutex                      g_trials_mutex;
 std::map<TrialKey, TrialRecord> g_trials;
@@ -441,8 +449,8 @@ TrialKey trial_key(const yh_context* ctx) {
 }
 void trials_store(const yh_context* ctx) {
   TrialRecord r;
-  for (int k = 0; k < 4; k++) r.ms[k] = ctx->shape_ms[k], r.trials[k] = ctx->shape_trials[k];
-  r.dense = ctx->dense;
+  for (int k = 0; k < YH_SHAPES; k++) r.ms[k] = ctx->shape_ms[k], r.trials[k] = ctx->shape_trials[k];
+  r.dense = ctx->dense, r.chain = ctx->chain;
   std::lock_guard<std::mutex> lock(g_trials_mutex);
   g_trials[trial_key(ctx)] = r;
 }
@@ -451,23 +459,28 @@ void trials_load(yh_context* ctx) {
   std::lock_guard<std::mutex> lock(g_trials_mutex);
   auto it = g_trials.find(trial_key(ctx));
   if (it == g_trials.end()) return;
-  for (int k = 0; k < 4; k++) ctx->shape_ms[k] = it->second.ms[k], ctx->shape_trials[k] = it->second.trials[k];
-  ctx->dense = it->second.dense;
+  for (int k = 0; k < YH_SHAPES; k++) ctx->shape_ms[k] = it->second.ms[k], ctx->shape_trials[k] = it->second.trials[k];
+  ctx->dense = it->second.dense, ctx->chain = it->second.chain;
 }
 bool trials_off() {
   static const bool off = getenv("YHAIR_NO_TRIALS") != nullptr;  // developer switch: the cost heuristic only
   return off || getenv("YHAIR_SHAPE") != nullptr;
 }
-int candidates(const yh_context* ctx, int cand[3]) {
-  cand[0] = 0, cand[1] = 1, cand[2] = 3;
-  return ctx->dense > 0 ? 3 : 2;
+// k_trace in both quad shapes always; k_stream on dense images; the octet kernel on chain-bound ones (a shard of a sparse
+// image on one of several GPUs, a small image). (Shape 2, quads over 8-wide nodes, is never one: profiles/r03/w8_oct_ab.txt.)
+int candidates(const yh_context* ctx, int cand[4]) {
+  int n = 0;
+  cand[n++] = 0, cand[n++] = 1;
+  if (ctx->dense > 0) cand[n++] = 3;
+  if (ctx->chain > 0 && ctx->dense <= 0) cand[n++] = 4;
+  return n;
 }
 // After a synchronous launch: its time if it was a trial-length one, and dense / sparse from fresh item costs of a
 // k_trace launch.
 void record_launch(yh_context* ctx, int nsamples, bool fresh_costs) {
   const int last = ctx->last_shape;
   bool trial = false;
-  if (nsamples >= YH_TRIAL_SPP && nsamples < 2 * YH_TRIAL_SPP && ctx->planned_settled && !ctx->last_counted && !ctx->params.hair_exact && last >= 0 && last < 4 && ctx->last_ms > 0) {
+  if (nsamples >= YH_TRIAL_SPP && nsamples < 2 * YH_TRIAL_SPP && ctx->planned_settled && !ctx->last_counted && !ctx->params.hair_exact && last >= 0 && last < YH_SHAPES && ctx->last_ms > 0) {
     const double ms = (double)ctx->last_ms / nsamples;
     ctx->shape_ms[last] = ctx->shape_trials[last] > 0 ? std::min(ctx->shape_ms[last], ms) : ms;
     ctx->shape_trials[last]++;
@@ -477,8 +490,8 @@ void record_launch(yh_context* ctx, int nsamples, bool fresh_costs) {
   // dense / sparse from the item costs of a k_trace launch long enough to mean something: a trial-length launch, or —
   // while nothing is known yet — one of a few samples (the 1-spp probe's costs are too flat to decide on)
   if (fresh_costs && (last == 0 || last == 1) && (nsamples >= YH_TRIAL_SPP || (ctx->dense < 0 && nsamples >= 4))) {
-    bool known = false, d = dense_by_costs(ctx, &known);
-    if (known) ctx->dense = d ? 1 : 0;
+    bool known = false, chain = false, d = dense_by_costs(ctx, &known, &chain);
+    if (known) ctx->dense = d ? 1 : 0, ctx->chain = (!d && chain) ? 1 : 0;
   }
   ctx->have_costs = true;
   if (trial) trials_store(ctx);
@@ -501,7 +514,7 @@ bool wants_trial(const yh_context* ctx, const int* cand, int n, int c) {
 bool trial_pending(const yh_context* ctx) {
   if (!ctx->have_state || !ctx->have_costs || ctx->state.shader != YH_SHADER_PATH || trials_off() || ctx->params.hair_exact) return false;
   if (!ctx->costs_settled) return true;  // (the first short launch settles the item costs; the trials follow it)
-  int cand[3], n = candidates(ctx, cand);
+  int cand[4], n = candidates(ctx, cand);
   for (int k = 0; k < n; k++)
     if (wants_trial(ctx, cand, n, cand[k])) return true;
   return false;
@@ -509,11 +522,11 @@ bool trial_pending(const yh_context* ctx) {
 // The kernel for a launch of `nsamples`.
 int pick_launch_shape(const yh_context* ctx, int nsamples) {
   if (ctx->params.hair_exact) return 0;  // the exact arithmetic exists as the 512 x 4 quad kernel only (csrc/exact.hip)
-  if (const char* env = getenv("YHAIR_SHAPE")) return std::max(0, std::min(3, atoi(env)));
+  if (const char* env = getenv("YHAIR_SHAPE")) return std::max(0, std::min(YH_SHAPES - 1, atoi(env)));
   if (!ctx->have_costs) return ctx->launch_shape;  // the first launch of an image: unplanned, not a measurement
   const int by_costs = ctx->dense > 0 ? 1 : 0;
   if (trials_off()) return by_costs;
-  int cand[3], n = candidates(ctx, cand), best = -1;
+  int cand[4], n = candidates(ctx, cand), best = -1;
   const bool trial_length = ctx->costs_settled && nsamples >= YH_TRIAL_SPP && nsamples < 2 * YH_TRIAL_SPP;
   for (int k = 0; k < n; k++) {
     const int c = cand[k];
@@ -551,6 +564,14 @@ void build_work_items(const yh_context* ctx, std::vector<int>& items) {
 extern "C" {
 
 static void deal_items_for_stream(yh_context* ctx, std::vector<int>& items);
+// The octet kernel (launch shape 4: eight lanes per path) takes HALF a quadrant per wave: entry = item << 1 | half, the two
+// halves of an item next to each other in the cost-sorted order.
+static void split_items_for_octets(std::vector<int>& items) {
+  std::vector<int> out;
+  out.reserve(items.size() * 2);
+  for (int it : items) out.push_back(it << 1), out.push_back((it << 1) | 1);
+  items.swap(out);
+}
 static int  trace_impl(yh_context* ctx, int nsamples, bool counted, bool sync);
 
 const char* yh_version(void) { return "yhair 0.1 (gfx950, HIP)"; }
@@ -615,11 +636,12 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
   // ---- per-shape BVHs and flattened arrays --------------------------------
   struct ShapeInfo {
     int kind, node_base, prim_base, vert_base, elem_base, has_normals, depth;
+    int node8_base, depth8;  // the same tree collapsed three levels at a time (yhd_scene::nodes8)
     yhh::Box root;
     int num_nodes;
   };
   std::vector<ShapeInfo>  info(sd->num_shapes);
-  std::vector<yhd_float4> nodes, prims, vpos;
+  std::vector<yhd_float4> nodes, nodes8, prims, vpos;
   std::vector<float>      vtex;  // 2 per vertex, zeros for shapes without texture coordinates
   std::vector<yhd_int4>   elems;
   int                     best_lines = -1, best_shape = -1;
@@ -691,6 +713,15 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
       size_t at = nodes.size();
       nodes.resize(at + wide.size() * 8);
       memcpy(&nodes[at], wide.data(), wide.size() * sizeof(yhh::WideNode));
+    }
+    {  // ... and three levels at a time: 8-wide nodes, 16 float4 each
+      std::vector<yhh::WideNode8> wide8;
+      I.depth8     = yhh::collapse_wide8(tree, wide8);
+      I.node8_base = (int)(nodes8.size() / 16);
+      size_t at    = nodes8.size();
+      nodes8.resize(at + wide8.size() * 16);
+      memcpy(&nodes8[at], wide8.data(), wide8.size() * sizeof(yhh::WideNode8));
+      lap("collapse to 8-wide");
     }
     auto nrm = [&](int v) { return s.normals ? ld3(s.normals + 3 * (size_t)v) : F3{0, 0, 0}; };
     {  // leaf-ordered records (yh_device.h), filled in parallel
@@ -772,12 +803,13 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
       float ext = fmax_(fmax_(hi[0] - lo[0], hi[1] - lo[1]), hi[2] - lo[2]);
       float eps = 1e-3f * ext + 1e-5f;
       for (int k = 0; k < 3; k++) d.wbox_min[k] = lo[k] - eps, d.wbox_max[k] = hi[k] + eps;
-      d.wbox_min[3] = d.wbox_max[3] = 0;
+      d.wbox_max[3] = 0;
+      memcpy(&d.wbox_min[3], &I.node8_base, 4);  // (int bits) first 8-wide node of the shape in yhd_scene::nodes8
     }
   }
   // array offsets on the device are 32-bit float4 indices
   if (prims.size() > (size_t)std::numeric_limits<int>::max() || nodes.size() > (size_t)std::numeric_limits<int>::max() ||
-      vpos.size() > (size_t)std::numeric_limits<int>::max())
+      nodes8.size() > (size_t)std::numeric_limits<int>::max() || vpos.size() > (size_t)std::numeric_limits<int>::max())
     return fail(ctx, YH_E_INVALID, "scene too large for 32-bit record offsets (%zu primitive, %zu node float4)", prims.size(), nodes.size());
   yhh::Tree scene_tree;
   yhh::build_bvh(scene_tree, obj_boxes);
@@ -787,6 +819,9 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
   for (auto& I : info) max_shape_depth = std::max(max_shape_depth, I.depth);
   // a wide node pushes at most three entries and keeps the fourth in a register
   ctx->stack_need = scene_tree.max_depth + 4 + 3 * max_shape_depth + 2;
+  int max_shape_depth8 = 0;
+  for (auto& I : info) max_shape_depth8 = std::max(max_shape_depth8, I.depth8);
+  ctx->stack_need8 = scene_tree.max_depth + 4 + 7 * max_shape_depth8 + 2;  // an 8-wide node pushes at most seven
   if (ctx->stack_need > yhk_stack_entries())
     return fail(ctx, YH_E_INVALID, "BVH too deep for the traversal stack (%d > %d)", ctx->stack_need, yhk_stack_entries());
   // ---- materials ---------------------------------------------------------
@@ -925,6 +960,7 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
   // ---- upload ------------------------------------------------------------
   int rc;
   if ((rc = upload(ctx, ctx->d_nodes, nodes.data(), nodes.size() * 16))) return rc;
+  if ((rc = upload(ctx, ctx->d_nodes8, nodes8.data(), nodes8.size() * 16))) return rc;
   if ((rc = upload(ctx, ctx->d_prims, prims.data(), prims.size() * 16))) return rc;
   if ((rc = upload(ctx, ctx->d_vpos, vpos.data(), vpos.size() * 16))) return rc;
   if ((rc = upload(ctx, ctx->d_elems, elems.data(), elems.size() * 16))) return rc;
@@ -952,6 +988,8 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
   sc.light_table = (const yhd_float4*)ctx->d_light_table.p, sc.light_table_f4 = (int)light_table.size();
   sc.env_tab = (const float*)ctx->d_env_tab.p;
   sc.stack_entries = std::max(8, (ctx->stack_need + 7) / 8 * 8);
+  sc.nodes8 = (const yhd_float4*)ctx->d_nodes8.p, sc.num_nodes8_total = (int)(nodes8.size() / 16);
+  sc.stack_entries8 = std::max(8, (ctx->stack_need8 + 7) / 8 * 8);
   sc.textures = (const yhd_texture*)ctx->d_textures.p, sc.tex_texels = (const yhd_float4*)ctx->d_tex_texels.p;
   sc.vtex = (const float*)ctx->d_vtex.p;
   memcpy(sc.camera.frame, sd->camera.frame, 48);
@@ -1009,7 +1047,7 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
   ctx->have_state = false;
   ctx->launch_shape = 0;  // a new scene: no measured costs yet
   ctx->item_cost.clear();
-  ctx->have_costs = false, ctx->costs_settled = false, ctx->dense = -1;
+  ctx->have_costs = false, ctx->costs_settled = false, ctx->dense = -1, ctx->chain = -1;
   for (double& t : ctx->shape_ms) t = 0;
   for (int& t : ctx->shape_trials) t = 0;
   return YH_OK;
@@ -1061,7 +1099,7 @@ int yh_init_state(yh_context* ctx, const yh_trace_params* params) {
   bool new_image = false;
   if ((int)ctx->item_cost.size() != ctx->num_tiles_total * 4) {  // scheduling hints survive a re-init of the same image
     ctx->item_cost.assign((size_t)ctx->num_tiles_total * 4, 0);
-    ctx->have_costs = false, ctx->costs_settled = false, ctx->dense = -1, ctx->launch_shape = 0;
+    ctx->have_costs = false, ctx->costs_settled = false, ctx->dense = -1, ctx->chain = -1, ctx->launch_shape = 0;
     for (double& t : ctx->shape_ms) t = 0;
     for (int& t : ctx->shape_trials) t = 0;
     new_image = true;
@@ -1071,12 +1109,19 @@ int yh_init_state(yh_context* ctx, const yh_trace_params* params) {
   const int first_shape = getenv("YHAIR_SHAPE") ? choose_launch_shape(ctx) : ctx->launch_shape;
   ctx->state.tiles_x = tx, ctx->state.num_groups = 1, ctx->state.group_begin[0] = 0, ctx->state.group_begin[1] = (int)tiles.size();
   if (params->shader == YH_SHADER_PATH && first_shape == 3) deal_items_for_stream(ctx, tiles);
+  if (params->shader == YH_SHADER_PATH && first_shape == 4) split_items_for_octets(tiles);
+  tiles.reserve(2 * (size_t)ctx->num_tiles_total * 4 + 4);  // (the list's buffer holds the octet kernel's doubled list too)
   int rc;
   if ((rc = upload(ctx, ctx->d_rng_state, st.data(), npix * 8))) return rc;
   if ((rc = upload(ctx, ctx->d_rng_inc, inc.data(), npix * 8))) return rc;
   if ((rc = alloc_zero(ctx, ctx->d_accum, npix * 16))) return rc;
   if ((rc = alloc_zero(ctx, ctx->d_image, npix * 16))) return rc;
-  if ((rc = upload(ctx, ctx->d_tiles, tiles.data(), tiles.size() * 4))) return rc;
+  {
+    const size_t n = tiles.size();
+    tiles.resize(std::max(n, 2 * owned.size() * 4), 0);
+    if ((rc = upload(ctx, ctx->d_tiles, tiles.data(), tiles.size() * 4))) return rc;
+    tiles.resize(n);
+  }
   if ((rc = alloc_zero(ctx, ctx->d_counters, sizeof(yhd_counters)))) return rc;
   if ((rc = alloc_zero(ctx, ctx->d_tile_cursor, 8 * 16 * 4))) return rc;  // one cursor, or k_stream's one per item group 64 bytes apart
   if ((rc = alloc_zero(ctx, ctx->d_tile_cost, (size_t)ctx->num_tiles_total * 16))) return rc;
@@ -1125,6 +1170,8 @@ static int upload_work_items(yh_context* ctx) {
   build_work_items(ctx, tiles);
   ctx->state.num_groups = 1, ctx->state.group_begin[0] = 0, ctx->state.group_begin[1] = (int)tiles.size();
   if (ctx->state.shader == YH_SHADER_PATH && ctx->state.launch_shape == 3) deal_items_for_stream(ctx, tiles);
+  if (ctx->state.shader == YH_SHADER_PATH && ctx->state.launch_shape == 4) split_items_for_octets(tiles);
+  ctx->state.num_tiles = (int)tiles.size();
   HIPCHK(ctx, hipMemcpy(ctx->d_tiles.p, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice));
   return YH_OK;
 }
@@ -1369,7 +1416,7 @@ static int trace_impl(yh_context* ctx, int nsamples, bool counted, bool sync) {
     const int want = pick_launch_shape(ctx, sync ? nsamples : 0);  // (an asynchronous launch is not timed: never a trial)
     if (want != ctx->state.launch_shape) {
       if (getenv("YHAIR_TIMING"))
-        fprintf(stderr, "[yhair] kernel times (ms per spp): 0: %.4f, 1: %.4f, 3: %.4f -> %d (%d spp)\n", ctx->shape_ms[0], ctx->shape_ms[1], ctx->shape_ms[3], want, nsamples);
+        fprintf(stderr, "[yhair] kernel times (ms per spp): 0: %.4f, 1: %.4f, 2: %.4f, 3: %.4f, 4: %.4f -> %d (%d spp)\n", ctx->shape_ms[0], ctx->shape_ms[1], ctx->shape_ms[2], ctx->shape_ms[3], ctx->shape_ms[4], want, nsamples);
       ctx->launch_shape = ctx->state.launch_shape = want;
       // The list is rewritten by a blocking copy on the null stream; the context's stream is non-blocking, so a launch
       // queued by yh_trace_samples_async may still be reading it: wait for it first.
@@ -1377,8 +1424,13 @@ static int trace_impl(yh_context* ctx, int nsamples, bool counted, bool sync) {
       if (int rc = upload_work_items(ctx)) return rc;
     }
   }
+  if (counted && ctx->state.launch_shape == 4 && ctx->scene.general_materials) {  // the octet kernel's list holds half-quadrant entries: the instrumented (quad) build needs its own
+    ctx->launch_shape = ctx->state.launch_shape = 0;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (int rc = upload_work_items(ctx)) return rc;
+  }
   int shape = path ? ctx->state.launch_shape : 0;  // the preview shaders have one launch shape
-  if (shape >= 2 && counted) shape = 1;            // the instrumented build exists for k_trace only
+  if (counted && (shape == 3 || (shape >= 2 && ctx->scene.general_materials))) shape = shape == 3 ? 1 : 0;  // no instrumented build of k_stream, nor of the GENERAL 8-wide forms
   if (shape == 3 && !getenv("YHAIR_SHAPE")) {      // a candidate that cannot run here is dropped, not an error: k_trace renders the same bits
     int P = 0, grid = 0;
     if (!stream_geometry(ctx, ctx->state.num_tiles, &P, &grid, nullptr)) {
@@ -1391,9 +1443,7 @@ static int trace_impl(yh_context* ctx, int nsamples, bool counted, bool sync) {
   }
   ctx->last_shape = shape, ctx->last_counted = counted, ctx->planned_settled = ctx->costs_settled;
 #ifdef YH_LAB_WAVEFRONT
-  if (shape == 2) return wavefront_impl(ctx, nsamples, sync);
-#else
-  if (shape == 2) return fail(ctx, YH_E_INVALID, "launch shape 2 (k_wavefront) is a developer kernel: build with make WAVEFRONT=1");
+  if (path && !counted && getenv("YHAIR_LAB_WAVEFRONT")) return wavefront_impl(ctx, nsamples, sync);  // developer build only (make WAVEFRONT=1)
 #endif
   if (shape == 3) return stream_impl(ctx, nsamples, sync);
   int waves_per_block = yhk_block_threads(shape) / 64;  // one work item per wave at a time
@@ -1408,7 +1458,7 @@ static int trace_impl(yh_context* ctx, int nsamples, bool counted, bool sync) {
   HIPCHK(ctx, hipMemsetAsync(ctx->d_tile_cost.p, 0, (size_t)ctx->num_tiles_total * 16, ctx->stream));
   HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   int e = exact ? yhk_trace_exact(&ctx->scene, &ctx->state, nsamples, lds_bytes, grid, ctx->stream)
-                : yhk_trace(&ctx->scene, &ctx->state, nsamples, counted ? (yhd_counters*)ctx->d_counters.p : nullptr, grid, ctx->stream);
+                : yhk_trace(&ctx->scene, &ctx->state, nsamples, counted ? (yhd_counters*)ctx->d_counters.p : nullptr, shape, grid, ctx->stream);
   if (e) return fail(ctx, YH_E_DEVICE, "k_trace launch: %s", hipGetErrorString((hipError_t)e));
   HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   ctx->state.samples_done += nsamples;
