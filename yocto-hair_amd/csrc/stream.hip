@@ -376,7 +376,97 @@ __global__ __launch_bounds__(YH_ST_BLOCK, WAVES) void k_stream(const yhd_scene s
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Closest-hit batches with one lane per ray (yh_intersect_batch on large batches): persistent wavefronts, the trace
+// stage of k_stream on its own — a lane that finishes its ray takes the next one of the batch (refill when enough
+// lanes are idle) — and nothing of the shading code around it, so the kernel fits 64-80 registers and runs at 6-8
+// waves per SIMD. Same lane_step, same closest hits as the quad form (k_intersect). tmin of every ray = ray_eps.
+// ---------------------------------------------------------------------------------------------------------------
+template <int WAVES>
+__global__ __launch_bounds__(256, WAVES) void k_intersect_lanes(const yhd_scene sc, const yhd_scene* sc_dev, int n, const float* rays,
+    int* cursor, unsigned int* stack_ovf, int ovf_entries, int* object, int* element, float* uv, float* dist) {
+  extern __shared__ v4f lds_dyn[];
+  YH_LDS v4f* lds_tabs = (YH_LDS v4f*)lds_dyn;
+  const int   lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+  YH_LDS unsigned int* w_stack = (YH_LDS unsigned int*)(lds_tabs + YHD_LDS_TABLES_F4(&sc)) + wib * 64 * YH_LSTACK;
+  trace_ctx tc;
+  tc.sc = &sc, tc.sc_dev = sc_dev, tc.lds_nodes = nullptr, tc.lds_stack = nullptr, tc.stats = nullptr;
+  YH_LDS float* lds_cam;
+  stage_tables(sc, lds_tabs, threadIdx.x, 256, tc, lds_cam);
+  __syncthreads();
+  const size_t wave_id = (size_t)blockIdx.x * 4 + wib;
+  lane_stack   stk;
+  stk.lds = w_stack + lane, stk.ovf = stack_ovf + wave_id * (size_t)ovf_entries * 64 + lane, stk.sp = 0, stk.base = 0;
+  tc.ls = &stk;
+  lane_trav t;
+  lane_begin(sc, t, mk3(0.0f), mk3(1.0f), -1);
+  bool have = false, dry = false;
+  int  ray = 0;
+  while (true) {
+    const unsigned long long idle  = __ballot(!have);
+    const int                nidle = (int)__popcll(idle);
+    if (!dry && (nidle >= YH_REFILL_LANES || nidle == 64)) {
+      int first = 0;
+      if (lane == 0) first = atomicAdd(cursor, nidle);
+      first = __builtin_amdgcn_readfirstlane(first);
+      if (first >= n) dry = true;
+      const int mine = first + lane_rank(idle);
+      if (!have && mine < n) {
+        ray            = mine;
+        const float* r = rays + 8 * (size_t)ray;
+        lane_begin(sc, t, ld3(r), ld3(r + 3), -1);
+        t.tmax = r[7];
+        have   = true;
+      }
+    }
+    if (__ballot(have) == 0) {
+      if (dry) break;
+      continue;
+    }
+    if (have) {
+      bool redo = false;
+      if (lane_step<false>(tc, t, stk, 0, redo)) {
+        have = false;
+        hit_t h = t.hit;
+        if (redo) {  // axis-parallel ray: the reference's compare-and-select box test throughout
+          stk.sp = 0, stk.base = 0;
+          const float*      r = rays + 8 * (size_t)ray;
+          lane_exact_result e = lane_trace_exact(sc_dev, tc.lds_scene, stk.lds, stk.ovf, 0, 0, ld3(r), ld3(r + 3), -1);
+          stk.base = e.base;
+          h        = e.hit;
+          if (h.object >= 0 && h.distance > r[7]) h.object = -1, h.slot = -1, h.u = 0, h.v = 0, h.distance = 0;  // (the exact form starts from tmax = flt_max)
+        }
+        object[ray] = h.object, element[ray] = hit_element(sc, h);
+        uv[2 * ray] = h.u, uv[2 * ray + 1] = h.v, dist[ray] = h.distance;
+      }
+    }
+  }
+}
+
 extern "C" {
+
+// waves: 4, 6 or 8 per SIMD (the register budget: 128 / 80 / 64)
+typedef void (*lanes_kernel_t)(const yhd_scene, const yhd_scene*, int, const float*, int*, unsigned int*, int, int*, int*, float*, float*);
+static lanes_kernel_t lanes_kernel(int waves) { return waves >= 8 ? k_intersect_lanes<8> : waves >= 6 ? k_intersect_lanes<6> : k_intersect_lanes<4>; }
+int yhk_intersect_lanes_lds(const yhd_scene* sc) { return YHD_LDS_TABLES_F4(sc) * 16 + 4 * 64 * YH_LSTACK * 4; }
+int yhk_intersect_lanes_occupancy(const yhd_scene* sc, int waves) {
+  int blocks = 0, lds = yhk_intersect_lanes_lds(sc);
+  lanes_kernel_t k = lanes_kernel(waves);
+  if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k, 256, lds) != hipSuccess) return 0;
+  return blocks;
+}
+int yhk_intersect_lanes(const yhd_scene* sc, const yhd_scene* sc_dev, int n, const float* rays, int* cursor, unsigned int* stack_ovf,
+    int ovf_entries, int* object, int* element, float* uv, float* dist, int waves, int grid_blocks, hipStream_t stream) {
+  int            lds = yhk_intersect_lanes_lds(sc);
+  lanes_kernel_t k   = lanes_kernel(waves);
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(k, dim3(grid_blocks), dim3(256), lds, stream, *sc, sc_dev, n, rays, cursor, stack_ovf, ovf_entries, object, element, uv, dist);
+  return (int)hipGetLastError();
+}
 
 typedef void (*stream_kernel_t)(const yhd_scene, const yhd_scene*, const yhd_state, int, const yhd_stream);
 static stream_kernel_t stream_kernel(bool general, bool prof = false) {

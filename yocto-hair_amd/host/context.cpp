@@ -54,6 +54,9 @@ int yhk_stream(const yhd_scene*, const yhd_scene* sc_dev, const yhd_state*, int,
 int yhk_stream_block_threads(void);
 int yhk_stream_lds_bytes(int tables_f4, int slots_per_wave);
 int yhk_stream_occupancy(int lds_bytes, int general);
+int yhk_intersect_lanes_occupancy(const yhd_scene* sc, int waves);
+int yhk_intersect_lanes(const yhd_scene* sc, const yhd_scene* sc_dev, int n, const float* rays, int* cursor, unsigned int* stack_ovf,
+    int ovf_entries, int* object, int* element, float* uv, float* dist, int waves, int grid_blocks, hipStream_t stream);
 int yhk_resolve(const yhd_state*, int, int, void*, hipStream_t);
 int yhk_pack(const yhd_state*, int, int, void*, hipStream_t);
 int yhk_unpack(const void*, int, int, int, int, int, int, int, void*, hipStream_t);
@@ -1935,9 +1938,39 @@ int yh_intersect_batch(yh_context* ctx, int n, const float* rays, int* object, i
   auto   duv = (float*)s.out(8 * (size_t)n);
   auto   dd  = (float*)s.out(4 * (size_t)n);
   if (s.rc) return s.rc;
-  int e = yhk_intersect(&ctx->scene, n, dr, dob, del, duv, dd, ctx->stream);
-  if (e) return fail(ctx, YH_E_DEVICE, "k_intersect launch: %s", hipGetErrorString((hipError_t)e));
+  // Large batches of rays that start at the reference's ray_eps (every ray the path tracer itself makes) go one lane
+  // per ray through the trace-only kernel (csrc/stream.hip: k_intersect_lanes), five waves per SIMD; small
+  // ones, and rays with another tmin, a quad per ray (k_intersect). Same closest hits either way.
+  // YHAIR_INTERSECT=quad | lane4 | lane5 | lane6 | lane8: developer switch (waves per SIMD of the lane kernel).
+  const char* mode  = getenv("YHAIR_INTERSECT");
+  int         waves = 5;  // 91 registers without a spill: five waves per SIMD (6 and 8 spill 39 / 61 registers, measured slower)
+  bool        lanes = n >= 65536;
+  if (mode && !strcmp(mode, "quad")) lanes = false;
+  else if (mode && !strncmp(mode, "lane", 4)) lanes = true, waves = std::max(4, std::min(8, atoi(mode + 4)));
+  for (int i = 0; lanes && i < n; i++) lanes = rays[8 * (size_t)i + 6] == 1e-4f;
+  HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  if (lanes) {
+    const int occupancy = std::min(waves, yhk_intersect_lanes_occupancy(&ctx->scene, waves));  // (256-thread blocks: one wave per SIMD each)
+    if (occupancy < 1) return fail(ctx, YH_E_DEVICE, "k_intersect_lanes cannot run with its LDS layout on this device");
+    const int    grid        = (int)std::max<int64_t>(1, std::min<int64_t>(((int64_t)n + 255) / 256, (int64_t)ctx->num_cus * occupancy));
+    const int    ovf_entries = 2 * std::max(8, ctx->stack_need);
+    auto         dcur        = (int*)s.out(16);
+    auto         dovf        = (unsigned int*)s.out((size_t)grid * 4 * ovf_entries * 64 * 4);
+    if (s.rc) return s.rc;
+    if (!ctx->d_scene_copy.p) {
+      int rc = upload(ctx, ctx->d_scene_copy, &ctx->scene, sizeof(yhd_scene));
+      if (rc) return rc;
+    }
+    int e = yhk_intersect_lanes(&ctx->scene, (const yhd_scene*)ctx->d_scene_copy.p, n, dr, dcur, dovf, ovf_entries, dob, del, duv, dd, waves, grid, ctx->stream);
+    if (e) return fail(ctx, YH_E_DEVICE, "k_intersect_lanes launch: %s", hipGetErrorString((hipError_t)e));
+  } else {
+    int e = yhk_intersect(&ctx->scene, n, dr, dob, del, duv, dd, ctx->stream);
+    if (e) return fail(ctx, YH_E_DEVICE, "k_intersect launch: %s", hipGetErrorString((hipError_t)e));
+  }
+  HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, hipEventElapsedTime(&ctx->last_ms, ctx->ev0, ctx->ev1));  // (yh_last_trace_ms: the kernel alone, without the copies)
+  ctx->last_launches = 1;
   HIPCHK(ctx, hipMemcpy(object, dob, 4 * (size_t)n, hipMemcpyDeviceToHost));
   HIPCHK(ctx, hipMemcpy(element, del, 4 * (size_t)n, hipMemcpyDeviceToHost));
   HIPCHK(ctx, hipMemcpy(uv, duv, 8 * (size_t)n, hipMemcpyDeviceToHost));
