@@ -19,6 +19,9 @@
 // Compiled with -ffp-contract=off (see dev_math.h).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+#include <cstring>
+
 #include "yhair.h"
 #include "dev_items.h"
 
@@ -437,6 +440,14 @@ static trace_kernel_t trace_kernel(bool counted, bool general, int shape, int sh
   if (shape == 2 && !counted) return general ? k_trace<false, true, YH_BLOCK, YH_MIN_WAVES, YH_MODE_W8> : k_trace<false, false, YH_BLOCK, YH_MIN_WAVES, YH_MODE_W8>;
   if (shape == 4 && !counted) return general ? k_trace<false, true, YH_OCT_BLOCK, YH_MIN_WAVES, YH_MODE_OCT> : k_trace<false, false, YH_OCT_BLOCK, YH_MIN_WAVES, YH_MODE_OCT>;
   if (shape == 2 || shape == 4) return nullptr;
+  // The GENERAL variants carry the surface lobes, volumes, textures and the through-memory light code. The dense shape
+  // spilled 184 registers at the plain variant's 96 (7 scratch instructions inside its traversal loops): it runs at 256 x 4
+  // (128 registers, 49 spilled, none in the traversal loops; lobes / volumes +15-20 %, profiles/r03/general_waves_ab.txt).
+  // The 512-thread shape stays at 4 waves per SIMD (68 spilled, none in the traversal loops): at 3 (168 registers, 2
+  // spilled) its expensive items no longer fit the resident waves and it loses a third.
+  // YHAIR_GENERAL_WAVES=hi: the plain variants' budget for the dense shape too (developer A/B switch).
+  static const bool general_hi = getenv("YHAIR_GENERAL_WAVES") && !strcmp(getenv("YHAIR_GENERAL_WAVES"), "hi");
+  if (general && !counted && !general_hi && shape == 1) return k_trace<false, true, 256, YH_DENSE_WAVES - 1>;
   if (shape == 1)
     return counted ? (general ? k_trace<true, true, 256, YH_DENSE_WAVES> : k_trace<true, false, 256, YH_DENSE_WAVES>)
                    : (general ? k_trace<false, true, 256, YH_DENSE_WAVES> : k_trace<false, false, 256, YH_DENSE_WAVES>);
