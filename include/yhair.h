@@ -287,6 +287,9 @@ int yh_launch_shape(const yh_context* ctx);
  * relative costs for scheduling, comparable within one launch only.
  * `count` = number of tiles the caller's buffer holds.                       */
 int yh_tile_costs(yh_context* ctx, uint32_t* ticks, int count);
+/* The same per WORK ITEM (a tile's four 4x4-pixel quadrants, item = 4 * tile + quadrant: what a wavefront takes
+ * at a time and what the launch's hand-out order is planned from). `count` >= 4 * number of tiles.              */
+int yh_item_costs(yh_context* ctx, uint32_t* costs, int count);
 
 /* ------------------------------------------------------------------------ */
 /* Unit-level API: replaces yocto::extension and the intersect_* functions    */

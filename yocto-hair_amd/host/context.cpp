@@ -260,11 +260,16 @@ void parallel_for(int n, F&& fn) {
   for (auto& th : pool) th.join();
 }
 
-constexpr int YH_SHAPES = 5;  // launch shapes: 0, 1 k_trace (4-wide nodes) | 2 k_trace over 8-wide nodes | 3 k_stream | 4 k_trace with octets
+constexpr int YH_SHAPES = 6;  // launch shapes: 0, 1 k_trace (4-wide nodes) | 2 k_trace over 8-wide nodes | 3 k_stream | 4 k_trace with octets | 5 quads and octets side by side
 struct yh_context {
   int         device = 0;
   hipStream_t stream = nullptr;
   hipEvent_t  ev0 = nullptr, ev1 = nullptr;
+  // the side-by-side launch (shape 5): the octet kernel runs on a second stream, forked from and joined to `stream` by events
+  hipStream_t stream2 = nullptr;
+  hipEvent_t  ev_fork = nullptr, ev_join = nullptr;
+  int         hy_quad_items = 0, hy_oct_entries = 0;  // layout of the work list for shape 5: [quad items][octet entries]
+  std::vector<int> hy_oct_items;                       // ... and the items that run as octets
   int         num_cus = 0;
   std::string error = "no error";
   // scene
@@ -471,11 +476,11 @@ bool trials_off() {
 }
 // k_trace in both quad shapes always; k_stream on dense images; the octet kernel on chain-bound ones (a shard of a sparse
 // image on one of several GPUs, a small image). (Shape 2, quads over 8-wide nodes, is never one: profiles/r03/w8_oct_ab.txt.)
-int candidates(const yh_context* ctx, int cand[4]) {
+int candidates(const yh_context* ctx, int cand[5]) {
   int n = 0;
   cand[n++] = 0, cand[n++] = 1;
   if (ctx->dense > 0) cand[n++] = 3;
-  if (ctx->chain > 0 && ctx->dense <= 0) cand[n++] = 4;
+  if (ctx->chain > 0 && ctx->dense <= 0) cand[n++] = 4, cand[n++] = 5;  // all items as octets | the expensive ones as octets beside the quads
   return n;
 }
 // After a synchronous launch: its time if it was a trial-length one, and dense / sparse from fresh item costs of a
@@ -517,7 +522,7 @@ bool wants_trial(const yh_context* ctx, const int* cand, int n, int c) {
 bool trial_pending(const yh_context* ctx) {
   if (!ctx->have_state || !ctx->have_costs || ctx->state.shader != YH_SHADER_PATH || trials_off() || ctx->params.hair_exact) return false;
   if (!ctx->costs_settled) return true;  // (the first short launch settles the item costs; the trials follow it)
-  int cand[4], n = candidates(ctx, cand);
+  int cand[5], n = candidates(ctx, cand);
   for (int k = 0; k < n; k++)
     if (wants_trial(ctx, cand, n, cand[k])) return true;
   return false;
@@ -529,7 +534,7 @@ int pick_launch_shape(const yh_context* ctx, int nsamples) {
   if (!ctx->have_costs) return ctx->launch_shape;  // the first launch of an image: unplanned, not a measurement
   const int by_costs = ctx->dense > 0 ? 1 : 0;
   if (trials_off()) return by_costs;
-  int cand[4], n = candidates(ctx, cand), best = -1;
+  int cand[5], n = candidates(ctx, cand), best = -1;
   const bool trial_length = ctx->costs_settled && nsamples >= YH_TRIAL_SPP && nsamples < 2 * YH_TRIAL_SPP;
   for (int k = 0; k < n; k++) {
     const int c = cand[k];
@@ -575,6 +580,7 @@ static void split_items_for_octets(std::vector<int>& items) {
   for (int it : items) out.push_back(it << 1), out.push_back((it << 1) | 1);
   items.swap(out);
 }
+static void split_items_side_by_side(yh_context* ctx, std::vector<int>& items);
 static int  trace_impl(yh_context* ctx, int nsamples, bool counted, bool sync);
 
 const char* yh_version(void) { return "yhair 0.1 (gfx950, HIP)"; }
@@ -611,6 +617,9 @@ void yh_destroy(yh_context* ctx) {
   destroy_communicators(ctx);
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2), (void)hipStreamDestroy(ctx->stream2);
+  if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+  if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -1113,6 +1122,7 @@ int yh_init_state(yh_context* ctx, const yh_trace_params* params) {
   ctx->state.tiles_x = tx, ctx->state.num_groups = 1, ctx->state.group_begin[0] = 0, ctx->state.group_begin[1] = (int)tiles.size();
   if (params->shader == YH_SHADER_PATH && first_shape == 3) deal_items_for_stream(ctx, tiles);
   if (params->shader == YH_SHADER_PATH && first_shape == 4) split_items_for_octets(tiles);
+  if (params->shader == YH_SHADER_PATH && first_shape == 5) split_items_side_by_side(ctx, tiles);
   tiles.reserve(2 * (size_t)ctx->num_tiles_total * 4 + 4);  // (the list's buffer holds the octet kernel's doubled list too)
   int rc;
   if ((rc = upload(ctx, ctx->d_rng_state, st.data(), npix * 8))) return rc;
@@ -1174,10 +1184,51 @@ static int upload_work_items(yh_context* ctx) {
   ctx->state.num_groups = 1, ctx->state.group_begin[0] = 0, ctx->state.group_begin[1] = (int)tiles.size();
   if (ctx->state.shader == YH_SHADER_PATH && ctx->state.launch_shape == 3) deal_items_for_stream(ctx, tiles);
   if (ctx->state.shader == YH_SHADER_PATH && ctx->state.launch_shape == 4) split_items_for_octets(tiles);
+  if (ctx->state.shader == YH_SHADER_PATH && ctx->state.launch_shape == 5) split_items_side_by_side(ctx, tiles);
   ctx->state.num_tiles = (int)tiles.size();
   HIPCHK(ctx, hipMemcpy(ctx->d_tiles.p, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice));
   return YH_OK;
 }
+
+// SIDE BY SIDE (launch shape 5). A launch whose expensive items all fit the resident waves ends with its most expensive
+// item: every such item runs from the start, and the launch is as long as the longest chain (C1: the most expensive
+// quadrant takes 14.8 ms per 64 samples, the median expensive one 9 ms: a third of the wave slots' time is idle).
+// On an idle GPU the octet kernel runs an item in 0.74 x the time for two waves instead of one. So the wave slots the
+// expensive items leave free go to the MOST expensive of them: the first n of the cost-sorted list run as octets
+// (k_trace, shape 4's kernel, on a second stream), everything else as quads (shape 0's kernel), n = as many as there
+// are spare slots. Both kernels render the quad kernel's bits, each pixel belongs to one of them.
+// MEASURED (profiles/r03/side_by_side_ab.txt): on C1 at 720^2, where the expensive items already fill the waves, it LOSES
+// (18.7 against 14.8 ms: under that load an octet half takes 16.8 ms — the octet's gain is trips of an otherwise idle
+// SIMD, not instructions), so it is a candidate only where the octet kernel is (chain-bound images), as the form
+// that leaves the cheap items to the quad kernel.
+// Expensive = within 5 x of the most expensive item. Returns how many of them there are.
+static int expensive_items(const yh_context* ctx, const std::vector<int>& items) {
+  if (items.empty()) return 0;
+  const uint64_t top = ctx->item_cost[(size_t)items[0]];
+  int n = 0;
+  for (int it : items) {  // (cost-sorted as far as the expensive ones go)
+    if ((uint64_t)ctx->item_cost[(size_t)it] * 5 < top || top == 0) break;
+    n++;
+  }
+  return n;
+}
+static int resident_waves_quads(const yh_context* ctx) {
+  const int lds = yhk_trace_lds_bytes(&ctx->scene, 0);
+  return ctx->num_cus * std::max(1, yhk_trace_occupancy(lds, ctx->scene.general_materials, 0)) * (yhk_block_threads(0) / 64);
+}
+static void split_items_side_by_side(yh_context* ctx, std::vector<int>& items) {
+  const int H = expensive_items(ctx, items), S = resident_waves_quads(ctx);
+  int n_oct = std::max(0, std::min(H, S - H));
+  if (const char* env = getenv("YHAIR_HY_OCT")) n_oct = std::max(0, std::min((int)items.size(), atoi(env)));  // developer switch
+  std::vector<int> out;
+  out.reserve(items.size() + n_oct);
+  for (size_t i = (size_t)n_oct; i < items.size(); i++) out.push_back(items[i]);                   // quads: the rest, most expensive first
+  for (int i = 0; i < n_oct; i++) out.push_back(items[i] << 1), out.push_back((items[i] << 1) | 1);  // octets: two half-quadrant entries each
+  ctx->hy_quad_items = (int)items.size() - n_oct, ctx->hy_oct_entries = 2 * n_oct;
+  ctx->hy_oct_items.assign(items.begin(), items.begin() + n_oct);
+  items.swap(out);
+}
+static int side_by_side_impl(yh_context* ctx, int nsamples, bool sync);
 
 // Bookkeeping after a synchronous launch: its time (kernel selection) and, after launches 1, 2, 4, 8, ... of a state,
 // the longest-processing-time-first order for the next ones (the pixel results do not depend on either).
@@ -1190,6 +1241,8 @@ static int replan_after_launch(yh_context* ctx, int nsamples) {
   // (... and after the first launch long enough to settle the costs, whenever it comes: the kernel trials wait for it)
   const bool     refresh = (li & (li - 1)) == 0 || (!ctx->costs_settled && nsamples >= YH_TRIAL_SPP && ctx->state.shader == YH_SHADER_PATH);
   if (refresh) HIPCHK(ctx, hipMemcpy(ctx->item_cost.data(), ctx->d_tile_cost.p, ctx->item_cost.size() * 4, hipMemcpyDeviceToHost));
+  if (refresh && ctx->last_shape == 5)  // an item that ran as octets reports the time of its two halves, 2 x 0.74 of what it costs as a quad
+    for (int it : ctx->hy_oct_items) ctx->item_cost[(size_t)it] = (unsigned int)((double)ctx->item_cost[(size_t)it] * (1.0 / 1.48));
   if (ctx->state.shader == YH_SHADER_PATH && (refresh || ctx->have_costs)) record_launch(ctx, nsamples, refresh);
   if (!refresh) return YH_OK;
   return upload_work_items(ctx);
@@ -1419,7 +1472,7 @@ static int trace_impl(yh_context* ctx, int nsamples, bool counted, bool sync) {
     const int want = pick_launch_shape(ctx, sync ? nsamples : 0);  // (an asynchronous launch is not timed: never a trial)
     if (want != ctx->state.launch_shape) {
       if (getenv("YHAIR_TIMING"))
-        fprintf(stderr, "[yhair] kernel times (ms per spp): 0: %.4f, 1: %.4f, 2: %.4f, 3: %.4f, 4: %.4f -> %d (%d spp)\n", ctx->shape_ms[0], ctx->shape_ms[1], ctx->shape_ms[2], ctx->shape_ms[3], ctx->shape_ms[4], want, nsamples);
+        fprintf(stderr, "[yhair] kernel times (ms per spp): 0: %.4f, 1: %.4f, 2: %.4f, 3: %.4f, 4: %.4f, 5: %.4f -> %d (%d spp)\n", ctx->shape_ms[0], ctx->shape_ms[1], ctx->shape_ms[2], ctx->shape_ms[3], ctx->shape_ms[4], ctx->shape_ms[5], want, nsamples);
       ctx->launch_shape = ctx->state.launch_shape = want;
       // The list is rewritten by a blocking copy on the null stream; the context's stream is non-blocking, so a launch
       // queued by yh_trace_samples_async may still be reading it: wait for it first.
@@ -1427,7 +1480,7 @@ static int trace_impl(yh_context* ctx, int nsamples, bool counted, bool sync) {
       if (int rc = upload_work_items(ctx)) return rc;
     }
   }
-  if (counted && ctx->state.launch_shape == 4 && ctx->scene.general_materials) {  // the octet kernel's list holds half-quadrant entries: the instrumented (quad) build needs its own
+  if (counted && (ctx->state.launch_shape == 5 || (ctx->state.launch_shape == 4 && ctx->scene.general_materials))) {  // the octet kernel's list holds half-quadrant entries: the instrumented (quad) build needs its own
     ctx->launch_shape = ctx->state.launch_shape = 0;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     if (int rc = upload_work_items(ctx)) return rc;
@@ -1449,6 +1502,8 @@ static int trace_impl(yh_context* ctx, int nsamples, bool counted, bool sync) {
   if (path && !counted && getenv("YHAIR_LAB_WAVEFRONT")) return wavefront_impl(ctx, nsamples, sync);  // developer build only (make WAVEFRONT=1)
 #endif
   if (shape == 3) return stream_impl(ctx, nsamples, sync);
+  if (shape == 5 && !counted) return side_by_side_impl(ctx, nsamples, sync);
+  if (shape == 5) shape = 0;  // (instrumented: guarded above, the list was rebuilt for the quad kernel)
   int waves_per_block = yhk_block_threads(shape) / 64;  // one work item per wave at a time
   int lds_bytes       = yhk_trace_lds_bytes(&ctx->scene, shape);
   const bool exact    = path && ctx->params.hair_exact && !counted;
@@ -1463,6 +1518,52 @@ static int trace_impl(yh_context* ctx, int nsamples, bool counted, bool sync) {
   int e = exact ? yhk_trace_exact(&ctx->scene, &ctx->state, nsamples, lds_bytes, grid, ctx->stream)
                 : yhk_trace(&ctx->scene, &ctx->state, nsamples, counted ? (yhd_counters*)ctx->d_counters.p : nullptr, shape, grid, ctx->stream);
   if (e) return fail(ctx, YH_E_DEVICE, "k_trace launch: %s", hipGetErrorString((hipError_t)e));
+  HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  ctx->state.samples_done += nsamples;
+  ctx->last_launches = 1;
+  if (sync) {
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipEventElapsedTime(&ctx->last_ms, ctx->ev0, ctx->ev1));
+    return replan_after_launch(ctx, nsamples);
+  }
+  return YH_OK;
+}
+// One side-by-side launch: the quad kernel over [0, hy_quad_items) of the work list on the context's stream, the octet
+// kernel over the entries behind them on a second stream, forked and joined by events (so the pair behaves like one
+// launch on `stream`, also for yh_trace_samples_async). Grids: the octet entries get a wave each, the quad kernel the rest.
+static int side_by_side_impl(yh_context* ctx, int nsamples, bool sync) {
+  if (!ctx->stream2) {
+    HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+    HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+  }
+  const int lds_q = yhk_trace_lds_bytes(&ctx->scene, 0), lds_o = yhk_trace_lds_bytes(&ctx->scene, 4);
+  const int occ_q = yhk_trace_occupancy(lds_q, ctx->scene.general_materials, 0), occ_o = yhk_trace_occupancy(lds_o, ctx->scene.general_materials, 4);
+  if (occ_q < 1 || occ_o < 1) return fail(ctx, YH_E_DEVICE, "k_trace cannot run with %d / %d bytes of LDS per block", lds_q, lds_o);
+  const int wpb_q = yhk_block_threads(0) / 64, wpb_o = yhk_block_threads(4) / 64;
+  const int slots = ctx->num_cus * occ_q * wpb_q;  // resident waves (both kernels: four per SIMD)
+  const int grid_o = ctx->hy_oct_entries > 0 ? std::min((ctx->hy_oct_entries + wpb_o - 1) / wpb_o, ctx->num_cus * occ_o) : 0;
+  const int left   = std::max(wpb_q, slots - grid_o * wpb_o);
+  const int grid_q = ctx->hy_quad_items > 0 ? std::max(1, std::min((ctx->hy_quad_items + wpb_q - 1) / wpb_q, left / wpb_q)) : 0;
+  yhd_state st_q = ctx->state, st_o = ctx->state;
+  st_q.num_tiles = ctx->hy_quad_items;
+  st_o.tiles = ctx->state.tiles + ctx->hy_quad_items, st_o.num_tiles = ctx->hy_oct_entries, st_o.tile_cursor = ctx->state.tile_cursor + 16;
+  HIPCHK(ctx, hipMemsetAsync(ctx->d_tile_cursor.p, 0, 8 * 16 * 4, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(ctx->d_tile_cost.p, 0, (size_t)ctx->num_tiles_total * 16, ctx->stream));
+  HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+  int e = 0;
+  if (grid_o > 0) {  // the expensive items first: their chains are the longest
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+    e = yhk_trace(&ctx->scene, &st_o, nsamples, nullptr, 4, grid_o, ctx->stream2);
+    if (e) return fail(ctx, YH_E_DEVICE, "k_trace (octets) launch: %s", hipGetErrorString((hipError_t)e));
+    HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
+  }
+  if (grid_q > 0) {
+    e = yhk_trace(&ctx->scene, &st_q, nsamples, nullptr, 0, grid_q, ctx->stream);
+    if (e) return fail(ctx, YH_E_DEVICE, "k_trace launch: %s", hipGetErrorString((hipError_t)e));
+  }
+  if (grid_o > 0) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
   HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   ctx->state.samples_done += nsamples;
   ctx->last_launches = 1;
@@ -1734,6 +1835,16 @@ int yh_tile_costs(yh_context* ctx, uint32_t* ticks, int count) {
   HIPCHK(ctx, hipMemcpy(cost.data(), ctx->d_tile_cost.p, cost.size() * 4, hipMemcpyDeviceToHost));
   for (int t = 0; t < ctx->num_tiles_total; t++)  // a tile is four work items (4x4 quadrants): report their sum
     ticks[t] = cost[4 * t] + cost[4 * t + 1] + cost[4 * t + 2] + cost[4 * t + 3];
+  return YH_OK;
+}
+
+int yh_item_costs(yh_context* ctx, uint32_t* costs, int count) {
+  if (!ctx || !costs) return YH_E_INVALID;
+  if (!ctx->have_state) return fail(ctx, YH_E_STATE, "yh_item_costs before yh_init_state");
+  if (count < ctx->num_tiles_total * 4) return fail(ctx, YH_E_INVALID, "buffer holds %d items, image has %d", count, ctx->num_tiles_total * 4);
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, hipMemcpy(costs, ctx->d_tile_cost.p, (size_t)ctx->num_tiles_total * 16, hipMemcpyDeviceToHost));
   return YH_OK;
 }
 

@@ -147,6 +147,7 @@ _SIGS = {
     "yh_last_trace_ms": (C.c_int, [C.c_void_p, c_float_p, c_int_p]),
     "yh_launch_shape": (C.c_int, [C.c_void_p]),
     "yh_tile_costs": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_int]),
+    "yh_item_costs": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_int]),
     "yh_hair_brdf_batch": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Material), c_float_p,
                                      c_float_p, c_float_p, c_float_p]),
     "yh_curves_to_lines": (C.c_int, [C.c_void_p, C.c_int, c_float_p, c_float_p, c_float_p, C.c_int, c_float_p,
@@ -295,6 +296,15 @@ class Context:
         out = np.zeros(tx * ty, np.uint32)
         self._chk(self.lib.yh_tile_costs(self.h, out.ctypes.data_as(C.POINTER(C.c_uint32)), len(out)))
         return out.reshape(ty, tx)
+
+    def item_costs(self):
+        """Per work item (tile * 4 + quadrant) cost of the most recent launch."""
+        w, h = C.c_int(), C.c_int()
+        self._chk(self.lib.yh_image_size(self.h, C.byref(w), C.byref(h)))
+        n = ((w.value + 7) // 8) * ((h.value + 7) // 8) * 4
+        out = np.zeros(n, np.uint32)
+        self._chk(self.lib.yh_item_costs(self.h, out.ctypes.data_as(C.POINTER(C.c_uint32)), n))
+        return out
 
     def download(self):
         img = np.zeros((self.height, self.width, 4), np.float32)
