@@ -397,10 +397,9 @@ def main():
         try:
             allp = json.load(open(os.path.join(ROOT, "profiles", "k_trace_traffic.json")))
             allp = allp if isinstance(allp, list) else [allp]
-            pmc_kernel = {0: "k_trace<false, false, 512, 4>", 1: "k_trace<false, false, 256, 5>", 3: "k_stream"}.get(shape_used, "?")
             for cand in allp:  # the passes were taken on one kernel: they describe this run only if it chose the same one
                 if (cand["scene"], cand["resolution"], cand["scale"]) == (scene_name, res_main, a.scale) and world == 1 and not scene_kw \
-                        and cand.get("kernel", pmc_kernel) == pmc_kernel:
+                        and cand.get("launch_shape") == shape_used:
                     if cand.get("csrc_sha16") != csrc_sha16():  # taken on other device code: not a statement about this run
                         traffic_src = f"stale: {cand['source'].split(' ')[0]} was taken on other kernels (csrc fingerprint differs); retake with tools/profile_configs.sh"
                         continue

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Developer tool: profiles/k_trace_traffic.json (what bench.py's `roofline.traffic` and `roofline.valu` quote) from the
 outputs of tools/profile_configs.sh.
-usage: tools/traffic_from_pmc.py [--append] TAG PROFILES_PREFIX "C1:k_trace<false, false, 512, 4>" ...
+usage: tools/traffic_from_pmc.py [--append] TAG PROFILES_PREFIX "C1:0:k_trace<false, false, 512, 4, 0>" ...   (config : launch shape : kernel-name filter,
+       the specs of tools/profile_configs.sh)
   reads  gpurun_out/TAG/<cfg>/pmc.json and gpurun_out/TAG/<cfg>/stats/**/run_kernel_trace.csv
   writes profiles/k_trace_traffic.json; the entries cite PROFILES_PREFIX_<cfg>_pmc.json as their source
 
@@ -11,7 +12,8 @@ Conventions (MI355X_MICROARCH.md, HBM / rocprofv3 section): FETCH_SIZE counts KB
 yh_init_state) are left out of every average."""
 import csv, glob, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CONFIGS = {"C1": ("sphere-hairblock", 720, 64), "C2": ("straight-hair", 720, 64), "C3": ("curly-hair", 1280, 32), "C4": ("hair-curls", 1280, 32)}
+CONFIGS = {"C1": ("sphere-hairblock", 720, 64), "C2": ("straight-hair", 720, 64), "C3": ("curly-hair", 1280, 32), "C4": ("hair-curls", 1280, 32),
+           "lobes": ("lobes", 720, 64), "volumes": ("volumes", 720, 64), "textured": ("textured", 720, 64)}
 SIMDS, CLOCK = 1024, 2.0e9  # 256 CUs x 4 SIMDs; a vector instruction of a 64-wide wave holds its SIMD for 2 cycles at full rate
 
 
@@ -20,7 +22,7 @@ def main():
     tag, prefix, specs = args[0], args[1], args[2:]
     entries = json.load(open(os.path.join(ROOT, "profiles", "k_trace_traffic.json"))) if "--append" in sys.argv else []
     for spec in specs:
-        cfg, kern = spec.split(":", 1)
+        cfg, shape, kern = spec.split(":", 2)
         d = os.path.join(ROOT, "gpurun_out", tag, cfg)
         p = json.load(open(os.path.join(d, "pmc.json")))
         durs = []
@@ -38,7 +40,7 @@ def main():
         import bench
         entries.append({
             "csrc_sha16": bench.csrc_sha16(),  # the device code the passes were taken on (bench.py quotes them only for the same)
-            "kernel": kern, "config": f"{cfg} {res}x{res}, {spp} spp per launch, 1 GPU", "scene": scene, "resolution": res, "scale": 1.0,
+            "kernel": kern, "launch_shape": int(shape), "config": f"{cfg} {res}x{res}, {spp} spp per launch, 1 GPU", "scene": scene, "resolution": res, "scale": 1.0,
             "spp_per_launch": spp, "source": src,
             "hbm_fetch_bytes_per_launch": p["FETCH_SIZE"] * 1024 * 2, "hbm_write_bytes_per_launch": p["WRITE_SIZE"] * 1024,
             "valu_issue_fraction": p["SQ_ACTIVE_INST_VALU"] / p["SQ_WAVE_CYCLES"], "wait_any_fraction": p["SQ_WAIT_ANY"] / p["SQ_WAVE_CYCLES"],
