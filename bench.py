@@ -299,6 +299,9 @@ def main():
     ALGO = ("samples", "rays", "nodes", "seg_tests", "tri_tests", "hair_shades", "surf_shades", "env_lookups", "env_samples")
     ctx.init_state(yh.TraceParams.default(resolution=base_res))
     gpu_counts = ctx.trace_samples_counted(2).as_dict()
+    gpu_general = any(sf.desc.contents.materials[i].specular or sf.desc.contents.materials[i].metallic or sf.desc.contents.materials[i].transmission
+                      or sf.desc.contents.materials[i].opacity < 1 or sf.desc.contents.materials[i].color_tex or sf.desc.contents.materials[i].emission_tex
+                      for i in range(sf.desc.contents.num_materials))  # (label only: the GENERAL dense shape runs at 256 x 4)
     cpu = ref_wc = parity = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu, cpu_a, cpu_b, cpu_spp, seed_b, ref_wc = cpu_leg(scene_json, base_res, a.cpu_budget, a.cpu_spp)
@@ -447,7 +450,7 @@ def main():
                          "note": "hbm is the contract's designated roofline; the scene lives in L2 / Infinity Cache and the kernel is bound by "
                                  "vector-instruction issue (see valu)",
                          "valu": valu,
-                         "kernel": KERNELS.get(shape_used, "k_trace"), "launch_shape": shape_used,
+                         "kernel": KERNELS.get(shape_used, "k_trace") if not (shape_used == 1 and gpu_general) else "k_trace<256 x 4>", "launch_shape": shape_used,
                          "avg_launch_ms": round(launch_s * 1e3, 3), "avg_spp_per_launch": round(spp_launch, 2),
                          "algorithmic_bytes_per_sample": round(bytes_per_sample, 1),
                          "work_counts_from": counts_from,
