@@ -31,6 +31,9 @@
 
 namespace yhd {
 
+#ifndef YH_LANE_LEAF4
+#define YH_LANE_LEAF4 0 /* A/B switch: a line leaf's third and fourth segment in the same step as the first two. Bit-identical; the trace-only batch kernel +4 %, k_stream 0 to -3 % (its step loop grows from 1018 to 1259 vector instructions and spills five registers more): off (profiles/r03/lane_leaf4_ab.txt) */
+#endif
 #ifndef YH_LSTACK
 #define YH_LSTACK 16 /* LDS stack window per lane, entries (power of two) */
 #endif
@@ -181,10 +184,12 @@ YH_DEV bool lane_step(const trace_ctx& tc, lane_trav& t, lane_stack& s, int sp0,
     //   line leaf      primitive i < 2 = {p0 r0, p1 r1} = {A_i, B_i} at a + 4 i   (A2, A3: not used)
     //   triangle leaf  primitive i < 2 = {p0, p1} = {A_i, B_i} at a + 6 i, its p2 = A_(2 + i)
     // (a leaf of one primitive re-reads it as the second; a leaf longer than two takes another step)
+    //   line leaf, YH_LANE_LEAF4: all (up to four) primitives of the leaf in this one step: A2 B2 / A3 B3 = primitives 2 / 3
+    //   (the loads are issued anyway); a leaf of three or four segments costs one round trip instead of two
     const yhd_float4* a  = is_leaf ? sc.prims + (size_t)t.prim_base + (size_t)leaf_start * rec : sc.nodes + 8 * (size_t)t.cur;
     const int         o1 = is_leaf ? (leaf_num > 1 ? rec : 0) : 2;
-    const int         o2 = is_leaf ? (lines ? 0 : 2) : 4;
-    const int         o3 = is_leaf ? (lines ? 0 : o1 + 2) : 6;
+    const int         o2 = is_leaf ? (lines ? ((YH_LANE_LEAF4 && leaf_num > 2) ? 2 * rec : 0) : 2) : 4;
+    const int         o3 = is_leaf ? (lines ? ((YH_LANE_LEAF4 && leaf_num > 3) ? 3 * rec : 0) : o1 + 2) : 6;
     const v4f A0 = ldg4(a), B0 = ldg4(a + 1), A1 = ldg4(a + o1), B1 = ldg4(a + o1 + 1);
 #ifdef YH_LANE_SPLIT_LOADS /* developer A/B switch: the second half only where it is used */
     v4f A2 = A0, B2 = B0, A3 = A0, B3 = B0;
@@ -221,7 +226,7 @@ YH_DEV bool lane_step(const trace_ctx& tc, lane_trav& t, lane_stack& s, int sp0,
       }
     } else {
       // ---- leaf: its primitives in leaf order, tmax shrinking after each accepted hit (pt.cpp:905-923) ----
-      t.cur = leaf_num > 2 ? (YH_TAG_LEAF | ((unsigned)(leaf_num - 2) << 27) | (unsigned)(leaf_start + 2)) : YH_NONE;
+      t.cur = (leaf_num > 2 && !(YH_LANE_LEAF4 && lines)) ? (YH_TAG_LEAF | ((unsigned)(leaf_num - 2) << 27) | (unsigned)(leaf_start + 2)) : YH_NONE;
 #define YH_LANE_ACCEPT(I, LINES)                          \
   if (ok && I < leaf_num) {                               \
     t.hit.object = t.cur_obj, t.hit.slot = leaf_start + I; \
@@ -238,6 +243,18 @@ YH_DEV bool lane_step(const trace_ctx& tc, lane_trav& t, lane_stack& s, int sp0,
           float uu = 0, vv = 0, dist = 0;
           bool  ok = intersect_line<true>(t.lo, t.ld, ray_eps, t.tmax, xyz(A1), xyz(B1), A1.w, B1.w, uu, vv, dist);
           YH_LANE_ACCEPT(1, true)
+        }
+        if (YH_LANE_LEAF4 && leaf_num > 2) {
+          {
+            float uu = 0, vv = 0, dist = 0;
+            bool  ok = intersect_line<true>(t.lo, t.ld, ray_eps, t.tmax, xyz(A2), xyz(B2), A2.w, B2.w, uu, vv, dist);
+            YH_LANE_ACCEPT(2, true)
+          }
+          {
+            float uu = 0, vv = 0, dist = 0;
+            bool  ok = intersect_line<true>(t.lo, t.ld, ray_eps, t.tmax, xyz(A3), xyz(B3), A3.w, B3.w, uu, vv, dist);
+            YH_LANE_ACCEPT(3, true)
+          }
         }
       } else {
         {
