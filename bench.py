@@ -317,6 +317,7 @@ def main():
     res_main = weak_res if (a.weak and world > 1) else base_res
     width, height, elapsed, kernel_ms, p = timed_run(res_main, step_spp, a.warmup)
     shape_used = ctx.launch_shape() if hasattr(ctx, "launch_shape") else None
+    trials = {KERNELS.get(k, str(k)): {"ms_per_spp": v[0], "trials": v[1]} for k, v in ctx.kernel_trials().items()}
 
     # ---- one rank: what ONE GPU of N would take on this image (its shard rendered alone here) ----------
     projected = None
@@ -451,6 +452,7 @@ def main():
                                  "vector-instruction issue (see valu)",
                          "valu": valu,
                          "kernel": KERNELS.get(shape_used, "k_trace") if not (shape_used == 1 and gpu_general) else "k_trace<256 x 4>", "launch_shape": shape_used,
+                         "kernel_trials": trials,  # what the choice rests on: the fastest 32-sample trial of every candidate on this image
                          "avg_launch_ms": round(launch_s * 1e3, 3), "avg_spp_per_launch": round(spp_launch, 2),
                          "algorithmic_bytes_per_sample": round(bytes_per_sample, 1),
                          "work_counts_from": counts_from,

@@ -278,6 +278,10 @@ int yh_last_trace_ms(const yh_context* ctx, float* ms, int* launches);
  * path: few expensive pixels per GPU); 2 = quads over 8-wide nodes, never chosen (YHAIR_SHAPE=2 forces it).
  * < 0 = nothing launched yet (or an error code). With yh_trace_params::hair_exact it is always 0.        */
 int yh_launch_shape(const yh_context* ctx);
+/* The measurements behind that choice on the current image: for launch shape k < count, the milliseconds per sample
+ * of its fastest 32-sample trial launch (0 = not tried, < 0 = cannot run on this device) and the number of trials.
+ * Returns the number of launch shapes (6), or a negative error code.                                               */
+int yh_kernel_trials(const yh_context* ctx, double* ms_per_sample, int* trials, int count);
 
 /* Load-balance telemetry: for every tile id (row-major over ceil(W/8) x
  * ceil(H/8) tiles) the time its wavefront spent on it in the most recent

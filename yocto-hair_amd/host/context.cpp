@@ -1602,6 +1602,15 @@ int yh_synchronize(yh_context* ctx) {
   return YH_OK;
 }
 int yh_launch_shape(const yh_context* ctx) { return ctx ? ctx->last_shape : YH_E_INVALID; }
+int yh_kernel_trials(const yh_context* ctx, double* ms_per_sample, int* trials, int count) {
+  if (!ctx || !ms_per_sample || !trials || count < 1) return YH_E_INVALID;
+  for (int k = 0; k < count; k++) {
+    ms_per_sample[k] = k < YH_SHAPES ? ctx->shape_ms[k] : 0.0;
+    trials[k]        = k < YH_SHAPES ? ctx->shape_trials[k] : 0;
+    if (std::isinf(ms_per_sample[k])) ms_per_sample[k] = -1.0;  // a candidate that cannot run on this device
+  }
+  return YH_SHAPES;
+}
 int yh_last_trace_ms(const yh_context* ctx, float* ms, int* launches) {
   if (!ctx) return YH_E_INVALID;
   if (ms) *ms = ctx->last_ms;

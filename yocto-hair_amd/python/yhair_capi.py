@@ -148,6 +148,7 @@ _SIGS = {
     "yh_launch_shape": (C.c_int, [C.c_void_p]),
     "yh_tile_costs": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_int]),
     "yh_item_costs": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_int]),
+    "yh_kernel_trials": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_int]),
     "yh_hair_brdf_batch": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Material), c_float_p,
                                      c_float_p, c_float_p, c_float_p]),
     "yh_curves_to_lines": (C.c_int, [C.c_void_p, C.c_int, c_float_p, c_float_p, c_float_p, C.c_int, c_float_p,
@@ -296,6 +297,13 @@ class Context:
         out = np.zeros(tx * ty, np.uint32)
         self._chk(self.lib.yh_tile_costs(self.h, out.ctypes.data_as(C.POINTER(C.c_uint32)), len(out)))
         return out.reshape(ty, tx)
+
+    def kernel_trials(self):
+        """{launch shape: (ms per sample of its fastest trial, number of trials)} for the shapes tried on this image."""
+        ms, tr = (C.c_double * 8)(), (C.c_int * 8)()
+        n = self.lib.yh_kernel_trials(self.h, ms, tr, 8)
+        self._chk(min(n, 0))
+        return {k: (round(ms[k], 5), tr[k]) for k in range(n) if tr[k] or ms[k]}
 
     def item_costs(self):
         """Per work item (tile * 4 + quadrant) cost of the most recent launch."""
