@@ -66,10 +66,19 @@ YH_DEV void trace_items(const yhd_scene& sc, const yhd_state& st, int nsamples, 
   tc.stats = COUNT ? &stats : nullptr;
 
   const int lane = threadIdx.x & 63;
+  // The first item of a wave by position (the host placed the list: which items share a SIMD), the others from the cursor.
+  // (Whatever the grid: the entries no wave takes by position are served by the cursor.)
+  const int by_position  = min(st.static_items, (int)(gridDim.x * (BLOCK / 64)));
+  int       first_static = (int)(blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6));
   while (true) {
     int t = 0;
-    if (lane == 0) t = atomicAdd(st.tile_cursor, 1);
-    t = __builtin_amdgcn_readfirstlane(t);
+    if (first_static >= 0 && first_static < by_position) {
+      t = first_static;
+    } else {
+      if (lane == 0) t = atomicAdd(st.tile_cursor, 1);
+      t = __builtin_amdgcn_readfirstlane(t) + by_position;
+    }
+    first_static = -1;
     if (t >= st.num_tiles) break;
 #ifdef YH_PRIO /* developer A/B switch: issue priority for the waves that hold the most expensive items (the head of the cost-sorted list) */
     if (t < st.num_tiles / YH_PRIO) __builtin_amdgcn_s_setprio(3);

@@ -209,6 +209,10 @@ typedef struct yhd_state {
   int         bounces;
   float       clamp;
   int         shard_rank, shard_world;  // tile ids owned: rank, rank + world, ...
+  // k_trace: the first `static_items` entries of `tiles` are handed out BY POSITION — wave w of workgroup b starts with
+  // entry b * (waves per workgroup) + w — so that the host decides which items share a SIMD (host/context.cpp:
+  // place_first_round); the rest go through the cursor as before. 0: everything through the cursor.
+  int         static_items;
 } yhd_state;
 
 // Path pool of the wavefront integrator (csrc/wavefront.hip): SoA ray / hit / path-state buffers in

@@ -581,6 +581,7 @@ static void split_items_for_octets(std::vector<int>& items) {
   items.swap(out);
 }
 static void split_items_side_by_side(yh_context* ctx, std::vector<int>& items);
+static void place_first_round(yh_context* ctx, std::vector<int>& items);
 static int  trace_impl(yh_context* ctx, int nsamples, bool counted, bool sync);
 
 const char* yh_version(void) { return "yhair 0.1 (gfx950, HIP)"; }
@@ -1120,6 +1121,8 @@ int yh_init_state(yh_context* ctx, const yh_trace_params* params) {
   build_work_items(ctx, tiles);
   const int first_shape = getenv("YHAIR_SHAPE") ? choose_launch_shape(ctx) : ctx->launch_shape;
   ctx->state.tiles_x = tx, ctx->state.num_groups = 1, ctx->state.group_begin[0] = 0, ctx->state.group_begin[1] = (int)tiles.size();
+  ctx->state.static_items = 0;
+  if (params->shader == YH_SHADER_PATH && first_shape == 0) place_first_round(ctx, tiles);
   if (params->shader == YH_SHADER_PATH && first_shape == 3) deal_items_for_stream(ctx, tiles);
   if (params->shader == YH_SHADER_PATH && first_shape == 4) split_items_for_octets(tiles);
   if (params->shader == YH_SHADER_PATH && first_shape == 5) split_items_side_by_side(ctx, tiles);
@@ -1182,6 +1185,8 @@ static int upload_work_items(yh_context* ctx) {
   std::vector<int> tiles;
   build_work_items(ctx, tiles);
   ctx->state.num_groups = 1, ctx->state.group_begin[0] = 0, ctx->state.group_begin[1] = (int)tiles.size();
+  ctx->state.static_items = 0;
+  if (ctx->state.shader == YH_SHADER_PATH && ctx->state.launch_shape == 0) place_first_round(ctx, tiles);
   if (ctx->state.shader == YH_SHADER_PATH && ctx->state.launch_shape == 3) deal_items_for_stream(ctx, tiles);
   if (ctx->state.shader == YH_SHADER_PATH && ctx->state.launch_shape == 4) split_items_for_octets(tiles);
   if (ctx->state.shader == YH_SHADER_PATH && ctx->state.launch_shape == 5) split_items_side_by_side(ctx, tiles);
@@ -1229,6 +1234,55 @@ static void split_items_side_by_side(yh_context* ctx, std::vector<int>& items) {
   items.swap(out);
 }
 static int side_by_side_impl(yh_context* ctx, int nsamples, bool sync);
+
+// WHO SHARES A SIMD (k_trace 512 x 4 on a sparse image) — a developer experiment, OFF unless YHAIR_PLACEMENT=1: measured
+// without gain (profiles/r03/first_round_placement_ab.txt: C1 16.6 ms with the placement below, 16.1 with cost bands
+// only, 16.2 without, same box; whichever wave sits beside a critical one, its chain takes as long). The idea:
+// All expensive items of such a launch are resident from its
+// start, 3.5 per SIMD on C1, and the launch ends with the most expensive one: 14.8 ms per 64 spp where the median
+// expensive item takes 9.0 — while the same chain takes 12.3 ms on an idle GPU: a fifth of it is waiting for an issue
+// slot behind the three other expensive waves of its SIMD (SQ_WAIT_INST_ANY 23 % of the wave cycles at 720^2, 5 % at
+// 180^2). Which waves those are is the host's to decide: a workgroup's waves go to the SIMDs in cyclic order, so waves w
+// and w + 4 of a 512-thread workgroup share one, and the first item of a wave can be handed out by position
+// (yhd_state::static_items). The G most expensive items (G = workgroups of the launch) go to wave 0 of each workgroup
+// with a CHEAP item on wave 4 beside them — the SIMD of a critical chain holds two of them and two cheap waves instead
+// of four expensive ones — and the other expensive items, dealt by cost band, fill waves 1-3 and 5-7: they have a third
+// of the launch to spare. Everything else goes through the cursor as before. Pixels do not depend on any of it.
+static void place_first_round(yh_context* ctx, std::vector<int>& items) {
+  if (!getenv("YHAIR_PLACEMENT") || ctx->dense != 0 || !ctx->costs_settled) return;  // (developer switch; sparse images with settled costs only)
+  const int wpb = yhk_block_threads(0) / 64;
+  if (wpb != 8) return;
+  const int lds = yhk_trace_lds_bytes(&ctx->scene, 0);
+  const int occ = yhk_trace_occupancy(lds, ctx->scene.general_materials, 0);
+  if (occ < 1) return;
+  const int G = std::min(((int)items.size() + wpb - 1) / wpb, ctx->num_cus * occ);  // the grid trace_impl will launch
+  const int H = expensive_items(ctx, items);
+  if (G < 1 || (int)items.size() < 16 * G || H < 2 * G) return;  // (too few expensive items to matter, or no cheap items to put beside them)
+  if (getenv("YHAIR_TIMING")) fprintf(stderr, "[yhair] first round placed: %d workgroups, %d expensive items\n", G, H);
+  std::vector<int> out((size_t)8 * G, -1);
+  std::vector<char> used(items.size(), 0);
+  size_t cheap = items.size();  // cheap partners: from the list's end
+  const int mode = getenv("YHAIR_PLACE_MODE") ? atoi(getenv("YHAIR_PLACE_MODE")) : 0;  // developer A/B: 1 = cheap partner on wave 1, 2 = cost bands only (no cheap partner)
+  const int cheap_slot = mode == 1 ? 1 : 4;
+  for (int b = 0; b < G; b++) {
+    out[(size_t)8 * b] = items[(size_t)b], used[(size_t)b] = 1;  // wave 0: the b-th most expensive item
+    int k = 0;
+    for (int w = 1; w < 8; w++) {  // the other waves: one item of each following cost band
+      if (w == cheap_slot && mode != 2) continue;
+      const size_t r = (size_t)G + (size_t)k * G + (size_t)b;
+      out[(size_t)8 * b + w] = items[r], used[r] = 1, k++;
+    }
+  }
+  for (int b = 0; b < G && mode != 2; b++) {  // wave 4 (the SIMD of wave 0): a cheap item
+    while (cheap > 0 && used[cheap - 1]) cheap--;
+    if (cheap == 0) return;  // (cannot happen: items.size() >= 8 G)
+    out[(size_t)8 * b + cheap_slot] = items[cheap - 1], used[cheap - 1] = 1, cheap--;
+  }
+  for (size_t i = 0; i < items.size(); i++)
+    if (!used[i]) out.push_back(items[i]);  // the rest in the list's order: through the cursor
+  ctx->state.static_items = 8 * G;
+  items.swap(out);
+}
 
 // Bookkeeping after a synchronous launch: its time (kernel selection) and, after launches 1, 2, 4, 8, ... of a state,
 // the longest-processing-time-first order for the next ones (the pixel results do not depend on either).
