@@ -713,7 +713,7 @@ def test_launch_shapes_and_kernels_render_identical_pixels(ctx, yh, name, kw, mo
     ctx.upload_scene(sf.desc)
     p = yh.TraceParams.default(resolution=88)
     images = {}
-    for shape in ("0", "1", "2", "3", "4"):  # k_trace 512 x 4, 256 x 5, 512 x 4 over 8-wide nodes, k_stream, k_trace with octets
+    for shape in ("0", "1", "2", "3", "4", "5", "6", "7"):  # k_trace 512 x 4, 256 x 5, 512 x 4 over 8-wide nodes, k_stream, k_trace with octets, quads + octets side by side, sixteen lanes per path, octets with leaf pairs
         monkeypatch.setenv("YHAIR_SHAPE", shape)
         ctx.init_state(p)
         ctx.trace_samples(3), ctx.trace_samples(5)
@@ -750,12 +750,16 @@ def test_kernel_trials_are_cut_off_a_long_request(ctx, yh, name, kw, monkeypatch
     ms, launches = ctx.last_trace_ms()
     assert 3 <= launches <= 5 and ms > 0, launches  # the settling launch, two or three trials, then the rest (150 samples hold at most four 32-sample launches)
     assert np.array_equal(ctx.download(), base[0]) and np.array_equal(ctx.download_rng(), base[1])
-    for _ in range(3):  # (a tie between two kernels is tried again, fresh item costs may turn a sparse reading into a dense one)
+    # up to four candidates (a chain-bound image: quads, octets without and with leaf pairs, sixteen lanes), each tried
+    # twice when it ties with the best, fresh item costs may change the reading: the trials end within a few requests
+    for _ in range(6):
         ctx.trace_samples(150)
-        assert ctx.last_trace_ms()[1] <= 3
+        assert ctx.last_trace_ms()[1] <= 4
+        if ctx.last_trace_ms()[1] == 1:
+            break
     ctx.trace_samples(150)
     assert ctx.last_trace_ms()[1] == 1
-    assert ctx.launch_shape() in (0, 1, 3, 4)
+    assert ctx.launch_shape() in (0, 1, 3, 4, 6, 7)
     sf.close()
 
 
@@ -978,7 +982,7 @@ def test_octet_kernel_is_chosen_for_a_chain_bound_shard_and_renders_the_same_pix
     c.init_state(p)
     c.trace_samples(32 * 7)
     c.trace_samples(64)
-    assert c.launch_shape() == 4, c.launch_shape()
+    assert c.launch_shape() in (4, 6, 7), c.launch_shape()  # eight or sixteen lanes per path
     got = (c.download(), c.download_rng())
     monkeypatch.setenv("YHAIR_SHAPE", "0")
     c.init_state(p)

@@ -307,10 +307,13 @@ struct trav_state {
 #define YH_MODE_QUAD 0
 #define YH_MODE_W8 1
 #define YH_MODE_OCT 2
+#define YH_MODE_HEX 3 /* SIXTEEN lanes, 16-wide nodes (four levels, host/bvh_build.h: WideNode16): lane o tests slot o; the four quads hold the same path */
 #define YH_ROW_HALF_MIRROR 0x141 /* DPP: lane i of every eight reads lane 7 - i */
-#ifndef YH_OCT_LEAF_PAIRS
-#define YH_OCT_LEAF_PAIRS 0 /* A/B switch: the octet's two quads test two leaves in one step (below). Bit-identical, 6 % fewer trips, and 2-6 % SLOWER (profiles/r03/oct_leaf_pairs_ab.txt): the look at the stack's top and the exchange between the quads cost every leaf step more than the saved steps return. Off. */
-#endif
+#define YH_ROW_MIRROR 0x140      /* DPP: lane i of every sixteen reads lane 15 - i */
+#define YH_MODE_OCTP 4 /* YH_MODE_OCT with LEAF PAIRS: the octet's two quads test two leaves in one step (below). Bit-identical; 6 % fewer trips and
+                          2-6 % slower on C1 (the look at the stack's top and the exchange between the quads cost every leaf step), 17 % FASTER on hair-curls
+                          (many leaf steps per ray): its own launch shape, the trials decide (profiles/r03/oct_leaf_pairs_ab.txt, hex_ab.txt) */
+#define YH_IS_OCT(MODE) ((MODE) == YH_MODE_OCT || (MODE) == YH_MODE_OCTP)
 template <bool COUNT, int STRIDE, bool EXACT, bool PHASE = false, bool LDS_SCENE = false, int MODE = YH_MODE_QUAD>
 YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_object, unsigned int* steps_out, bool& redo,
     trav_state* rs = nullptr, int leave_at = 0) {
@@ -446,12 +449,14 @@ YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_obj
         v4f a = ob[3], b = ob[4], c = ob[5], d = ob[6];
         inv.x = {a.x, a.y, a.z}, inv.y = {a.w, b.x, b.y}, inv.z = {b.z, b.w, c.x}, inv.o = {c.y, c.z, c.w};
         kind = __float_as_int(d.x), node_base = __float_as_int(d.y), prim_base = __float_as_int(d.z);
-        if (MODE != YH_MODE_QUAD) node_base = __float_as_int(ob[8].w);  // the shape's first 8-wide node (yhd_object::wbox_min[3])
+        if (MODE == YH_MODE_W8 || YH_IS_OCT(MODE)) node_base = __float_as_int(ob[8].w);  // the shape's first 8-wide node (yhd_object::wbox_min[3])
+        if (MODE == YH_MODE_HEX) node_base = __float_as_int(ob[9].w);                          // ... first 16-wide node (wbox_max[3])
       } else {
         const yhd_object& o = sc.objects[cur_obj];
         inv  = ldframe(o.inv_frame);
         kind = o.kind, node_base = o.node_base, prim_base = o.prim_base;
-        if (MODE != YH_MODE_QUAD) node_base = __float_as_int(o.wbox_min[3]);
+        if (MODE == YH_MODE_W8 || YH_IS_OCT(MODE)) node_base = __float_as_int(o.wbox_min[3]);
+        if (MODE == YH_MODE_HEX) node_base = __float_as_int(o.wbox_max[3]);
       }
       lo    = transform_point(inv, ray.o);
       ld    = transform_vector(inv, ray.d);
@@ -473,11 +478,11 @@ YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_obj
       // longer `tmax` and rejecting afterwards accepts exactly what the sequential order accepts.
       bool         pair = false;
       unsigned int peek = YH_NONE;
-      if (MODE == YH_MODE_OCT && YH_OCT_LEAF_PAIRS) {
+      if (MODE == YH_MODE_OCTP) {
         peek = sp > 0 ? lstk[(sp - 1) * STRIDE] : 0u;  // (YH_NONE itself carries the leaf tag: an empty stack must not read as a leaf)
         pair = is_leaf && sp > 0 && (peek & YH_TAG_MASK) == YH_TAG_LEAF;
       }
-      const bool   upper = MODE == YH_MODE_OCT && YH_OCT_LEAF_PAIRS && (__lane_id() & 4u) != 0;
+      const bool   upper = MODE == YH_MODE_OCTP && (__lane_id() & 4u) != 0;
       unsigned int mycur = (pair && upper) ? peek : cur;  // the leaf this lane's quad tests
       int  leaf_start = (int)(mycur & 0x07FFFFFFu), leaf_num = (int)((mycur >> 27) & 7u);
       int  rec        = kind == YH_KIND_LINES ? 4 : 6;  // float4 per leaf record
@@ -497,7 +502,8 @@ YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_obj
       const yhd_float4* addr;
       if (MODE == YH_MODE_QUAD) addr = is_leaf ? sc.prims + (size_t)prim_base + (size_t)(leaf_start + pq) * rec : sc.nodes + 8 * (size_t)cur + 2 * q;
       else if (MODE == YH_MODE_W8) addr = is_leaf ? sc.prims + (size_t)prim_base + (size_t)(leaf_start + pq) * rec : sc.nodes8 + 16 * (size_t)cur + 4 * q;
-      else addr = is_leaf ? sc.prims + (size_t)prim_base + (size_t)(leaf_start + pq) * rec : sc.nodes8 + 16 * (size_t)cur + 2 * (__lane_id() & 7u);
+      else if (YH_IS_OCT(MODE)) addr = is_leaf ? sc.prims + (size_t)prim_base + (size_t)(leaf_start + pq) * rec : sc.nodes8 + 16 * (size_t)cur + 2 * (__lane_id() & 7u);
+      else addr = is_leaf ? sc.prims + (size_t)prim_base + (size_t)(leaf_start + pq) * rec : sc.nodes16 + 32 * (size_t)cur + 2 * (__lane_id() & 15u);
       v4f s0, s1, s2w, s3w;  // (s2w, s3w: the lane's second slot in YH_MODE_W8; of a leaf record they are the rest of its 64 bytes)
       int rel = (int)cur - sc.lds_node_base;
       if (MODE == YH_MODE_QUAD && YH_LDS_NODELETS && tc.lds_nodes && !is_leaf && rel >= 0 && rel < sc.lds_node_count) {
@@ -507,7 +513,37 @@ YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_obj
         s0 = ldg4(addr), s1 = ldg4(addr + 1);
         if (MODE == YH_MODE_W8) s2w = ldg4(addr + 2), s3w = ldg4(addr + 3);
       }
-      if (MODE != YH_MODE_QUAD && !is_leaf) {
+      if (MODE == YH_MODE_HEX && !is_leaf) {
+        // ---- 16-wide node: slot o = s1 << 3 | s2 << 2 | s3 << 1 | s4, one per lane of the sixteen; the rank of a slot in the
+        // reference's visiting order is the four near / far decisions of pt.cpp:887-893 at the four collapsed levels.
+        if (q == 0) n_nodes++;
+        if (COUNT) count_branch<COUNT>(tc.stats->t_node, tc.stats->l_node);
+        const unsigned int o    = __lane_id() & 15u;
+        const unsigned int axes = __float_as_uint(s1.w);
+        const unsigned int n0   = (lsign >> (axes & 3)) & 1;
+        const unsigned int n1   = (lsign >> ((axes >> (2 + 2 * (o >> 3))) & 3)) & 1;
+        const unsigned int n2   = (lsign >> ((axes >> (6 + 2 * (o >> 2))) & 3)) & 1;
+        const unsigned int n3   = (lsign >> ((axes >> (14 + 2 * (o >> 1))) & 3)) & 1;
+        const unsigned int rank = (((o >> 3) ^ n0) << 3) | ((((o >> 2) & 1) ^ n1) << 2) | ((((o >> 1) & 1) ^ n2) << 1) | ((o & 1) ^ n3);
+        unsigned int ref = __float_as_uint(s1.z);
+        const bool   h   = box_test(lo, ldinv, ray.tmin, tmax, f3{s0.x, s0.y, s0.z}, f3{s0.w, s1.x, s1.y}) && ref != YH_NONE;
+        if ((ref & YH_TAG_MASK) == 0) ref += (unsigned)node_base;  // child wide nodes are shape-local indices
+        unsigned int bits = h ? (1u << rank) : 0u;
+        unsigned int M    = bits | (unsigned int)dpp_i<YH_QUAD_XOR1>((int)bits);
+        M |= (unsigned int)dpp_i<YH_QUAD_XOR2>((int)M);
+        M |= (unsigned int)dpp_i<YH_ROW_HALF_MIRROR>((int)M);
+        M |= (unsigned int)dpp_i<YH_ROW_MIRROR>((int)M);  // hits in visiting order, bit k = k-th visited
+        const bool first = h && (1u << rank) == (M & (0u - M));
+        if (h && !first) lstk[(sp + (int)__popc(M >> (rank + 1))) * STRIDE] = ref;
+        unsigned int mine = first ? ref : 0u;
+        mine |= (unsigned int)dpp_i<YH_QUAD_XOR1>((int)mine);
+        mine |= (unsigned int)dpp_i<YH_QUAD_XOR2>((int)mine);
+        mine |= (unsigned int)dpp_i<YH_ROW_HALF_MIRROR>((int)mine);
+        mine |= (unsigned int)dpp_i<YH_ROW_MIRROR>((int)mine);
+        int nh = __popc(M);
+        sp += nh > 0 ? nh - 1 : 0;
+        cur = nh > 0 ? mine : YH_NONE;
+      } else if (MODE != YH_MODE_QUAD && !is_leaf) {
         // ---- 8-wide node: slot o = s1 << 2 | s2 << 1 | s3 (host/bvh_build.h). The visiting order applies pt.cpp:887-893
         // at the three collapsed levels: rank bit 2 = side of the node's own axis, bit 1 = side of the child's, bit 0 =
         // side of the grandchild's, each flipped when the ray runs against that axis. Every hit slot pushes itself so
@@ -537,7 +573,7 @@ YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_obj
         unsigned int bits = (h_a ? (1u << rank_a) : 0u) | (h_b ? (1u << rank_b) : 0u);
         unsigned int M    = bits | (unsigned int)dpp_i<YH_QUAD_XOR1>((int)bits);
         M |= (unsigned int)dpp_i<YH_QUAD_XOR2>((int)M);
-        if (MODE == YH_MODE_OCT) M |= (unsigned int)dpp_i<YH_ROW_HALF_MIRROR>((int)M);  // hits in visiting order, bit k = k-th visited
+        if (YH_IS_OCT(MODE)) M |= (unsigned int)dpp_i<YH_ROW_HALF_MIRROR>((int)M);  // hits in visiting order, bit k = k-th visited
         const unsigned int low     = M & (0u - M);                                      // the first visited hit slot
         const bool         first_a = h_a && (1u << rank_a) == low, first_b = h_b && (1u << rank_b) == low;
         if (h_a && !first_a) lstk[(sp + (int)__popc(M >> (rank_a + 1))) * STRIDE] = ref_a;
@@ -545,7 +581,7 @@ YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_obj
         unsigned int mine = first_a ? ref_a : (first_b ? ref_b : 0u);  // child refs are never 0 (node 0 is a root)
         mine |= (unsigned int)dpp_i<YH_QUAD_XOR1>((int)mine);
         mine |= (unsigned int)dpp_i<YH_QUAD_XOR2>((int)mine);
-        if (MODE == YH_MODE_OCT) mine |= (unsigned int)dpp_i<YH_ROW_HALF_MIRROR>((int)mine);
+        if (YH_IS_OCT(MODE)) mine |= (unsigned int)dpp_i<YH_ROW_HALF_MIRROR>((int)mine);
         int nh = __popc(M);
         sp += nh > 0 ? nh - 1 : 0;
         cur = nh > 0 ? mine : YH_NONE;
@@ -622,7 +658,7 @@ YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_obj
         YH_QUAD_MERGE(YH_QUAD_XOR1)
         YH_QUAD_MERGE(YH_QUAD_XOR2)
 #undef YH_QUAD_MERGE
-        if (MODE == YH_MODE_OCT && YH_OCT_LEAF_PAIRS) {
+        if (MODE == YH_MODE_OCTP) {
           // every lane takes the first leaf's result (the lower quad's) and then, of a pair, the second's
           int   o_i = dpp_i<YH_ROW_HALF_MIRROR>(key_i), o_s = dpp_i<YH_ROW_HALF_MIRROR>(leaf_start);
           float o_t = dpp_f<YH_ROW_HALF_MIRROR>(key_t), o_u = dpp_f<YH_ROW_HALF_MIRROR>(uu), o_v = dpp_f<YH_ROW_HALF_MIRROR>(vv);

@@ -47,7 +47,7 @@ typedef struct yhd_object {
   // world-space box of the object (transform_bbox of the shape's root box, pt.cpp:806) grown by a
   // safety margin: a ray that misses it by that much cannot hit anything in the object, so ENTER
   // and the root fetch are skipped for it (dev_trace.h)
-  float wbox_min[4], wbox_max[4];  // wbox_min[3] = (int bits) first 8-wide node of the shape in yhd_scene::nodes8
+  float wbox_min[4], wbox_max[4];  // wbox_min[3] / wbox_max[3] = (int bits) first 8-wide / 16-wide node of the shape in yhd_scene::nodes8 / nodes16
 } yhd_object;
 #define YH_OBJECT_F4 10 /* sizeof(yhd_object) / 16 */
 
@@ -175,6 +175,10 @@ typedef struct yhd_scene {
   const yhd_float4* nodes8;
   int               num_nodes8_total;
   int               stack_entries8;  // traversal stack depth per ray over the 8-wide trees (up to seven pushes per node)
+  // ... and FOUR levels per node (WideNode16, 32 float4 each): YH_MODE_HEX
+  const yhd_float4* nodes16;
+  int               num_nodes16_total;
+  int               stack_entries16;
 } yhd_scene;
 #ifndef YH_LDS_NODELETS
 #define YH_LDS_NODELETS 0 /* developer switch: stage the top wide nodes of the dominant hair shape in LDS (YHAIR_LDS_NODES=n); measured twice without gain */

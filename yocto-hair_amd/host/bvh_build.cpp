@@ -224,4 +224,59 @@ int collapse_wide8(const Tree& tree, std::vector<WideNode8>& out) {
   return max_depth;
 }
 
+int collapse_wide16(const Tree& tree, std::vector<WideNode16>& out) {
+  out.clear();
+  const float inf = std::numeric_limits<float>::infinity();
+  auto leaf_ref = [](const Node& n) { return 0xC0000000u | ((unsigned)n.num << 27) | (unsigned)n.start; };
+  struct Item {
+    int binary, wide, depth;
+  };
+  std::deque<Item> queue;
+  auto new_wide = [&](int binary, int depth) {
+    out.emplace_back();
+    queue.push_back({binary, (int)out.size() - 1, depth});
+    return (unsigned)out.size() - 1;
+  };
+  constexpr int LEVELS          = 4;
+  const int     axes_at[LEVELS] = {0, 2, 6, 14};  // bit offset of the axes of the nodes at each level below the wide node's root
+  int max_depth = 1;
+  new_wide(0, 1);
+  while (!queue.empty()) {
+    Item it = queue.front();
+    queue.pop_front();
+    max_depth = std::max(max_depth, it.depth);
+    WideNode16 w;
+    unsigned   axes = 0;
+    for (int s = 0; s < 16; s++) {
+      for (int k = 0; k < 3; k++) w.slot[s].bmin[k] = inf, w.slot[s].bmax[k] = -inf;
+      w.slot[s].ref = 0xFFFFFFFFu, w.slot[s].axes = 0;
+    }
+    // walk the four levels below the root of this wide node: (binary node, level, path = side bits taken so far)
+    struct Walk {
+      int binary, level;
+      unsigned path;
+    };
+    std::vector<Walk> todo{{it.binary, 0, 0u}};
+    while (!todo.empty()) {
+      Walk wk = todo.back();
+      todo.pop_back();
+      const Node& n = tree.nodes[wk.binary];
+      const bool  root_leaf = wk.level == 0 && !n.internal;  // a shape whose binary root is a leaf
+      if (wk.level == LEVELS || !n.internal) {                 // becomes a slot: the first of its group
+        if (wk.level == 0 && !root_leaf) continue;
+        const int s = (int)(wk.path << (LEVELS - wk.level));
+        for (int k = 0; k < 3; k++) w.slot[s].bmin[k] = n.bbox.min[k], w.slot[s].bmax[k] = n.bbox.max[k];
+        w.slot[s].ref = n.internal ? new_wide(wk.binary, it.depth + 1) : leaf_ref(n);
+        continue;
+      }
+      axes |= (unsigned)n.axis << (axes_at[wk.level] + 2 * (int)wk.path);
+      todo.push_back({n.start + 1, wk.level + 1, (wk.path << 1) | 1u});
+      todo.push_back({n.start + 0, wk.level + 1, (wk.path << 1) | 0u});
+    }
+    for (int s = 0; s < 16; s++) w.slot[s].axes = axes;
+    out[it.wide] = w;
+  }
+  return max_depth;
+}
+
 }  // namespace yhh

@@ -68,5 +68,15 @@ struct WideNode8 {
 static_assert(sizeof(WideNode8) == 256, "8-wide node is 256 bytes");
 int collapse_wide8(const Tree& tree, std::vector<WideNode8>& out);
 
+// 16-wide node: FOUR levels per 512-byte record, for the kernels that give a path sixteen lanes (dev_trace.h,
+// YH_MODE_HEX). Slot o = s1 << 3 | s2 << 2 | s3 << 1 | s4; a subtree that ends in a leaf above the fourth level sits in
+// the first slot of its group. axes: bits 0-1 the node's split axis, 2-5 its two children's, 6-13 the four
+// grandchildren's (index 2 s1 + s2), 14-29 the eight great-grandchildren's (index 4 s1 + 2 s2 + s3).
+struct WideNode16 {
+  WideSlot slot[16];
+};
+static_assert(sizeof(WideNode16) == 512, "16-wide node is 512 bytes");
+int collapse_wide16(const Tree& tree, std::vector<WideNode16>& out);
+
 }  // namespace yhh
 #endif

@@ -260,7 +260,7 @@ void parallel_for(int n, F&& fn) {
   for (auto& th : pool) th.join();
 }
 
-constexpr int YH_SHAPES = 6;  // launch shapes: 0, 1 k_trace (4-wide nodes) | 2 k_trace over 8-wide nodes | 3 k_stream | 4 k_trace with octets | 5 quads and octets side by side
+constexpr int YH_SHAPES = 8;  // launch shapes: 0, 1 k_trace (4-wide nodes) | 2 k_trace over 8-wide nodes | 3 k_stream | 4 k_trace with octets | 5 quads and octets side by side | 6 k_trace with sixteen lanes per path | 7 octets with leaf pairs
 struct yh_context {
   int         device = 0;
   hipStream_t stream = nullptr;
@@ -275,9 +275,9 @@ struct yh_context {
   // scene
   bool      have_scene = false;
   yhd_scene scene{};
-  DevBuf    d_nodes, d_nodes8, d_prims, d_vpos, d_elems, d_objects, d_materials, d_scene_nodes,
+  DevBuf    d_nodes, d_nodes8, d_nodes16, d_prims, d_vpos, d_elems, d_objects, d_materials, d_scene_nodes,
       d_scene_prims, d_light_cdf, d_env_texels, d_light_table, d_env_tab;
-  int       stack_need = 0, stack_need8 = 0;
+  int       stack_need = 0, stack_need8 = 0, stack_need16 = 0;
   // state
   bool             have_state = false;
   yhd_state        state{};
@@ -310,6 +310,7 @@ struct yh_context {
   bool             costs_settled = false;   // the item costs come from a launch of at least YH_TRIAL_SPP samples (not from the 1-spp probe)
   bool             planned_settled = false; // ... and the most recent launch was planned from such costs (only then does its time rank a kernel)
   int              dense = -1;
+  int              chain16 = -1; // 1: ... and four times as many: the sixteen-lane form (shape 6) is a candidate too
   int              chain = -1;   // 1: so few expensive items that even twice as many waves would all be resident: the launch is bound by the
                                  // chain of steps of ONE path, and the octet kernel (half the paths per wave, shape 4) is a candidate
   // path pool of the wavefront integrator (csrc/wavefront.hip), allocated at its first launch
@@ -394,7 +395,7 @@ namespace {
 // fewer expensive items than slots every wave that can run already does. This only picks the CANDIDATES; which
 // kernel runs is measured (pick_launch_shape). YHAIR_SHAPE=0..3 overrides.
 // Is the launch worth more max-cost work items than there are resident waves? (item costs of a k_trace launch)
-bool dense_by_costs(const yh_context* ctx, bool* known, bool* chain_bound = nullptr) {
+bool dense_by_costs(const yh_context* ctx, bool* known, bool* chain_bound = nullptr, bool* chain16 = nullptr) {
   uint64_t sum = 0, mx = 0;
   for (int t : ctx->owned)
     for (int p = 0; p < 4; p++) {
@@ -410,6 +411,7 @@ bool dense_by_costs(const yh_context* ctx, bool* known, bool* chain_bound = null
     const int    lds4 = yhk_trace_lds_bytes(&ctx->scene, 4);
     const double res4 = (double)ctx->num_cus * std::max(1, yhk_trace_occupancy(lds4, ctx->scene.general_materials, 4)) * (yhk_block_threads(4) / 64);
     *chain_bound      = 2.0 * (double)sum / (double)mx <= 0.9 * res4;
+    if (chain16) *chain16 = 4.0 * (double)sum / (double)mx <= 0.9 * res4;
   }
   return (double)sum / (double)mx >= resident;
 }
@@ -448,7 +450,7 @@ struct TrialKey {
 };
 struct TrialRecord {
   double ms[YH_SHAPES];
-  int    trials[YH_SHAPES], dense, chain;
+  int    trials[YH_SHAPES], dense, chain, chain16;
 };
 std::mutex                      g_trials_mutex;
 std::map<TrialKey, TrialRecord> g_trials;
@@ -458,7 +460,7 @@ TrialKey trial_key(const yh_context* ctx) {
 void trials_store(const yh_context* ctx) {
   TrialRecord r;
   for (int k = 0; k < YH_SHAPES; k++) r.ms[k] = ctx->shape_ms[k], r.trials[k] = ctx->shape_trials[k];
-  r.dense = ctx->dense, r.chain = ctx->chain;
+  r.dense = ctx->dense, r.chain = ctx->chain, r.chain16 = ctx->chain16;
   std::lock_guard<std::mutex> lock(g_trials_mutex);
   g_trials[trial_key(ctx)] = r;
 }
@@ -468,19 +470,25 @@ void trials_load(yh_context* ctx) {
   auto it = g_trials.find(trial_key(ctx));
   if (it == g_trials.end()) return;
   for (int k = 0; k < YH_SHAPES; k++) ctx->shape_ms[k] = it->second.ms[k], ctx->shape_trials[k] = it->second.trials[k];
-  ctx->dense = it->second.dense, ctx->chain = it->second.chain;
+  ctx->dense = it->second.dense, ctx->chain = it->second.chain, ctx->chain16 = it->second.chain16;
 }
 bool trials_off() {
   static const bool off = getenv("YHAIR_NO_TRIALS") != nullptr;  // developer switch: the cost heuristic only
   return off || getenv("YHAIR_SHAPE") != nullptr;
 }
-// k_trace in both quad shapes always; k_stream on dense images; the octet kernel on chain-bound ones (a shard of a sparse
-// image on one of several GPUs, a small image). (Shape 2, quads over 8-wide nodes, is never one: profiles/r03/w8_oct_ab.txt.)
+// k_trace 512 x 4 always; the dense quad shape unless the image is chain-bound; k_stream on dense images; on chain-bound
+// ones (a shard of a sparse image on one of several GPUs, a small image) the octet kernel and, when even four waves per
+// expensive item are all resident, the sixteen-lane one. (Shapes 2 and 5 are never tried: profiles/r03/.)
 int candidates(const yh_context* ctx, int cand[5]) {
   int n = 0;
-  cand[n++] = 0, cand[n++] = 1;
+  cand[n++] = 0;
+  if (ctx->chain > 0 && ctx->dense <= 0) {  // chain-bound: more lanes per path (the dense quad shape and the side-by-side launch never win there: not tried)
+    cand[n++] = 4, cand[n++] = 7;  // octets, without and with leaf pairs (which of the two wins depends on the share of leaf steps)
+    if (ctx->chain16 > 0) cand[n++] = 6;
+    return n;
+  }
+  cand[n++] = 1;
   if (ctx->dense > 0) cand[n++] = 3;
-  if (ctx->chain > 0 && ctx->dense <= 0) cand[n++] = 4, cand[n++] = 5;  // all items as octets | the expensive ones as octets beside the quads
   return n;
 }
 // After a synchronous launch: its time if it was a trial-length one, and dense / sparse from fresh item costs of a
@@ -498,8 +506,8 @@ void record_launch(yh_context* ctx, int nsamples, bool fresh_costs) {
   // dense / sparse from the item costs of a k_trace launch long enough to mean something: a trial-length launch, or —
   // while nothing is known yet — one of a few samples (the 1-spp probe's costs are too flat to decide on)
   if (fresh_costs && (last == 0 || last == 1) && (nsamples >= YH_TRIAL_SPP || (ctx->dense < 0 && nsamples >= 4))) {
-    bool known = false, chain = false, d = dense_by_costs(ctx, &known, &chain);
-    if (known) ctx->dense = d ? 1 : 0, ctx->chain = (!d && chain) ? 1 : 0;
+    bool known = false, chain = false, chain16 = false, d = dense_by_costs(ctx, &known, &chain, &chain16);
+    if (known) ctx->dense = d ? 1 : 0, ctx->chain = (!d && chain) ? 1 : 0, ctx->chain16 = (!d && chain16) ? 1 : 0;
   }
   ctx->have_costs = true;
   if (trial) trials_store(ctx);
@@ -580,6 +588,14 @@ static void split_items_for_octets(std::vector<int>& items) {
   for (int it : items) out.push_back(it << 1), out.push_back((it << 1) | 1);
   items.swap(out);
 }
+// ... and the sixteen-lane form (shape 6) a QUARTER: entry = item << 2 | row of the 4x4 block.
+static void split_items_for_hex(std::vector<int>& items) {
+  std::vector<int> out;
+  out.reserve(items.size() * 4);
+  for (int it : items)
+    for (int k = 0; k < 4; k++) out.push_back((it << 2) | k);
+  items.swap(out);
+}
 static void split_items_side_by_side(yh_context* ctx, std::vector<int>& items);
 static void place_first_round(yh_context* ctx, std::vector<int>& items);
 static int  trace_impl(yh_context* ctx, int nsamples, bool counted, bool sync);
@@ -650,11 +666,12 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
   struct ShapeInfo {
     int kind, node_base, prim_base, vert_base, elem_base, has_normals, depth;
     int node8_base, depth8;  // the same tree collapsed three levels at a time (yhd_scene::nodes8)
+    int node16_base, depth16;  // ... and four (yhd_scene::nodes16)
     yhh::Box root;
     int num_nodes;
   };
   std::vector<ShapeInfo>  info(sd->num_shapes);
-  std::vector<yhd_float4> nodes, nodes8, prims, vpos;
+  std::vector<yhd_float4> nodes, nodes8, nodes16, prims, vpos;
   std::vector<float>      vtex;  // 2 per vertex, zeros for shapes without texture coordinates
   std::vector<yhd_int4>   elems;
   int                     best_lines = -1, best_shape = -1;
@@ -736,6 +753,15 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
       memcpy(&nodes8[at], wide8.data(), wide8.size() * sizeof(yhh::WideNode8));
       lap("collapse to 8-wide");
     }
+    {  // ... and four: 16-wide nodes, 32 float4 each
+      std::vector<yhh::WideNode16> wide16;
+      I.depth16     = yhh::collapse_wide16(tree, wide16);
+      I.node16_base = (int)(nodes16.size() / 32);
+      size_t at     = nodes16.size();
+      nodes16.resize(at + wide16.size() * 32);
+      memcpy(&nodes16[at], wide16.data(), wide16.size() * sizeof(yhh::WideNode16));
+      lap("collapse to 16-wide");
+    }
     auto nrm = [&](int v) { return s.normals ? ld3(s.normals + 3 * (size_t)v) : F3{0, 0, 0}; };
     {  // leaf-ordered records (yh_device.h), filled in parallel
       const size_t per = lines ? 4 : 6, at = prims.size();
@@ -816,13 +842,13 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
       float ext = fmax_(fmax_(hi[0] - lo[0], hi[1] - lo[1]), hi[2] - lo[2]);
       float eps = 1e-3f * ext + 1e-5f;
       for (int k = 0; k < 3; k++) d.wbox_min[k] = lo[k] - eps, d.wbox_max[k] = hi[k] + eps;
-      d.wbox_max[3] = 0;
-      memcpy(&d.wbox_min[3], &I.node8_base, 4);  // (int bits) first 8-wide node of the shape in yhd_scene::nodes8
+      memcpy(&d.wbox_min[3], &I.node8_base, 4);   // (int bits) first 8-wide node of the shape in yhd_scene::nodes8
+      memcpy(&d.wbox_max[3], &I.node16_base, 4);  // ... first 16-wide node in yhd_scene::nodes16
     }
   }
   // array offsets on the device are 32-bit float4 indices
   if (prims.size() > (size_t)std::numeric_limits<int>::max() || nodes.size() > (size_t)std::numeric_limits<int>::max() ||
-      nodes8.size() > (size_t)std::numeric_limits<int>::max() || vpos.size() > (size_t)std::numeric_limits<int>::max())
+      nodes8.size() > (size_t)std::numeric_limits<int>::max() || nodes16.size() > (size_t)std::numeric_limits<int>::max() || vpos.size() > (size_t)std::numeric_limits<int>::max())
     return fail(ctx, YH_E_INVALID, "scene too large for 32-bit record offsets (%zu primitive, %zu node float4)", prims.size(), nodes.size());
   yhh::Tree scene_tree;
   yhh::build_bvh(scene_tree, obj_boxes);
@@ -835,6 +861,9 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
   int max_shape_depth8 = 0;
   for (auto& I : info) max_shape_depth8 = std::max(max_shape_depth8, I.depth8);
   ctx->stack_need8 = scene_tree.max_depth + 4 + 7 * max_shape_depth8 + 2;  // an 8-wide node pushes at most seven
+  int max_shape_depth16 = 0;
+  for (auto& I : info) max_shape_depth16 = std::max(max_shape_depth16, I.depth16);
+  ctx->stack_need16 = scene_tree.max_depth + 4 + 15 * max_shape_depth16 + 2;
   if (ctx->stack_need > yhk_stack_entries())
     return fail(ctx, YH_E_INVALID, "BVH too deep for the traversal stack (%d > %d)", ctx->stack_need, yhk_stack_entries());
   // ---- materials ---------------------------------------------------------
@@ -974,6 +1003,7 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
   int rc;
   if ((rc = upload(ctx, ctx->d_nodes, nodes.data(), nodes.size() * 16))) return rc;
   if ((rc = upload(ctx, ctx->d_nodes8, nodes8.data(), nodes8.size() * 16))) return rc;
+  if ((rc = upload(ctx, ctx->d_nodes16, nodes16.data(), nodes16.size() * 16))) return rc;
   if ((rc = upload(ctx, ctx->d_prims, prims.data(), prims.size() * 16))) return rc;
   if ((rc = upload(ctx, ctx->d_vpos, vpos.data(), vpos.size() * 16))) return rc;
   if ((rc = upload(ctx, ctx->d_elems, elems.data(), elems.size() * 16))) return rc;
@@ -1003,6 +1033,8 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
   sc.stack_entries = std::max(8, (ctx->stack_need + 7) / 8 * 8);
   sc.nodes8 = (const yhd_float4*)ctx->d_nodes8.p, sc.num_nodes8_total = (int)(nodes8.size() / 16);
   sc.stack_entries8 = std::max(8, (ctx->stack_need8 + 7) / 8 * 8);
+  sc.nodes16 = (const yhd_float4*)ctx->d_nodes16.p, sc.num_nodes16_total = (int)(nodes16.size() / 32);
+  sc.stack_entries16 = std::max(8, (ctx->stack_need16 + 7) / 8 * 8);
   sc.textures = (const yhd_texture*)ctx->d_textures.p, sc.tex_texels = (const yhd_float4*)ctx->d_tex_texels.p;
   sc.vtex = (const float*)ctx->d_vtex.p;
   memcpy(sc.camera.frame, sd->camera.frame, 48);
@@ -1060,7 +1092,7 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
   ctx->have_state = false;
   ctx->launch_shape = 0;  // a new scene: no measured costs yet
   ctx->item_cost.clear();
-  ctx->have_costs = false, ctx->costs_settled = false, ctx->dense = -1, ctx->chain = -1;
+  ctx->have_costs = false, ctx->costs_settled = false, ctx->dense = -1, ctx->chain = -1, ctx->chain16 = -1;
   for (double& t : ctx->shape_ms) t = 0;
   for (int& t : ctx->shape_trials) t = 0;
   return YH_OK;
@@ -1112,7 +1144,7 @@ int yh_init_state(yh_context* ctx, const yh_trace_params* params) {
   bool new_image = false;
   if ((int)ctx->item_cost.size() != ctx->num_tiles_total * 4) {  // scheduling hints survive a re-init of the same image
     ctx->item_cost.assign((size_t)ctx->num_tiles_total * 4, 0);
-    ctx->have_costs = false, ctx->costs_settled = false, ctx->dense = -1, ctx->chain = -1, ctx->launch_shape = 0;
+    ctx->have_costs = false, ctx->costs_settled = false, ctx->dense = -1, ctx->chain = -1, ctx->chain16 = -1, ctx->launch_shape = 0;
     for (double& t : ctx->shape_ms) t = 0;
     for (int& t : ctx->shape_trials) t = 0;
     new_image = true;
@@ -1124,9 +1156,10 @@ int yh_init_state(yh_context* ctx, const yh_trace_params* params) {
   ctx->state.static_items = 0;
   if (params->shader == YH_SHADER_PATH && first_shape == 0) place_first_round(ctx, tiles);
   if (params->shader == YH_SHADER_PATH && first_shape == 3) deal_items_for_stream(ctx, tiles);
-  if (params->shader == YH_SHADER_PATH && first_shape == 4) split_items_for_octets(tiles);
+  if (params->shader == YH_SHADER_PATH && (first_shape == 4 || first_shape == 7)) split_items_for_octets(tiles);
   if (params->shader == YH_SHADER_PATH && first_shape == 5) split_items_side_by_side(ctx, tiles);
-  tiles.reserve(2 * (size_t)ctx->num_tiles_total * 4 + 4);  // (the list's buffer holds the octet kernel's doubled list too)
+  if (params->shader == YH_SHADER_PATH && first_shape == 6) split_items_for_hex(tiles);
+  tiles.reserve(4 * (size_t)ctx->num_tiles_total * 4 + 4);  // (the list's buffer holds the octet / sixteen-lane kernels' longer lists too)
   int rc;
   if ((rc = upload(ctx, ctx->d_rng_state, st.data(), npix * 8))) return rc;
   if ((rc = upload(ctx, ctx->d_rng_inc, inc.data(), npix * 8))) return rc;
@@ -1134,7 +1167,7 @@ int yh_init_state(yh_context* ctx, const yh_trace_params* params) {
   if ((rc = alloc_zero(ctx, ctx->d_image, npix * 16))) return rc;
   {
     const size_t n = tiles.size();
-    tiles.resize(std::max(n, 2 * owned.size() * 4), 0);
+    tiles.resize(std::max(n, 4 * owned.size() * 4), 0);
     if ((rc = upload(ctx, ctx->d_tiles, tiles.data(), tiles.size() * 4))) return rc;
     tiles.resize(n);
   }
@@ -1188,8 +1221,9 @@ static int upload_work_items(yh_context* ctx) {
   ctx->state.static_items = 0;
   if (ctx->state.shader == YH_SHADER_PATH && ctx->state.launch_shape == 0) place_first_round(ctx, tiles);
   if (ctx->state.shader == YH_SHADER_PATH && ctx->state.launch_shape == 3) deal_items_for_stream(ctx, tiles);
-  if (ctx->state.shader == YH_SHADER_PATH && ctx->state.launch_shape == 4) split_items_for_octets(tiles);
+  if (ctx->state.shader == YH_SHADER_PATH && (ctx->state.launch_shape == 4 || ctx->state.launch_shape == 7)) split_items_for_octets(tiles);
   if (ctx->state.shader == YH_SHADER_PATH && ctx->state.launch_shape == 5) split_items_side_by_side(ctx, tiles);
+  if (ctx->state.shader == YH_SHADER_PATH && ctx->state.launch_shape == 6) split_items_for_hex(tiles);
   ctx->state.num_tiles = (int)tiles.size();
   HIPCHK(ctx, hipMemcpy(ctx->d_tiles.p, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice));
   return YH_OK;
@@ -1526,7 +1560,7 @@ static int trace_impl(yh_context* ctx, int nsamples, bool counted, bool sync) {
     const int want = pick_launch_shape(ctx, sync ? nsamples : 0);  // (an asynchronous launch is not timed: never a trial)
     if (want != ctx->state.launch_shape) {
       if (getenv("YHAIR_TIMING"))
-        fprintf(stderr, "[yhair] kernel times (ms per spp): 0: %.4f, 1: %.4f, 2: %.4f, 3: %.4f, 4: %.4f, 5: %.4f -> %d (%d spp)\n", ctx->shape_ms[0], ctx->shape_ms[1], ctx->shape_ms[2], ctx->shape_ms[3], ctx->shape_ms[4], ctx->shape_ms[5], want, nsamples);
+        fprintf(stderr, "[yhair] kernel times (ms per spp): 0: %.4f, 1: %.4f, 2: %.4f, 3: %.4f, 4: %.4f, 5: %.4f, 6: %.4f, 7: %.4f -> %d (%d spp)\n", ctx->shape_ms[0], ctx->shape_ms[1], ctx->shape_ms[2], ctx->shape_ms[3], ctx->shape_ms[4], ctx->shape_ms[5], ctx->shape_ms[6], ctx->shape_ms[7], want, nsamples);
       ctx->launch_shape = ctx->state.launch_shape = want;
       // The list is rewritten by a blocking copy on the null stream; the context's stream is non-blocking, so a launch
       // queued by yh_trace_samples_async may still be reading it: wait for it first.
@@ -1534,7 +1568,7 @@ static int trace_impl(yh_context* ctx, int nsamples, bool counted, bool sync) {
       if (int rc = upload_work_items(ctx)) return rc;
     }
   }
-  if (counted && (ctx->state.launch_shape == 5 || (ctx->state.launch_shape == 4 && ctx->scene.general_materials))) {  // the octet kernel's list holds half-quadrant entries: the instrumented (quad) build needs its own
+  if (counted && (ctx->state.launch_shape == 5 || (ctx->state.launch_shape >= 4 && (ctx->scene.general_materials || ctx->state.launch_shape == 7)))) {  // the octet kernel's list holds half-quadrant entries: the instrumented (quad) build needs its own
     ctx->launch_shape = ctx->state.launch_shape = 0;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     if (int rc = upload_work_items(ctx)) return rc;

@@ -185,7 +185,12 @@ def load(path=None):
                                "(there is no CPU fallback for the product path)")
         lib = C.CDLL(p)
         for name, (res, args) in _SIGS.items():
-            fn = getattr(lib, name)
+            try:
+                fn = getattr(lib, name)
+            except AttributeError:
+                if "YHAIR_LIB" in os.environ:  # developer A/B against an older build (tools/_ab/): it may lack newer entry points
+                    continue
+                raise
             fn.restype, fn.argtypes = res, args
         if path:
             return lib
