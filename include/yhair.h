@@ -356,6 +356,13 @@ int yh_curves_to_lines(yh_context* ctx, int n, const float* P, const float* widt
  * then as int bits: start, num | internal << 16 | axis << 24), primitives = n
  * ints (leaf order). Needs no GPU and no context. Returns the node count.     */
 int yh_bvh_build(int n, const float* boxes, float* nodes, int* primitives);
+/* The same tree as the device traverses it: `width` (4, 8 or 16) children per node = two, three or four levels of
+ * the binary tree collapsed into one record of `width` 32-byte slots {min.xyz, max.x} {max.yz, ref, axes}
+ * (yocto-hair_amd/host/bvh_build.h). ref: 0xFFFFFFFF empty; top two bits set = leaf (count << 27 | first
+ * primitive position); else the index of the child node. axes: the split axes of the collapsed binary nodes, from
+ * which a traversal ranks the children into the reference's near-first order (yocto_pathtrace.cpp:887-893).
+ * Writes width * 8 floats per node to `slots` (NULL: count only); returns the number of nodes. No GPU needed.       */
+int yh_bvh_build_wide(int n, const float* boxes, int width, float* slots);
 
 /* The same tree built on the GPU (csrc/bvh_gpu.hip; what yh_upload_scene uses for
  * shapes of 32 768 primitives and more). Same arguments and result as yh_bvh_build;

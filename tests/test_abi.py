@@ -155,6 +155,91 @@ def test_host_bvh_is_the_reference_tree(yh, oracle, name, kw):
     osc.close(), sf.close()
 
 
+def _binary_leaf_order(nodes, sign, tests):
+    """Leaves of the reference's binary tree in the order intersect_shape_bvh visits them (pt.cpp:887-893: near side of
+    the split axis first) for a ray whose direction has sign bits `sign` and that enters every node. `tests`: in place
+    of "enters every node", a set of binary node ids whose box the ray misses."""
+    meta = nodes[:, 7].view(np.int32)
+    start = nodes[:, 6].view(np.int32)
+    out, stack = [], [0]
+    while stack:
+        i = stack.pop()
+        if i in tests:
+            continue
+        internal, axis, num = (meta[i] >> 16) & 1, (meta[i] >> 24) & 3, meta[i] & 0xFFFF
+        if not internal:
+            out.append((int(start[i]), int(num)))
+        elif (sign >> axis) & 1:  # direction negative on the axis: the second child is nearer
+            stack.append(int(start[i])), stack.append(int(start[i]) + 1)
+        else:
+            stack.append(int(start[i]) + 1), stack.append(int(start[i]))
+    return out
+
+
+def _wide_leaf_order(slots, width, sign, missed_leaves):
+    """The same for the collapsed tree, with the device's rank arithmetic (csrc/dev_trace.h: the node steps of
+    YH_MODE_QUAD / _OCT / _HEX): rank bit per collapsed level = side bit xor near bit of that level's split axis."""
+    levels = {4: 2, 8: 3, 16: 4}[width]
+    at = [0, 2, 6, 14]
+    ref = slots[:, :, 6].view(np.uint32)
+    axes = slots[:, :, 7].view(np.uint32)
+    out, stack = [], [0]
+    while stack:
+        cur = stack.pop()
+        if cur & 0xC0000000 == 0xC0000000:
+            leaf = (int(cur & 0x07FFFFFF), int((cur >> 27) & 7))
+            if leaf not in missed_leaves:
+                out.append(leaf)
+            continue
+        ranked = []
+        for o in range(width):
+            r = int(ref[cur, o])
+            if r == 0xFFFFFFFF:
+                continue
+            ax = int(axes[cur, o])
+            rank = 0
+            for lv in range(levels):
+                path = o >> (levels - lv)              # the side bits above this level
+                side = (o >> (levels - 1 - lv)) & 1
+                near = (sign >> ((ax >> (at[lv] + 2 * path)) & 3)) & 1
+                rank |= (side ^ near) << (levels - 1 - lv)
+            ranked.append((rank, r))
+        for _, r in sorted(ranked, reverse=True):       # pushed so that they pop in visiting order
+            stack.append(r)
+    return out
+
+
+@pytest.mark.parametrize("width", [4, 8, 16])
+def test_wide_nodes_keep_the_reference_visiting_order(yh, width):
+    """The 4- / 8- / 16-wide collapses of the reference's tree (host/bvh_build.cpp), without a GPU: every leaf of the
+    binary tree appears once, slot boxes are the binary nodes' boxes, and the children ranked by the device's formula
+    are visited in the order the reference's binary traversal visits them, for all eight direction-sign triples."""
+    rng = np.random.default_rng(11)
+    lib = yh.load()
+    for n in (1, 3, 4, 5, 37, 1000, 5003):
+        c = rng.uniform(-1, 1, (n, 3)).astype(np.float32) * np.array([1, 0.3, 2], np.float32)
+        boxes = np.ascontiguousarray(np.concatenate([c - 0.01, c + 0.01], axis=1).astype(np.float32))
+        nb = lib.yh_bvh_build(n, yh.fptr(boxes), None, None)
+        nodes = np.zeros((nb, 8), np.float32)
+        lib.yh_bvh_build(n, yh.fptr(boxes), yh.fptr(nodes), None)
+        nw = lib.yh_bvh_build_wide(n, yh.fptr(boxes), width, None)
+        slots = np.zeros((nw, width, 8), np.float32)
+        assert lib.yh_bvh_build_wide(n, yh.fptr(boxes), width, yh.fptr(slots)) == nw
+        for sign in range(8):
+            want = _binary_leaf_order(nodes, sign, set())
+            assert _wide_leaf_order(slots, width, sign, set()) == want, (n, width, sign)
+            assert sorted(want) == sorted(set(want)) and sum(k for _, k in want) == n  # every primitive once
+        # slot boxes: a leaf slot carries the box of its binary leaf
+        meta, start = nodes[:, 7].view(np.int32), nodes[:, 6].view(np.int32)
+        leaf_box = {(int(start[i]), int(meta[i] & 0xFFFF)): nodes[i, :6] for i in range(nb) if not (meta[i] >> 16) & 1}
+        ref = slots[:, :, 6].view(np.uint32)
+        for w, o in zip(*np.nonzero((ref & 0xC0000000) == 0xC0000000)):
+            if ref[w, o] == 0xFFFFFFFF:
+                continue
+            key = (int(ref[w, o] & 0x07FFFFFF), int((ref[w, o] >> 27) & 7))
+            assert np.array_equal(slots[w, o, :6], leaf_box[key])
+
+
 def test_traversal_loops_do_not_spill():
     """The traversal loop of the product kernels (plain k_trace in both launch shapes, plain k_stream) must not contain
     scratch instructions: a spill reload there stalls every step of every ray (0.75-0.8x on the dense configs), and

@@ -2080,6 +2080,25 @@ int yh_bvh_build_gpu(yh_context* ctx, int n, const float* boxes, float* nodes, i
   return (int)tree.nodes.size();
 }
 
+int yh_bvh_build_wide(int n, const float* boxes, int width, float* slots) {
+  if (n < 0 || (n && !boxes) || (width != 4 && width != 8 && width != 16)) return YH_E_INVALID;
+  std::vector<yhh::Box> b((size_t)n);
+  for (int i = 0; i < n; i++)
+    for (int k = 0; k < 3; k++) b[(size_t)i].min[k] = boxes[6 * (size_t)i + k], b[(size_t)i].max[k] = boxes[6 * (size_t)i + 3 + k];
+  yhh::Tree tree;
+  yhh::build_bvh(tree, b);
+  const void* data  = nullptr;
+  size_t      count = 0;
+  std::vector<yhh::WideNode>   w4;
+  std::vector<yhh::WideNode8>  w8;
+  std::vector<yhh::WideNode16> w16;
+  if (width == 4) yhh::collapse_wide(tree, w4), data = w4.data(), count = w4.size();
+  if (width == 8) yhh::collapse_wide8(tree, w8), data = w8.data(), count = w8.size();
+  if (width == 16) yhh::collapse_wide16(tree, w16), data = w16.data(), count = w16.size();
+  if (slots && count) memcpy(slots, data, count * (size_t)width * sizeof(yhh::WideSlot));
+  return (int)count;
+}
+
 int yh_bvh_build(int n, const float* boxes, float* nodes, int* primitives) {
   if (n < 0 || (n && !boxes)) return YH_E_INVALID;
   std::vector<yhh::Box> b((size_t)n);
