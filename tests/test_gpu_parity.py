@@ -708,12 +708,12 @@ def test_launch_shapes_and_kernels_render_identical_pixels(ctx, yh, name, kw, mo
     """The host picks the integrator kernel — k_trace with a quad per path at 512 x 4 or at 256 x 5 (single-predicate
     line test), with an OCTET per path over 8-wide nodes (chain-bound launches), or the one-lane-per-path k_stream
     (csrc/stream.hip) — by measurement, so which kernel a render runs depends on history. Every choice must give
-    the same bits: YHAIR_SHAPE forces each (2 = quads over 8-wide nodes, a developer shape)."""
+    the same bits: YHAIR_SHAPE forces each."""
     sf = yh.SceneFile(scene_path(name, **kw))
     ctx.upload_scene(sf.desc)
     p = yh.TraceParams.default(resolution=88)
     images = {}
-    for shape in ("0", "1", "2", "3", "4", "5", "6", "7"):  # k_trace 512 x 4, 256 x 5, 512 x 4 over 8-wide nodes, k_stream, k_trace with octets, quads + octets side by side, sixteen lanes per path, octets with leaf pairs
+    for shape in ("0", "1", "3", "4", "5", "6", "7"):  # k_trace 512 x 4, 256 x 5, k_stream, k_trace with octets, quads + octets side by side, sixteen lanes per path, octets with leaf pairs (2: a developer build only)
         monkeypatch.setenv("YHAIR_SHAPE", shape)
         ctx.init_state(p)
         ctx.trace_samples(3), ctx.trace_samples(5)

@@ -436,9 +436,11 @@ static trace_kernel_t trace_kernel(bool counted, bool general, int shape, int sh
   if (shader == YH_SHADER_EYELIGHT) return k_trace_shader<YH_SHADER_EYELIGHT>;
   if (shader == YH_SHADER_NORMAL) return k_trace_shader<YH_SHADER_NORMAL>;
   // (instrumented builds of the 8-wide forms: plain scenes only; their per-quad counters count an octet twice, the wave-level ones hold)
+#ifdef YH_LAB_W8  // developer build (make W8=1): quads over 8-wide nodes, measured without gain (profiles/r03/w8_oct_ab.txt): not in the product library
   if (shape == 2 && counted && !general) return k_trace<true, false, YH_BLOCK, YH_MIN_WAVES, YH_MODE_W8>;
-  if (shape == 4 && counted && !general) return k_trace<true, false, YH_OCT_BLOCK, YH_MIN_WAVES, YH_MODE_OCT>;
   if (shape == 2 && !counted) return general ? k_trace<false, true, YH_BLOCK, YH_MIN_WAVES, YH_MODE_W8> : k_trace<false, false, YH_BLOCK, YH_MIN_WAVES, YH_MODE_W8>;
+#endif
+  if (shape == 4 && counted && !general) return k_trace<true, false, YH_OCT_BLOCK, YH_MIN_WAVES, YH_MODE_OCT>;
   if (shape == 4 && !counted) return general ? k_trace<false, true, YH_OCT_BLOCK, YH_MIN_WAVES, YH_MODE_OCT> : k_trace<false, false, YH_OCT_BLOCK, YH_MIN_WAVES, YH_MODE_OCT>;
   if (shape == 6 && !counted) return general ? k_trace<false, true, YH_OCT_BLOCK, YH_MIN_WAVES, YH_MODE_HEX> : k_trace<false, false, YH_OCT_BLOCK, YH_MIN_WAVES, YH_MODE_HEX>;
   if (shape == 6 && counted && !general) return k_trace<true, false, YH_OCT_BLOCK, YH_MIN_WAVES, YH_MODE_HEX>;
@@ -486,6 +488,7 @@ int yhk_trace_lds_bytes(const yhd_scene* sc, int shape) { return (int)trace_lds(
 int yhk_trace_occupancy(int lds_bytes, int general, int shape) {
   int            blocks = 0;
   trace_kernel_t k      = trace_kernel(false, general != 0, shape);
+  if (!k) return 0;  // a launch shape this build does not contain
   if (lds_bytes > 64 * 1024 &&
       hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
     return 0;  // the kernel cannot be launched with this much LDS: the caller reports it

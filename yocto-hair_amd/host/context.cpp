@@ -1590,6 +1590,8 @@ static int trace_impl(yh_context* ctx, int nsamples, bool counted, bool sync) {
   if (path && !counted && getenv("YHAIR_LAB_WAVEFRONT")) return wavefront_impl(ctx, nsamples, sync);  // developer build only (make WAVEFRONT=1)
 #endif
   if (shape == 3) return stream_impl(ctx, nsamples, sync);
+  if (shape == 2 && yhk_trace_occupancy(yhk_trace_lds_bytes(&ctx->scene, 2), ctx->scene.general_materials, 2) < 1)
+    return fail(ctx, YH_E_INVALID, "launch shape 2 (quads over 8-wide nodes) is a developer kernel: build with make W8=1");
   if (shape == 5 && !counted) return side_by_side_impl(ctx, nsamples, sync);
   if (shape == 5) shape = 0;  // (instrumented: guarded above, the list was rebuilt for the quad kernel)
   int waves_per_block = yhk_block_threads(shape) / 64;  // one work item per wave at a time
