@@ -412,7 +412,7 @@ bool dense_by_costs(const yh_context* ctx, bool* known, bool* chain_bound = null
     const double res4 = (double)ctx->num_cus * std::max(1, yhk_trace_occupancy(lds4, ctx->scene.general_materials, 4)) * (yhk_block_threads(4) / 64);
     // (candidacy only — the trials decide: generous bounds cost a wasted trial, tight ones a missed kernel; `textured`, whose
     // item costs are very uneven, is worth 1 500 items and still renders 1.45 x faster with sixteen lanes per path)
-    *chain_bound      = 2.0 * (double)sum / (double)mx <= 1.2 * res4;
+    *chain_bound      = 2.0 * (double)sum / (double)mx <= 1.0 * res4;  // (C1 at 720^2 is worth 2 400-3 100 items: not one)
     if (chain16) *chain16 = 4.0 * (double)sum / (double)mx <= 1.5 * res4;
   }
   return (double)sum / (double)mx >= resident;
@@ -1103,6 +1103,7 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
 int yh_set_shard(yh_context* ctx, int rank, int world) {
   if (!ctx) return YH_E_INVALID;
   if (world < 1 || rank < 0 || rank >= world) return fail(ctx, YH_E_INVALID, "bad shard %d of %d", rank, world);
+  if (rank != ctx->rank || world != ctx->world) ctx->item_cost.clear();  // another shard is another image to plan and to time kernels on: yh_init_state starts over
   ctx->rank = rank, ctx->world = world;
   ctx->have_state = false;
   return YH_OK;
