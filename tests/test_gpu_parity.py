@@ -989,3 +989,27 @@ def test_octet_kernel_is_chosen_for_a_chain_bound_shard_and_renders_the_same_pix
     c.trace_samples(32 * 7 + 64)
     assert np.array_equal(c.download(), got[0]) and np.array_equal(c.download_rng(), got[1])
     c.close(), sf.close()
+
+
+def test_another_shard_is_another_image_for_the_kernel_trials(yh, monkeypatch):
+    """yh_set_shard with another (rank, world) makes the context plan and time its kernels afresh: a quarter of the
+    image is bound by other things than the whole (bench.py's projected strong scaling renders shard 0 of N on the
+    context that rendered the full image)."""
+    monkeypatch.delenv("YHAIR_SHAPE", raising=False)
+    monkeypatch.setenv("YHAIR_NO_TRIAL_CACHE", "1")
+    sf = yh.SceneFile(scene_path("sphere-hairblock", scale=0.05, zoom=True))
+    c = yh.Context(0)
+    c.upload_scene(sf.desc)
+    p = yh.TraceParams.default(resolution=160)
+    c.init_state(p)
+    c.trace_samples(200)
+    assert c.kernel_trials()  # the full image has timed its candidates
+    c.set_shard(0, 4)
+    c.init_state(p)
+    assert not c.kernel_trials()  # the shard starts over
+    c.trace_samples(200)
+    assert c.kernel_trials()
+    c.set_shard(0, 4)  # the same shard again: its record stays
+    c.init_state(p)
+    assert c.kernel_trials()
+    c.close(), sf.close()
