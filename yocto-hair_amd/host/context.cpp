@@ -1588,6 +1588,14 @@ static int trace_impl(yh_context* ctx, int nsamples, bool counted, bool sync) {
       if (int rc = upload_work_items(ctx)) return rc;
     }
   }
+  if ((shape == 4 || shape == 6 || shape == 7) && !counted && !getenv("YHAIR_SHAPE") &&
+      yhk_trace_occupancy(yhk_trace_lds_bytes(&ctx->scene, shape), ctx->scene.general_materials, shape) < 1) {  // (likewise: a tree too deep for the wide forms' LDS stacks)
+    ctx->shape_ms[shape] = std::numeric_limits<double>::infinity();
+    shape = 0;
+    ctx->launch_shape = ctx->state.launch_shape = shape;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (int rc = upload_work_items(ctx)) return rc;
+  }
   ctx->last_shape = shape, ctx->last_counted = counted, ctx->planned_settled = ctx->costs_settled;
 #ifdef YH_LAB_WAVEFRONT
   if (path && !counted && getenv("YHAIR_LAB_WAVEFRONT")) return wavefront_impl(ctx, nsamples, sync);  // developer build only (make WAVEFRONT=1)
