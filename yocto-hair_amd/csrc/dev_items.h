@@ -80,10 +80,10 @@ YH_DEV void trace_items(const yhd_scene& sc, const yhd_state& st, int nsamples, 
     }
     first_static = -1;
     if (t >= st.num_tiles) break;
-#ifdef YH_PRIO /* developer A/B switch: issue priority for the waves that hold the most expensive items (the head of the cost-sorted list) */
-    if (t < st.num_tiles / YH_PRIO) __builtin_amdgcn_s_setprio(3);
-    else __builtin_amdgcn_s_setprio(0);
-#endif
+    if (st.prio_items > 0) {  // issue priority for the waves that hold the most expensive items (the head of the cost-sorted list)
+      if (t < st.prio_items) __builtin_amdgcn_s_setprio(3);
+      else __builtin_amdgcn_s_setprio(0);
+    }
     unsigned long long t0 = wall_clock64();
     int  item  = st.tiles[t];
     int  half  = 0;  // which half (octets) / quarter (sixteen lanes per path) of the quadrant this entry is

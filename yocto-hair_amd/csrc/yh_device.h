@@ -217,6 +217,9 @@ typedef struct yhd_state {
   // entry b * (waves per workgroup) + w — so that the host decides which items share a SIMD (host/context.cpp:
   // place_first_round); the rest go through the cursor as before. 0: everything through the cursor.
   int         static_items;
+  // k_trace: the waves that take one of the first `prio_items` entries of `tiles` (the most expensive items: the list is
+  // cost-sorted) run at raised issue priority (s_setprio); 0: off
+  int         prio_items;
 } yhd_state;
 
 // Path pool of the wavefront integrator (csrc/wavefront.hip): SoA ray / hit / path-state buffers in

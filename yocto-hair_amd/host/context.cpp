@@ -1222,6 +1222,7 @@ static int upload_work_items(yh_context* ctx) {
   build_work_items(ctx, tiles);
   ctx->state.num_groups = 1, ctx->state.group_begin[0] = 0, ctx->state.group_begin[1] = (int)tiles.size();
   ctx->state.static_items = 0;
+  ctx->state.prio_items   = getenv("YHAIR_PRIO_ITEMS") ? atoi(getenv("YHAIR_PRIO_ITEMS")) : 0;  // developer A/B switch
   if (ctx->state.shader == YH_SHADER_PATH && ctx->state.launch_shape == 0) place_first_round(ctx, tiles);
   if (ctx->state.shader == YH_SHADER_PATH && ctx->state.launch_shape == 3) deal_items_for_stream(ctx, tiles);
   if (ctx->state.shader == YH_SHADER_PATH && (ctx->state.launch_shape == 4 || ctx->state.launch_shape == 7)) split_items_for_octets(tiles);
