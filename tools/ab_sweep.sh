@@ -20,14 +20,15 @@ done
 wait
 for v in "${variants[@]}"; do
   name=${v%%:*}
-  [ -f /tmp/yh_sweep/libyhair_$name.so ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o /tmp/yh_sweep/libyhair_$name.so /tmp/yh_sweep/k_$name.o $R/yocto-hair_amd/csrc/wavefront.o $R/yocto-hair_amd/csrc/stream.o $R/yocto-hair_amd/csrc/bvh_gpu.o \
+  [ -f /tmp/yh_sweep/libyhair_$name.so ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o /tmp/yh_sweep/libyhair_$name.so /tmp/yh_sweep/k_$name.o $R/yocto-hair_amd/csrc/exact.o $R/yocto-hair_amd/csrc/stream.o $R/yocto-hair_amd/csrc/bvh_gpu.o \
       $R/yocto-hair_amd/host/context.o $R/yocto-hair_amd/host/bvh_build.o $R/yocto-hair_amd/host/scene_io.o -lpthread -lz -ldl
 done
+[ -n "${AB_PREBUILT:-}" ] && cp "$AB_PREBUILT" /tmp/yh_sweep/libyhair_prebuilt.so && variants+=("prebuilt:")   # e.g. AB_PREBUILT=tools/_ab/libyhair_<commit>.so
 for r in $(seq 1 $rounds); do
   for v in "${variants[@]}"; do
     name=${v%%:*}
     printf "%s r%d: " "$name" "$r"
-    YHAIR_LIB=/tmp/yh_sweep/libyhair_$name.so python3 $R/bench.py --no-cpu-baseline "$@" 2>&1 | grep -o '"value": [0-9.]*' | tr '\n' ' '
+    YHAIR_LIB=/tmp/yh_sweep/libyhair_$name.so python3 $R/bench.py --no-cpu-baseline --no-project-scaling "$@" 2>&1 | grep -o '"value": [0-9.]*' | tr '\n' ' '
     echo
   done
 done

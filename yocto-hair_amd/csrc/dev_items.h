@@ -68,8 +68,15 @@ YH_DEV void trace_items(const yhd_scene& sc, const yhd_state& st, int nsamples, 
   const int lane = threadIdx.x & 63;
   // The first item of a wave by position (the host placed the list: which items share a SIMD), the others from the cursor.
   // (Whatever the grid: the entries no wave takes by position are served by the cursor.)
+  // Compiled only with -DYH_LAB_PLACEMENT (a developer experiment, measured without gain, host/context.cpp: place_first_round): its mere
+  // presence costs the quad kernel 3.5 % on C1 (register allocation of the loops below; tools/ab_sweep.sh, profiles/r03/).
+#ifdef YH_LAB_PLACEMENT
   const int by_position  = min(st.static_items, (int)(gridDim.x * (BLOCK / 64)));
   int       first_static = (int)(blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6));
+#else
+  const int by_position  = 0;
+  int       first_static = -1;
+#endif
   while (true) {
     int t = 0;
     if (first_static >= 0 && first_static < by_position) {
@@ -80,10 +87,12 @@ YH_DEV void trace_items(const yhd_scene& sc, const yhd_state& st, int nsamples, 
     }
     first_static = -1;
     if (t >= st.num_tiles) break;
+#ifdef YH_LAB_PRIO /* developer experiment (YHAIR_PRIO_ITEMS), measured without effect: compiled out */
     if (st.prio_items > 0) {  // issue priority for the waves that hold the most expensive items (the head of the cost-sorted list)
       if (t < st.prio_items) __builtin_amdgcn_s_setprio(3);
       else __builtin_amdgcn_s_setprio(0);
     }
+#endif
     unsigned long long t0 = wall_clock64();
     int  item  = st.tiles[t];
     int  half  = 0;  // which half (octets) / quarter (sixteen lanes per path) of the quadrant this entry is

@@ -1222,7 +1222,7 @@ static int upload_work_items(yh_context* ctx) {
   build_work_items(ctx, tiles);
   ctx->state.num_groups = 1, ctx->state.group_begin[0] = 0, ctx->state.group_begin[1] = (int)tiles.size();
   ctx->state.static_items = 0;
-  ctx->state.prio_items   = getenv("YHAIR_PRIO_ITEMS") ? atoi(getenv("YHAIR_PRIO_ITEMS")) : 0;  // developer A/B switch
+  ctx->state.prio_items   = getenv("YHAIR_PRIO_ITEMS") ? atoi(getenv("YHAIR_PRIO_ITEMS")) : 0;  // developer A/B switch (a library built with -DYH_LAB_PRIO)
   if (ctx->state.shader == YH_SHADER_PATH && ctx->state.launch_shape == 0) place_first_round(ctx, tiles);
   if (ctx->state.shader == YH_SHADER_PATH && ctx->state.launch_shape == 3) deal_items_for_stream(ctx, tiles);
   if (ctx->state.shader == YH_SHADER_PATH && (ctx->state.launch_shape == 4 || ctx->state.launch_shape == 7)) split_items_for_octets(tiles);
@@ -1287,7 +1287,7 @@ static int side_by_side_impl(yh_context* ctx, int nsamples, bool sync);
 // of four expensive ones — and the other expensive items, dealt by cost band, fill waves 1-3 and 5-7: they have a third
 // of the launch to spare. Everything else goes through the cursor as before. Pixels do not depend on any of it.
 static void place_first_round(yh_context* ctx, std::vector<int>& items) {
-  if (!getenv("YHAIR_PLACEMENT") || ctx->dense != 0 || !ctx->costs_settled) return;  // (developer switch; sparse images with settled costs only)
+  if (!getenv("YHAIR_PLACEMENT") || ctx->dense != 0 || !ctx->costs_settled) return;  // (developer switch, needs a library built with -DYH_LAB_PLACEMENT; sparse images with settled costs only)
   const int wpb = yhk_block_threads(0) / 64;
   if (wpb != 8) return;
   const int lds = yhk_trace_lds_bytes(&ctx->scene, 0);
