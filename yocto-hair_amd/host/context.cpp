@@ -737,6 +737,11 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
       yhh::build_bvh(tree, boxes);
     }
     lap("build_bvh (reference tree)");
+    // the three collapses of the tree side by side (they only read it): 4-wide here, 8- and 16-wide on two helper threads
+    std::vector<yhh::WideNode8>  wide8;
+    std::vector<yhh::WideNode16> wide16;
+    std::thread t8([&] { I.depth8 = yhh::collapse_wide8(tree, wide8); });
+    std::thread t16([&] { I.depth16 = yhh::collapse_wide16(tree, wide16); });
     std::vector<yhh::WideNode> wide;
     I.depth = yhh::collapse_wide(tree, wide);
     lap("collapse to 4-wide");
@@ -745,24 +750,6 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
       size_t at = nodes.size();
       nodes.resize(at + wide.size() * 8);
       memcpy(&nodes[at], wide.data(), wide.size() * sizeof(yhh::WideNode));
-    }
-    {  // ... and three levels at a time: 8-wide nodes, 16 float4 each
-      std::vector<yhh::WideNode8> wide8;
-      I.depth8     = yhh::collapse_wide8(tree, wide8);
-      I.node8_base = (int)(nodes8.size() / 16);
-      size_t at    = nodes8.size();
-      nodes8.resize(at + wide8.size() * 16);
-      memcpy(&nodes8[at], wide8.data(), wide8.size() * sizeof(yhh::WideNode8));
-      lap("collapse to 8-wide");
-    }
-    {  // ... and four: 16-wide nodes, 32 float4 each
-      std::vector<yhh::WideNode16> wide16;
-      I.depth16     = yhh::collapse_wide16(tree, wide16);
-      I.node16_base = (int)(nodes16.size() / 32);
-      size_t at     = nodes16.size();
-      nodes16.resize(at + wide16.size() * 32);
-      memcpy(&nodes16[at], wide16.data(), wide16.size() * sizeof(yhh::WideNode16));
-      lap("collapse to 16-wide");
     }
     auto nrm = [&](int v) { return s.normals ? ld3(s.normals + 3 * (size_t)v) : F3{0, 0, 0}; };
     {  // leaf-ordered records (yh_device.h), filled in parallel
@@ -814,6 +801,18 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
     }
     if (lines && s.num_lines > best_lines) best_lines = s.num_lines, best_shape = si;
     lap("leaf records + vertex arrays");
+    t8.join(), t16.join();
+    {  // three levels per node: 8-wide, 16 float4 each; four levels: 16-wide, 32 float4 each
+      I.node8_base = (int)(nodes8.size() / 16);
+      size_t at    = nodes8.size();
+      nodes8.resize(at + wide8.size() * 16);
+      memcpy(&nodes8[at], wide8.data(), wide8.size() * sizeof(yhh::WideNode8));
+      I.node16_base = (int)(nodes16.size() / 32);
+      at            = nodes16.size();
+      nodes16.resize(at + wide16.size() * 32);
+      memcpy(&nodes16[at], wide16.data(), wide16.size() * sizeof(yhh::WideNode16));
+      lap("8- and 16-wide collapses (beside the above)");
+    }
   }
   // ---- objects and the scene-level BVH (pt.cpp:792-814) -------------------
   std::vector<yhd_object> objects(sd->num_objects);
