@@ -1015,3 +1015,22 @@ def test_another_shard_is_another_image_for_the_kernel_trials(yh, monkeypatch):
     c.init_state(p)
     assert c.kernel_trials()
     c.close(), sf.close()
+
+
+@pytest.mark.parametrize("res", [100, 61, 7])
+def test_every_launch_shape_on_ragged_image_sizes(ctx, yh, res, monkeypatch):
+    """Image sizes that are not multiples of the 8x8 tile, down to less than one tile: every kernel (quads, octets with
+    and without leaf pairs, sixteen lanes, side by side, k_stream) renders the quad kernel's bits on the partial tiles too."""
+    sf = yh.SceneFile(scene_path("sphere-hairblock", scale=0.05, zoom=True))
+    ctx.upload_scene(sf.desc)
+    ctx.set_shard(0, 1)
+    ref = None
+    for shape in ("0", "4", "6", "7", "5", "3", "1"):
+        monkeypatch.setenv("YHAIR_SHAPE", shape)
+        ctx.init_state(yh.TraceParams.default(resolution=res))
+        ctx.trace_samples(5), ctx.trace_samples(3)
+        got = (ctx.download(), ctx.download_rng())
+        ref = ref or got
+        assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]), f"shape {shape} at {res} x {res}"
+    monkeypatch.delenv("YHAIR_SHAPE")
+    sf.close()
