@@ -327,7 +327,7 @@ def main():
         try:
             for n_proj in (2, 4, 8):
                 ctx.set_shard(0, n_proj)
-                pw, ph, pel, _, _ = timed_run(res_main, step_spp, 1)
+                pw, ph, pel, _, _ = timed_run(res_main, step_spp, 3)  # (three warm-up steps: the shard's kernel trials — and the wide BVH nodes the octet kernels build at their first launch — stay out of the timed steps, as the run's own warm-up keeps them out of a rank's)
                 projected.append({"n_gpus": n_proj, "shard": f"0 of {n_proj}", "seconds": round(pel, 4),
                                   "value_if_every_gpu_takes_this_long": round(pw * ph * spp_total / pel / 1e6, 1),
                                   "kernel": KERNELS.get(ctx.launch_shape(), "?")})

@@ -278,6 +278,13 @@ struct yh_context {
   DevBuf    d_nodes, d_nodes8, d_nodes16, d_prims, d_vpos, d_elems, d_objects, d_materials, d_scene_nodes,
       d_scene_prims, d_light_cdf, d_env_texels, d_light_table, d_env_tab;
   int       stack_need = 0, stack_need8 = 0, stack_need16 = 0;
+  // The 8- and 16-wide node arrays (launch shapes 4, 6, 7) are built and uploaded at their first use (ensure_wide_nodes):
+  // an image that never runs those kernels pays neither the collapses nor the memory. Until then the host keeps the
+  // shapes' binary trees and the object records.
+  bool                     wide_built = false;
+  std::vector<yhh::Tree>   host_trees;    // per shape (emptied once the wide arrays exist)
+  std::vector<yhd_object>  host_objects;  // as uploaded; wbox_min[3] / wbox_max[3] = the wide arrays' bases once built
+  std::vector<int>         object_shape;  // shape index of every object
   // state
   bool             have_state = false;
   yhd_state        state{};
@@ -599,6 +606,7 @@ static void split_items_for_hex(std::vector<int>& items) {
   items.swap(out);
 }
 static void split_items_side_by_side(yh_context* ctx, std::vector<int>& items);
+static int  ensure_wide_nodes(yh_context* ctx);
 static void place_first_round(yh_context* ctx, std::vector<int>& items);
 static int  trace_impl(yh_context* ctx, int nsamples, bool counted, bool sync);
 
@@ -673,7 +681,10 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
     int num_nodes;
   };
   std::vector<ShapeInfo>  info(sd->num_shapes);
-  std::vector<yhd_float4> nodes, nodes8, nodes16, prims, vpos;
+  std::vector<yhd_float4> nodes, prims, vpos;
+  ctx->wide_built = false;
+  ctx->host_trees.assign((size_t)sd->num_shapes, yhh::Tree{});
+  ctx->d_nodes8.reset(), ctx->d_nodes16.reset();
   std::vector<float>      vtex;  // 2 per vertex, zeros for shapes without texture coordinates
   std::vector<yhd_int4>   elems;
   int                     best_lines = -1, best_shape = -1;
@@ -737,14 +748,21 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
       yhh::build_bvh(tree, boxes);
     }
     lap("build_bvh (reference tree)");
-    // the three collapses of the tree side by side (they only read it): 4-wide here, 8- and 16-wide on two helper threads
-    std::vector<yhh::WideNode8>  wide8;
-    std::vector<yhh::WideNode16> wide16;
-    std::thread t8([&] { I.depth8 = yhh::collapse_wide8(tree, wide8); });
-    std::thread t16([&] { I.depth16 = yhh::collapse_wide16(tree, wide16); });
     std::vector<yhh::WideNode> wide;
     I.depth = yhh::collapse_wide(tree, wide);
     lap("collapse to 4-wide");
+    {  // depths of the 8- and 16-wide collapses (built at first use, ensure_wide_nodes): a wide node stands for every
+       // internal binary node at a level that is a multiple of 3 (4), so the wide depth is 1 + deepest internal level / 3 (4)
+      std::vector<int> level(tree.nodes.size(), 0);
+      int deepest = 0;
+      for (size_t n = 0; n < tree.nodes.size(); n++)
+        if (tree.nodes[n].internal) {
+          deepest = std::max(deepest, level[n]);
+          level[(size_t)tree.nodes[n].start] = level[(size_t)tree.nodes[n].start + 1] = level[n] + 1;
+        }
+      I.depth8 = 1 + deepest / 3, I.depth16 = 1 + deepest / 4;
+      I.node8_base = I.node16_base = 0;
+    }
     I.root = tree.nodes[0].bbox, I.num_nodes = (int)wide.size();
     {
       size_t at = nodes.size();
@@ -801,18 +819,7 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
     }
     if (lines && s.num_lines > best_lines) best_lines = s.num_lines, best_shape = si;
     lap("leaf records + vertex arrays");
-    t8.join(), t16.join();
-    {  // three levels per node: 8-wide, 16 float4 each; four levels: 16-wide, 32 float4 each
-      I.node8_base = (int)(nodes8.size() / 16);
-      size_t at    = nodes8.size();
-      nodes8.resize(at + wide8.size() * 16);
-      memcpy(&nodes8[at], wide8.data(), wide8.size() * sizeof(yhh::WideNode8));
-      I.node16_base = (int)(nodes16.size() / 32);
-      at            = nodes16.size();
-      nodes16.resize(at + wide16.size() * 32);
-      memcpy(&nodes16[at], wide16.data(), wide16.size() * sizeof(yhh::WideNode16));
-      lap("8- and 16-wide collapses (beside the above)");
-    }
+    ctx->host_trees[(size_t)si] = std::move(tree);
   }
   // ---- objects and the scene-level BVH (pt.cpp:792-814) -------------------
   std::vector<yhd_object> objects(sd->num_objects);
@@ -843,13 +850,12 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
       float ext = fmax_(fmax_(hi[0] - lo[0], hi[1] - lo[1]), hi[2] - lo[2]);
       float eps = 1e-3f * ext + 1e-5f;
       for (int k = 0; k < 3; k++) d.wbox_min[k] = lo[k] - eps, d.wbox_max[k] = hi[k] + eps;
-      memcpy(&d.wbox_min[3], &I.node8_base, 4);   // (int bits) first 8-wide node of the shape in yhd_scene::nodes8
-      memcpy(&d.wbox_max[3], &I.node16_base, 4);  // ... first 16-wide node in yhd_scene::nodes16
+      d.wbox_min[3] = d.wbox_max[3] = 0;  // (int bits) the shape's first 8- / 16-wide node once those arrays exist (ensure_wide_nodes)
     }
   }
   // array offsets on the device are 32-bit float4 indices
   if (prims.size() > (size_t)std::numeric_limits<int>::max() || nodes.size() > (size_t)std::numeric_limits<int>::max() ||
-      nodes8.size() > (size_t)std::numeric_limits<int>::max() || nodes16.size() > (size_t)std::numeric_limits<int>::max() || vpos.size() > (size_t)std::numeric_limits<int>::max())
+      vpos.size() > (size_t)std::numeric_limits<int>::max())
     return fail(ctx, YH_E_INVALID, "scene too large for 32-bit record offsets (%zu primitive, %zu node float4)", prims.size(), nodes.size());
   yhh::Tree scene_tree;
   yhh::build_bvh(scene_tree, obj_boxes);
@@ -1003,12 +1009,13 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
   // ---- upload ------------------------------------------------------------
   int rc;
   if ((rc = upload(ctx, ctx->d_nodes, nodes.data(), nodes.size() * 16))) return rc;
-  if ((rc = upload(ctx, ctx->d_nodes8, nodes8.data(), nodes8.size() * 16))) return rc;
-  if ((rc = upload(ctx, ctx->d_nodes16, nodes16.data(), nodes16.size() * 16))) return rc;
   if ((rc = upload(ctx, ctx->d_prims, prims.data(), prims.size() * 16))) return rc;
   if ((rc = upload(ctx, ctx->d_vpos, vpos.data(), vpos.size() * 16))) return rc;
   if ((rc = upload(ctx, ctx->d_elems, elems.data(), elems.size() * 16))) return rc;
   if ((rc = upload(ctx, ctx->d_objects, objects.data(), objects.size() * sizeof(yhd_object)))) return rc;
+  ctx->host_objects = objects;
+  ctx->object_shape.resize((size_t)sd->num_objects);
+  for (int oi = 0; oi < sd->num_objects; oi++) ctx->object_shape[(size_t)oi] = sd->objects[oi].shape;
   if ((rc = upload(ctx, ctx->d_materials, materials.data(), materials.size() * sizeof(yhd_material)))) return rc;
   if ((rc = upload(ctx, ctx->d_scene_nodes, scene_nodes.data(), scene_nodes.size() * 16))) return rc;
   std::vector<int> scene_prims_padded = scene_tree.primitives;
@@ -1032,9 +1039,9 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
   sc.light_table = (const yhd_float4*)ctx->d_light_table.p, sc.light_table_f4 = (int)light_table.size();
   sc.env_tab = (const float*)ctx->d_env_tab.p;
   sc.stack_entries = std::max(8, (ctx->stack_need + 7) / 8 * 8);
-  sc.nodes8 = (const yhd_float4*)ctx->d_nodes8.p, sc.num_nodes8_total = (int)(nodes8.size() / 16);
+  sc.nodes8 = nullptr, sc.num_nodes8_total = 0;  // built at first use: ensure_wide_nodes
   sc.stack_entries8 = std::max(8, (ctx->stack_need8 + 7) / 8 * 8);
-  sc.nodes16 = (const yhd_float4*)ctx->d_nodes16.p, sc.num_nodes16_total = (int)(nodes16.size() / 32);
+  sc.nodes16 = nullptr, sc.num_nodes16_total = 0;
   sc.stack_entries16 = std::max(8, (ctx->stack_need16 + 7) / 8 * 8);
   sc.textures = (const yhd_texture*)ctx->d_textures.p, sc.tex_texels = (const yhd_float4*)ctx->d_tex_texels.p;
   sc.vtex = (const float*)ctx->d_vtex.p;
@@ -1271,6 +1278,63 @@ static void split_items_side_by_side(yh_context* ctx, std::vector<int>& items) {
   items.swap(out);
 }
 static int side_by_side_impl(yh_context* ctx, int nsamples, bool sync);
+
+// The 8- and 16-wide collapses of the shapes' trees (host/bvh_build.h), built, uploaded and wired into the object records
+// when a kernel that traverses them is about to run for the first time (launch shapes 4, 5, 6, 7).
+static int ensure_wide_nodes(yh_context* ctx) {
+  if (ctx->wide_built) return YH_OK;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // (a queued launch may be reading the object records)
+  const size_t ns = ctx->host_trees.size();
+  std::vector<std::vector<yhh::WideNode8>>  w8(ns);
+  std::vector<std::vector<yhh::WideNode16>> w16(ns);
+  std::vector<int>                          d8(ns, 0), d16(ns, 0);
+  {
+    std::vector<std::thread> pool;
+    for (size_t si = 0; si < ns; si++) {
+      pool.emplace_back([&, si] { d8[si] = yhh::collapse_wide8(ctx->host_trees[si], w8[si]); });
+      pool.emplace_back([&, si] { d16[si] = yhh::collapse_wide16(ctx->host_trees[si], w16[si]); });
+      if (pool.size() >= 8) {
+        for (auto& t : pool) t.join();
+        pool.clear();
+      }
+    }
+    for (auto& t : pool) t.join();
+  }
+  {  // the LDS stacks were sized at upload from the depths these collapses were expected to have
+    int m8 = 0, m16 = 0;
+    for (size_t si = 0; si < ns; si++) m8 = std::max(m8, d8[si]), m16 = std::max(m16, d16[si]);
+    if (7 * m8 > ctx->stack_need8 || 15 * m16 > ctx->stack_need16)
+      return fail(ctx, YH_E_INVALID, "wide trees deeper than their traversal stacks were sized for (%d / %d levels)", m8, m16);
+  }
+  std::vector<int>        base8(ns), base16(ns);
+  std::vector<yhd_float4> nodes8, nodes16;
+  for (size_t si = 0; si < ns; si++) {
+    base8[si] = (int)(nodes8.size() / 16), base16[si] = (int)(nodes16.size() / 32);
+    size_t at = nodes8.size();
+    nodes8.resize(at + w8[si].size() * 16);
+    if (!w8[si].empty()) memcpy(&nodes8[at], w8[si].data(), w8[si].size() * sizeof(yhh::WideNode8));
+    at = nodes16.size();
+    nodes16.resize(at + w16[si].size() * 32);
+    if (!w16[si].empty()) memcpy(&nodes16[at], w16[si].data(), w16[si].size() * sizeof(yhh::WideNode16));
+  }
+  if (nodes8.size() > (size_t)std::numeric_limits<int>::max() || nodes16.size() > (size_t)std::numeric_limits<int>::max())
+    return fail(ctx, YH_E_INVALID, "scene too large for 32-bit wide-node offsets");
+  int rc;
+  if ((rc = upload(ctx, ctx->d_nodes8, nodes8.data(), nodes8.size() * 16))) return rc;
+  if ((rc = upload(ctx, ctx->d_nodes16, nodes16.data(), nodes16.size() * 16))) return rc;
+  for (size_t oi = 0; oi < ctx->host_objects.size(); oi++) {
+    const size_t si = (size_t)ctx->object_shape[oi];
+    memcpy(&ctx->host_objects[oi].wbox_min[3], &base8[si], 4);
+    memcpy(&ctx->host_objects[oi].wbox_max[3], &base16[si], 4);
+  }
+  HIPCHK(ctx, hipMemcpy(ctx->d_objects.p, ctx->host_objects.data(), ctx->host_objects.size() * sizeof(yhd_object), hipMemcpyHostToDevice));
+  ctx->scene.nodes8 = (const yhd_float4*)ctx->d_nodes8.p, ctx->scene.num_nodes8_total = (int)(nodes8.size() / 16);
+  ctx->scene.nodes16 = (const yhd_float4*)ctx->d_nodes16.p, ctx->scene.num_nodes16_total = (int)(nodes16.size() / 32);
+  ctx->d_scene_copy.reset();  // (the copy of the scene table in device memory is made again at its next use)
+  ctx->wide_built = true;
+  ctx->host_trees.clear(), ctx->host_trees.shrink_to_fit();
+  return YH_OK;
+}
 
 // WHO SHARES A SIMD (k_trace 512 x 4 on a sparse image) — a developer experiment, OFF unless YHAIR_PLACEMENT=1: measured
 // without gain (profiles/r03/first_round_placement_ab.txt: C1 16.6 ms with the placement below, 16.1 with cost bands
@@ -1596,6 +1660,8 @@ static int trace_impl(yh_context* ctx, int nsamples, bool counted, bool sync) {
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     if (int rc = upload_work_items(ctx)) return rc;
   }
+  if (shape == 2 || shape >= 4)
+    if (int rc = ensure_wide_nodes(ctx)) return rc;
   ctx->last_shape = shape, ctx->last_counted = counted, ctx->planned_settled = ctx->costs_settled;
 #ifdef YH_LAB_WAVEFRONT
   if (path && !counted && getenv("YHAIR_LAB_WAVEFRONT")) return wavefront_impl(ctx, nsamples, sync);  // developer build only (make WAVEFRONT=1)
