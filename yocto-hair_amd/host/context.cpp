@@ -420,7 +420,7 @@ bool dense_by_costs(const yh_context* ctx, bool* known, bool* chain_bound = null
     // (candidacy only — the trials decide: generous bounds cost a wasted trial, tight ones a missed kernel; `textured`, whose
     // item costs are very uneven, is worth 1 500 items and still renders 1.45 x faster with sixteen lanes per path)
     *chain_bound      = 2.0 * (double)sum / (double)mx <= 1.1 * res4;  // (C1 at 720^2 is worth 2 400-3 100 items: not one; half of it 1 400-1 700: one)
-    if (chain16) *chain16 = 4.0 * (double)sum / (double)mx <= 1.5 * res4;
+    if (chain16) *chain16 = 4.0 * (double)sum / (double)mx <= 2.5 * res4;
   }
   return (double)sum / (double)mx >= resident;
 }
