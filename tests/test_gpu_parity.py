@@ -713,7 +713,7 @@ def test_launch_shapes_and_kernels_render_identical_pixels(ctx, yh, name, kw, mo
     ctx.upload_scene(sf.desc)
     p = yh.TraceParams.default(resolution=88)
     images = {}
-    for shape in ("0", "1", "3", "4", "5", "6", "7"):  # k_trace 512 x 4, 256 x 5, k_stream, k_trace with octets, quads + octets side by side, sixteen lanes per path, octets with leaf pairs (2: a developer build only)
+    for shape in ("0", "1", "3", "4", "5", "6", "7", "8"):  # k_trace 512 x 4, 256 x 5, k_stream, k_trace with octets, quads + octets side by side, sixteen lanes per path, octets with leaf pairs, sixteen lanes with leaf groups (2: a developer build only)
         monkeypatch.setenv("YHAIR_SHAPE", shape)
         ctx.init_state(p)
         ctx.trace_samples(3), ctx.trace_samples(5)
@@ -759,7 +759,7 @@ def test_kernel_trials_are_cut_off_a_long_request(ctx, yh, name, kw, monkeypatch
             break
     ctx.trace_samples(150)
     assert ctx.last_trace_ms()[1] == 1
-    assert ctx.launch_shape() in (0, 1, 3, 4, 6, 7)
+    assert ctx.launch_shape() in (0, 1, 3, 4, 6, 7, 8)
     sf.close()
 
 
@@ -985,7 +985,7 @@ def test_octet_kernel_is_chosen_for_a_chain_bound_shard_and_renders_the_same_pix
     c.init_state(p)
     c.trace_samples(32 * 7)
     c.trace_samples(64)
-    assert c.launch_shape() in (4, 6, 7), c.launch_shape()  # eight or sixteen lanes per path
+    assert c.launch_shape() in (4, 6, 7, 8), c.launch_shape()  # eight or sixteen lanes per path
     got = (c.download(), c.download_rng())
     monkeypatch.setenv("YHAIR_SHAPE", "0")
     c.init_state(p)
@@ -1026,7 +1026,7 @@ def test_every_launch_shape_on_ragged_image_sizes(ctx, yh, res, monkeypatch):
     ctx.upload_scene(sf.desc)
     ctx.set_shard(0, 1)
     ref = None
-    for shape in ("0", "4", "6", "7", "5", "3", "1"):
+    for shape in ("0", "4", "6", "7", "8", "5", "3", "1"):
         monkeypatch.setenv("YHAIR_SHAPE", shape)
         ctx.init_state(yh.TraceParams.default(resolution=res))
         ctx.trace_samples(5), ctx.trace_samples(3)

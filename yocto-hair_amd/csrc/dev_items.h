@@ -41,14 +41,14 @@ using namespace yhd;
 // 4x4 block) — half the paths per wave, twice the waves, for launches bound by the chain of one path.
 template <bool COUNT, bool GENERAL, int BLOCK, int SHADER, int MODE = YH_MODE_QUAD>
 YH_DEV void trace_items(const yhd_scene& sc, const yhd_state& st, int nsamples, yhd_counters* counters) {
-  constexpr int LPP    = MODE == YH_MODE_HEX ? 16 : YH_IS_OCT(MODE) ? 8 : 4;  // lanes per path
+  constexpr int LPP    = YH_IS_HEX(MODE) ? 16 : YH_IS_OCT(MODE) ? 8 : 4;  // lanes per path
   constexpr int GROUPS = BLOCK / LPP;                   // paths per block = columns of the LDS stack
   extern __shared__ v4f lds_dyn[];
   // LDS carve-out: [nodelets: 8 * lds_node_count float4][stacks: stack entries x GROUPS uint]
   //                [tables: scene level | camera | small area lights | environment cdf index] (dev_trace.h: stage_tables)
   YH_LDS v4f*          lds_nodes = (YH_LDS v4f*)lds_dyn;
   YH_LDS unsigned int* lds_stack = (YH_LDS unsigned int*)(lds_nodes + 8 * sc.lds_node_count);
-  YH_LDS v4f*          lds_tabs  = (YH_LDS v4f*)(lds_stack + (MODE == YH_MODE_QUAD ? sc.stack_entries : MODE == YH_MODE_HEX ? sc.stack_entries16 : sc.stack_entries8) * GROUPS);
+  YH_LDS v4f*          lds_tabs  = (YH_LDS v4f*)(lds_stack + (MODE == YH_MODE_QUAD ? sc.stack_entries : YH_IS_HEX(MODE) ? sc.stack_entries16 : sc.stack_entries8) * GROUPS);
   // stage the nodelets: the first lds_node_count wide nodes (breadth-first =
   // top levels) of the dominant hair shape, 128 B each, coalesced dwordx4 loads
   if (YH_LDS_NODELETS)
@@ -97,9 +97,9 @@ YH_DEV void trace_items(const yhd_scene& sc, const yhd_state& st, int nsamples, 
     int  item  = st.tiles[t];
     int  half  = 0;  // which half (octets) / quarter (sixteen lanes per path) of the quadrant this entry is
     if (YH_IS_OCT(MODE)) half = item & 1, item >>= 1;
-    if (MODE == YH_MODE_HEX) half = item & 3, item >>= 2;
+    if (YH_IS_HEX(MODE)) half = item & 3, item >>= 2;
     int  tile  = item >> 2, part = item & 3;
-    int  pq    = MODE == YH_MODE_HEX ? half * 4 + (lane >> 4) : YH_IS_OCT(MODE) ? half * 8 + (lane >> 3) : lane >> 2;  // pixel of the 4x4 quadrant owned by this lane's group
+    int  pq    = YH_IS_HEX(MODE) ? half * 4 + (lane >> 4) : YH_IS_OCT(MODE) ? half * 8 + (lane >> 3) : lane >> 2;  // pixel of the 4x4 quadrant owned by this lane's group
     int  i     = (tile % st.tiles_x) * YH_TILE + (part & 1) * 4 + (pq & 3);
     int  j     = (tile / st.tiles_x) * YH_TILE + (part >> 1) * 4 + (pq >> 2);
     bool owner = i < st.width && j < st.height;
@@ -207,7 +207,7 @@ YH_DEV void trace_items(const yhd_scene& sc, const yhd_state& st, int nsamples, 
     }
     if (lane == 0) {
       unsigned int dt = (unsigned int)(wall_clock64() - t0);
-      if (YH_IS_OCT(MODE) || MODE == YH_MODE_HEX) atomicAdd(&st.tile_cost[item], dt);  // the halves / quarters of a quadrant add up (zeroed before the launch)
+      if (YH_IS_OCT(MODE) || YH_IS_HEX(MODE)) atomicAdd(&st.tile_cost[item], dt);  // the halves / quarters of a quadrant add up (zeroed before the launch)
       else st.tile_cost[item] = dt;
       if (COUNT) atomicAdd(&counters->cyc_tile, (unsigned long long)dt);
     }

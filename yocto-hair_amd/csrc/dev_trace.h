@@ -310,10 +310,14 @@ struct trav_state {
 #define YH_MODE_HEX 3 /* SIXTEEN lanes, 16-wide nodes (four levels, host/bvh_build.h: WideNode16): lane o tests slot o; the four quads hold the same path */
 #define YH_ROW_HALF_MIRROR 0x141 /* DPP: lane i of every eight reads lane 7 - i */
 #define YH_ROW_MIRROR 0x140      /* DPP: lane i of every sixteen reads lane 15 - i */
-#define YH_MODE_OCTP 4 /* YH_MODE_OCT with LEAF PAIRS: the octet's two quads test two leaves in one step (below). Bit-identical; 6 % fewer trips and
+#define YH_MODE_OCTP 4 /* YH_MODE_OCT with LEAF PAIRS: the octet's two quads test two leaves in one step (leaf groups, below). Bit-identical; 6 % fewer trips and
                           2-6 % slower on C1 (the look at the stack's top and the exchange between the quads cost every leaf step), 17 % FASTER on hair-curls
                           (many leaf steps per ray): its own launch shape, the trials decide (profiles/r03/oct_leaf_pairs_ab.txt, hex_ab.txt) */
 #define YH_IS_OCT(MODE) ((MODE) == YH_MODE_OCT || (MODE) == YH_MODE_OCTP)
+#define YH_MODE_HEXP 5 /* YH_MODE_HEX with LEAF GROUPS: the four quads of the sixteen test up to four leaves in one step (the entry and the leaves on top of it
+                          on the stack); the merge keeps the reference's order. C1 at 180^2 +5-8 %, hair-curls at 320^2 1.47 x over YH_MODE_HEX, `textured` equal
+                          (profiles/r03/hex_leaf_groups_ab.txt). Its own launch shape (8), the trials decide */
+#define YH_IS_HEX(MODE) ((MODE) == YH_MODE_HEX || (MODE) == YH_MODE_HEXP)
 template <bool COUNT, int STRIDE, bool EXACT, bool PHASE = false, bool LDS_SCENE = false, int MODE = YH_MODE_QUAD>
 YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_object, unsigned int* steps_out, bool& redo,
     trav_state* rs = nullptr, int leave_at = 0) {
@@ -450,13 +454,13 @@ YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_obj
         inv.x = {a.x, a.y, a.z}, inv.y = {a.w, b.x, b.y}, inv.z = {b.z, b.w, c.x}, inv.o = {c.y, c.z, c.w};
         kind = __float_as_int(d.x), node_base = __float_as_int(d.y), prim_base = __float_as_int(d.z);
         if (MODE == YH_MODE_W8 || YH_IS_OCT(MODE)) node_base = __float_as_int(ob[8].w);  // the shape's first 8-wide node (yhd_object::wbox_min[3])
-        if (MODE == YH_MODE_HEX) node_base = __float_as_int(ob[9].w);                          // ... first 16-wide node (wbox_max[3])
+        if (YH_IS_HEX(MODE)) node_base = __float_as_int(ob[9].w);                          // ... first 16-wide node (wbox_max[3])
       } else {
         const yhd_object& o = sc.objects[cur_obj];
         inv  = ldframe(o.inv_frame);
         kind = o.kind, node_base = o.node_base, prim_base = o.prim_base;
         if (MODE == YH_MODE_W8 || YH_IS_OCT(MODE)) node_base = __float_as_int(o.wbox_min[3]);
-        if (MODE == YH_MODE_HEX) node_base = __float_as_int(o.wbox_max[3]);
+        if (YH_IS_HEX(MODE)) node_base = __float_as_int(o.wbox_max[3]);
       }
       lo    = transform_point(inv, ray.o);
       ld    = transform_vector(inv, ray.d);
@@ -471,19 +475,27 @@ YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_obj
     }
     {
       bool is_leaf    = tag == YH_TAG_LEAF;
-      // YH_MODE_OCT, LEAF PAIRS: when the entry is a leaf and the stack's top is a leaf too (siblings that were both hit:
-      // the common case in hair), the upper quad of the octet tests the second leaf in the same step and the two
-      // results are applied in the reference's order (first leaf, then the second against the shortened ray): the
-      // primitive test depends on `tmax` only through its final `t > tmax` reject, so testing against the older,
-      // longer `tmax` and rejecting afterwards accepts exactly what the sequential order accepts.
-      bool         pair = false;
-      unsigned int peek = YH_NONE;
-      if (MODE == YH_MODE_OCTP) {
-        peek = sp > 0 ? lstk[(sp - 1) * STRIDE] : 0u;  // (YH_NONE itself carries the leaf tag: an empty stack must not read as a leaf)
-        pair = is_leaf && sp > 0 && (peek & YH_TAG_MASK) == YH_TAG_LEAF;
+      // LEAF GROUPS (YH_MODE_OCTP: pairs, YH_MODE_HEXP: up to four): when the entry is a leaf and the entries on top of the
+      // stack are leaves too (siblings that were both hit: the common case in hair), the other quads of the path's lanes
+      // test those in the same step: quad j (j = 1..) looks at the j-th entry below the stack's top; the first k of them
+      // that are leaves (consecutive from the top) are tested next to the entry, quad j testing the one that would be
+      // popped j-th. The primitive test depends on `tmax` only through its final `t > tmax` reject, so testing against
+      // the older, longer `tmax` accepts a superset, and the merge below picks what the sequential order keeps.
+      constexpr bool     GROUPS = MODE == YH_MODE_OCTP || MODE == YH_MODE_HEXP;
+      const unsigned int qj     = MODE == YH_MODE_HEXP ? (__lane_id() >> 2) & 3u : MODE == YH_MODE_OCTP ? (__lane_id() >> 2) & 1u : 0u;
+      int                grp    = 0;      // k
+      bool               idle   = false;  // a quad beyond the group: tests the entry again, its result is dropped
+      unsigned int       mycur  = cur;    // the leaf this lane's quad tests
+      if (GROUPS) {
+        const bool   look = is_leaf && qj > 0 && sp >= (int)qj;  // (YH_NONE itself carries the leaf tag: an empty stack must not read as a leaf)
+        unsigned int pk   = look ? lstk[(sp - (int)qj) * STRIDE] : 0u;
+        unsigned int lb   = (look && (pk & YH_TAG_MASK) == YH_TAG_LEAF) ? (1u << qj) : 0u;
+        lb |= (unsigned int)dpp_i<YH_ROW_HALF_MIRROR>((int)lb);
+        if (MODE == YH_MODE_HEXP) lb |= (unsigned int)dpp_i<YH_ROW_MIRROR>((int)lb);
+        grp   = (lb & 2u) ? ((lb & 4u) ? ((lb & 8u) ? 3 : 2) : 1) : 0;
+        idle  = is_leaf && (int)qj > grp;
+        mycur = (qj > 0 && !idle) ? pk : cur;
       }
-      const bool   upper = MODE == YH_MODE_OCTP && (__lane_id() & 4u) != 0;
-      unsigned int mycur = (pair && upper) ? peek : cur;  // the leaf this lane's quad tests
       int  leaf_start = (int)(mycur & 0x07FFFFFFu), leaf_num = (int)((mycur >> 27) & 7u);
       int  rec        = kind == YH_KIND_LINES ? 4 : 6;  // float4 per leaf record
       bool mine       = !is_leaf || (int)q < leaf_num;  // lanes beyond the leaf's count re-read its last record
@@ -504,6 +516,7 @@ YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_obj
       else if (MODE == YH_MODE_W8) addr = is_leaf ? sc.prims + (size_t)prim_base + (size_t)(leaf_start + pq) * rec : sc.nodes8 + 16 * (size_t)cur + 4 * q;
       else if (YH_IS_OCT(MODE)) addr = is_leaf ? sc.prims + (size_t)prim_base + (size_t)(leaf_start + pq) * rec : sc.nodes8 + 16 * (size_t)cur + 2 * (__lane_id() & 7u);
       else addr = is_leaf ? sc.prims + (size_t)prim_base + (size_t)(leaf_start + pq) * rec : sc.nodes16 + 32 * (size_t)cur + 2 * (__lane_id() & 15u);
+      if (GROUPS) mine = mine && !idle;
       v4f s0, s1, s2w, s3w;  // (s2w, s3w: the lane's second slot in YH_MODE_W8; of a leaf record they are the rest of its 64 bytes)
       int rel = (int)cur - sc.lds_node_base;
       if (MODE == YH_MODE_QUAD && YH_LDS_NODELETS && tc.lds_nodes && !is_leaf && rel >= 0 && rel < sc.lds_node_count) {
@@ -513,7 +526,7 @@ YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_obj
         s0 = ldg4(addr), s1 = ldg4(addr + 1);
         if (MODE == YH_MODE_W8) s2w = ldg4(addr + 2), s3w = ldg4(addr + 3);
       }
-      if (MODE == YH_MODE_HEX && !is_leaf) {
+      if (YH_IS_HEX(MODE) && !is_leaf) {
         // ---- 16-wide node: slot o = s1 << 3 | s2 << 2 | s3 << 1 | s4, one per lane of the sixteen; the rank of a slot in the
         // reference's visiting order is the four near / far decisions of pt.cpp:887-893 at the four collapsed levels.
         if (q == 0) n_nodes++;
@@ -646,7 +659,7 @@ YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_obj
         // The reference tests the leaf's primitives in order, shrinking tmax after
         // each accepted hit: the survivor is the accepted primitive of minimum t,
         // the LATER one among equal t. Same result as a quad min-reduction.
-        int   key_i = ok ? (int)q : -1;
+        int   key_i = ok ? (int)(4 * qj + q) : -1;  // (qj: the quad's place in a leaf group, 0 in the modes without)
         float key_t = dist;
 #define YH_QUAD_MERGE(CTRL)                                                                \
   {                                                                                        \
@@ -658,24 +671,27 @@ YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_obj
         YH_QUAD_MERGE(YH_QUAD_XOR1)
         YH_QUAD_MERGE(YH_QUAD_XOR2)
 #undef YH_QUAD_MERGE
-        if (MODE == YH_MODE_OCTP) {
-          // every lane takes the first leaf's result (the lower quad's) and then, of a pair, the second's
-          int   o_i = dpp_i<YH_ROW_HALF_MIRROR>(key_i), o_s = dpp_i<YH_ROW_HALF_MIRROR>(leaf_start);
-          float o_t = dpp_f<YH_ROW_HALF_MIRROR>(key_t), o_u = dpp_f<YH_ROW_HALF_MIRROR>(uu), o_v = dpp_f<YH_ROW_HALF_MIRROR>(vv);
-          int   a_i = upper ? o_i : key_i, a_s = upper ? o_s : leaf_start, b_i = upper ? key_i : o_i, b_s = upper ? leaf_start : o_s;
-          float a_t = upper ? o_t : key_t, a_u = upper ? o_u : uu, a_v = upper ? o_v : vv;
-          float b_t = upper ? key_t : o_t, b_u = upper ? uu : o_u, b_v = upper ? vv : o_v;
-          if (a_i >= 0) {
-            hit.object = cur_obj, hit.slot = a_s + a_i;
-            hit.u = a_u, hit.v = a_v, hit.distance = a_t;
-            tmax = a_t;
+        if (GROUPS) {
+          // The reference meets the group's leaves one after the other, each against the ray shortened by the hits before
+          // it: the survivor is the accepted primitive of minimum t, the LATER one among equal t (math.h:3450) — the same
+          // rule as inside a leaf, so the merge simply goes on across the quads with the leaf's place in the key.
+          int slot = leaf_start + (key_i & 3);
+#define YH_GROUP_MERGE(CTRL)                                                               \
+  {                                                                                        \
+    int   oi = dpp_i<CTRL>(key_i), os = dpp_i<CTRL>(slot);                                 \
+    float ot = dpp_f<CTRL>(key_t), ou = dpp_f<CTRL>(uu), ov = dpp_f<CTRL>(vv);             \
+    bool  take = (oi >= 0) & ((key_i < 0) | (ot < key_t) | ((ot == key_t) & (oi > key_i))); \
+    key_i = take ? oi : key_i, key_t = take ? ot : key_t, uu = take ? ou : uu, vv = take ? ov : vv, slot = take ? os : slot; \
+  }
+          YH_GROUP_MERGE(YH_ROW_HALF_MIRROR)
+          if (MODE == YH_MODE_HEXP) YH_GROUP_MERGE(YH_ROW_MIRROR)
+#undef YH_GROUP_MERGE
+          if (key_i >= 0) {
+            hit.object = cur_obj, hit.slot = slot;
+            hit.u = uu, hit.v = vv, hit.distance = key_t;
+            tmax = key_t;
           }
-          if (pair && b_i >= 0 && !(b_t > tmax)) {  // math.h:3450: the later primitive is rejected only when farther
-            hit.object = cur_obj, hit.slot = b_s + b_i;
-            hit.u = b_u, hit.v = b_v, hit.distance = b_t;
-            tmax = b_t;
-          }
-          if (pair) sp--;  // the second leaf came off the stack
+          sp -= grp;  // the group's leaves came off the stack
         } else if (key_i >= 0) {
           hit.object = cur_obj, hit.slot = leaf_start + key_i;
           hit.u = uu, hit.v = vv, hit.distance = key_t;

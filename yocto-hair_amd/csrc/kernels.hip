@@ -427,10 +427,12 @@ typedef void (*trace_kernel_t)(const yhd_scene, const yhd_state, int, yhd_counte
 // shape 0 = 512 threads x 4 waves per SIMD, shape 1 = 256 threads x YH_DENSE_WAVES (5) waves per SIMD: quads over 4-wide nodes;
 // shape 2 = 512 x 4, quads over 8-wide nodes (YH_MODE_W8); shape 4 = 256 x 4, octets over 8-wide nodes (YH_MODE_OCT);
 // shape 6 = 256 x 4, sixteen lanes per path over 16-wide nodes (YH_MODE_HEX); shape 7 = shape 4 with leaf pairs (YH_MODE_OCTP). (3 is k_stream, csrc/stream.hip; 5 the host's
-// side-by-side launch of shapes 0 and 4.)
+// side-by-side launch of shapes 0 and 4.) shape 8 = shape 6 with leaf groups (YH_MODE_HEXP).
 #define YH_OCT_BLOCK 256
-static int shape_block(int shape) { return shape == 1 ? 256 : (shape == 4 || shape == 6 || shape == 7) ? YH_OCT_BLOCK : YH_BLOCK; }
-static int shape_groups(int shape) { return shape_block(shape) / (shape == 6 ? 16 : (shape == 4 || shape == 7) ? 8 : 4); }
+static bool shape_oct(int shape) { return shape == 4 || shape == 7; }
+static bool shape_hex(int shape) { return shape == 6 || shape == 8; }
+static int shape_block(int shape) { return shape == 1 ? 256 : (shape_oct(shape) || shape_hex(shape)) ? YH_OCT_BLOCK : YH_BLOCK; }
+static int shape_groups(int shape) { return shape_block(shape) / (shape_hex(shape) ? 16 : shape_oct(shape) ? 8 : 4); }
 static trace_kernel_t trace_kernel(bool counted, bool general, int shape, int shader = YH_SHADER_PATH) {
   if (shader == YH_SHADER_NAIVE) return k_trace_shader<YH_SHADER_NAIVE>;
   if (shader == YH_SHADER_EYELIGHT) return k_trace_shader<YH_SHADER_EYELIGHT>;
@@ -445,7 +447,8 @@ static trace_kernel_t trace_kernel(bool counted, bool general, int shape, int sh
   if (shape == 6 && !counted) return general ? k_trace<false, true, YH_OCT_BLOCK, YH_MIN_WAVES, YH_MODE_HEX> : k_trace<false, false, YH_OCT_BLOCK, YH_MIN_WAVES, YH_MODE_HEX>;
   if (shape == 6 && counted && !general) return k_trace<true, false, YH_OCT_BLOCK, YH_MIN_WAVES, YH_MODE_HEX>;
   if (shape == 7 && !counted) return general ? k_trace<false, true, YH_OCT_BLOCK, YH_MIN_WAVES, YH_MODE_OCTP> : k_trace<false, false, YH_OCT_BLOCK, YH_MIN_WAVES, YH_MODE_OCTP>;
-  if (shape == 2 || shape == 4 || shape == 6 || shape == 7) return nullptr;
+  if (shape == 8 && !counted) return general ? k_trace<false, true, YH_OCT_BLOCK, YH_MIN_WAVES, YH_MODE_HEXP> : k_trace<false, false, YH_OCT_BLOCK, YH_MIN_WAVES, YH_MODE_HEXP>;
+  if (shape == 2 || shape_oct(shape) || shape_hex(shape)) return nullptr;
   // The GENERAL variants carry the surface lobes, volumes, textures and the through-memory light code. The dense shape
   // spilled 184 registers at the plain variant's 96 (7 scratch instructions inside its traversal loops): it runs at 256 x 4
   // (128 registers, 49 spilled, none in the traversal loops; lobes / volumes +15-20 %, profiles/r03/general_waves_ab.txt).
@@ -461,7 +464,7 @@ static trace_kernel_t trace_kernel(bool counted, bool general, int shape, int sh
                  : (general ? k_trace<false, true, YH_BLOCK, YH_MIN_WAVES> : k_trace<false, false, YH_BLOCK, YH_MIN_WAVES>);
 }
 static size_t trace_lds(const yhd_scene* sc, int shape) {
-  const int entries = shape == 6 ? sc->stack_entries16 : (shape == 2 || shape == 4 || shape == 7) ? sc->stack_entries8 : sc->stack_entries;
+  const int entries = shape_hex(shape) ? sc->stack_entries16 : (shape == 2 || shape_oct(shape)) ? sc->stack_entries8 : sc->stack_entries;
   return (size_t)sc->lds_node_count * 128 + (size_t)entries * shape_groups(shape) * 4 + (size_t)YHD_LDS_TABLES_F4(sc) * 16;
 }
 // `shape`: 0, 1, 2 or 4 (above); the caller built the work list for it (shape 4: half-quadrant entries)
@@ -470,7 +473,7 @@ int yhk_trace(const yhd_scene* sc, const yhd_state* st, int nsamples, yhd_counte
   const bool path  = st->shader == YH_SHADER_PATH;
   if (!path) shape = 0;  // the other shaders have one shape (512 x 4)
   if (!path && counters) return (int)hipErrorInvalidValue;
-  if (shape == 3 || shape == 5 || shape < 0 || shape > 7) return (int)hipErrorInvalidValue;
+  if (shape == 3 || shape == 5 || shape < 0 || shape > 8) return (int)hipErrorInvalidValue;
   size_t    lds   = trace_lds(sc, shape);
   trace_kernel_t k     = trace_kernel(counters != nullptr, sc->general_materials != 0, shape, st->shader);
   if (!k) return (int)hipErrorInvalidValue;

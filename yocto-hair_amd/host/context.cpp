@@ -260,7 +260,7 @@ void parallel_for(int n, F&& fn) {
   for (auto& th : pool) th.join();
 }
 
-constexpr int YH_SHAPES = 8;  // launch shapes: 0, 1 k_trace (4-wide nodes) | 2 k_trace over 8-wide nodes | 3 k_stream | 4 k_trace with octets | 5 quads and octets side by side | 6 k_trace with sixteen lanes per path | 7 octets with leaf pairs
+constexpr int YH_SHAPES = 9;  // launch shapes: 0, 1 k_trace (4-wide nodes) | 2 k_trace over 8-wide nodes | 3 k_stream | 4 k_trace with octets | 5 quads and octets side by side | 6 k_trace with sixteen lanes per path | 7 octets with leaf pairs | 8 sixteen lanes with leaf groups
 struct yh_context {
   int         device = 0;
   hipStream_t stream = nullptr;
@@ -488,12 +488,12 @@ bool trials_off() {
 // k_trace 512 x 4 always; the dense quad shape unless the image is chain-bound; k_stream on dense images; on chain-bound
 // ones (a shard of a sparse image on one of several GPUs, a small image) the octet kernel and, when even four waves per
 // expensive item are all resident, the sixteen-lane one. (Shapes 2 and 5 are never tried: profiles/r03/.)
-int candidates(const yh_context* ctx, int cand[5]) {
+int candidates(const yh_context* ctx, int cand[6]) {
   int n = 0;
   cand[n++] = 0;
   if (ctx->chain > 0 && ctx->dense <= 0) {  // chain-bound: more lanes per path (the dense quad shape and the side-by-side launch never win there: not tried)
     cand[n++] = 4, cand[n++] = 7;  // octets, without and with leaf pairs (which of the two wins depends on the share of leaf steps)
-    if (ctx->chain16 > 0) cand[n++] = 6;
+    if (ctx->chain16 > 0) cand[n++] = 6, cand[n++] = 8;  // (likewise without and with leaf groups)
     return n;
   }
   cand[n++] = 1;
@@ -539,7 +539,7 @@ bool wants_trial(const yh_context* ctx, const int* cand, int n, int c) {
 bool trial_pending(const yh_context* ctx) {
   if (!ctx->have_state || !ctx->have_costs || ctx->state.shader != YH_SHADER_PATH || trials_off() || ctx->params.hair_exact) return false;
   if (!ctx->costs_settled) return true;  // (the first short launch settles the item costs; the trials follow it)
-  int cand[5], n = candidates(ctx, cand);
+  int cand[6], n = candidates(ctx, cand);
   for (int k = 0; k < n; k++)
     if (wants_trial(ctx, cand, n, cand[k])) return true;
   return false;
@@ -551,7 +551,7 @@ int pick_launch_shape(const yh_context* ctx, int nsamples) {
   if (!ctx->have_costs) return ctx->launch_shape;  // the first launch of an image: unplanned, not a measurement
   const int by_costs = ctx->dense > 0 ? 1 : 0;
   if (trials_off()) return by_costs;
-  int cand[5], n = candidates(ctx, cand), best = -1;
+  int cand[6], n = candidates(ctx, cand), best = -1;
   const bool trial_length = ctx->costs_settled && nsamples >= YH_TRIAL_SPP && nsamples < 2 * YH_TRIAL_SPP;
   for (int k = 0; k < n; k++) {
     const int c = cand[k];
@@ -1167,7 +1167,7 @@ int yh_init_state(yh_context* ctx, const yh_trace_params* params) {
   if (params->shader == YH_SHADER_PATH && first_shape == 3) deal_items_for_stream(ctx, tiles);
   if (params->shader == YH_SHADER_PATH && (first_shape == 4 || first_shape == 7)) split_items_for_octets(tiles);
   if (params->shader == YH_SHADER_PATH && first_shape == 5) split_items_side_by_side(ctx, tiles);
-  if (params->shader == YH_SHADER_PATH && first_shape == 6) split_items_for_hex(tiles);
+  if (params->shader == YH_SHADER_PATH && (first_shape == 6 || first_shape == 8)) split_items_for_hex(tiles);
   tiles.reserve(4 * (size_t)ctx->num_tiles_total * 4 + 4);  // (the list's buffer holds the octet / sixteen-lane kernels' longer lists too)
   int rc;
   if ((rc = upload(ctx, ctx->d_rng_state, st.data(), npix * 8))) return rc;
@@ -1233,7 +1233,7 @@ static int upload_work_items(yh_context* ctx) {
   if (ctx->state.shader == YH_SHADER_PATH && ctx->state.launch_shape == 3) deal_items_for_stream(ctx, tiles);
   if (ctx->state.shader == YH_SHADER_PATH && (ctx->state.launch_shape == 4 || ctx->state.launch_shape == 7)) split_items_for_octets(tiles);
   if (ctx->state.shader == YH_SHADER_PATH && ctx->state.launch_shape == 5) split_items_side_by_side(ctx, tiles);
-  if (ctx->state.shader == YH_SHADER_PATH && ctx->state.launch_shape == 6) split_items_for_hex(tiles);
+  if (ctx->state.shader == YH_SHADER_PATH && (ctx->state.launch_shape == 6 || ctx->state.launch_shape == 8)) split_items_for_hex(tiles);
   ctx->state.num_tiles = (int)tiles.size();
   HIPCHK(ctx, hipMemcpy(ctx->d_tiles.p, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice));
   return YH_OK;
@@ -1627,7 +1627,7 @@ static int trace_impl(yh_context* ctx, int nsamples, bool counted, bool sync) {
     const int want = pick_launch_shape(ctx, sync ? nsamples : 0);  // (an asynchronous launch is not timed: never a trial)
     if (want != ctx->state.launch_shape) {
       if (getenv("YHAIR_TIMING"))
-        fprintf(stderr, "[yhair] kernel times (ms per spp): 0: %.4f, 1: %.4f, 2: %.4f, 3: %.4f, 4: %.4f, 5: %.4f, 6: %.4f, 7: %.4f -> %d (%d spp)\n", ctx->shape_ms[0], ctx->shape_ms[1], ctx->shape_ms[2], ctx->shape_ms[3], ctx->shape_ms[4], ctx->shape_ms[5], ctx->shape_ms[6], ctx->shape_ms[7], want, nsamples);
+        fprintf(stderr, "[yhair] kernel times (ms per spp): 0: %.4f, 1: %.4f, 2: %.4f, 3: %.4f, 4: %.4f, 5: %.4f, 6: %.4f, 7: %.4f, 8: %.4f -> %d (%d spp)\n", ctx->shape_ms[0], ctx->shape_ms[1], ctx->shape_ms[2], ctx->shape_ms[3], ctx->shape_ms[4], ctx->shape_ms[5], ctx->shape_ms[6], ctx->shape_ms[7], ctx->shape_ms[8], want, nsamples);
       ctx->launch_shape = ctx->state.launch_shape = want;
       // The list is rewritten by a blocking copy on the null stream; the context's stream is non-blocking, so a launch
       // queued by yh_trace_samples_async may still be reading it: wait for it first.
@@ -1635,7 +1635,7 @@ static int trace_impl(yh_context* ctx, int nsamples, bool counted, bool sync) {
       if (int rc = upload_work_items(ctx)) return rc;
     }
   }
-  if (counted && (ctx->state.launch_shape == 5 || (ctx->state.launch_shape >= 4 && (ctx->scene.general_materials || ctx->state.launch_shape == 7)))) {  // the octet kernel's list holds half-quadrant entries: the instrumented (quad) build needs its own
+  if (counted && (ctx->state.launch_shape == 5 || (ctx->state.launch_shape >= 4 && (ctx->scene.general_materials || ctx->state.launch_shape >= 7)))) {  // the octet kernel's list holds half-quadrant entries: the instrumented (quad) build needs its own
     ctx->launch_shape = ctx->state.launch_shape = 0;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     if (int rc = upload_work_items(ctx)) return rc;
@@ -1652,7 +1652,7 @@ static int trace_impl(yh_context* ctx, int nsamples, bool counted, bool sync) {
       if (int rc = upload_work_items(ctx)) return rc;
     }
   }
-  if ((shape == 4 || shape == 6 || shape == 7) && !counted && !getenv("YHAIR_SHAPE") &&
+  if ((shape == 4 || shape >= 6) && !counted && !getenv("YHAIR_SHAPE") &&
       yhk_trace_occupancy(yhk_trace_lds_bytes(&ctx->scene, shape), ctx->scene.general_materials, shape) < 1) {  // (likewise: a tree too deep for the wide forms' LDS stacks)
     ctx->shape_ms[shape] = std::numeric_limits<double>::infinity();
     shape = 0;

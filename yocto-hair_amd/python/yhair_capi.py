@@ -306,10 +306,10 @@ class Context:
 
     def kernel_trials(self):
         """{launch shape: (ms per sample of its fastest trial, number of trials)} for the shapes tried on this image."""
-        ms, tr = (C.c_double * 8)(), (C.c_int * 8)()
-        n = self.lib.yh_kernel_trials(self.h, ms, tr, 8)
+        ms, tr = (C.c_double * 16)(), (C.c_int * 16)()
+        n = self.lib.yh_kernel_trials(self.h, ms, tr, 16)
         self._chk(min(n, 0))
-        return {k: (round(ms[k], 5), tr[k]) for k in range(n) if tr[k] or ms[k]}
+        return {k: (round(ms[k], 5), tr[k]) for k in range(min(n, 16)) if tr[k] or ms[k]}
 
     def item_costs(self):
         """Per work item (tile * 4 + quadrant) cost of the most recent launch."""
