@@ -275,14 +275,14 @@ int yh_last_trace_ms(const yh_context* ctx, float* ms, int* launches);
  * measured times; every choice renders the same bits): 0 = k_trace, a quad of lanes per path, 512 threads
  * x 4 waves per SIMD; 1 = the same at 256 x 5 (dense images); 3 = k_stream, one lane per path (dense
  * images); 4 = k_trace with an OCTET per path over 8-wide BVH nodes, 7 = the same with leaf pairs, 6 =
- * SIXTEEN lanes per path over 16-wide nodes (launches bound by the chain of one path: few expensive pixels
- * per GPU); 2 = quads over 8-wide nodes and 5 = quads and octets side by side on two streams: never
+ * SIXTEEN lanes per path over 16-wide nodes, 8 = the same with leaf groups (launches bound by the chain of
+ * one path: few expensive pixels per GPU); 2 = quads over 8-wide nodes and 5 = quads and octets side by side on two streams: never
  * chosen (YHAIR_SHAPE=n forces a shape). < 0 = nothing launched yet (or an error code). With
  * yh_trace_params::hair_exact it is always 0.                                                            */
 int yh_launch_shape(const yh_context* ctx);
 /* The measurements behind that choice on the current image: for launch shape k < count, the milliseconds per sample
  * of its fastest 32-sample trial launch (0 = not tried, < 0 = cannot run on this device) and the number of trials.
- * Returns the number of launch shapes (8), or a negative error code.                                               */
+ * Returns the number of launch shapes (9), or a negative error code.                                               */
 int yh_kernel_trials(const yh_context* ctx, double* ms_per_sample, int* trials, int count);
 
 /* Load-balance telemetry: for every tile id (row-major over ceil(W/8) x

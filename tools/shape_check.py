@@ -3,7 +3,7 @@
 4-wide nodes, 2 k_trace over 8-wide nodes, 3 k_stream, 4 k_trace with octets) — bitwise image / RNG comparison on
 small scenes, then throughput of each on a BASELINE config.
 usage: shape_check.py check            (WF_SHAPE=n against shape 0 on seven small scenes)
-       shape_check.py SCENE RES SPP SHAPES   e.g. sphere-hairblock 720 64 0,2,4"""
+       shape_check.py SCENE RES SPP SHAPES [WORLD]   e.g. sphere-hairblock 720 64 0,2,4   (WORLD: shard 0 of WORLD only)"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -42,6 +42,9 @@ else:
     shapes = [int(x) for x in (sys.argv[4] if len(sys.argv) > 4 else "0,1,2").split(",")]
     sf = yh.SceneFile(make_scenes.ensure_scene(name, SCENES, scale=1.0))
     ctx.upload_scene(sf.desc)
+    world = int(sys.argv[5]) if len(sys.argv) > 5 else 1
+    ctx.set_shard(0, world)
+    if world > 1: name += f" (shard 0 of {world})"
     ref = None
     for rnd in range(2):
         for shape in shapes:
