@@ -237,6 +237,11 @@ def main():
     if a.gpus > 1 and world == 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE=1")
     ndev = max(1, torch.cuda.device_count())  # (counting devices does not initialise the GPU)
+    # stdout carries the ONE JSON line and nothing else: whatever native libraries print there (gloo's "[Gloo] Rank ..."
+    # banner, RCCL's NCCL_DEBUG lines) goes to stderr instead
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     backend = a.backend
     if backend == "nccl" and world > ndev:  # ranks share a device: RCCL refuses duplicate GPUs, stage through gloo
         backend = "gloo"
@@ -472,7 +477,7 @@ def main():
             out["parity"] = parity
         if cpu is not None and world == 1:
             out["cpu_baseline"] = cpu
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=json_out, flush=True)
     if grouped:
         dist.barrier()
         dist.destroy_process_group()
