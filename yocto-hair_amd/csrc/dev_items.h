@@ -61,6 +61,9 @@ YH_DEV void trace_items(const yhd_scene& sc, const yhd_state& st, int nsamples, 
   __syncthreads();
 
   tc.lds_nodes = sc.lds_node_count ? lds_nodes : nullptr;
+#if YH_PREFETCH
+  tc.lds_pf = (unsigned int)(size_t)(lds_tabs + YHD_LDS_TABLES_F4(&sc));  // (kernels.hip: trace_lds adds the row)
+#endif
   tc.lds_stack = lds_stack + (threadIdx.x / LPP);
   stats_t stats = {};
   tc.stats = COUNT ? &stats : nullptr;

@@ -198,6 +198,9 @@ struct trace_ctx {
   lane_stack*           ls;         // one lane per path (YH_LANE, dev_lane.h): this lane's stack, else unused
   const yhd_scene*      sc_dev;     // YH_LANE: a copy of *sc in device memory, for out-of-line callees (the kernel
                                     // argument itself must not have its address escape: it would be copied to scratch)
+#if YH_PREFETCH
+  unsigned int          lds_pf;     // byte address of the block's 256-byte LDS row that the prefetch loads land in
+#endif
 };
 // Stages the tables every kernel keeps in LDS — the scene level (objects, scene BVH nodes and primitives; when it
 // fits), the camera, the small area lights and the environment cdf index — at `at` (YHD_LDS_TABLES_F4 float4) and
@@ -304,6 +307,16 @@ struct trav_state {
 //                 sixteen: for launches bound by the chain of steps of ONE path (few expensive pixels per GPU).
 // The children of a wide node are visited in the reference's order in every mode (ranks below), so closest hits,
 // `tmax` and exact-t ties are the same.
+#ifndef YH_PREFETCH
+#define YH_PREFETCH 0 /* developer switch, bit mask by lanes per path (1: quads, 2: octets, 4: sixteen): a lane that pushes a child touches the child's cache lines */
+#endif
+// A load whose result nobody reads: the line is on its way into the L1 / L2 while the traversal is busy with the children
+// visited first (every pushed entry is popped and fetched later). An LDS-DMA load (the dword lands in a 256-byte scratch
+// row of the block's LDS, trace_ctx::lds_pf), so no register waits for data that arrives whenever it arrives; inline
+// assembly, so that the compiler neither waits for it nor counts it (its own s_waitcnt values stay correct: loads return in
+// order, more outstanding loads only make a count-based wait wait longer). M0 is not used by the compiled kernels.
+YH_DEV void prefetch_line(const void* p, unsigned int lds_row) { asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" ::"s"(lds_row), "v"(p)); }  // (s_nop: one wait state between a write of M0 and the LDS-DMA that reads it)
+YH_DEV void prefetch_drain() { asm volatile("s_waitcnt vmcnt(0)"); }
 #define YH_MODE_QUAD 0
 #define YH_MODE_W8 1
 #define YH_MODE_OCT 2
@@ -498,6 +511,28 @@ YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_obj
       }
       int  leaf_start = (int)(mycur & 0x07FFFFFFu), leaf_num = (int)((mycur >> 27) & 7u);
       int  rec        = kind == YH_KIND_LINES ? 4 : 6;  // float4 per leaf record
+#if YH_PREFETCH
+      constexpr bool PF = (YH_PREFETCH & (YH_IS_HEX(MODE) ? 4 : YH_IS_OCT(MODE) ? 2 : MODE == YH_MODE_QUAD ? 1 : 0)) != 0;
+      auto prefetch_entry = [&](unsigned int ref) {  // (YH_PREFETCH) the cache lines of a pushed child: a wide node, or a leaf's records
+        if ((ref & YH_TAG_MASK) == YH_TAG_LEAF) {
+          const char* a     = (const char*)(sc.prims + (size_t)prim_base + (size_t)(ref & 0x07FFFFFFu) * rec);
+          const int   bytes = (int)((ref >> 27) & 7u) * rec * 16;
+          prefetch_line(a, tc.lds_pf);
+          if (bytes > 128) prefetch_line(a + 128, tc.lds_pf);
+          if (bytes > 256) prefetch_line(a + 256, tc.lds_pf);
+        } else {
+          const char* a = MODE == YH_MODE_QUAD ? (const char*)(sc.nodes + 8 * (size_t)ref)
+                          : YH_IS_HEX(MODE)    ? (const char*)(sc.nodes16 + 32 * (size_t)ref)
+                                               : (const char*)(sc.nodes8 + 16 * (size_t)ref);
+          prefetch_line(a, tc.lds_pf);
+          if (MODE != YH_MODE_QUAD) prefetch_line(a + 128, tc.lds_pf);
+          if (YH_IS_HEX(MODE)) prefetch_line(a + 256, tc.lds_pf), prefetch_line(a + 384, tc.lds_pf);
+        }
+      };
+#else
+      constexpr bool PF = false;
+      auto prefetch_entry = [](unsigned int) {};
+#endif
       bool mine       = !is_leaf || (int)q < leaf_num;  // lanes beyond the leaf's count re-read its last record
 #ifdef YH_DEBUG_BOUNDS
       {
@@ -547,7 +582,10 @@ YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_obj
         M |= (unsigned int)dpp_i<YH_ROW_HALF_MIRROR>((int)M);
         M |= (unsigned int)dpp_i<YH_ROW_MIRROR>((int)M);  // hits in visiting order, bit k = k-th visited
         const bool first = h && (1u << rank) == (M & (0u - M));
-        if (h && !first) lstk[(sp + (int)__popc(M >> (rank + 1))) * STRIDE] = ref;
+        if (h && !first) {
+          lstk[(sp + (int)__popc(M >> (rank + 1))) * STRIDE] = ref;
+          if (PF) prefetch_entry(ref);
+        }
         unsigned int mine = first ? ref : 0u;
         mine |= (unsigned int)dpp_i<YH_QUAD_XOR1>((int)mine);
         mine |= (unsigned int)dpp_i<YH_QUAD_XOR2>((int)mine);
@@ -589,7 +627,10 @@ YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_obj
         if (YH_IS_OCT(MODE)) M |= (unsigned int)dpp_i<YH_ROW_HALF_MIRROR>((int)M);  // hits in visiting order, bit k = k-th visited
         const unsigned int low     = M & (0u - M);                                      // the first visited hit slot
         const bool         first_a = h_a && (1u << rank_a) == low, first_b = h_b && (1u << rank_b) == low;
-        if (h_a && !first_a) lstk[(sp + (int)__popc(M >> (rank_a + 1))) * STRIDE] = ref_a;
+        if (h_a && !first_a) {
+          lstk[(sp + (int)__popc(M >> (rank_a + 1))) * STRIDE] = ref_a;
+          if (PF) prefetch_entry(ref_a);
+        }
         if (MODE == YH_MODE_W8 && h_b && !first_b) lstk[(sp + (int)__popc(M >> (rank_b + 1))) * STRIDE] = ref_b;
         unsigned int mine = first_a ? ref_a : (first_b ? ref_b : 0u);  // child refs are never 0 (node 0 is a root)
         mine |= (unsigned int)dpp_i<YH_QUAD_XOR1>((int)mine);
@@ -630,7 +671,10 @@ YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_obj
         M |= (unsigned int)dpp_i<YH_QUAD_XOR2>((int)M);                     // hits in visiting order, bit k = k-th visited
         bool         first = h && (M & (bit - 1)) == 0;
         unsigned int after = (unsigned int)__popc(M >> (rank + 1));         // hit slots visited after this one
-        if (h && !first) lstk[(sp + (int)after) * STRIDE] = ref;
+        if (h && !first) {
+          lstk[(sp + (int)after) * STRIDE] = ref;
+          if (PF) prefetch_entry(ref);
+        }
         unsigned int mine = first ? ref : 0u;                                // child refs are never 0 (node 0 is a root)
         mine |= (unsigned int)dpp_i<YH_QUAD_XOR1>((int)mine);
         mine |= (unsigned int)dpp_i<YH_QUAD_XOR2>((int)mine);
@@ -700,6 +744,9 @@ YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_obj
       }
     }
   }
+#if YH_PREFETCH
+  prefetch_drain();
+#endif
   if (COUNT) {
     if (steps_out) *steps_out = n_steps;
     tc.stats->nodes += (unsigned int)n_nodes, tc.stats->seg += (unsigned int)n_seg, tc.stats->tri += (unsigned int)n_tri;

@@ -186,6 +186,10 @@ __global__ __launch_bounds__(256) void k_intersect(const yhd_scene sc, int n, co
   trace_ctx tc;
   tc.sc = &sc, tc.lds_nodes = nullptr, tc.stats = nullptr, tc.lds_scene = nullptr, tc.ls = nullptr, tc.sc_dev = nullptr, tc.lds_lights = nullptr, tc.lds_envtab = nullptr, tc.lds_mats = nullptr;
   tc.lds_stack   = (YH_LDS unsigned int*)stacks + (threadIdx.x >> 2);
+#if YH_PREFETCH
+  __shared__ unsigned int pf_row[64];
+  tc.lds_pf = (unsigned int)(size_t)(YH_LDS unsigned int*)pf_row;
+#endif
   const float* r = rays + 8 * (size_t)i;
   ray_t ray      = ray_t{ld3(r), ld3(r + 3), r[6], r[7]};
   hit_t h        = trace_ray<false, 64>(tc, ray, -1);
@@ -465,7 +469,7 @@ static trace_kernel_t trace_kernel(bool counted, bool general, int shape, int sh
 }
 static size_t trace_lds(const yhd_scene* sc, int shape) {
   const int entries = shape_hex(shape) ? sc->stack_entries16 : (shape == 2 || shape_oct(shape)) ? sc->stack_entries8 : sc->stack_entries;
-  return (size_t)sc->lds_node_count * 128 + (size_t)entries * shape_groups(shape) * 4 + (size_t)YHD_LDS_TABLES_F4(sc) * 16;
+  return (size_t)sc->lds_node_count * 128 + (size_t)entries * shape_groups(shape) * 4 + (size_t)YHD_LDS_TABLES_F4(sc) * 16 + (YH_PREFETCH ? 256 : 0);
 }
 // `shape`: 0, 1, 2 or 4 (above); the caller built the work list for it (shape 4: half-quadrant entries)
 int yhk_trace(const yhd_scene* sc, const yhd_state* st, int nsamples, yhd_counters* counters, int shape,
