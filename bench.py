@@ -247,6 +247,8 @@ def main():
         backend = "gloo"
     if backend == "gloo":
         local_rank %= ndev
+    if world > ndev:  # several ranks render on one device at once: each plans for its share of the resident waves
+        os.environ["YHAIR_DEVICE_SHARE"] = str(-(-world // ndev))
     collective = (f"{backend}" + (f" ({world} ranks on {ndev} device(s): CPU staging)" if backend == "gloo" and world > 1 else
                                   " = RCCL" if backend == "nccl" else ""))
     torch.cuda.set_device(local_rank)

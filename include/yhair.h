@@ -277,7 +277,8 @@ int yh_last_trace_ms(const yh_context* ctx, float* ms, int* launches);
  * images); 4 = k_trace with an OCTET per path over 8-wide BVH nodes, 7 = the same with leaf pairs, 6 =
  * SIXTEEN lanes per path over 16-wide nodes, 8 = the same with leaf groups (launches bound by the chain of
  * one path: few expensive pixels per GPU); 2 = quads over 8-wide nodes and 5 = quads and octets side by side on two streams: never
- * chosen (YHAIR_SHAPE=n forces a shape). < 0 = nothing launched yet (or an error code). With
+ * chosen (YHAIR_SHAPE=n forces a shape; YHAIR_DEVICE_SHARE=k tells the choice that k processes render on
+ * this device at once). < 0 = nothing launched yet (or an error code). With
  * yh_trace_params::hair_exact it is always 0.                                                            */
 int yh_launch_shape(const yh_context* ctx);
 /* The measurements behind that choice on the current image: for launch shape k < count, the milliseconds per sample

@@ -210,6 +210,12 @@ YH_DEV void trace_items(const yhd_scene& sc, const yhd_state& st, int nsamples, 
     }
     if (lane == 0) {
       unsigned int dt = (unsigned int)(wall_clock64() - t0);
+#ifdef YH_LAB_WHERE /* developer experiment (tools/where_items_ran.py): the low 13 bits of the cost say where the wave ran — XCC, SE, SH, CU, SIMD */
+      {
+        const unsigned int hw = __builtin_amdgcn_s_getreg(63492), xcc = __builtin_amdgcn_s_getreg(63508);  // HW_REG_HW_ID, HW_REG_XCC_ID
+        dt = (dt & ~0x1FFFu) | ((xcc & 7u) << 10) | (((hw >> 13) & 7u) << 7) | (((hw >> 12) & 1u) << 6) | (((hw >> 8) & 15u) << 2) | ((hw >> 4) & 3u);
+      }
+#endif
       if (YH_IS_OCT(MODE) || YH_IS_HEX(MODE)) atomicAdd(&st.tile_cost[item], dt);  // the halves / quarters of a quadrant add up (zeroed before the launch)
       else st.tile_cost[item] = dt;
       if (COUNT) atomicAdd(&counters->cyc_tile, (unsigned long long)dt);

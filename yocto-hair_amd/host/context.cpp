@@ -411,12 +411,14 @@ bool dense_by_costs(const yh_context* ctx, bool* known, bool* chain_bound = null
     }
   *known = mx != 0;
   if (mx == 0) return false;
+  // YHAIR_DEVICE_SHARE=k: k processes render on this device at once (bench.py with more ranks than devices): a k-th of the waves is ours
+  static const double share = std::max(1, getenv("YHAIR_DEVICE_SHARE") ? atoi(getenv("YHAIR_DEVICE_SHARE")) : 1);
   int    lds      = yhk_trace_lds_bytes(&ctx->scene, 0);
-  double resident = (double)ctx->num_cus * std::max(1, yhk_trace_occupancy(lds, ctx->scene.general_materials, 0)) * (yhk_block_threads(0) / 64);
+  double resident = (double)ctx->num_cus * std::max(1, yhk_trace_occupancy(lds, ctx->scene.general_materials, 0)) * (yhk_block_threads(0) / 64) / share;
   if (getenv("YHAIR_TIMING")) fprintf(stderr, "[yhair] launch shape: worth %.0f items, resident waves %.0f\n", (double)sum / (double)mx, resident);
   if (chain_bound) {  // the octet kernel needs two waves per expensive item: all of them resident at once, with room to spare
     const int    lds4 = yhk_trace_lds_bytes(&ctx->scene, 4);
-    const double res4 = (double)ctx->num_cus * std::max(1, yhk_trace_occupancy(lds4, ctx->scene.general_materials, 4)) * (yhk_block_threads(4) / 64);
+    const double res4 = (double)ctx->num_cus * std::max(1, yhk_trace_occupancy(lds4, ctx->scene.general_materials, 4)) * (yhk_block_threads(4) / 64) / share;
     // (candidacy only — the trials decide: generous bounds cost a wasted trial, tight ones a missed kernel; `textured`, whose
     // item costs are very uneven, is worth 1 500 items and still renders 1.45 x faster with sixteen lanes per path)
     *chain_bound      = 2.0 * (double)sum / (double)mx <= 1.1 * res4;  // (C1 at 720^2 is worth 2 400-3 100 items: not one; half of it 1 400-1 700: one)
