@@ -44,3 +44,11 @@ def per_cu(run):
 p1, p2 = per_cu(runs[1]), per_cu(runs[2])
 common = sorted(set(p1) & set(p2))
 print("correlation of per-CU mean item time between two launches: %.2f" % np.corrcoef([p1[v] for v in common], [p2[v] for v in common])[0, 1])
+# the slow XCC: its hardware, or the items it was handed? The same items' times in the PREVIOUS launch (wherever they ran then)
+for k in (2, 3):
+    ms, c, w = runs[k]
+    cp = runs[k - 1][1]
+    heavy = c > 0.5 * c.max()
+    xcc = (w >> 10) & 7
+    print(f"launch {k}: per XCC, mean time of its heavy items now | of the same items in launch {k - 1}: " +
+          "  ".join(f"{c[heavy & (xcc == x)].mean():.2f}|{cp[heavy & (xcc == x)].mean():.2f}" for x in range(8) if (heavy & (xcc == x)).any()))
