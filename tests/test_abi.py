@@ -240,6 +240,30 @@ def test_wide_nodes_keep_the_reference_visiting_order(yh, width):
             assert np.array_equal(slots[w, o, :6], leaf_box[key])
 
 
+def test_leaf_group_merge_is_the_sequential_rule():
+    """Leaf groups (csrc/dev_trace.h, YH_MODE_OCTP / YH_MODE_HEXP) test up to four leaves of up to four primitives in one
+    step, every primitive against the ray as it was BEFORE the step, and keep the accepted primitive of minimum t, the
+    later one on a tie. The reference meets the primitives one after the other, each against the ray shortened by the
+    hits before it (pt.cpp:905-923: `ray.tmax = distance` after every hit; the primitive test rejects only t > tmax,
+    math.h:3450). Same survivor, also with ties and with misses in between: checked here on random cases."""
+    rng = np.random.default_rng(7)
+    for _ in range(20000):
+        n = int(rng.integers(1, 17))
+        t = rng.integers(1, 6, n).astype(np.float32)  # few distinct values: many exact ties
+        hits_if_reachable = rng.random(n) < 0.6      # the primitive test's verdict apart from its t > tmax reject
+        tmax0 = np.float32(rng.integers(2, 7))
+        best, tmax = -1, tmax0  # the reference: sequential, shrinking tmax
+        for i in range(n):
+            if hits_if_reachable[i] and not t[i] > tmax:
+                best, tmax = i, t[i]
+        cand = [i for i in range(n) if hits_if_reachable[i] and not t[i] > tmax0]  # the device: all against the old tmax ...
+        merged = -1
+        for i in cand:  # ... then minimum t, the later index on a tie
+            if merged < 0 or t[i] < t[merged] or (t[i] == t[merged] and i > merged):
+                merged = i
+        assert merged == best
+
+
 def test_traversal_loops_do_not_spill():
     """The traversal loop of the product kernels (plain k_trace in both launch shapes, plain k_stream) must not contain
     scratch instructions: a spill reload there stalls every step of every ray (0.75-0.8x on the dense configs), and
