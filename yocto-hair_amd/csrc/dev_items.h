@@ -69,26 +69,24 @@ YH_DEV void trace_items(const yhd_scene& sc, const yhd_state& st, int nsamples, 
   tc.stats = COUNT ? &stats : nullptr;
 
   const int lane = threadIdx.x & 63;
-  // The first item of a wave by position (the host placed the list: which items share a SIMD), the others from the cursor.
-  // (Whatever the grid: the entries no wave takes by position are served by the cursor.)
-  // Compiled only with -DYH_LAB_PLACEMENT (a developer experiment, measured without gain, host/context.cpp: place_first_round): its mere
-  // presence costs the quad kernel 3.5 % on C1 (register allocation of the loops below; tools/ab_sweep.sh, profiles/r03/).
-#ifdef YH_LAB_PLACEMENT
-  const int by_position  = min(st.static_items, (int)(gridDim.x * (BLOCK / 64)));
-  int       first_static = (int)(blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6));
-#else
-  const int by_position  = 0;
-  int       first_static = -1;
+  // The FIRST item of a wave is the list entry at the wave's own position (workgroup x waves per workgroup + wave), the
+  // others come from the cursor, which starts behind those positions. The four wave slots of a SIMD do not run at the same
+  // speed (slot 0: 10.4 ms for the kind of item that takes 13.3 ms in slot 3 on C1, profiles/r03/where_items_ran.txt) and a
+  // wave's slot follows from the dispatch order of its workgroup, so the host lays the head of the list out by position: the
+  // most expensive items on the fastest slots, none on the slowest (host/context.cpp: lay_out_first_round). Any list is
+  // rendered correctly — every entry is taken exactly once, by position or through the cursor; the layout is a matter of time.
+#ifndef YH_FIRST_BY_POSITION
+#define YH_FIRST_BY_POSITION 1
 #endif
+  const int by_position = YH_FIRST_BY_POSITION ? (int)(gridDim.x * (BLOCK / 64)) : 0;
+  int       t_first     = YH_FIRST_BY_POSITION ? __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6))) : -1;
   while (true) {
-    int t = 0;
-    if (first_static >= 0 && first_static < by_position) {
-      t = first_static;
-    } else {
+    int t = t_first;
+    if (t < 0) {
       if (lane == 0) t = atomicAdd(st.tile_cursor, 1);
       t = __builtin_amdgcn_readfirstlane(t) + by_position;
     }
-    first_static = -1;
+    t_first = -1;
     if (t >= st.num_tiles) break;
 #ifdef YH_LAB_PRIO /* developer experiment (YHAIR_PRIO_ITEMS), measured without effect: compiled out */
     if (st.prio_items > 0) {  // issue priority for the waves that hold the most expensive items (the head of the cost-sorted list)
@@ -213,7 +211,11 @@ YH_DEV void trace_items(const yhd_scene& sc, const yhd_state& st, int nsamples, 
 #ifdef YH_LAB_WHERE /* developer experiment (tools/where_items_ran.py): the low 13 bits of the cost say where the wave ran — XCC, SE, SH, CU, SIMD */
       {
         const unsigned int hw = __builtin_amdgcn_s_getreg(63492), xcc = __builtin_amdgcn_s_getreg(63508);  // HW_REG_HW_ID, HW_REG_XCC_ID
+#ifdef YH_LAB_WHERE_SLOT /* ... or XCC, second half of the grid, wave of the workgroup, hardware wave slot, SIMD */
+        dt = (dt & ~0x1FFFu) | ((xcc & 7u) << 10) | ((blockIdx.x * 2 >= gridDim.x ? 1u : 0u) << 9) | (((threadIdx.x >> 6) & 7u) << 6) | ((hw & 15u) << 2) | ((hw >> 4) & 3u);
+#else
         dt = (dt & ~0x1FFFu) | ((xcc & 7u) << 10) | (((hw >> 13) & 7u) << 7) | (((hw >> 12) & 1u) << 6) | (((hw >> 8) & 15u) << 2) | ((hw >> 4) & 3u);
+#endif
       }
 #endif
       if (YH_IS_OCT(MODE) || YH_IS_HEX(MODE)) atomicAdd(&st.tile_cost[item], dt);  // the halves / quarters of a quadrant add up (zeroed before the launch)

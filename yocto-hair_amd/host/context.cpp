@@ -317,6 +317,7 @@ struct yh_context {
   bool             costs_settled = false;   // the item costs come from a launch of at least YH_TRIAL_SPP samples (not from the 1-spp probe)
   bool             planned_settled = false; // ... and the most recent launch was planned from such costs (only then does its time rank a kernel)
   int              dense = -1;
+  int              avg_shape = -1;  // (YHAIR_COST_AVG) the launch shape the blended item costs were measured with
   int              chain16 = -1; // 1: ... and four times as many: the sixteen-lane form (shape 6) is a candidate too
   int              chain = -1;   // 1: so few expensive items that even twice as many waves would all be resident: the launch is bound by the
                                  // chain of steps of ONE path, and the octet kernel (half the paths per wave, shape 4) is a candidate
@@ -609,7 +610,7 @@ static void split_items_for_hex(std::vector<int>& items) {
 }
 static void split_items_side_by_side(yh_context* ctx, std::vector<int>& items);
 static int  ensure_wide_nodes(yh_context* ctx);
-static void place_first_round(yh_context* ctx, std::vector<int>& items);
+static void lay_out_first_round(const yh_context* ctx, std::vector<int>& items, int shape);
 static int  trace_impl(yh_context* ctx, int nsamples, bool counted, bool sync);
 
 const char* yh_version(void) { return "yhair 0.1 (gfx950, HIP)"; }
@@ -1165,11 +1166,11 @@ int yh_init_state(yh_context* ctx, const yh_trace_params* params) {
   const int first_shape = getenv("YHAIR_SHAPE") ? choose_launch_shape(ctx) : ctx->launch_shape;
   ctx->state.tiles_x = tx, ctx->state.num_groups = 1, ctx->state.group_begin[0] = 0, ctx->state.group_begin[1] = (int)tiles.size();
   ctx->state.static_items = 0;
-  if (params->shader == YH_SHADER_PATH && first_shape == 0) place_first_round(ctx, tiles);
   if (params->shader == YH_SHADER_PATH && first_shape == 3) deal_items_for_stream(ctx, tiles);
   if (params->shader == YH_SHADER_PATH && (first_shape == 4 || first_shape == 7)) split_items_for_octets(tiles);
   if (params->shader == YH_SHADER_PATH && first_shape == 5) split_items_side_by_side(ctx, tiles);
   if (params->shader == YH_SHADER_PATH && (first_shape == 6 || first_shape == 8)) split_items_for_hex(tiles);
+  if (!getenv("YHAIR_NO_LAYOUT")) lay_out_first_round(ctx, tiles, params->shader == YH_SHADER_PATH ? first_shape : 0);  // (developer switch: the plain cost order)
   tiles.reserve(4 * (size_t)ctx->num_tiles_total * 4 + 4);  // (the list's buffer holds the octet / sixteen-lane kernels' longer lists too)
   int rc;
   if ((rc = upload(ctx, ctx->d_rng_state, st.data(), npix * 8))) return rc;
@@ -1231,11 +1232,11 @@ static int upload_work_items(yh_context* ctx) {
   ctx->state.num_groups = 1, ctx->state.group_begin[0] = 0, ctx->state.group_begin[1] = (int)tiles.size();
   ctx->state.static_items = 0;
   ctx->state.prio_items   = getenv("YHAIR_PRIO_ITEMS") ? atoi(getenv("YHAIR_PRIO_ITEMS")) : 0;  // developer A/B switch (a library built with -DYH_LAB_PRIO)
-  if (ctx->state.shader == YH_SHADER_PATH && ctx->state.launch_shape == 0) place_first_round(ctx, tiles);
   if (ctx->state.shader == YH_SHADER_PATH && ctx->state.launch_shape == 3) deal_items_for_stream(ctx, tiles);
   if (ctx->state.shader == YH_SHADER_PATH && (ctx->state.launch_shape == 4 || ctx->state.launch_shape == 7)) split_items_for_octets(tiles);
   if (ctx->state.shader == YH_SHADER_PATH && ctx->state.launch_shape == 5) split_items_side_by_side(ctx, tiles);
   if (ctx->state.shader == YH_SHADER_PATH && (ctx->state.launch_shape == 6 || ctx->state.launch_shape == 8)) split_items_for_hex(tiles);
+  if (!getenv("YHAIR_NO_LAYOUT")) lay_out_first_round(ctx, tiles, ctx->state.shader == YH_SHADER_PATH ? ctx->state.launch_shape : 0);
   ctx->state.num_tiles = (int)tiles.size();
   HIPCHK(ctx, hipMemcpy(ctx->d_tiles.p, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice));
   return YH_OK;
@@ -1338,53 +1339,32 @@ static int ensure_wide_nodes(yh_context* ctx) {
   return YH_OK;
 }
 
-// WHO SHARES A SIMD (k_trace 512 x 4 on a sparse image) — a developer experiment, OFF unless YHAIR_PLACEMENT=1: measured
-// without gain (profiles/r03/first_round_placement_ab.txt: C1 16.6 ms with the placement below, 16.1 with cost bands
-// only, 16.2 without, same box; whichever wave sits beside a critical one, its chain takes as long). The idea:
-// All expensive items of such a launch are resident from its
-// start, 3.5 per SIMD on C1, and the launch ends with the most expensive one: 14.8 ms per 64 spp where the median
-// expensive item takes 9.0 — while the same chain takes 12.3 ms on an idle GPU: a fifth of it is waiting for an issue
-// slot behind the three other expensive waves of its SIMD (SQ_WAIT_INST_ANY 23 % of the wave cycles at 720^2, 5 % at
-// 180^2). Which waves those are is the host's to decide: a workgroup's waves go to the SIMDs in cyclic order, so waves w
-// and w + 4 of a 512-thread workgroup share one, and the first item of a wave can be handed out by position
-// (yhd_state::static_items). The G most expensive items (G = workgroups of the launch) go to wave 0 of each workgroup
-// with a CHEAP item on wave 4 beside them — the SIMD of a critical chain holds two of them and two cheap waves instead
-// of four expensive ones — and the other expensive items, dealt by cost band, fill waves 1-3 and 5-7: they have a third
-// of the launch to spare. Everything else goes through the cursor as before. Pixels do not depend on any of it.
-static void place_first_round(yh_context* ctx, std::vector<int>& items) {
-  if (!getenv("YHAIR_PLACEMENT") || ctx->dense != 0 || !ctx->costs_settled) return;  // (developer switch, needs a library built with -DYH_LAB_PLACEMENT; sparse images with settled costs only)
-  const int wpb = yhk_block_threads(0) / 64;
-  if (wpb != 8) return;
-  const int lds = yhk_trace_lds_bytes(&ctx->scene, 0);
-  const int occ = yhk_trace_occupancy(lds, ctx->scene.general_materials, 0);
-  if (occ < 1) return;
-  const int G = std::min(((int)items.size() + wpb - 1) / wpb, ctx->num_cus * occ);  // the grid trace_impl will launch
-  const int H = expensive_items(ctx, items);
-  if (G < 1 || (int)items.size() < 16 * G || H < 2 * G) return;  // (too few expensive items to matter, or no cheap items to put beside them)
-  if (getenv("YHAIR_TIMING")) fprintf(stderr, "[yhair] first round placed: %d workgroups, %d expensive items\n", G, H);
-  std::vector<int> out((size_t)8 * G, -1);
-  std::vector<char> used(items.size(), 0);
-  size_t cheap = items.size();  // cheap partners: from the list's end
-  const int mode = getenv("YHAIR_PLACE_MODE") ? atoi(getenv("YHAIR_PLACE_MODE")) : 0;  // developer A/B: 1 = cheap partner on wave 1, 2 = cost bands only (no cheap partner)
-  const int cheap_slot = mode == 1 ? 1 : 4;
-  for (int b = 0; b < G; b++) {
-    out[(size_t)8 * b] = items[(size_t)b], used[(size_t)b] = 1;  // wave 0: the b-th most expensive item
-    int k = 0;
-    for (int w = 1; w < 8; w++) {  // the other waves: one item of each following cost band
-      if (w == cheap_slot && mode != 2) continue;
-      const size_t r = (size_t)G + (size_t)k * G + (size_t)b;
-      out[(size_t)8 * b + w] = items[r], used[r] = 1, k++;
-    }
+// THE HEAD OF THE LIST BY POSITION. A wave of k_trace takes its first item from the list entry at its own position
+// (workgroup x waves per workgroup + wave; csrc/dev_items.h) and later ones from the cursor behind those positions. The four
+// wave slots of a SIMD do not run at the same speed: on C1 the same kind of item takes 10.4 ms in hardware slot 0, 11.0 in
+// slot 1, 11.8 in slot 2 and 13.3 in slot 3 (profiles/r03/where_items_ran.txt: the issue arbiter favours the older wave), and
+// the launch ends with its slowest item. A wave's slot follows from the dispatch order: the workgroups come round by round,
+// one per CU and round, and waves w and w + 4 of a 512-thread workgroup share a SIMD — so slot = round x (waves per workgroup
+// / 4) + wave / 4. The most expensive items go to the slot-0 waves, the next to slot 1, and so on: on a sparse image the
+// slowest slot holds none of the expensive items. Purely a matter of time: whatever the layout, every entry is taken once.
+static void lay_out_first_round(const yh_context* ctx, std::vector<int>& items, int shape) {
+  if (shape == 3 || shape == 5 || items.empty()) return;  // (k_stream deals its items itself; side by side keeps two lists in cost order)
+  const int wpb = yhk_block_threads(shape) / 64;
+  const int occ = yhk_trace_occupancy(yhk_trace_lds_bytes(&ctx->scene, shape), ctx->scene.general_materials, shape);
+  if (occ < 1 || wpb < 1) return;
+  const int    G = std::max(1, std::min(((int)items.size() + wpb - 1) / wpb, ctx->num_cus * occ));  // the grid trace_impl launches
+  const size_t P = std::min((size_t)G * wpb, items.size());                                           // entries taken by position
+  std::vector<std::pair<uint64_t, uint32_t>> order;  // (slot class, place inside it) -> position
+  order.reserve(P);
+  for (size_t pos = 0; pos < P; pos++) {
+    const uint64_t b = pos / wpb, w = pos % wpb;
+    const uint64_t cls = (b / ctx->num_cus) * ((wpb + 3) / 4) + w / 4;
+    order.emplace_back((cls << 40) | ((b % ctx->num_cus) << 8) | (w % 4), (uint32_t)pos);
   }
-  for (int b = 0; b < G && mode != 2; b++) {  // wave 4 (the SIMD of wave 0): a cheap item
-    while (cheap > 0 && used[cheap - 1]) cheap--;
-    if (cheap == 0) return;  // (cannot happen: items.size() >= 8 G)
-    out[(size_t)8 * b + cheap_slot] = items[cheap - 1], used[cheap - 1] = 1, cheap--;
-  }
-  for (size_t i = 0; i < items.size(); i++)
-    if (!used[i]) out.push_back(items[i]);  // the rest in the list's order: through the cursor
-  ctx->state.static_items = 8 * G;
-  items.swap(out);
+  std::sort(order.begin(), order.end());
+  std::vector<int> head(P);
+  for (size_t k = 0; k < P; k++) head[order[k].second] = items[k];  // the k-th most expensive item on the k-th fastest wave
+  std::copy(head.begin(), head.end(), items.begin());
 }
 
 // Bookkeeping after a synchronous launch: its time (kernel selection) and, after launches 1, 2, 4, 8, ... of a state,
@@ -1396,8 +1376,25 @@ static int replan_after_launch(yh_context* ctx, int nsamples) {
   // read-back, sort and upload are a few hundred microseconds of a 16 ms launch.
   const unsigned li      = ++ctx->launches_of_state;
   // (... and after the first launch long enough to settle the costs, whenever it comes: the kernel trials wait for it)
-  const bool     refresh = (li & (li - 1)) == 0 || (!ctx->costs_settled && nsamples >= YH_TRIAL_SPP && ctx->state.shader == YH_SHADER_PATH);
-  if (refresh) HIPCHK(ctx, hipMemcpy(ctx->item_cost.data(), ctx->d_tile_cost.p, ctx->item_cost.size() * 4, hipMemcpyDeviceToHost));
+  bool           refresh = (li & (li - 1)) == 0 || (!ctx->costs_settled && nsamples >= YH_TRIAL_SPP && ctx->state.shader == YH_SHADER_PATH);
+  // EXPERIMENT (YHAIR_COST_AVG=w, YHAIR_REFRESH_EVERY=n): the cost an item reports is its work divided by the speed of the wave
+  // slot it happened to get; ranking by the LAST measurement alone sends a heavy item that sat in a fast slot to a slow one
+  // next time. Blend the measurements (normalised to 64 samples) instead.
+  static const double avg_w = getenv("YHAIR_COST_AVG") ? atof(getenv("YHAIR_COST_AVG")) : 0.0;
+  static const int    every = getenv("YHAIR_REFRESH_EVERY") ? atoi(getenv("YHAIR_REFRESH_EVERY")) : 0;
+  if (every > 0 && li <= (unsigned)every) refresh = true;
+  if (refresh && avg_w > 0 && ctx->state.shader == YH_SHADER_PATH && nsamples > 0) {
+    std::vector<unsigned int> m(ctx->item_cost.size());
+    HIPCHK(ctx, hipMemcpy(m.data(), ctx->d_tile_cost.p, m.size() * 4, hipMemcpyDeviceToHost));
+    const double norm  = 64.0 / (double)nsamples;
+    const bool   blend = ctx->costs_settled && nsamples >= YH_TRIAL_SPP && ctx->last_shape == ctx->avg_shape;
+    for (size_t i = 0; i < m.size(); i++) {
+      const double v = (double)m[i] * norm;
+      ctx->item_cost[i] = (unsigned int)std::min(4.0e9, blend ? avg_w * v + (1.0 - avg_w) * (double)ctx->item_cost[i] : v);
+    }
+    ctx->avg_shape = ctx->last_shape;
+  } else if (refresh)
+    HIPCHK(ctx, hipMemcpy(ctx->item_cost.data(), ctx->d_tile_cost.p, ctx->item_cost.size() * 4, hipMemcpyDeviceToHost));
   if (refresh && ctx->last_shape == 5)  // an item that ran as octets reports the time of its two halves, 2 x 0.74 of what it costs as a quad
     for (int it : ctx->hy_oct_items) ctx->item_cost[(size_t)it] = (unsigned int)((double)ctx->item_cost[(size_t)it] * (1.0 / 1.48));
   if (ctx->state.shader == YH_SHADER_PATH && (refresh || ctx->have_costs)) record_launch(ctx, nsamples, refresh);
