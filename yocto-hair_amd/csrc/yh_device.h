@@ -213,9 +213,9 @@ typedef struct yhd_state {
   int         bounces;
   float       clamp;
   int         shard_rank, shard_world;  // tile ids owned: rank, rank + world, ...
-  // k_trace: the first `static_items` entries of `tiles` are handed out BY POSITION — wave w of workgroup b starts with
-  // entry b * (waves per workgroup) + w — so that the host decides which items share a SIMD (host/context.cpp:
-  // place_first_round); the rest go through the cursor as before. 0: everything through the cursor.
+  // (k_trace hands the first grid x waves-per-workgroup entries of `tiles` out BY POSITION — wave w of workgroup b starts
+  // with entry b * (waves per workgroup) + w, the rest go through the cursor — and the host lays that head of the list out by
+  // hardware wave slot, host/context.cpp: lay_out_first_round. This field is not read any more.)
   int         static_items;
   // k_trace: the waves that take one of the first `prio_items` entries of `tiles` (the most expensive items: the list is
   // cost-sorted) run at raised issue priority (s_setprio); 0: off

@@ -317,7 +317,6 @@ struct yh_context {
   bool             costs_settled = false;   // the item costs come from a launch of at least YH_TRIAL_SPP samples (not from the 1-spp probe)
   bool             planned_settled = false; // ... and the most recent launch was planned from such costs (only then does its time rank a kernel)
   int              dense = -1;
-  int              avg_shape = -1;  // (YHAIR_COST_AVG) the launch shape the blended item costs were measured with
   int              chain16 = -1; // 1: ... and four times as many: the sixteen-lane form (shape 6) is a candidate too
   int              chain = -1;   // 1: so few expensive items that even twice as many waves would all be resident: the launch is bound by the
                                  // chain of steps of ONE path, and the octet kernel (half the paths per wave, shape 4) is a candidate
@@ -1376,25 +1375,8 @@ static int replan_after_launch(yh_context* ctx, int nsamples) {
   // read-back, sort and upload are a few hundred microseconds of a 16 ms launch.
   const unsigned li      = ++ctx->launches_of_state;
   // (... and after the first launch long enough to settle the costs, whenever it comes: the kernel trials wait for it)
-  bool           refresh = (li & (li - 1)) == 0 || (!ctx->costs_settled && nsamples >= YH_TRIAL_SPP && ctx->state.shader == YH_SHADER_PATH);
-  // EXPERIMENT (YHAIR_COST_AVG=w, YHAIR_REFRESH_EVERY=n): the cost an item reports is its work divided by the speed of the wave
-  // slot it happened to get; ranking by the LAST measurement alone sends a heavy item that sat in a fast slot to a slow one
-  // next time. Blend the measurements (normalised to 64 samples) instead.
-  static const double avg_w = getenv("YHAIR_COST_AVG") ? atof(getenv("YHAIR_COST_AVG")) : 0.0;
-  static const int    every = getenv("YHAIR_REFRESH_EVERY") ? atoi(getenv("YHAIR_REFRESH_EVERY")) : 0;
-  if (every > 0 && li <= (unsigned)every) refresh = true;
-  if (refresh && avg_w > 0 && ctx->state.shader == YH_SHADER_PATH && nsamples > 0) {
-    std::vector<unsigned int> m(ctx->item_cost.size());
-    HIPCHK(ctx, hipMemcpy(m.data(), ctx->d_tile_cost.p, m.size() * 4, hipMemcpyDeviceToHost));
-    const double norm  = 64.0 / (double)nsamples;
-    const bool   blend = ctx->costs_settled && nsamples >= YH_TRIAL_SPP && ctx->last_shape == ctx->avg_shape;
-    for (size_t i = 0; i < m.size(); i++) {
-      const double v = (double)m[i] * norm;
-      ctx->item_cost[i] = (unsigned int)std::min(4.0e9, blend ? avg_w * v + (1.0 - avg_w) * (double)ctx->item_cost[i] : v);
-    }
-    ctx->avg_shape = ctx->last_shape;
-  } else if (refresh)
-    HIPCHK(ctx, hipMemcpy(ctx->item_cost.data(), ctx->d_tile_cost.p, ctx->item_cost.size() * 4, hipMemcpyDeviceToHost));
+  const bool     refresh = (li & (li - 1)) == 0 || (!ctx->costs_settled && nsamples >= YH_TRIAL_SPP && ctx->state.shader == YH_SHADER_PATH);
+  if (refresh) HIPCHK(ctx, hipMemcpy(ctx->item_cost.data(), ctx->d_tile_cost.p, ctx->item_cost.size() * 4, hipMemcpyDeviceToHost));
   if (refresh && ctx->last_shape == 5)  // an item that ran as octets reports the time of its two halves, 2 x 0.74 of what it costs as a quad
     for (int it : ctx->hy_oct_items) ctx->item_cost[(size_t)it] = (unsigned int)((double)ctx->item_cost[(size_t)it] * (1.0 / 1.48));
   if (ctx->state.shader == YH_SHADER_PATH && (refresh || ctx->have_costs)) record_launch(ctx, nsamples, refresh);
