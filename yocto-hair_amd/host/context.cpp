@@ -610,6 +610,7 @@ static void split_items_for_hex(std::vector<int>& items) {
 static void split_items_side_by_side(yh_context* ctx, std::vector<int>& items);
 static int  ensure_wide_nodes(yh_context* ctx);
 static void lay_out_first_round(const yh_context* ctx, std::vector<int>& items, int shape);
+static void lay_out_range(const yh_context* ctx, int* items, size_t n, int wpb, int G);
 static int  trace_impl(yh_context* ctx, int nsamples, bool counted, bool sync);
 
 const char* yh_version(void) { return "yhair 0.1 (gfx950, HIP)"; }
@@ -1278,6 +1279,18 @@ static void split_items_side_by_side(yh_context* ctx, std::vector<int>& items) {
   ctx->hy_quad_items = (int)items.size() - n_oct, ctx->hy_oct_entries = 2 * n_oct;
   ctx->hy_oct_items.assign(items.begin(), items.begin() + n_oct);
   items.swap(out);
+  if (!getenv("YHAIR_NO_LAYOUT")) {  // both lists by wave slot, each for its own grid (side_by_side_impl: the octet kernel is launched first and gets the fastest slots)
+    const int occ_q = yhk_trace_occupancy(yhk_trace_lds_bytes(&ctx->scene, 0), ctx->scene.general_materials, 0);
+    const int occ_o = yhk_trace_occupancy(yhk_trace_lds_bytes(&ctx->scene, 4), ctx->scene.general_materials, 4);
+    if (occ_q >= 1 && occ_o >= 1) {
+      const int wq = yhk_block_threads(0) / 64, wo = yhk_block_threads(4) / 64, slots = ctx->num_cus * occ_q * wq;
+      const int grid_o = ctx->hy_oct_entries > 0 ? std::min((ctx->hy_oct_entries + wo - 1) / wo, ctx->num_cus * occ_o) : 0;
+      const int left   = std::max(wq, slots - grid_o * wo);
+      const int grid_q = ctx->hy_quad_items > 0 ? std::max(1, std::min((ctx->hy_quad_items + wq - 1) / wq, left / wq)) : 0;
+      if (grid_q > 0) lay_out_range(ctx, items.data(), (size_t)ctx->hy_quad_items, wq, grid_q);
+      if (grid_o > 0) lay_out_range(ctx, items.data() + ctx->hy_quad_items, (size_t)ctx->hy_oct_entries, wo, grid_o);
+    }
+  }
 }
 static int side_by_side_impl(yh_context* ctx, int nsamples, bool sync);
 
@@ -1346,13 +1359,8 @@ static int ensure_wide_nodes(yh_context* ctx) {
 // one per CU and round, and waves w and w + 4 of a 512-thread workgroup share a SIMD — so slot = round x (waves per workgroup
 // / 4) + wave / 4. The most expensive items go to the slot-0 waves, the next to slot 1, and so on: on a sparse image the
 // slowest slot holds none of the expensive items. Purely a matter of time: whatever the layout, every entry is taken once.
-static void lay_out_first_round(const yh_context* ctx, std::vector<int>& items, int shape) {
-  if (shape == 3 || shape == 5 || items.empty()) return;  // (k_stream deals its items itself; side by side keeps two lists in cost order)
-  const int wpb = yhk_block_threads(shape) / 64;
-  const int occ = yhk_trace_occupancy(yhk_trace_lds_bytes(&ctx->scene, shape), ctx->scene.general_materials, shape);
-  if (occ < 1 || wpb < 1) return;
-  const int    G = std::max(1, std::min(((int)items.size() + wpb - 1) / wpb, ctx->num_cus * occ));  // the grid trace_impl launches
-  const size_t P = std::min((size_t)G * wpb, items.size());                                           // entries taken by position
+static void lay_out_range(const yh_context* ctx, int* items, size_t n, int wpb, int G) {  // entries [0, n) of one kernel's list, its grid G
+  const size_t P = std::min((size_t)G * wpb, n);  // entries taken by position
   std::vector<std::pair<uint64_t, uint32_t>> order;  // (slot class, place inside it) -> position
   order.reserve(P);
   for (size_t pos = 0; pos < P; pos++) {
@@ -1363,7 +1371,15 @@ static void lay_out_first_round(const yh_context* ctx, std::vector<int>& items, 
   std::sort(order.begin(), order.end());
   std::vector<int> head(P);
   for (size_t k = 0; k < P; k++) head[order[k].second] = items[k];  // the k-th most expensive item on the k-th fastest wave
-  std::copy(head.begin(), head.end(), items.begin());
+  std::copy(head.begin(), head.end(), items);
+}
+static void lay_out_first_round(const yh_context* ctx, std::vector<int>& items, int shape) {
+  if (shape == 3 || shape == 5 || items.empty()) return;  // (k_stream deals its items itself; side by side lays its two lists out when it splits them)
+  const int wpb = yhk_block_threads(shape) / 64;
+  const int occ = yhk_trace_occupancy(yhk_trace_lds_bytes(&ctx->scene, shape), ctx->scene.general_materials, shape);
+  if (occ < 1 || wpb < 1) return;
+  const int G = std::max(1, std::min(((int)items.size() + wpb - 1) / wpb, ctx->num_cus * occ));  // the grid trace_impl launches
+  lay_out_range(ctx, items.data(), items.size(), wpb, G);
 }
 
 // Bookkeeping after a synchronous launch: its time (kernel selection) and, after launches 1, 2, 4, 8, ... of a state,
