@@ -107,11 +107,11 @@ def kernels(src):
 
 if __name__ == "__main__":
     bad = 0
-    for src, pat in (("kernels.hip", r"k_traceILb0ELb[01]E"), ("exact.hip", r"k_trace_exact"), ("stream.hip", r"k_streamILb[01]ELi\dELb0")):
+    for src, pat in (("kernels.hip", r"k_traceILb0ELb[01]E|k_trace_sbsILb[01]E"), ("exact.hip", r"k_trace_exact"), ("stream.hip", r"k_streamILb[01]ELi\dELb0")):
         for name, k in sorted(kernels(src).items()):
             if not re.search(pat, name):
                 continue
-            product = ("k_traceILb0ELb0" in name or "k_streamILb0" in name or "k_trace_exactILb0" in name)  # the plain variants every BASELINE config runs
+            product = ("k_traceILb0ELb0" in name or "k_trace_sbsILb0" in name or "k_streamILb0" in name or "k_trace_exactILb0" in name)  # the plain variants every BASELINE config runs
             print(f"{name[:64]:64s} vgprs {k['vgprs']:3d} spilled {k['vgpr_spills']:3d} (sgpr {k['sgpr_spills']:3d}) scratch {k['scratch_bytes']:4d} B")
             for h, r in k["trav"].items():
                 flag = ""

@@ -39,8 +39,11 @@ using namespace yhd;
 // YH_MODE_OCT = EIGHT lanes per path (two quads that run the same path and share the box tests of an 8-wide node): a
 // wave holds 8 pixels, a work-list entry is HALF a quadrant (entry = item << 1 | half: rows 2 half, 2 half + 1 of the
 // 4x4 block) — half the paths per wave, twice the waves, for launches bound by the chain of one path.
+// `block`, `blocks`: this workgroup's index among the workgroups that share `st`'s work list, and their number (the whole grid,
+// except in k_trace_sbs, where two lists share one launch).
 template <bool COUNT, bool GENERAL, int BLOCK, int SHADER, int MODE = YH_MODE_QUAD>
-YH_DEV void trace_items(const yhd_scene& sc, const yhd_state& st, int nsamples, yhd_counters* counters) {
+YH_DEV void trace_items(const yhd_scene& sc, const yhd_state& st, int nsamples, yhd_counters* counters, unsigned int block = blockIdx.x,
+    unsigned int blocks = gridDim.x) {
   constexpr int LPP    = YH_IS_HEX(MODE) ? 16 : YH_IS_OCT(MODE) ? 8 : 4;  // lanes per path
   constexpr int GROUPS = BLOCK / LPP;                   // paths per block = columns of the LDS stack
   extern __shared__ v4f lds_dyn[];
@@ -78,8 +81,8 @@ YH_DEV void trace_items(const yhd_scene& sc, const yhd_state& st, int nsamples, 
 #ifndef YH_FIRST_BY_POSITION
 #define YH_FIRST_BY_POSITION 1
 #endif
-  const int by_position = YH_FIRST_BY_POSITION ? (int)(gridDim.x * (BLOCK / 64)) : 0;
-  int       t_first     = YH_FIRST_BY_POSITION ? __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6))) : -1;
+  const int by_position = YH_FIRST_BY_POSITION ? (int)(blocks * (BLOCK / 64)) : 0;
+  int       t_first     = YH_FIRST_BY_POSITION ? __builtin_amdgcn_readfirstlane((int)(block * (BLOCK / 64) + (threadIdx.x >> 6))) : -1;
   while (true) {
     int t = t_first;
     if (t < 0) {

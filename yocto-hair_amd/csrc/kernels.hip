@@ -19,6 +19,7 @@
 // Compiled with -ffp-contract=off (see dev_math.h).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 
@@ -29,6 +30,24 @@ template <bool COUNT, bool GENERAL, int BLOCK, int WAVES, int MODE = YH_MODE_QUA
 __global__ __launch_bounds__(BLOCK, WAVES) void k_trace(const yhd_scene sc, const yhd_state st,
     int nsamples, yhd_counters* counters) {
   trace_items<COUNT, GENERAL, BLOCK, YH_SHADER_PATH, MODE>(sc, st, nsamples, counters);
+}
+// SIDE BY SIDE in one launch (launch shape 5): the first `oct_blocks` workgroups run the octet form over the second part of
+// the work list (`oct_entries` half-quadrant entries behind the `quad_items` quad entries, its own cursor), the others the
+// quad form over the first part. The first workgroups of a launch get the fastest wave slots of their CUs (dev_items.h), so
+// the few items whose chain bounds the launch run with eight lanes per path AND in the best slots; same workgroup size, so
+// the two forms pack on a CU like one kernel's workgroups.
+template <bool GENERAL>
+__global__ __launch_bounds__(YH_BLOCK, YH_MIN_WAVES) void k_trace_sbs(const yhd_scene sc, const yhd_state st, int nsamples, int oct_blocks,
+    int quad_items, int oct_entries) {
+  if ((int)blockIdx.x < oct_blocks) {
+    yhd_state so   = st;
+    so.tiles       = st.tiles + quad_items, so.num_tiles = oct_entries, so.tile_cursor = st.tile_cursor + 16;
+    trace_items<false, GENERAL, YH_BLOCK, YH_SHADER_PATH, YH_MODE_OCT>(sc, so, nsamples, nullptr, blockIdx.x, (unsigned)oct_blocks);
+  } else {
+    yhd_state sq = st;
+    sq.num_tiles = quad_items;
+    trace_items<false, GENERAL, YH_BLOCK, YH_SHADER_PATH, YH_MODE_QUAD>(sc, sq, nsamples, nullptr, blockIdx.x - (unsigned)oct_blocks, gridDim.x - (unsigned)oct_blocks);
+  }
 }
 template <int SHADER>
 __global__ __launch_bounds__(YH_BLOCK, YH_MIN_WAVES) void k_trace_shader(const yhd_scene sc, const yhd_state st,
@@ -487,6 +506,30 @@ int yhk_trace(const yhd_scene* sc, const yhd_state* st, int nsamples, yhd_counte
     if (e != hipSuccess) return (int)e;
   }
   hipLaunchKernelGGL(k, dim3(grid_blocks), dim3(shape_block(shape)), lds, stream, *sc, *st, nsamples, counters);
+  return (int)hipGetLastError();
+}
+// (side by side: both forms at YH_BLOCK threads; the LDS of the larger layout)
+static size_t sbs_lds(const yhd_scene* sc) {
+  const size_t stacks = (size_t)std::max(sc->stack_entries * (YH_BLOCK / 4), sc->stack_entries8 * (YH_BLOCK / 8)) * 4;
+  return (size_t)sc->lds_node_count * 128 + stacks + (size_t)YHD_LDS_TABLES_F4(sc) * 16 + (YH_PREFETCH ? 256 : 0);
+}
+int yhk_trace_sbs_lds_bytes(const yhd_scene* sc) { return (int)sbs_lds(sc); }
+int yhk_trace_sbs_occupancy(int lds_bytes, int general) {
+  int  blocks = 0;
+  auto k      = general ? k_trace_sbs<true> : k_trace_sbs<false>;
+  if (lds_bytes > 64 * 1024 && hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess) return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k, YH_BLOCK, lds_bytes) != hipSuccess) return 1;
+  return blocks < 1 ? 0 : blocks;
+}
+int yhk_trace_sbs(const yhd_scene* sc, const yhd_state* st, int nsamples, int oct_blocks, int quad_items, int oct_entries, int grid_blocks,
+    hipStream_t stream) {
+  const size_t lds = sbs_lds(sc);
+  auto         k   = sc->general_materials ? k_trace_sbs<true> : k_trace_sbs<false>;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(k, dim3(grid_blocks), dim3(YH_BLOCK), lds, stream, *sc, *st, nsamples, oct_blocks, quad_items, oct_entries);
   return (int)hipGetLastError();
 }
 int yhk_block_threads(int shape) { return shape_block(shape); }

@@ -42,6 +42,9 @@ int yhk_trace_exact(const yhd_scene*, const yhd_state*, int nsamples, int lds_by
 int yhk_trace_exact_occupancy(int lds_bytes, int general);
 int yhk_block_threads(int shape);
 int yhk_trace_occupancy(int lds_bytes, int general, int shape);
+int yhk_trace_sbs(const yhd_scene*, const yhd_state*, int nsamples, int oct_blocks, int quad_items, int oct_entries, int grid_blocks, hipStream_t);
+int yhk_trace_sbs_lds_bytes(const yhd_scene* sc);
+int yhk_trace_sbs_occupancy(int lds_bytes, int general);
 int yhk_trace_lds_bytes(const yhd_scene* sc, int shape);
 int yhk_stack_entries(void);
 #ifdef YH_LAB_WAVEFRONT  // developer build (make WAVEFRONT=1): the workgroup-staged kernel of csrc/lab/, YHAIR_SHAPE=2
@@ -266,8 +269,6 @@ struct yh_context {
   hipStream_t stream = nullptr;
   hipEvent_t  ev0 = nullptr, ev1 = nullptr;
   // the side-by-side launch (shape 5): the octet kernel runs on a second stream, forked from and joined to `stream` by events
-  hipStream_t stream2 = nullptr;
-  hipEvent_t  ev_fork = nullptr, ev_join = nullptr;
   int         hy_quad_items = 0, hy_oct_entries = 0;  // layout of the work list for shape 5: [quad items][octet entries]
   std::vector<int> hy_oct_items;                       // ... and the items that run as octets
   int         num_cus = 0;
@@ -487,9 +488,10 @@ bool trials_off() {
   static const bool off = getenv("YHAIR_NO_TRIALS") != nullptr;  // developer switch: the cost heuristic only
   return off || getenv("YHAIR_SHAPE") != nullptr;
 }
-// k_trace 512 x 4 always; the dense quad shape unless the image is chain-bound; k_stream on dense images; on chain-bound
+// k_trace 512 x 4 always; the dense quad shape unless the image is chain-bound; k_stream on dense images; the side-by-side
+// launch on sparse ones; on chain-bound
 // ones (a shard of a sparse image on one of several GPUs, a small image) the octet kernel and, when even four waves per
-// expensive item are all resident, the sixteen-lane one. (Shapes 2 and 5 are never tried: profiles/r03/.)
+// expensive item are all resident, the sixteen-lane one. (Shape 2 is never tried: profiles/r03/.)
 int candidates(const yh_context* ctx, int cand[6]) {
   int n = 0;
   cand[n++] = 0;
@@ -498,6 +500,7 @@ int candidates(const yh_context* ctx, int cand[6]) {
     if (ctx->chain16 > 0) cand[n++] = 6, cand[n++] = 8;  // (likewise without and with leaf groups)
     return n;
   }
+  if (ctx->dense == 0) cand[n++] = 5;  // sparse, not chain-bound: the few items that top every launch as octets beside the quads (side by side in one launch)
   cand[n++] = 1;
   if (ctx->dense > 0) cand[n++] = 3;
   return n;
@@ -610,7 +613,7 @@ static void split_items_for_hex(std::vector<int>& items) {
 static void split_items_side_by_side(yh_context* ctx, std::vector<int>& items);
 static int  ensure_wide_nodes(yh_context* ctx);
 static void lay_out_first_round(const yh_context* ctx, std::vector<int>& items, int shape);
-static void lay_out_range(const yh_context* ctx, int* items, size_t n, int wpb, int G);
+static void lay_out_range(const yh_context* ctx, int* items, size_t n, int wpb, int G, int block_offset = 0);
 static int  trace_impl(yh_context* ctx, int nsamples, bool counted, bool sync);
 
 const char* yh_version(void) { return "yhair 0.1 (gfx950, HIP)"; }
@@ -647,9 +650,6 @@ void yh_destroy(yh_context* ctx) {
   destroy_communicators(ctx);
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-  if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2), (void)hipStreamDestroy(ctx->stream2);
-  if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
-  if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -1264,13 +1264,21 @@ static int expensive_items(const yh_context* ctx, const std::vector<int>& items)
   }
   return n;
 }
-static int resident_waves_quads(const yh_context* ctx) {
-  const int lds = yhk_trace_lds_bytes(&ctx->scene, 0);
-  return ctx->num_cus * std::max(1, yhk_trace_occupancy(lds, ctx->scene.general_materials, 0)) * (yhk_block_threads(0) / 64);
+// The side-by-side launch's workgroups: octet ones first (eight waves each, one half-quadrant entry per wave at a time), quad ones behind.
+static bool side_by_side_grids(const yh_context* ctx, int* oct_blocks, int* quad_blocks) {
+  const int lds = yhk_trace_sbs_lds_bytes(&ctx->scene), occ = yhk_trace_sbs_occupancy(lds, ctx->scene.general_materials);
+  if (occ < 1) return false;
+  const int resident = ctx->num_cus * occ;
+  *oct_blocks  = std::min((ctx->hy_oct_entries + 7) / 8, std::max(0, resident - 1));
+  *quad_blocks = ctx->hy_quad_items > 0 ? std::max(1, std::min((ctx->hy_quad_items + 7) / 8, resident - *oct_blocks)) : 0;
+  return true;
 }
 static void split_items_side_by_side(yh_context* ctx, std::vector<int>& items) {
-  const int H = expensive_items(ctx, items), S = resident_waves_quads(ctx);
-  int n_oct = std::max(0, std::min(H, S - H));
+  // How many: the launch of a sparse image ends with a handful of quadrants that are the most expensive ones in EVERY launch
+  // (C1: sixteen widened items take 10 % off the launch, 128 no more, 512 lose it again to the extra waves —
+  // profiles/r03/side_by_side_fused_ab.txt): a sixty-fourth of the expensive items, sixteen at least.
+  const int H = expensive_items(ctx, items);
+  int n_oct = std::min(H / 2, std::max(16, std::min(256, H / 64)));
   if (const char* env = getenv("YHAIR_HY_OCT")) n_oct = std::max(0, std::min((int)items.size(), atoi(env)));  // developer switch
   std::vector<int> out;
   out.reserve(items.size() + n_oct);
@@ -1279,17 +1287,11 @@ static void split_items_side_by_side(yh_context* ctx, std::vector<int>& items) {
   ctx->hy_quad_items = (int)items.size() - n_oct, ctx->hy_oct_entries = 2 * n_oct;
   ctx->hy_oct_items.assign(items.begin(), items.begin() + n_oct);
   items.swap(out);
-  if (!getenv("YHAIR_NO_LAYOUT")) {  // both lists by wave slot, each for its own grid (side_by_side_impl: the octet kernel is launched first and gets the fastest slots)
-    const int occ_q = yhk_trace_occupancy(yhk_trace_lds_bytes(&ctx->scene, 0), ctx->scene.general_materials, 0);
-    const int occ_o = yhk_trace_occupancy(yhk_trace_lds_bytes(&ctx->scene, 4), ctx->scene.general_materials, 4);
-    if (occ_q >= 1 && occ_o >= 1) {
-      const int wq = yhk_block_threads(0) / 64, wo = yhk_block_threads(4) / 64, slots = ctx->num_cus * occ_q * wq;
-      const int grid_o = ctx->hy_oct_entries > 0 ? std::min((ctx->hy_oct_entries + wo - 1) / wo, ctx->num_cus * occ_o) : 0;
-      const int left   = std::max(wq, slots - grid_o * wo);
-      const int grid_q = ctx->hy_quad_items > 0 ? std::max(1, std::min((ctx->hy_quad_items + wq - 1) / wq, left / wq)) : 0;
-      if (grid_q > 0) lay_out_range(ctx, items.data(), (size_t)ctx->hy_quad_items, wq, grid_q);
-      if (grid_o > 0) lay_out_range(ctx, items.data() + ctx->hy_quad_items, (size_t)ctx->hy_oct_entries, wo, grid_o);
-    }
+  if (!getenv("YHAIR_NO_LAYOUT")) {  // both lists by wave slot: the octet workgroups are the first of the launch, the quad ones follow (side_by_side_impl)
+    int G_o = 0, G_q = 0;
+    side_by_side_grids(ctx, &G_o, &G_q);
+    if (G_o > 0) lay_out_range(ctx, items.data() + ctx->hy_quad_items, (size_t)ctx->hy_oct_entries, 8, G_o, 0);
+    if (G_q > 0) lay_out_range(ctx, items.data(), (size_t)ctx->hy_quad_items, 8, G_q, G_o);
   }
 }
 static int side_by_side_impl(yh_context* ctx, int nsamples, bool sync);
@@ -1359,14 +1361,14 @@ static int ensure_wide_nodes(yh_context* ctx) {
 // one per CU and round, and waves w and w + 4 of a 512-thread workgroup share a SIMD — so slot = round x (waves per workgroup
 // / 4) + wave / 4. The most expensive items go to the slot-0 waves, the next to slot 1, and so on: on a sparse image the
 // slowest slot holds none of the expensive items. Purely a matter of time: whatever the layout, every entry is taken once.
-static void lay_out_range(const yh_context* ctx, int* items, size_t n, int wpb, int G) {  // entries [0, n) of one kernel's list, its grid G
+static void lay_out_range(const yh_context* ctx, int* items, size_t n, int wpb, int G, int block_offset) {  // entries [0, n) of one list, its G workgroups; block_offset: workgroups of the same launch dispatched before them
   const size_t P = std::min((size_t)G * wpb, n);  // entries taken by position
   std::vector<std::pair<uint64_t, uint32_t>> order;  // (slot class, place inside it) -> position
   order.reserve(P);
   for (size_t pos = 0; pos < P; pos++) {
     const uint64_t b = pos / wpb, w = pos % wpb;
-    const uint64_t cls = (b / ctx->num_cus) * ((wpb + 3) / 4) + w / 4;
-    order.emplace_back((cls << 40) | ((b % ctx->num_cus) << 8) | (w % 4), (uint32_t)pos);  // (which item shares a SIMD with which makes no difference: snake order measured equal)
+    const uint64_t g = b + (uint64_t)block_offset, cls = (g / ctx->num_cus) * ((wpb + 3) / 4) + w / 4;
+    order.emplace_back((cls << 40) | ((g % ctx->num_cus) << 8) | (w % 4), (uint32_t)pos);  // (which item shares a SIMD with which makes no difference: snake order measured equal)
   }
   std::sort(order.begin(), order.end());
   std::vector<int> head(P);
@@ -1696,38 +1698,13 @@ static int trace_impl(yh_context* ctx, int nsamples, bool counted, bool sync) {
 // kernel over the entries behind them on a second stream, forked and joined by events (so the pair behaves like one
 // launch on `stream`, also for yh_trace_samples_async). Grids: the octet entries get a wave each, the quad kernel the rest.
 static int side_by_side_impl(yh_context* ctx, int nsamples, bool sync) {
-  if (!ctx->stream2) {
-    HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
-    HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-    HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
-  }
-  const int lds_q = yhk_trace_lds_bytes(&ctx->scene, 0), lds_o = yhk_trace_lds_bytes(&ctx->scene, 4);
-  const int occ_q = yhk_trace_occupancy(lds_q, ctx->scene.general_materials, 0), occ_o = yhk_trace_occupancy(lds_o, ctx->scene.general_materials, 4);
-  if (occ_q < 1 || occ_o < 1) return fail(ctx, YH_E_DEVICE, "k_trace cannot run with %d / %d bytes of LDS per block", lds_q, lds_o);
-  const int wpb_q = yhk_block_threads(0) / 64, wpb_o = yhk_block_threads(4) / 64;
-  const int slots = ctx->num_cus * occ_q * wpb_q;  // resident waves (both kernels: four per SIMD)
-  const int grid_o = ctx->hy_oct_entries > 0 ? std::min((ctx->hy_oct_entries + wpb_o - 1) / wpb_o, ctx->num_cus * occ_o) : 0;
-  const int left   = std::max(wpb_q, slots - grid_o * wpb_o);
-  const int grid_q = ctx->hy_quad_items > 0 ? std::max(1, std::min((ctx->hy_quad_items + wpb_q - 1) / wpb_q, left / wpb_q)) : 0;
-  yhd_state st_q = ctx->state, st_o = ctx->state;
-  st_q.num_tiles = ctx->hy_quad_items;
-  st_o.tiles = ctx->state.tiles + ctx->hy_quad_items, st_o.num_tiles = ctx->hy_oct_entries, st_o.tile_cursor = ctx->state.tile_cursor + 16;
+  int G_o = 0, G_q = 0;
+  if (!side_by_side_grids(ctx, &G_o, &G_q)) return fail(ctx, YH_E_DEVICE, "k_trace_sbs cannot run with %d bytes of LDS per block", yhk_trace_sbs_lds_bytes(&ctx->scene));
   HIPCHK(ctx, hipMemsetAsync(ctx->d_tile_cursor.p, 0, 8 * 16 * 4, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(ctx->d_tile_cost.p, 0, (size_t)ctx->num_tiles_total * 16, ctx->stream));
   HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-  HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
-  int e = 0;
-  if (grid_o > 0) {  // the expensive items first: their chains are the longest
-    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
-    e = yhk_trace(&ctx->scene, &st_o, nsamples, nullptr, 4, grid_o, ctx->stream2);
-    if (e) return fail(ctx, YH_E_DEVICE, "k_trace (octets) launch: %s", hipGetErrorString((hipError_t)e));
-    HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
-  }
-  if (grid_q > 0) {
-    e = yhk_trace(&ctx->scene, &st_q, nsamples, nullptr, 0, grid_q, ctx->stream);
-    if (e) return fail(ctx, YH_E_DEVICE, "k_trace launch: %s", hipGetErrorString((hipError_t)e));
-  }
-  if (grid_o > 0) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+  int e = yhk_trace_sbs(&ctx->scene, &ctx->state, nsamples, G_o, ctx->hy_quad_items, ctx->hy_oct_entries, std::max(1, G_o + G_q), ctx->stream);
+  if (e) return fail(ctx, YH_E_DEVICE, "k_trace_sbs launch: %s", hipGetErrorString((hipError_t)e));
   HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   ctx->state.samples_done += nsamples;
   ctx->last_launches = 1;
