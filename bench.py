@@ -61,7 +61,7 @@ CONFIGS = {
     "C4": dict(scene="hair-curls", resolution=1280, spp=4096, kw={}),
 }
 KERNELS = {0: "k_trace<512 x 4>", 1: "k_trace<256 x 5>", 2: "k_trace<512 x 4, 8-wide nodes>", 3: "k_stream", 4: "k_trace<256 x 4, octets>",
-           5: "k_trace<512 x 4> + octets side by side", 6: "k_trace<256 x 4, 16 lanes per path>", 7: "k_trace<256 x 4, octets, leaf pairs>",
+           5: "k_trace_sbs<512 x 4>: quads + the top items as octets, one launch", 6: "k_trace<256 x 4, 16 lanes per path>", 7: "k_trace<256 x 4, octets, leaf pairs>",
            8: "k_trace<256 x 4, 16 lanes per path, leaf groups>"}
 
 

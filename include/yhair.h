@@ -276,8 +276,9 @@ int yh_last_trace_ms(const yh_context* ctx, float* ms, int* launches);
  * x 4 waves per SIMD; 1 = the same at 256 x 5 (dense images); 3 = k_stream, one lane per path (dense
  * images); 4 = k_trace with an OCTET per path over 8-wide BVH nodes, 7 = the same with leaf pairs, 6 =
  * SIXTEEN lanes per path over 16-wide nodes, 8 = the same with leaf groups (launches bound by the chain of
- * one path: few expensive pixels per GPU); 2 = quads over 8-wide nodes and 5 = quads and octets side by side on two streams: never
- * chosen (YHAIR_SHAPE=n forces a shape; YHAIR_DEVICE_SHARE=k tells the choice that k processes render on
+ * one path: few expensive pixels per GPU); 5 = side by side in one launch: the few items that top every
+ * launch of a sparse image as octets, everything else as quads; 2 = quads over 8-wide nodes: a developer
+ * build, never chosen (YHAIR_SHAPE=n forces a shape; YHAIR_DEVICE_SHARE=k tells the choice that k processes render on
  * this device at once). < 0 = nothing launched yet (or an error code). With
  * yh_trace_params::hair_exact it is always 0.                                                            */
 int yh_launch_shape(const yh_context* ctx);

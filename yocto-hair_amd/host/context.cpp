@@ -268,7 +268,6 @@ struct yh_context {
   int         device = 0;
   hipStream_t stream = nullptr;
   hipEvent_t  ev0 = nullptr, ev1 = nullptr;
-  // the side-by-side launch (shape 5): the octet kernel runs on a second stream, forked from and joined to `stream` by events
   int         hy_quad_items = 0, hy_oct_entries = 0;  // layout of the work list for shape 5: [quad items][octet entries]
   std::vector<int> hy_oct_items;                       // ... and the items that run as octets
   int         num_cus = 0;
@@ -495,7 +494,7 @@ bool trials_off() {
 int candidates(const yh_context* ctx, int cand[6]) {
   int n = 0;
   cand[n++] = 0;
-  if (ctx->chain > 0 && ctx->dense <= 0) {  // chain-bound: more lanes per path (the dense quad shape and the side-by-side launch never win there: not tried)
+  if (ctx->chain > 0 && ctx->dense <= 0) {  // chain-bound: more lanes per path for every item (the dense quad shape and the side-by-side launch are not tried there)
     cand[n++] = 4, cand[n++] = 7;  // octets, without and with leaf pairs (which of the two wins depends on the share of leaf steps)
     if (ctx->chain16 > 0) cand[n++] = 6, cand[n++] = 8;  // (likewise without and with leaf groups)
     return n;
@@ -1242,17 +1241,19 @@ static int upload_work_items(yh_context* ctx) {
   return YH_OK;
 }
 
-// SIDE BY SIDE (launch shape 5). A launch whose expensive items all fit the resident waves ends with its most expensive
-// item: every such item runs from the start, and the launch is as long as the longest chain (C1: the most expensive
-// quadrant takes 14.8 ms per 64 samples, the median expensive one 9 ms: a third of the wave slots' time is idle).
-// On an idle GPU the octet kernel runs an item in 0.74 x the time for two waves instead of one. So the wave slots the
-// expensive items leave free go to the MOST expensive of them: the first n of the cost-sorted list run as octets
-// (k_trace, shape 4's kernel, on a second stream), everything else as quads (shape 0's kernel), n = as many as there
-// are spare slots. Both kernels render the quad kernel's bits, each pixel belongs to one of them.
-// MEASURED (profiles/r03/side_by_side_ab.txt): on C1 at 720^2, where the expensive items already fill the waves, it LOSES
-// (18.7 against 14.8 ms: under that load an octet half takes 16.8 ms — the octet's gain is trips of an otherwise idle
-// SIMD, not instructions), so it is a candidate only where the octet kernel is (chain-bound images), as the form
-// that leaves the cheap items to the quad kernel.
+// SIDE BY SIDE (launch shape 5). The launch of a sparse image ends with its most expensive items: every expensive item runs
+// from the start, and the launch is as long as the longest chain (C1: the most expensive quadrant takes 14.8 ms per 64
+// samples, the median expensive one 9 ms). The same handful of quadrants tops EVERY launch, and the octet form runs an item
+// in 0.74 x the time for two waves instead of one — so the first K items of the cost-sorted list run as octets and
+// everything else as quads, in ONE launch (csrc/kernels.hip: k_trace_sbs): its first workgroups take the octet entries,
+// the others the quad items. The first workgroups of a launch get the fastest wave slots (lay_out_first_round below), the
+// workgroups are of one size, and there is one dispatch order — the three things the earlier forms of this idea lacked
+// (two kernels on two streams: the streams raced for the slots and the workgroup sizes did not pack, 14.8 -> 18.7 ms;
+// one kernel whose waves pick the form per item: 5-10 % behind before any item was widened). Both forms render the quad
+// kernel's bits; each pixel belongs to one of them. MEASURED (profiles/r03/side_by_side_fused_ab.txt): C1 at 720^2 14.9 ->
+// 13.4 ms per 64 samples with 16-128 items widened (4: 14.5, 512: 14.7, 1024: 16.2; 0, the control: 15.4), the bench
+// 2 182 -> 2 457 Msamples/s. A trial candidate on sparse images that are not chain-bound (on those the wider kernels run
+// every item wide).
 // Expensive = within 5 x of the most expensive item. Returns how many of them there are.
 static int expensive_items(const yh_context* ctx, const std::vector<int>& items) {
   if (items.empty()) return 0;
@@ -1694,9 +1695,8 @@ static int trace_impl(yh_context* ctx, int nsamples, bool counted, bool sync) {
   }
   return YH_OK;
 }
-// One side-by-side launch: the quad kernel over [0, hy_quad_items) of the work list on the context's stream, the octet
-// kernel over the entries behind them on a second stream, forked and joined by events (so the pair behaves like one
-// launch on `stream`, also for yh_trace_samples_async). Grids: the octet entries get a wave each, the quad kernel the rest.
+// One side-by-side launch: k_trace_sbs over the whole list — its first G_o workgroups the octet entries behind the quad items,
+// the other G_q the quad items [0, hy_quad_items).
 static int side_by_side_impl(yh_context* ctx, int nsamples, bool sync) {
   int G_o = 0, G_q = 0;
   if (!side_by_side_grids(ctx, &G_o, &G_q)) return fail(ctx, YH_E_DEVICE, "k_trace_sbs cannot run with %d bytes of LDS per block", yhk_trace_sbs_lds_bytes(&ctx->scene));
