@@ -28,6 +28,7 @@
 #include <mutex>
 #include <tuple>
 #include <string>
+#include <memory>
 #include <thread>
 #include <vector>
 
@@ -264,6 +265,15 @@ void parallel_for(int n, F&& fn) {
 }
 
 constexpr int YH_SHAPES = 9;  // launch shapes: 0, 1 k_trace (4-wide nodes) | 2 k_trace over 8-wide nodes | 3 k_stream | 4 k_trace with octets | 5 quads and octets side by side | 6 k_trace with sixteen lanes per path | 7 octets with leaf pairs | 8 sixteen lanes with leaf groups
+// The 8- and 16-wide collapses of a scene's trees take a tenth of a second of host time for a million-segment hair
+// model; the kernels that need them are chosen after the first launches. yh_upload_scene starts them in the background,
+// ensure_wide_nodes (host/context.cpp, below) waits for them — so the first launch of a wide kernel does not pay for them.
+struct WideBuild {
+  std::thread                               th;
+  std::vector<std::vector<yhh::WideNode8>>  w8;
+  std::vector<std::vector<yhh::WideNode16>> w16;
+  std::vector<int>                          d8, d16;
+};
 struct yh_context {
   int         device = 0;
   hipStream_t stream = nullptr;
@@ -282,6 +292,7 @@ struct yh_context {
   // an image that never runs those kernels pays neither the collapses nor the memory. Until then the host keeps the
   // shapes' binary trees and the object records.
   bool                     wide_built = false;
+  std::unique_ptr<struct WideBuild> wide_job;  // the collapses of host_trees, started in the background by yh_upload_scene
   std::vector<yhh::Tree>   host_trees;    // per shape (emptied once the wide arrays exist)
   std::vector<yhd_object>  host_objects;  // as uploaded; wbox_min[3] / wbox_max[3] = the wide arrays' bases once built
   std::vector<int>         object_shape;  // shape index of every object
@@ -611,6 +622,8 @@ static void split_items_for_hex(std::vector<int>& items) {
 }
 static void split_items_side_by_side(yh_context* ctx, std::vector<int>& items);
 static int  ensure_wide_nodes(yh_context* ctx);
+static void wide_build_join(yh_context* ctx);
+static void wide_build_start(yh_context* ctx);
 static void lay_out_first_round(const yh_context* ctx, std::vector<int>& items, int shape);
 static void lay_out_range(const yh_context* ctx, int* items, size_t n, int wpb, int G, int block_offset = 0);
 static int  trace_impl(yh_context* ctx, int nsamples, bool counted, bool sync);
@@ -646,6 +659,7 @@ yh_context* yh_create(int device) {
 static void destroy_communicators(yh_context* ctx);
 void yh_destroy(yh_context* ctx) {
   if (!ctx) return;
+  if (ctx->wide_job && ctx->wide_job->th.joinable()) ctx->wide_job->th.join();
   destroy_communicators(ctx);
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
@@ -684,6 +698,7 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
   };
   std::vector<ShapeInfo>  info(sd->num_shapes);
   std::vector<yhd_float4> nodes, prims, vpos;
+  wide_build_join(ctx), ctx->wide_job.reset();  // (a previous scene's collapses may still be running on the trees replaced below)
   ctx->wide_built = false;
   ctx->host_trees.assign((size_t)sd->num_shapes, yhh::Tree{});
   ctx->d_nodes8.reset(), ctx->d_nodes16.reset();
@@ -1105,6 +1120,7 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
   ctx->have_costs = false, ctx->costs_settled = false, ctx->dense = -1, ctx->chain = -1, ctx->chain16 = -1;
   for (double& t : ctx->shape_ms) t = 0;
   for (int& t : ctx->shape_trials) t = 0;
+  wide_build_start(ctx);  // the wide collapses in the background: ready by the time a kernel that needs them is tried
   return YH_OK;
 }
 
@@ -1297,27 +1313,40 @@ static void split_items_side_by_side(yh_context* ctx, std::vector<int>& items) {
 }
 static int side_by_side_impl(yh_context* ctx, int nsamples, bool sync);
 
-// The 8- and 16-wide collapses of the shapes' trees (host/bvh_build.h), built, uploaded and wired into the object records
-// when a kernel that traverses them is about to run for the first time (launch shapes 4, 5, 6, 7).
-static int ensure_wide_nodes(yh_context* ctx) {
-  if (ctx->wide_built) return YH_OK;
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // (a queued launch may be reading the object records)
-  const size_t ns = ctx->host_trees.size();
-  std::vector<std::vector<yhh::WideNode8>>  w8(ns);
-  std::vector<std::vector<yhh::WideNode16>> w16(ns);
-  std::vector<int>                          d8(ns, 0), d16(ns, 0);
-  {
+static void wide_build_join(yh_context* ctx) {
+  if (ctx->wide_job && ctx->wide_job->th.joinable()) ctx->wide_job->th.join();
+}
+static void wide_build_start(yh_context* ctx) {  // (ctx->host_trees must stay untouched until wide_build_join)
+  wide_build_join(ctx);
+  ctx->wide_job.reset(new WideBuild());
+  WideBuild*                    job   = ctx->wide_job.get();
+  const std::vector<yhh::Tree>* trees = &ctx->host_trees;
+  const size_t                  ns    = trees->size();
+  job->w8.resize(ns), job->w16.resize(ns), job->d8.assign(ns, 0), job->d16.assign(ns, 0);
+  job->th = std::thread([job, trees, ns] {
     std::vector<std::thread> pool;
     for (size_t si = 0; si < ns; si++) {
-      pool.emplace_back([&, si] { d8[si] = yhh::collapse_wide8(ctx->host_trees[si], w8[si]); });
-      pool.emplace_back([&, si] { d16[si] = yhh::collapse_wide16(ctx->host_trees[si], w16[si]); });
+      pool.emplace_back([job, trees, si] { job->d8[si] = yhh::collapse_wide8((*trees)[si], job->w8[si]); });
+      pool.emplace_back([job, trees, si] { job->d16[si] = yhh::collapse_wide16((*trees)[si], job->w16[si]); });
       if (pool.size() >= 8) {
         for (auto& t : pool) t.join();
         pool.clear();
       }
     }
     for (auto& t : pool) t.join();
-  }
+  });
+}
+// The 8- and 16-wide collapses of the shapes' trees (host/bvh_build.h), built, uploaded and wired into the object records
+// when a kernel that traverses them is about to run for the first time (launch shapes 4, 5, 6, 7).
+static int ensure_wide_nodes(yh_context* ctx) {
+  if (ctx->wide_built) return YH_OK;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // (a queued launch may be reading the object records)
+  if (!ctx->wide_job) wide_build_start(ctx);  // (normally started by yh_upload_scene)
+  wide_build_join(ctx);
+  const size_t ns = ctx->host_trees.size();
+  std::vector<std::vector<yhh::WideNode8>>&  w8  = ctx->wide_job->w8;
+  std::vector<std::vector<yhh::WideNode16>>& w16 = ctx->wide_job->w16;
+  std::vector<int>&                          d8 = ctx->wide_job->d8, &d16 = ctx->wide_job->d16;
   {  // the LDS stacks were sized at upload from the depths these collapses were expected to have
     int m8 = 0, m16 = 0;
     for (size_t si = 0; si < ns; si++) m8 = std::max(m8, d8[si]), m16 = std::max(m16, d16[si]);
@@ -1350,6 +1379,7 @@ static int ensure_wide_nodes(yh_context* ctx) {
   ctx->scene.nodes16 = (const yhd_float4*)ctx->d_nodes16.p, ctx->scene.num_nodes16_total = (int)(nodes16.size() / 32);
   ctx->d_scene_copy.reset();  // (the copy of the scene table in device memory is made again at its next use)
   ctx->wide_built = true;
+  ctx->wide_job.reset();
   ctx->host_trees.clear(), ctx->host_trees.shrink_to_fit();
   return YH_OK;
 }
