@@ -1286,7 +1286,7 @@ static bool side_by_side_grids(const yh_context* ctx, int* oct_blocks, int* quad
   const int lds = yhk_trace_sbs_lds_bytes(&ctx->scene), occ = yhk_trace_sbs_occupancy(lds, ctx->scene.general_materials);
   if (occ < 1) return false;
   const int resident = ctx->num_cus * occ;
-  *oct_blocks  = std::min((ctx->hy_oct_entries + 7) / 8, std::max(0, resident - 1));
+  *oct_blocks  = std::min((ctx->hy_oct_entries + 7) / 8, resident / 2);  // (the quad workgroups keep at least half of the device, whatever YHAIR_HY_OCT says)
   *quad_blocks = ctx->hy_quad_items > 0 ? std::max(1, std::min((ctx->hy_quad_items + 7) / 8, resident - *oct_blocks)) : 0;
   return true;
 }
