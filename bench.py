@@ -60,6 +60,8 @@ CONFIGS = {
     "C3": dict(scene="curly-hair", resolution=1280, spp=4096, kw={}),
     "C4": dict(scene="hair-curls", resolution=1280, spp=4096, kw={}),
 }
+# What the headline line reports next to C1 (config.other_configs): BASELINE.json configs[2..4], C2 at the middle of its beta_m sweep
+OTHER_CONFIGS = [("C2", {"beta_m": 0.25}, 8), ("C3", {}, 8), ("C4", {}, 8)]  # (config, scene overrides, launches the spp are cut into)
 KERNELS = {0: "k_trace<512 x 4>", 1: "k_trace<256 x 5>", 2: "k_trace<512 x 4, 8-wide nodes>", 3: "k_stream", 4: "k_trace<256 x 4, octets>",
            5: "k_trace_sbs<512 x 4>: quads + the top items as octets, one launch", 6: "k_trace<256 x 4, 16 lanes per path>", 7: "k_trace<256 x 4, octets, leaf pairs>",
            8: "k_trace<256 x 4, 16 lanes per path, leaf groups>"}
@@ -147,6 +149,65 @@ def csrc_sha16():
     return h.hexdigest()[:16]
 
 
+ALGO = ("samples", "rays", "nodes", "seg_tests", "tri_tests", "hair_shades", "surf_shades", "env_lookups", "env_samples")
+
+
+def env_is_textured(desc):
+    """SURVEY.md 8(d) counts the environment's bilinear texels for a TEXTURED environment only (a constant one reads nothing:
+    eval_environment, pt.cpp:536-547, returns its emission)."""
+    d = desc.contents
+    return any(d.environments[i].tex_width > 0 for i in range(d.num_environments))
+
+
+def algorithmic_bytes_per_sample(per_sample, spp_launch, env_textured, node_bytes=32):
+    """bytes per camera sample of the reference algorithm from its per-sample work counts."""
+    return (node_bytes * per_sample["nodes"] + 44 * per_sample["seg_tests"] + 52 * per_sample["tri_tests"] + 104 * per_sample["hair_shades"] +
+            (48 * per_sample["env_lookups"] if env_textured else 0.0) + 88 * per_sample["env_samples"]) + 32.0 / spp_launch
+
+
+def committed_workcounts(scene_name, scene_kw, resolution, scale):
+    """The committed counts of the reference algorithm for this scene (tests/golden/workcounts.json, oracle/make_workcounts.py;
+    the per-sample averages do not depend on the image size), or None."""
+    try:
+        fx = json.load(open(os.path.join(ROOT, "tests", "golden", "workcounts.json")))
+        kw = {k: float(v) for k, v in scene_kw.items()}
+        cands = [c for c in fx.values() if c["scene"] == scene_name and {k: float(v) for k, v in c["overrides"].items()} == kw and scale == 1.0]
+        return min(cands, key=lambda c: abs(c["resolution"] - resolution)) if cands else None
+    except Exception:
+        return None
+
+
+def committed_counters(scene_name, scene_kw, resolution, scale, world, shape_used):
+    """Counters of the sample-loop kernel from the committed PMC passes (profiles/k_trace_traffic.json), valid for the scene,
+    overrides, image size, launch shape AND device code they were taken on. Returns (entry or None, why not)."""
+    why = None
+    try:
+        allp = json.load(open(os.path.join(ROOT, "profiles", "k_trace_traffic.json")))
+        allp = allp if isinstance(allp, list) else [allp]
+        kw = {k: float(v) for k, v in scene_kw.items()}
+        for cand in allp:  # the passes were taken on one kernel: they describe this run only if it chose the same one
+            ckw = {k: float(v) for k, v in cand.get("scene_kw", {}).items()}
+            if (cand["scene"], cand["resolution"], cand["scale"]) == (scene_name, resolution, scale) and world == 1 and ckw == kw \
+                    and cand.get("launch_shape") == shape_used:
+                if cand.get("csrc_sha16") != csrc_sha16():  # taken on other device code: not a statement about this run
+                    why = f"stale: {cand['source'].split(' ')[0]} was taken on other kernels (csrc fingerprint differs); retake with tools/profile_configs.sh"
+                    continue
+                return cand, None
+    except Exception:
+        pass
+    return None, why
+
+
+def valu_block(pmc):
+    if not pmc:
+        return None
+    issue, lanes = pmc.get("valu_issue_fraction"), pmc.get("valu_lane_utilisation")
+    return {"bound": "valu", "issue_fraction": issue, "lane_utilisation": lanes,
+            "achieved": round(issue * lanes, 4) if issue and lanes else None, "peak": 1.0, "unit": "share of vector lane-cycles doing work",
+            "simd_busy": pmc.get("valu_simd_busy_at_2GHz"),
+            "wait_fraction": pmc.get("wait_any_fraction"), "l2_hit_rate": pmc.get("l2_hit_rate"), "source": pmc.get("source")}
+
+
 def spawn_ranks(n):
     """Bare `bench.py --gpus N`: N rank processes of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as the
     launcher would set them). The parent never touches the GPU; it waits, ends the others when one fails, and
@@ -199,6 +260,8 @@ def main():
                     help="collective backend; gloo (CPU staging) lets the N > 1 flow be exercised on a one-GPU box")
     ap.add_argument("--no-project-scaling", dest="project_scaling", action="store_false",
                     help="N = 1: skip the three extra renders of shard 0 of 2 / 4 / 8 (config.projected_strong_scaling)")
+    ap.add_argument("--no-other-configs", dest="other_configs", action="store_false",
+                    help="headline run at N = 1: skip the renders of C2 (beta_m 0.25), C3 and C4 at their full sample counts (config.other_configs)")
     ap.add_argument("--force-collective", action="store_true",
                     help="N = 1: still create the process group and run the framebuffer gather through the collective "
                          "(a one-rank RCCL communicator: how a one-GPU box executes the nccl branch)")
@@ -283,19 +346,26 @@ def main():
     ctx.set_shard(rank, world)
     weak_res = int(round(base_res * world ** 0.5 / 8.0)) * 8
 
-    def timed_run(resolution, spps, warmup):
+    ctx_launches = []  # kernel launches of each timed step of the last timed_run (1 each once the kernel trials are over)
+
+    def timed_run(resolution, spps, warmup, warm_spps=None):
         """W untimed steps, then the steps of `spps` between barriers; returns the max over ranks."""
         p = yh.TraceParams.default(resolution=resolution)
         width, height = ctx.init_state(p)
         for k in range(warmup):
             ctx.trace_samples(spps[k % len(spps)])
+        for n in (warm_spps or []):
+            ctx.trace_samples(n)
         ctx.init_state(p)
         kernel_ms = 0.0
+        del ctx_launches[:]
         barrier()
         t0 = time.perf_counter()
         for n in spps:
             ctx.trace_samples(n)  # one launch of the sample-loop kernel, blocking
-            kernel_ms += ctx.last_trace_ms()[0]
+            ms, launches = ctx.last_trace_ms()
+            kernel_ms += ms
+            ctx_launches.append(int(launches))
         barrier()
         elapsed = time.perf_counter() - t0
         if world > 1:
@@ -304,8 +374,43 @@ def main():
             elapsed, kernel_ms = t.tolist()
         return width, height, elapsed, kernel_ms, p
 
+    def other_config(name, kw, steps):
+        """One more BASELINE config on this GPU at its FULL sample count, with its own warm-up (its kernel trials stay out of
+        the timed steps): value, ms per step, the kernel chosen and its roofline against the committed work counts and
+        counter passes. The scene replaces the context's; the caller is done with the headline scene."""
+        c = CONFIGS[name]
+        path = make_scenes.ensure_scene(c["scene"], scenes_dir, scale=1.0, **kw)
+        osf = yh.SceneFile(path)
+        try:
+            ctx.upload_scene(osf.desc)
+            ctx.set_shard(0, 1)
+            spps = [c["spp"] // steps + (1 if k < c["spp"] % steps else 0) for k in range(steps)]
+            w, h, el, kms, _ = timed_run(c["resolution"], spps, 0, warm_spps=[96, 96, 96])
+            shape = ctx.launch_shape()
+            launches = sum(ctx_launches)
+            spp_launch, launch_s = c["spp"] / steps, kms / 1e3 / steps
+            fx = committed_workcounts(c["scene"], kw, c["resolution"], 1.0)
+            env_tex = env_is_textured(osf.desc)
+            if fx is not None:
+                bps, src = algorithmic_bytes_per_sample(fx["per_sample"], spp_launch, env_tex), "committed fixture tests/golden/workcounts.json"
+            else:
+                osc_counts = ctx.trace_samples_counted(1).as_dict()
+                g = {k: osc_counts[k] / max(1, osc_counts["samples"]) for k in ALGO[1:]}
+                bps, src = algorithmic_bytes_per_sample(g, spp_launch, env_tex, node_bytes=128), "instrumented kernel (no fixture)"
+            achieved = bps * w * h * spp_launch / launch_s / 1e9
+            pmc, why = committed_counters(c["scene"], kw, c["resolution"], 1.0, 1, shape)
+            traffic = round((pmc["hbm_fetch_bytes_per_launch"] + pmc["hbm_write_bytes_per_launch"]) * spp_launch / pmc["spp_per_launch"] / 1e9, 3) if pmc else None
+            return {"workload": f"{name}: {c['scene']} {w}x{h} x {c['spp']} spp" + "".join(f" {k} {v:g}" for k, v in kw.items()),
+                    "value": round(w * h * c["spp"] / el / 1e6, 2), "unit": "Msamples/s", "steps": steps, "ms_per_step": round(el * 1e3 / steps, 3),
+                    "kernel": KERNELS.get(shape, "?"), "launch_shape": shape, "launches_in_timed_steps": launches,
+                    "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                                 "traffic": traffic, "traffic_unit": "GB per launch", "traffic_source": pmc["source"] if pmc else why,
+                                 "avg_launch_ms": round(launch_s * 1e3, 3), "algorithmic_bytes_per_sample": round(bps, 1), "work_counts_from": src,
+                                 "valu": valu_block(pmc)}}
+        finally:
+            osf.close()
+
     # ---- work counts and the CPU leg (outside the timed region, rank 0 at N = 1 only) --------------
-    ALGO = ("samples", "rays", "nodes", "seg_tests", "tri_tests", "hair_shades", "surf_shades", "env_lookups", "env_samples")
     ctx.init_state(yh.TraceParams.default(resolution=base_res))
     gpu_counts = ctx.trace_samples_counted(2).as_dict()
     gpu_general = any(sf.desc.contents.materials[i].specular or sf.desc.contents.materials[i].metallic or sf.desc.contents.materials[i].transmission
@@ -325,6 +430,7 @@ def main():
     # ---- the reported run (strong: the config's own image; --weak: N times the pixels) ---------------
     res_main = weak_res if (a.weak and world > 1) else base_res
     width, height, elapsed, kernel_ms, p = timed_run(res_main, step_spp, a.warmup)
+    ctx_launches_main = list(ctx_launches)
     shape_used = ctx.launch_shape() if hasattr(ctx, "launch_shape") else None
     trials = {KERNELS.get(k, str(k)): {"ms_per_spp": v[0], "trials": v[1]} for k, v in ctx.kernel_trials().items()}
 
@@ -367,8 +473,19 @@ def main():
         other = {"mode": "strong" if a.weak else "weak", "image": f"{ow}x{oh}", "steps": k_other,
                  "value": round(ow * oh * sum(step_spp[:k_other]) / oel / 1e6, 2), "unit": "Msamples/s"}
 
+    # ---- the other BASELINE configs, after everything the headline line needs has been measured -----------
+    main_launches = sum(ctx_launches_main)
+    img = image.cpu().numpy() if rank == 0 else None  # (a copy: the context's buffers are about to be reused)
+    others = None
+    if rank == 0 and world == 1 and headline and a.other_configs:
+        others = {}
+        for oname, okw, osteps in OTHER_CONFIGS:
+            try:
+                others[oname] = other_config(oname, okw, osteps)
+            except Exception as e:  # never at the expense of the reported line
+                others[oname] = {"error": str(e)}
+
     if rank == 0:
-        img = image.cpu().numpy()
         if a.save:
             err = C.create_string_buffer(256)
             yh.load().yh_save_image(a.save.encode(), width, height, yh.fptr(img), err, 256)
@@ -376,61 +493,33 @@ def main():
         value = samples / elapsed / 1e6
         launch_s = kernel_ms / 1e3 / max(1, a.steps)               # average launch duration (per rank)
         spp_launch = spp_total / max(1, a.steps)                   # average samples per launch
+        env_tex = env_is_textured(sf.desc)
         if ref_wc is not None:
             counts, counts_from = ref_wc.as_dict(), "reference algorithm (CPU oracle, 2 spp)"
-            bytes_per_sample = ref_wc.bytes_per_sample(spp_launch)
+            bytes_per_sample = ref_wc.bytes_per_sample(spp_launch, env_tex)
         else:
-            # no oracle run here (N > 1 or --no-cpu-baseline): the committed counts of the reference
-            # algorithm for this scene (tests/golden/workcounts.json, oracle/make_workcounts.py; the
-            # per-sample averages do not depend on the image size), else the kernel's own counters
-            # with its 4-wide nodes counted as 128 B
-            fixture = None
-            try:
-                fx = json.load(open(os.path.join(ROOT, "tests", "golden", "workcounts.json")))
-                cands = [c for c in fx.values() if c["scene"] == scene_name and not c["overrides"] and a.scale == 1.0 and not scene_kw]
-                fixture = min(cands, key=lambda c: abs(c["resolution"] - base_res)) if cands else None
-            except Exception:
-                pass
+            # no oracle run here (N > 1 or --no-cpu-baseline): the committed counts of the reference algorithm for this
+            # scene, else the kernel's own counters with its 4-wide nodes counted as 128 B
+            fixture = committed_workcounts(scene_name, scene_kw, base_res, a.scale)
             if fixture is not None:
                 p_ = fixture["per_sample"]
                 counts = {k: p_.get(k, 0.0) for k in ALGO[1:]}
                 counts["samples"] = 1
                 counts_from = "reference algorithm (committed fixture tests/golden/workcounts.json)"
-                bytes_per_sample = (32 * p_["nodes"] + 44 * p_["seg_tests"] + 52 * p_["tri_tests"] + 104 * p_["hair_shades"] +
-                                    48 * p_["env_lookups"] + 88 * p_["env_samples"]) + 32.0 / spp_launch
+                bytes_per_sample = algorithmic_bytes_per_sample(p_, spp_launch, env_tex)
             else:
                 counts, counts_from = gpu_counts, "instrumented kernel (4-wide BVH; no oracle run, no fixture for this scene)"
-                g = gpu_counts
-                bytes_per_sample = (128 * g["nodes"] + 44 * g["seg_tests"] + 52 * g["tri_tests"] + 104 * g["hair_shades"] +
-                                    48 * g["env_lookups"] + 88 * g["env_samples"]) / max(1, g["samples"]) + 32.0 / spp_launch
+                g = {k: gpu_counts[k] / max(1, gpu_counts["samples"]) for k in ALGO[1:]}
+                bytes_per_sample = algorithmic_bytes_per_sample(g, spp_launch, env_tex, node_bytes=128)
         bytes_per_launch = bytes_per_sample * width * height * spp_launch / world
         achieved = bytes_per_launch / launch_s / 1e9
-        # counters of the sample-loop kernel from the committed PMC passes (profiles/), valid for the config they were taken on
-        traffic, traffic_src, pmc = None, None, {}
-        try:
-            allp = json.load(open(os.path.join(ROOT, "profiles", "k_trace_traffic.json")))
-            allp = allp if isinstance(allp, list) else [allp]
-            for cand in allp:  # the passes were taken on one kernel: they describe this run only if it chose the same one
-                if (cand["scene"], cand["resolution"], cand["scale"]) == (scene_name, res_main, a.scale) and world == 1 and not scene_kw \
-                        and cand.get("launch_shape") == shape_used:
-                    if cand.get("csrc_sha16") != csrc_sha16():  # taken on other device code: not a statement about this run
-                        traffic_src = f"stale: {cand['source'].split(' ')[0]} was taken on other kernels (csrc fingerprint differs); retake with tools/profile_configs.sh"
-                        continue
-                    pmc = cand
-            if pmc:
-                traffic_src = None
-                scale_spp = spp_launch / pmc["spp_per_launch"]  # traffic is proportional to the samples of a launch
-                traffic = round((pmc["hbm_fetch_bytes_per_launch"] + pmc["hbm_write_bytes_per_launch"]) * scale_spp / 1e9, 3)
-                traffic_src = pmc["source"]
-        except Exception:
-            pass
-        valu = None
+        traffic = None
+        pmc, traffic_src = committed_counters(scene_name, scene_kw, res_main, a.scale, world, shape_used)
         if pmc:
-            issue, lanes = pmc.get("valu_issue_fraction"), pmc.get("valu_lane_utilisation")
-            valu = {"bound": "valu", "issue_fraction": issue, "lane_utilisation": lanes,
-                    "achieved": round(issue * lanes, 4) if issue and lanes else None, "peak": 1.0, "unit": "share of vector lane-cycles doing work",
-                    "simd_busy": pmc.get("valu_simd_busy_at_2GHz"),
-                    "wait_fraction": pmc.get("wait_any_fraction"), "l2_hit_rate": pmc.get("l2_hit_rate"), "source": pmc.get("source")}
+            scale_spp = spp_launch / pmc["spp_per_launch"]  # traffic is proportional to the samples of a launch
+            traffic = round((pmc["hbm_fetch_bytes_per_launch"] + pmc["hbm_write_bytes_per_launch"]) * scale_spp / 1e9, 3)
+            traffic_src = pmc["source"]
+        valu = valu_block(pmc)
         scaling = "weak" if (a.weak or world == 1) else "strong"
         if headline:
             metric = "Msamples/sec (whole node), 720x720x1536spp sphere-hairblock; per-pixel L2 vs CPU ref"
@@ -475,6 +564,12 @@ def main():
                 "what": "shard 0 of N (tile_id % N == 0) of this image rendered ALONE on this GPU, same steps: the time one GPU of N "
                         "would take (the shards are statistically alike: 8x8 tiles dealt round-robin); the gather is not in it. "
                         "A projection from one GPU, not a measurement on N.", "runs": projected}
+        out["roofline"]["launches_in_timed_steps"] = main_launches  # K when no kernel trial leaked into the timed region
+        if others:
+            out["config"]["other_configs"] = {
+                "what": "BASELINE.json configs[2..4] on this GPU after the headline run, each at its FULL sample count in 8 launches with its own "
+                        "warm-up (three 96-sample launches: the kernel trials); roofline as for the headline (committed work counts / counter passes)",
+                "runs": others}
         if parity is not None:
             out["parity"] = parity
         if cpu is not None and world == 1:

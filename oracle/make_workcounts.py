@@ -48,9 +48,10 @@ def main():
         s = wc.samples
         per = {k: round(v / s, 4) for k, v in wc.as_dict().items()
                if k in ("rays", "nodes", "seg_tests", "tri_tests", "hair_shades", "surf_shades", "env_lookups", "env_samples")}
-        out[name] = {"scene": scene, "overrides": kw, "hair_segments_instanced": int(segs), "resolution": res,
+        env_tex = any(d.environments[i].tex_width > 0 for i in range(d.num_environments))  # env texels count for a textured environment only
+        out[name] = {"scene": scene, "overrides": kw, "env_textured": env_tex, "hair_segments_instanced": int(segs), "resolution": res,
                      "image": [int(img.shape[1]), int(img.shape[0])], "spp_of_config": spp, "spp_counted": spp_here,
-                     "per_sample": per, "algorithmic_bytes_per_sample": round(wc.bytes_per_sample(spp_launch), 1),
+                     "per_sample": per, "algorithmic_bytes_per_sample": round(wc.bytes_per_sample(spp_launch, env_tex), 1),
                      "spp_per_launch_assumed": spp_launch,
                      "oracle_msamples_per_s_here": round(s / dt / 1e6, 3), "host_threads_here": os.cpu_count()}
         print(name, out[name]["per_sample"], out[name]["algorithmic_bytes_per_sample"], "B/sample,", f"{dt:.1f} s")

@@ -180,7 +180,7 @@ def test_reference_work_counts_fixture(oracle, yh):
     for name, c in fx.items():
         p = c["per_sample"]
         b = (32 * p["nodes"] + 44 * p["seg_tests"] + 52 * p["tri_tests"] + 104 * p["hair_shades"] +
-             48 * p["env_lookups"] + 88 * p["env_samples"] + 32.0 / c["spp_per_launch_assumed"])
+             (48 * p["env_lookups"] if c["env_textured"] else 0) + 88 * p["env_samples"] + 32.0 / c["spp_per_launch_assumed"])  # env texels: textured environments only
         assert abs(b - c["algorithmic_bytes_per_sample"]) < 0.6, name
     c0 = fx["C0"]
     sf = yh.SceneFile(scene_path("sphere-hairblock"))

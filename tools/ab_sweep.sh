@@ -28,7 +28,7 @@ for r in $(seq 1 $rounds); do
   for v in "${variants[@]}"; do
     name=${v%%:*}
     printf "%s r%d: " "$name" "$r"
-    YHAIR_LIB=/tmp/yh_sweep/libyhair_$name.so python3 $R/bench.py --no-cpu-baseline --no-project-scaling "$@" 2>&1 | grep -o '"value": [0-9.]*' | tr '\n' ' '
+    YHAIR_LIB=/tmp/yh_sweep/libyhair_$name.so python3 $R/bench.py --no-cpu-baseline --no-project-scaling --no-other-configs "$@" 2>&1 | grep -o '"value": [0-9.]*' | tr '\n' ' '
     echo
   done
 done

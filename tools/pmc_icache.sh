@@ -6,7 +6,7 @@ cd "$(dirname "$0")/.." && ROOT=$PWD
 export TMPDIR=/tmp
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
-(cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_IFETCH SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES -d "$OUT/p" -o run -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-project-scaling --steps 4 --warmup 1 "$@" > "$OUT/p.log" 2>&1) || { tail -5 "$OUT/p.log"; exit 1; }
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_IFETCH SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES -d "$OUT/p" -o run -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-project-scaling --no-other-configs --steps 4 --warmup 1 "$@" > "$OUT/p.log" 2>&1) || { tail -5 "$OUT/p.log"; exit 1; }
 python3 - "$OUT" "$KERN" <<'PY'
 import csv, glob, sys, collections
 out, kern = sys.argv[1], sys.argv[2]

@@ -11,7 +11,7 @@ i=0
 for grp in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM" \
            "SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU SQ_INSTS_SALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_MISC"; do
   i=$((i+1))
-  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc $grp -d "$OUT/p$i" -o run -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-project-scaling --steps 4 --warmup 1 "$@" > "$OUT/p$i.log" 2>&1) || { tail -5 "$OUT/p$i.log"; exit 1; }
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc $grp -d "$OUT/p$i" -o run -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-project-scaling --no-other-configs --steps 4 --warmup 1 "$@" > "$OUT/p$i.log" 2>&1) || { tail -5 "$OUT/p$i.log"; exit 1; }
 done
 python3 - "$OUT" "$KERN" <<'PY'
 import csv, glob, sys, collections

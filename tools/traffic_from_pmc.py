@@ -14,6 +14,8 @@ import csv, glob, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CONFIGS = {"C1": ("sphere-hairblock", 720, 64), "C2": ("straight-hair", 720, 64), "C3": ("curly-hair", 1280, 32), "C4": ("hair-curls", 1280, 32),
            "lobes": ("lobes", 720, 64), "volumes": ("volumes", 720, 64), "textured": ("textured", 720, 64)}
+SCENE_KW = {"C2b": {"beta_m": 0.25}}  # scene overrides of a config name (C2b = C2 at beta_m 0.25: bench.py's config.other_configs)
+CONFIGS["C2b"] = CONFIGS["C2"]
 SIMDS, CLOCK = 1024, 2.0e9  # 256 CUs x 4 SIMDs; a vector instruction of a 64-wide wave holds its SIMD for 2 cycles at full rate
 
 
@@ -41,7 +43,7 @@ def main():
         entries.append({
             "csrc_sha16": bench.csrc_sha16(),  # the device code the passes were taken on (bench.py quotes them only for the same)
             "kernel": kern, "launch_shape": int(shape), "config": f"{cfg} {res}x{res}, {spp} spp per launch, 1 GPU", "scene": scene, "resolution": res, "scale": 1.0,
-            "spp_per_launch": spp, "source": src,
+            "scene_kw": SCENE_KW.get(cfg, {}), "spp_per_launch": spp, "source": src,
             "hbm_fetch_bytes_per_launch": p["FETCH_SIZE"] * 1024 * 2, "hbm_write_bytes_per_launch": p["WRITE_SIZE"] * 1024,
             "valu_issue_fraction": p["SQ_ACTIVE_INST_VALU"] / p["SQ_WAVE_CYCLES"], "wait_any_fraction": p["SQ_WAIT_ANY"] / p["SQ_WAVE_CYCLES"],
             "l2_hit_rate": p["TCC_HIT_sum"] / (p["TCC_HIT_sum"] + p["TCC_MISS_sum"]),

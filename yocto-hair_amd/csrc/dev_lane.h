@@ -37,6 +37,22 @@ namespace yhd {
 #ifndef YH_LSTACK
 #define YH_LSTACK 16 /* LDS stack window per lane, entries (power of two) */
 #endif
+// Developer instrumentation of a step, both compiled out of the product kernels:
+//   YH_ISA_MARKS   comment lines in the assembly at the start of every branch of lane_step (tools/isa_blocks.py --marks
+//                  counts the instructions between them: the static half of profiles/r04/k_stream_branch_budget.txt)
+//   PROF           (template argument) per branch: how many wave steps ran it, with how many lanes (the dynamic half).
+//                  `pc` is per lane: a lane in a branch taken by n lanes adds 1 / n and 1, so the sums over the wave's
+//                  lanes (the caller's job) are the executions of the branch and the lanes in them
+#ifdef YH_ISA_MARKS
+#define YH_MARK(name) asm volatile("; YHMARK " name)
+#else
+#define YH_MARK(name)
+#endif
+enum { LP_STEP = 0, LP_POP, LP_SCENE, LP_ENTER, LP_FETCH, LP_NODE, LP_LINE_LEAF, LP_TRI_LEAF, LP_PUSH, LP_SEGS, LP_COUNT };  // pc[2 b]: wave steps that ran branch b, pc[2 b + 1]: lanes in them (summed over the lanes)
+#define YH_LPROF(b)                                                                   \
+  if (PROF) {                                                                         \
+    pc[2 * (b)] += 1.0f / (float)__popcll(__ballot(true)), pc[2 * (b) + 1] += 1.0f; \
+  }
 
 struct lane_stack {
   YH_LDS unsigned int* lds;  // this lane's column of the window: entry i at lds[(i & (YH_LSTACK - 1)) * 64]
@@ -93,9 +109,11 @@ YH_DEV void lane_begin(const yhd_scene& sc, lane_trav& t, f3 ro, f3 rd, int firs
 // One step of the ray in `t`. Returns true when the ray is finished (closest hit in t.hit), or —
 // EXACT = false only — when it has to be traced again by the EXACT form (`redo` set: a slab of a
 // box test could hold a NaN, dev_trace.h). `sp0` = stack height at which this ray started.
-template <bool EXACT>
-YH_DEV bool lane_step(const trace_ctx& tc, lane_trav& t, lane_stack& s, int sp0, bool& redo) {
+template <bool EXACT, bool PROF = false>
+YH_DEV bool lane_step(const trace_ctx& tc, lane_trav& t, lane_stack& s, int sp0, bool& redo, float* pc = nullptr) {
   const yhd_scene& sc = *tc.sc;
+  YH_MARK("step_begin");
+  YH_LPROF(LP_STEP)
   auto box_test = [](f3 o, f3 dinv, float t0, float t1, f3 bmin, f3 bmax) {
     return EXACT ? intersect_bbox(o, dinv, t0, t1, bmin, bmax) : intersect_bbox_nonan(o, dinv, t0, t1, bmin, bmax);
   };
@@ -108,11 +126,18 @@ YH_DEV bool lane_step(const trace_ctx& tc, lane_trav& t, lane_stack& s, int sp0,
     redo = true;
     return true;
   }
-  if (t.cur == YH_NONE && s.sp > sp0) t.cur = lane_pop(s);
+  if (t.cur == YH_NONE && s.sp > sp0) {
+    YH_MARK("pop");
+    YH_LPROF(LP_POP)
+    t.cur = lane_pop(s);
+  }
+  YH_MARK("step_head");
   t.steps++;
   unsigned int tag  = t.cur & YH_TAG_MASK;
   bool         skip = t.cur == YH_NONE;  // only a scene without objects
   if (!skip && tag == YH_TAG_SCENE) {  // scene-level node (binary, the reference's layout)
+    YH_MARK("scene");
+    YH_LPROF(LP_SCENE)
     int idx = (int)(t.cur & ~YH_TAG_MASK);
     v4f n0, n1;
     if (lds_snodes) n0 = lds_snodes[2 * idx], n1 = lds_snodes[2 * idx + 1];
@@ -135,6 +160,8 @@ YH_DEV bool lane_step(const trace_ctx& tc, lane_trav& t, lane_stack& s, int sp0,
     skip = t.cur == YH_NONE || tag == YH_TAG_SCENE;
   }
   if (!skip && tag == YH_TAG_ENTER) {  // transform_ray(inverse(object.frame, true), ray) (pt.cpp:1012-1013)
+    YH_MARK("enter");
+    YH_LPROF(LP_ENTER)
     t.cur_obj  = (int)(t.cur & ~YH_TAG_MASK);
     bool enter = true;
     if (t.wnonan) {  // the object's padded world box (dev_trace.h)
@@ -174,7 +201,10 @@ YH_DEV bool lane_step(const trace_ctx& tc, lane_trav& t, lane_stack& s, int sp0,
       tag   = YH_TAG_SHAPE;
     }
   }
+  YH_MARK("after_enter");
   if (!skip) {
+    YH_MARK("fetch");
+    YH_LPROF(LP_FETCH)
     const bool is_leaf    = tag == YH_TAG_LEAF;
     const bool lines      = t.kind == YH_KIND_LINES;
     const int  leaf_start = (int)(t.cur & 0x07FFFFFFu), leaf_num = (int)((t.cur >> 27) & 7u);
@@ -198,6 +228,8 @@ YH_DEV bool lane_step(const trace_ctx& tc, lane_trav& t, lane_stack& s, int sp0,
     const v4f A2 = ldg4(a + o2), B2 = ldg4(a + o2 + 1), A3 = ldg4(a + o3), B3 = ldg4(a + o3 + 1);
 #endif
     if (!is_leaf) {
+      YH_MARK("node");
+      YH_LPROF(LP_NODE)
       // ---- wide node: the four slots {min.xyz, max.x} {max.yz, ref, axes} ----
       const unsigned int axes = __float_as_uint(B0.w);
       unsigned int r0 = __float_as_uint(B0.z), r1 = __float_as_uint(B1.z), r2 = __float_as_uint(B2.z), r3 = __float_as_uint(B3.z);
@@ -213,6 +245,7 @@ YH_DEV bool lane_step(const trace_ctx& tc, lane_trav& t, lane_stack& s, int sp0,
       const unsigned int s0  = ((unsigned)t.lsign >> (axes & 3)) & 1;
       const unsigned int sg0 = ((unsigned)t.lsign >> ((axes >> 2) & 3)) & 1, sg1 = ((unsigned)t.lsign >> ((axes >> 4) & 3)) & 1;
       t.cur = YH_NONE;
+      YH_MARK("node_order");
 #pragma unroll
       for (int r = 3; r >= 0; r--) {
         const unsigned int pair = ((unsigned)r >> 1) ^ s0;
@@ -220,11 +253,15 @@ YH_DEV bool lane_step(const trace_ctx& tc, lane_trav& t, lane_stack& s, int sp0,
         if ((hm >> q) & 1) {
           unsigned int ref = (q & 2) ? ((q & 1) ? r3 : r2) : ((q & 1) ? r1 : r0);
           if ((ref & YH_TAG_MASK) == 0) ref += (unsigned)t.node_base;  // child wide nodes are shape-local indices
-          if (t.cur != YH_NONE) lane_push(s, t.cur);
+          if (t.cur != YH_NONE) {
+            YH_LPROF(LP_PUSH)
+            lane_push(s, t.cur);
+          }
           t.cur = ref;
         }
       }
     } else {
+      YH_MARK("leaf");
       // ---- leaf: its primitives in leaf order, tmax shrinking after each accepted hit (pt.cpp:905-923) ----
       t.cur = (leaf_num > 2 && !(YH_LANE_LEAF4 && lines)) ? (YH_TAG_LEAF | ((unsigned)(leaf_num - 2) << 27) | (unsigned)(leaf_start + 2)) : YH_NONE;
 #define YH_LANE_ACCEPT(I, LINES)                          \
@@ -234,6 +271,9 @@ YH_DEV bool lane_step(const trace_ctx& tc, lane_trav& t, lane_stack& s, int sp0,
     t.tmax = dist, t.hit_lines = LINES;                   \
   }
       if (lines) {
+        YH_MARK("line_leaf");
+        YH_LPROF(LP_LINE_LEAF)
+        if (PROF && leaf_num > 1) { YH_LPROF(LP_SEGS) }  // lanes whose second test of the step is a real segment
         {
           float uu = 0, vv = 0, dist = 0;
           bool  ok = intersect_line<true>(t.lo, t.ld, ray_eps, t.tmax, xyz(A0), xyz(B0), A0.w, B0.w, uu, vv, dist);
@@ -257,6 +297,8 @@ YH_DEV bool lane_step(const trace_ctx& tc, lane_trav& t, lane_stack& s, int sp0,
           }
         }
       } else {
+        YH_MARK("tri_leaf");
+        YH_LPROF(LP_TRI_LEAF)
         {
           float uu = 0, vv = 0, dist = 0;
           bool  ok = intersect_triangle(t.lo, t.ld, ray_eps, t.tmax, xyz(A0), xyz(B0), xyz(A2), uu, vv, dist);
@@ -271,6 +313,7 @@ YH_DEV bool lane_step(const trace_ctx& tc, lane_trav& t, lane_stack& s, int sp0,
 #undef YH_LANE_ACCEPT
     }
   }
+  YH_MARK("step_end");
   return t.cur == YH_NONE && s.sp == sp0;
 }
 

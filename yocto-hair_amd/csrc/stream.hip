@@ -45,6 +45,9 @@ using namespace yhd;
 #ifndef YH_ST_POLICY
 #define YH_ST_POLICY 0 /* developer A/B switch: 0 = every stage in batches of 64 or flushed, trace left only when few lanes are busy */
 #endif
+#ifndef YH_ST_TAKE
+#define YH_ST_TAKE 64 /* free slots of a wave before it takes new work items: 64 = four items at a time; 16 = one or more (developer A/B switch) */
+#endif
 #ifndef YH_SUSPEND_LANES
 #define YH_SUSPEND_LANES 16 /* ray list dry and at most this many lanes busy: go shading */
 #endif
@@ -147,7 +150,7 @@ __global__ __launch_bounds__(YH_ST_BLOCK, WAVES) void k_stream(const yhd_scene s
     int act;
 #if YH_ST_POLICY == 0
     const bool flush = n_ray + nact < 64;
-    if (!nomore && n_free >= 64) act = A_ITEMS;
+    if (!nomore && n_free >= YH_ST_TAKE) act = A_ITEMS;
     else if (n_done > 0) act = A_SORT;
     else if (n_fin >= 64 || (flush && n_fin > 0)) act = A_FINISH;
     else if (n_hair >= 64 || (flush && n_hair > 0)) act = A_HAIR;
@@ -169,13 +172,14 @@ __global__ __launch_bounds__(YH_ST_BLOCK, WAVES) void k_stream(const yhd_scene s
     if (act == A_ITEMS) {
       // ---- items: free slots take the pixels of the next work items (4 items = 64 pixels) ------------------
       // the next items of this workgroup's group (its XCD's image region); a group that is used up hands over to the next
-      int t0 = 0, got = 0;
+      int       t0 = 0, got = 0;
+      const int want = YH_ST_TAKE >= 64 ? 4 : min(4, n_free >> 4);
       while (true) {
         int c = 0;
-        if (lane == 0) c = atomicAdd(st.tile_cursor + 16 * my_group, 4);
+        if (lane == 0) c = atomicAdd(st.tile_cursor + 16 * my_group, want);
         c   = __builtin_amdgcn_readfirstlane(c);
         t0  = st.group_begin[my_group] + c;
-        got = max(0, min(4, st.group_begin[my_group + 1] - t0));
+        got = max(0, min(want, st.group_begin[my_group + 1] - t0));
         if (got > 0 || ++groups_done >= st.num_groups) break;
         my_group = (my_group + 1) % st.num_groups;
       }
@@ -326,7 +330,9 @@ __global__ __launch_bounds__(YH_ST_BLOCK, WAVES) void k_stream(const yhd_scene s
       n_fin = list_push(l_fin, n_fin, on && !alive, sl);
     } else {
       // ---- trace: one ray per lane; finished lanes refill from the ray list; leaves with rays suspended ---------
+      float pc[2 * LP_COUNT] = {};  // PROF: per branch of lane_step, this lane's share of the wave steps that ran it and of the lanes in them
       while (true) {
+        YH_MARK("trace_refill");
         {  // refill: the (divergent) refill code runs only when enough lanes are idle, or none is busy
           const unsigned long long idle  = __ballot(!have);
           const int                nidle = (int)__popcll(idle);
@@ -351,7 +357,8 @@ __global__ __launch_bounds__(YH_ST_BLOCK, WAVES) void k_stream(const yhd_scene s
         int  kind = 0;
         if (have) {
           bool redo = false;
-          if (lane_step<false>(tc, t, stk, 0, redo)) {
+          if (lane_step<false, PROF>(tc, t, stk, 0, redo, pc)) {
+            YH_MARK("trace_retire");
             have = false, fin = true;
             if (redo) {
               kind   = K_REDO;  // traced again by the exact form in the sort stage
@@ -361,9 +368,18 @@ __global__ __launch_bounds__(YH_ST_BLOCK, WAVES) void k_stream(const yhd_scene s
             }
           }
         }
+        YH_MARK("trace_lists");
         if (__ballot(fin) != 0) {
           n_done = list_push(l_done, n_done, fin, slot | (kind << 12));
           n_hair_done += (int)__popcll(__ballot(fin && kind == K_HAIR));
+        }
+        YH_MARK("trace_loop_end");
+      }
+      if (PROF) {
+        for (int k = 0; k < 2 * LP_COUNT; k++) {
+          float v = pc[k];
+          for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+          if (lane == 0 && v > 0) atomicAdd(&pl.prof[32 + k], (unsigned long long)(v + 0.5f));
         }
       }
     }

@@ -1604,7 +1604,7 @@ static int stream_impl(yh_context* ctx, int nsamples, bool sync) {
   ctx->stream_pool.slots_per_wave = P, ctx->stream_pool.ovf_entries = ovf_entries, ctx->stream_pool.total_slots = (long long)ctx->st_slots;
   const bool prof = getenv("YHAIR_ST_PROF") && atoi(getenv("YHAIR_ST_PROF")) != 0;  // developer switch: per-stage counters on stderr
   if (prof) {
-    if ((rc = alloc_zero(ctx, ctx->d_st_prof, 32 * 8))) return rc;
+    if ((rc = alloc_zero(ctx, ctx->d_st_prof, 64 * 8))) return rc;
     ctx->stream_pool.prof = (unsigned long long*)ctx->d_st_prof.p;
   } else {
     ctx->stream_pool.prof = nullptr;
@@ -1624,7 +1624,7 @@ static int stream_impl(yh_context* ctx, int nsamples, bool sync) {
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     HIPCHK(ctx, hipEventElapsedTime(&ctx->last_ms, ctx->ev0, ctx->ev1));
     if (prof) {
-      unsigned long long c[32];
+      unsigned long long c[64];
       HIPCHK(ctx, hipMemcpy(c, ctx->d_st_prof.p, sizeof(c), hipMemcpyDeviceToHost));
       const char* names[6] = {"items", "sort", "finish", "hair", "surf", "trace"};
       double total = 0;
@@ -1635,6 +1635,11 @@ static int stream_impl(yh_context* ctx, int nsamples, bool sync) {
             c[8 + k], c[8 + k] ? (double)c[16 + k] / (double)c[8 + k] : 0.0);
       fprintf(stderr, "[yhair]   trace: %llu wave steps, %.1f lanes busy on average, %.0f cycles per step\n", c[24],
           c[24] ? (double)c[25] / (double)c[24] : 0.0, c[24] ? (double)c[5] / (double)c[24] : 0.0);
+      // per branch of lane_step (csrc/dev_lane.h: LP_*): the share of the wave steps that ran it, and the lanes in it when it ran
+      const char* br[10] = {"step", "pop", "scene", "enter", "fetch", "node", "line-leaf", "tri-leaf", "push", "2nd-seg"};
+      for (int b = 0; b < 10; b++)
+        fprintf(stderr, "[yhair]   branch %-9s ran in %5.1f %% of the wave steps (%llu times), %.1f lanes on average\n", br[b],
+            c[32] ? 100.0 * (double)c[32 + 2 * b] / (double)c[32] : 0.0, c[32 + 2 * b], c[32 + 2 * b] ? (double)c[33 + 2 * b] / (double)c[32 + 2 * b] : 0.0);
     }
     return replan_after_launch(ctx, nsamples);
   }

@@ -94,11 +94,12 @@ class WorkCounts(C.Structure):
             d["trips_" + nm], d["lanes_" + nm] = int(self.branch[2 * k]), int(self.branch[2 * k + 1])
         return d
 
-    def bytes_per_sample(self, spp_per_launch):
-        """algorithmic bytes per sample of the reference algorithm."""
+    def bytes_per_sample(self, spp_per_launch, env_textured=True):
+        """algorithmic bytes per sample of the reference algorithm. The environment's texels count for a
+        TEXTURED environment only (the oracle counts every eval_environment, yh_oracle.cpp; a constant one reads nothing)."""
         s = max(1, self.samples)
         return (32 * self.nodes + 44 * self.seg_tests + 52 * self.tri_tests +
-                104 * self.hair_shades + 48 * self.env_lookups + 88 * self.env_samples) / s \
+                104 * self.hair_shades + (48 * self.env_lookups if env_textured else 0) + 88 * self.env_samples) / s \
             + 32.0 / spp_per_launch
 
 
