@@ -356,6 +356,12 @@ def main():
             ctx.trace_samples(spps[k % len(spps)])
         for n in (warm_spps or []):
             ctx.trace_samples(n)
+        # every kernel trial of this image (and shard) before the timed steps, whatever --warmup says: count trial launches,
+        # not steps (a trial is a 32-sample launch cut off the front of a request of 64 or more; yh_trials_pending)
+        extra = 0
+        while ctx.trials_pending() and extra < 16:
+            ctx.trace_samples(64)
+            extra += 1
         ctx.init_state(p)
         kernel_ms = 0.0
         del ctx_launches[:]

@@ -286,6 +286,12 @@ int yh_launch_shape(const yh_context* ctx);
  * of its fastest 32-sample trial launch (0 = not tried, < 0 = cannot run on this device) and the number of trials.
  * Returns the number of launch shapes (9), or a negative error code.                                               */
 int yh_kernel_trials(const yh_context* ctx, double* ms_per_sample, int* trials, int count);
+/* 1 while a candidate kernel of the current image still wants a timing trial — the next yh_trace_samples of 64 samples or
+ * more will start with a 32-sample launch of it — else 0: a caller that times its launches (bench.py) keeps warming up
+ * until this is 0. The record of an image is kept per process and in ~/.cache/yhair/trials_v1.txt (YHAIR_CACHE_DIR;
+ * YHAIR_NO_DISK_CACHE switches the file off), keyed by device, build, scene, image size, shard and bounces: an image
+ * found there runs no trial. Replaces nothing in the reference (host/context.cpp: pick_launch_shape).              */
+int yh_trials_pending(const yh_context* ctx);
 
 /* Load-balance telemetry: for every tile id (row-major over ceil(W/8) x
  * ceil(H/8) tiles) the time its wavefront spent on it in the most recent

@@ -23,8 +23,11 @@
 #define LDS __attribute__((address_space(3)))
 typedef float v4f __attribute__((ext_vector_type(4)));
 
+#ifndef MINW
+#define MINW 4
+#endif
 template <int MODE>
-__global__ __launch_bounds__(256, 4) void gather(const v4f* __restrict__ recs, unsigned mask, int steps, int filler, int active, float* sink) {
+__global__ __launch_bounds__(256, MINW) void gather(const v4f* __restrict__ recs, unsigned mask, int steps, int filler, int active, float* sink) {
   extern __shared__ v4f lds[];
   const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
   LDS v4f* stage = (LDS v4f*)lds + wib * 512;  // 8 KB per wave: 64 records x 8 chunks

@@ -34,6 +34,9 @@ namespace yhd {
 #ifndef YH_LANE_LEAF4
 #define YH_LANE_LEAF4 0 /* A/B switch: a line leaf's third and fourth segment in the same step as the first two. Bit-identical; the trace-only batch kernel +4 %, k_stream 0 to -3 % (its step loop grows from 1018 to 1259 vector instructions and spills five registers more): off (profiles/r03/lane_leaf4_ab.txt) */
 #endif
+#ifndef YH_LANE_BLOB
+#define YH_LANE_BLOB 1 /* 1: nodes and leaf test records from yhd_scene::lane_blob (one base, one address form: round 4); 0: from yhd_scene::nodes / prims as until round 3 (A/B) */
+#endif
 #ifndef YH_LSTACK
 #define YH_LSTACK 16 /* LDS stack window per lane, entries (power of two) */
 #endif
@@ -85,7 +88,12 @@ struct lane_trav {
   int          cur_obj, kind, node_base, prim_base;
   unsigned int cur;            // the entry being visited (YH_NONE: pop the next one)
   float        tmax;
+  // YH_LANE_BLOB: while the ray is in flight the hit is kept RAW — hit.slot = the primitive's test record (32-byte units of
+  // lane_blob) and, on a line, hit.v = the squared distance d2 with hit_r = the radius there: the reference's
+  // uv.y = sqrt(d2) / r (math.h:3465) is evaluated once, for the ray's final hit (lane_hit), not at every accepted test
   hit_t        hit;
+  float        hit_r;
+  float        ld2;            // dot(ld, ld): the `a` of every line test of this ray in this object (math.h:3437)
   bool         hit_lines;      // the closest hit so far is on a line shape (hair)
   unsigned int steps;
   bool         wnonan;         // no slab of a world-space box test can hold a NaN (dev_trace.h)
@@ -101,9 +109,46 @@ YH_DEV void lane_begin(const yhd_scene& sc, lane_trav& t, f3 ro, f3 rd, int firs
   t.cur_obj = -1, t.kind = 0, t.node_base = 0, t.prim_base = 0;
   t.tmax = flt_max, t.steps = 0;
   t.hit.object = -1, t.hit.slot = -1, t.hit.u = 0, t.hit.v = 0, t.hit.distance = 0;
-  t.hit_lines = false;
+  t.hit_lines = false, t.hit_r = 1.0f, t.ld2 = dot(rd, rd);
   if (first_object >= 0) t.cur = YH_TAG_ENTER | (unsigned)first_object;
   else t.cur = sc.num_scene_nodes ? (YH_TAG_SCENE | 0u) : YH_NONE;
+}
+
+// The line test of math.h:3426-3469 in dev_trace.h's STRAIGHT form, with `a` = dot(rd, rd) handed in (the same for every
+// segment a ray meets inside one object) and WITHOUT the uv.y = sqrt(d2) / r of an accepted hit: s, d2 and r are returned and
+// the caller evaluates it for the hit that survives (same operands, same operations: same bits).
+YH_DEV bool intersect_line_raw(f3 ro, f3 rd, float a, float tmin, float tmax, f3 p0, f3 p1, float r0, float r1, float& s_out, float& d2_out,
+    float& r_out, float& dist) {
+  f3    v = p1 - p0, w = ro - p0;
+  float b = dot(rd, v), c = dot(v, v), d = dot(rd, w), e = dot(v, w);
+  float det = a * c - b * b;
+  float t   = (b * e - c * d) / det;
+  float s   = (a * e - b * d) / det;
+  bool  ok  = det != 0 && !(t < tmin || t > tmax);
+  s         = fclamp(s, 0.0f, 1.0f);
+  f3    pr  = ro + rd * t;
+  f3    pl  = p0 + (p1 - p0) * s;
+  f3    prl = pr - pl;
+  float d2  = dot(prl, prl);
+  float r   = r0 * (1 - s) + r1 * s;
+  ok        = ok && !(d2 > r * r);
+  s_out = s, d2_out = d2, r_out = r, dist = t;
+  return ok;
+}
+
+// The finished ray's hit as the rest of the code knows it (hit_t of dev_trace.h: slot = leaf-order index of the primitive
+// in its shape, uv as the reference's intersect_line / intersect_triangle return them) from the raw form above.
+YH_DEV hit_t lane_hit(const trace_ctx& tc, hit_t raw, bool hit_lines, float hit_r) {
+#if YH_LANE_BLOB
+  if (raw.object >= 0) {
+    int lane_test;
+    if (tc.lds_scene) lane_test = __float_as_int(tc.lds_scene[YH_OBJECT_F4 * raw.object + 10].y);
+    else lane_test = tc.sc->objects[raw.object].lane_test;
+    raw.slot = hit_lines ? raw.slot - lane_test : (raw.slot - lane_test) >> 1;
+    if (hit_lines) raw.v = sqrtf(raw.v) / hit_r;
+  }
+#endif
+  return raw;
 }
 
 // One step of the ray in `t`. Returns true when the ray is finished (closest hit in t.hit), or —
@@ -197,11 +242,133 @@ YH_DEV bool lane_step(const trace_ctx& tc, lane_trav& t, lane_stack& s, int sp0,
         redo = true;
         return true;
       }
+#if YH_LANE_BLOB
+      {  // the shape's root in the blob (yhd_object::lane_root): fetched in this same step
+        int root;
+        if (tc.lds_scene) root = __float_as_int(tc.lds_scene[YH_OBJECT_F4 * t.cur_obj + 10].x);
+        else root = sc.objects[t.cur_obj].lane_root;
+        t.cur = (unsigned)root;
+        t.ld2 = dot(t.ld, t.ld);
+      }
+#else
       t.cur = YH_TAG_SHAPE | (unsigned)t.node_base;  // the shape's root: fetched in this same step
+#endif
       tag   = YH_TAG_SHAPE;
     }
   }
   YH_MARK("after_enter");
+#if YH_LANE_BLOB
+  if (!skip) {
+    YH_MARK("fetch");
+    YH_LPROF(LP_FETCH)
+    const bool         is_leaf  = tag == YH_TAG_LEAF;
+    const bool         lines    = t.kind == YH_KIND_LINES;
+    const int          leaf_num = (int)((t.cur >> 27) & 7u);
+    const unsigned int off      = t.cur & (is_leaf ? 0x07FFFFFFu : 0x3FFFFFFFu);  // 32-byte units into the blob
+    // Whatever the lane holds, its record is at lane_blob + 32 * off:
+    //   wide node      slot q = {A_q, B_q}
+    //   line leaf      segment i = {p0 r0, p1 r1} = {A_i, B_i}   (two per step; YH_LANE_LEAF4: up to four)
+    //   triangle leaf  triangle i = {p0}{p1}{p2}{-} = {A_2i, B_2i, A_2i+1}   (two per step)
+    // ONE round trip, one 64-bit address; the second 64 bytes are fetched only by the lanes that use them.
+    const yhd_float4* a = sc.lane_blob + 2 * (size_t)off;
+    const v4f A0 = ldg4(a), B0 = ldg4(a + 1), A1 = ldg4(a + 2), B1 = ldg4(a + 3);
+    v4f       A2, B2, A3, B3;
+    if (!is_leaf || (lines ? (YH_LANE_LEAF4 && leaf_num > 2) : leaf_num > 1)) A2 = ldg4(a + 4), B2 = ldg4(a + 5), A3 = ldg4(a + 6), B3 = ldg4(a + 7);
+    if (!is_leaf) {
+      YH_MARK("node");
+      YH_LPROF(LP_NODE)
+      // ---- wide node: the four slots {min.xyz, max.x} {max.yz, ref, axes}; refs are blob offsets, bits 8-11 of axes = occupied slots ----
+      const unsigned int axes = __float_as_uint(B0.w);
+      const unsigned int r0 = __float_as_uint(B0.z), r1 = __float_as_uint(B1.z), r2 = __float_as_uint(B2.z), r3 = __float_as_uint(B3.z);
+      unsigned int hm = 0;
+      hm |= box_test(t.lo, t.ldinv, ray_eps, t.tmax, f3{A0.x, A0.y, A0.z}, f3{A0.w, B0.x, B0.y}) ? 1u : 0u;
+      hm |= box_test(t.lo, t.ldinv, ray_eps, t.tmax, f3{A1.x, A1.y, A1.z}, f3{A1.w, B1.x, B1.y}) ? 2u : 0u;
+      hm |= box_test(t.lo, t.ldinv, ray_eps, t.tmax, f3{A2.x, A2.y, A2.z}, f3{A2.w, B2.x, B2.y}) ? 4u : 0u;
+      hm |= box_test(t.lo, t.ldinv, ray_eps, t.tmax, f3{A3.x, A3.y, A3.z}, f3{A3.w, B3.x, B3.y}) ? 8u : 0u;
+      hm &= axes >> 8;
+      // Visiting order of the slots (pt.cpp:887-893 at both collapsed levels, dev_trace.h): the pair on the near side of
+      // the node's axis first, inside a pair the slot on the near side of that child's axis. Slots are taken in REVERSE
+      // visiting order: each hit pushes the one found before it, so the first in visiting order ends up in `cur` and
+      // the others pop in order.
+      const unsigned int s0  = ((unsigned)t.lsign >> (axes & 3)) & 1;
+      const unsigned int sg0 = ((unsigned)t.lsign >> ((axes >> 2) & 3)) & 1, sg1 = ((unsigned)t.lsign >> ((axes >> 4) & 3)) & 1;
+      t.cur = YH_NONE;
+      YH_MARK("node_order");
+#pragma unroll
+      for (int r = 3; r >= 0; r--) {
+        const unsigned int pair = ((unsigned)r >> 1) ^ s0;
+        const unsigned int q    = (pair << 1) | (((unsigned)r & 1) ^ (pair ? sg1 : sg0));
+        if ((hm >> q) & 1) {
+          const unsigned int ref = (q & 2) ? ((q & 1) ? r3 : r2) : ((q & 1) ? r1 : r0);
+          if (t.cur != YH_NONE) {
+            YH_LPROF(LP_PUSH)
+            lane_push(s, t.cur);
+          }
+          t.cur = ref;
+        }
+      }
+    } else {
+      YH_MARK("leaf");
+      // ---- leaf: its primitives in leaf order, tmax shrinking after each accepted hit (pt.cpp:905-923) ----
+      const int per_step = lines ? (YH_LANE_LEAF4 ? 4 : 2) : 2;
+      t.cur = leaf_num > per_step ? (YH_TAG_LEAF | ((unsigned)(leaf_num - per_step) << 27) | (off + (unsigned)(lines ? per_step : 2 * per_step))) : YH_NONE;
+#define YH_LANE_ACCEPT_LINE(I)                                          \
+  if (ok && I < leaf_num) {                                             \
+    t.hit.object = t.cur_obj, t.hit.slot = (int)off + I;                \
+    t.hit.u = ss, t.hit.v = d2, t.hit_r = rr, t.hit.distance = dist;    \
+    t.tmax = dist, t.hit_lines = true;                                  \
+  }
+      if (lines) {
+        YH_MARK("line_leaf");
+        YH_LPROF(LP_LINE_LEAF)
+        if (PROF && leaf_num > 1) { YH_LPROF(LP_SEGS) }  // lanes whose second test of the step is a real segment
+        {
+          float ss, d2, rr, dist;
+          bool  ok = intersect_line_raw(t.lo, t.ld, t.ld2, ray_eps, t.tmax, xyz(A0), xyz(B0), A0.w, B0.w, ss, d2, rr, dist);
+          YH_LANE_ACCEPT_LINE(0)
+        }
+        {
+          float ss, d2, rr, dist;
+          bool  ok = intersect_line_raw(t.lo, t.ld, t.ld2, ray_eps, t.tmax, xyz(A1), xyz(B1), A1.w, B1.w, ss, d2, rr, dist);
+          YH_LANE_ACCEPT_LINE(1)
+        }
+        if (YH_LANE_LEAF4 && leaf_num > 2) {
+          {
+            float ss, d2, rr, dist;
+            bool  ok = intersect_line_raw(t.lo, t.ld, t.ld2, ray_eps, t.tmax, xyz(A2), xyz(B2), A2.w, B2.w, ss, d2, rr, dist);
+            YH_LANE_ACCEPT_LINE(2)
+          }
+          {
+            float ss, d2, rr, dist;
+            bool  ok = intersect_line_raw(t.lo, t.ld, t.ld2, ray_eps, t.tmax, xyz(A3), xyz(B3), A3.w, B3.w, ss, d2, rr, dist);
+            YH_LANE_ACCEPT_LINE(3)
+          }
+        }
+      } else {
+        YH_MARK("tri_leaf");
+        YH_LPROF(LP_TRI_LEAF)
+#define YH_LANE_ACCEPT_TRI(I)                                       \
+  if (ok && I < leaf_num) {                                         \
+    t.hit.object = t.cur_obj, t.hit.slot = (int)off + 2 * I;        \
+    t.hit.u = uu, t.hit.v = vv, t.hit.distance = dist;              \
+    t.tmax = dist, t.hit_lines = false;                             \
+  }
+        {
+          float uu = 0, vv = 0, dist = 0;
+          bool  ok = intersect_triangle(t.lo, t.ld, ray_eps, t.tmax, xyz(A0), xyz(B0), xyz(A1), uu, vv, dist);
+          YH_LANE_ACCEPT_TRI(0)
+        }
+        if (leaf_num > 1) {
+          float uu = 0, vv = 0, dist = 0;
+          bool  ok = intersect_triangle(t.lo, t.ld, ray_eps, t.tmax, xyz(A2), xyz(B2), xyz(A3), uu, vv, dist);
+          YH_LANE_ACCEPT_TRI(1)
+        }
+#undef YH_LANE_ACCEPT_TRI
+      }
+#undef YH_LANE_ACCEPT_LINE
+    }
+  }
+#else
   if (!skip) {
     YH_MARK("fetch");
     YH_LPROF(LP_FETCH)
@@ -313,6 +480,7 @@ YH_DEV bool lane_step(const trace_ctx& tc, lane_trav& t, lane_stack& s, int sp0,
 #undef YH_LANE_ACCEPT
     }
   }
+#endif
   YH_MARK("step_end");
   return t.cur == YH_NONE && s.sp == sp0;
 }
@@ -321,7 +489,8 @@ YH_DEV bool lane_step(const trace_ctx& tc, lane_trav& t, lane_stack& s, int sp0,
 // Out of line — one copy of the EXACT step for every caller — and everything by value, so that the
 // callers' stack and ray state stay in registers.
 struct lane_exact_result {
-  hit_t hit;
+  hit_t hit;    // raw, as lane_trav keeps it (lane_hit gives the final form)
+  float hit_r;
   int   hit_lines;
   int   base;  // the stack's window base afterwards (sp is back where it was)
 };
@@ -338,7 +507,7 @@ __device__ __attribute__((noinline)) lane_exact_result lane_trace_exact(const yh
   while (!lane_step<true>(tc, t, s, sp, dummy)) {
   }
   lane_exact_result r;
-  r.hit = t.hit, r.hit_lines = t.hit_lines ? 1 : 0, r.base = s.base;
+  r.hit = t.hit, r.hit_r = t.hit_r, r.hit_lines = t.hit_lines ? 1 : 0, r.base = s.base;
   return r;
 }
 
@@ -355,9 +524,9 @@ YH_DEV hit_t lane_trace(const trace_ctx& tc, lane_stack& s, f3 ro, f3 rd, int fi
     while (s.sp > sp0) (void)lane_pop(s);
     lane_exact_result r = lane_trace_exact(tc.sc_dev, tc.lds_scene, s.lds, s.ovf, s.sp, s.base, ro, rd, first_object);
     s.base = r.base;
-    return r.hit;
+    return lane_hit(tc, r.hit, r.hit_lines != 0, r.hit_r);
   }
-  return t.hit;
+  return lane_hit(tc, t.hit, t.hit_lines, t.hit_r);
 }
 
 }  // namespace yhd

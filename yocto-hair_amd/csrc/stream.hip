@@ -86,10 +86,12 @@ YH_DEV int list_push(YH_LDS unsigned short* list, int n, bool pred, int value) {
   if (pred) list[n + lane_rank(m)] = (unsigned short)value;
   return n + (int)__popcll(m);
 }
-// Closest hit of a finished ray into its slot; returns what it hit.
-YH_DEV int publish(const yhd_stream& pl, size_t g, const hit_t& hit, bool hit_lines, unsigned int steps) {
+// Closest hit of a finished ray into its slot, RAW as the traversal keeps it (dev_lane.h: the shading stage applies lane_hit
+// to the batch it shades, once per hit instead of in every step that retires a ray); returns what it hit.
+YH_DEV int publish(const yhd_stream& pl, size_t g, const hit_t& hit, bool hit_lines, float hit_r, unsigned int steps) {
   SLOT_HIT(pl, g)                 = yhd_int4{hit.object, hit.slot, __float_as_int(hit.u), __float_as_int(hit.v)};
   ((float*)&SLOT_RAY_O(pl, g))[3] = hit.distance;
+  ((float*)&SLOT_F4(pl, g, 7))[1] = hit_r;
   // steps of this ray: a scheduling hint of the pixel's work item, added to the pixel's total by the stage that
   // takes the path next (NOT an atomic add here: device-scope atomics execute at the memory side and drop the
   // slot's line from L2 — measured 1.6x on the whole kernel)
@@ -219,7 +221,7 @@ __global__ __launch_bounds__(YH_ST_BLOCK, WAVES) void k_stream(const yhd_scene s
             lane_exact_result r = lane_trace_exact(sc_dev, tc.lds_scene, stk.lds, stk.ovf, stk.sp, stk.base, f3{o.x, o.y, o.z},
                 f3{d.x, d.y, d.z}, -1);
             stk.base = r.base;
-            kd       = publish(pl, base + sl, r.hit, r.hit_lines != 0, 1u);
+            kd       = publish(pl, base + sl, r.hit, r.hit_lines != 0, r.hit_r, 1u);
           }
         }
         n_hair = list_push(l_hair, n_hair, kd == K_HAIR, sl);
@@ -307,6 +309,7 @@ __global__ __launch_bounds__(YH_ST_BLOCK, WAVES) void k_stream(const yhd_scene s
         }
         hit_t isec;
         isec.object = h.x, isec.slot = h.y, isec.u = __int_as_float(h.z), isec.v = __int_as_float(h.w), isec.distance = o.w;
+        isec = lane_hit(tc, isec, act == A_HAIR, ((const float*)&SLOT_F4(pl, g, 7))[1]);  // (hair batches hold the hits on lines)
         rng_t rng;
         rng.state = (uint64_t)(unsigned)r4.x | ((uint64_t)(unsigned)r4.y << 32);
         rng.inc   = (uint64_t)(unsigned)r4.z | ((uint64_t)(unsigned)r4.w << 32);
@@ -364,7 +367,7 @@ __global__ __launch_bounds__(YH_ST_BLOCK, WAVES) void k_stream(const yhd_scene s
               kind   = K_REDO;  // traced again by the exact form in the sort stage
               stk.sp = 0, stk.base = 0;
             } else {
-              kind = publish(pl, base + slot, t.hit, t.hit_lines, t.steps);
+              kind = publish(pl, base + slot, t.hit, t.hit_lines, t.hit_r, t.steps);
             }
           }
         }
@@ -443,13 +446,13 @@ __global__ __launch_bounds__(256, WAVES) void k_intersect_lanes(const yhd_scene 
       bool redo = false;
       if (lane_step<false>(tc, t, stk, 0, redo)) {
         have = false;
-        hit_t h = t.hit;
+        hit_t h = lane_hit(tc, t.hit, t.hit_lines, t.hit_r);
         if (redo) {  // axis-parallel ray: the reference's compare-and-select box test throughout
           stk.sp = 0, stk.base = 0;
           const float*      r = rays + 8 * (size_t)ray;
           lane_exact_result e = lane_trace_exact(sc_dev, tc.lds_scene, stk.lds, stk.ovf, 0, 0, ld3(r), ld3(r + 3), -1);
           stk.base = e.base;
-          h        = e.hit;
+          h        = lane_hit(tc, e.hit, e.hit_lines != 0, e.hit_r);
           if (h.object >= 0 && h.distance > r[7]) h.object = -1, h.slot = -1, h.u = 0, h.v = 0, h.distance = 0;  // (the exact form starts from tmax = flt_max)
         }
         object[ray] = h.object, element[ray] = hit_element(sc, h);
@@ -459,7 +462,51 @@ __global__ __launch_bounds__(256, WAVES) void k_intersect_lanes(const yhd_scene 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The one-lane kernels' copy of a shape's tree (yh_device.h: yhd_scene::lane_blob), made from the arrays the quad kernels
+// read: the ray-test halves of the leaf-ordered primitive records, and the 4-wide nodes with absolute references and a
+// bit per occupied slot. HBM-streaming, one thread per record.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void k_lane_tests(const yhd_float4* __restrict__ prims, yhd_float4* __restrict__ out, int kind, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (kind == YH_KIND_LINES) {
+    out[2 * (size_t)i] = prims[4 * (size_t)i], out[2 * (size_t)i + 1] = prims[4 * (size_t)i + 1];
+  } else {
+    out[4 * (size_t)i] = prims[6 * (size_t)i], out[4 * (size_t)i + 1] = prims[6 * (size_t)i + 1], out[4 * (size_t)i + 2] = prims[6 * (size_t)i + 2];
+    out[4 * (size_t)i + 3] = yhd_float4{0, 0, 0, 0};
+  }
+}
+__global__ void k_lane_nodes(const yhd_float4* __restrict__ nodes, yhd_float4* __restrict__ out, int kind, int n, unsigned int node_off,
+    unsigned int test_off) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  yhd_float4   s[8];
+  unsigned int occupied = 0;
+  for (int k = 0; k < 8; k++) s[k] = nodes[8 * (size_t)i + k];
+  for (int q = 0; q < 4; q++) {
+    unsigned int ref = __float_as_uint(s[2 * q + 1].z);
+    if (ref == YH_NONE) continue;
+    occupied |= 1u << q;
+    if ((ref & YH_TAG_MASK) == YH_TAG_LEAF) ref = (ref & 0xF8000000u) | (test_off + (ref & 0x07FFFFFFu) * (kind == YH_KIND_LINES ? 1u : 2u));
+    else ref = node_off + 4u * ref;  // child wide nodes were shape-local indices
+    s[2 * q + 1].z = __uint_as_float(ref);
+  }
+  for (int q = 0; q < 4; q++) s[2 * q + 1].w = __uint_as_float((__float_as_uint(s[2 * q + 1].w) & 0xFFu) | (occupied << 8));
+  for (int k = 0; k < 8; k++) out[8 * (size_t)i + k] = s[k];
+}
+
 extern "C" {
+
+int yhk_lane_blob_shape(const yhd_float4* nodes, const yhd_float4* prims, yhd_float4* blob, int kind, int node_base, int num_nodes, int prim_base,
+    int num_prims, long long node_off, long long test_off, hipStream_t stream) {
+  if (num_prims > 0)
+    hipLaunchKernelGGL(k_lane_tests, dim3((num_prims + 255) / 256), dim3(256), 0, stream, prims + prim_base, blob + 2 * test_off, kind, num_prims);
+  if (num_nodes > 0)
+    hipLaunchKernelGGL(k_lane_nodes, dim3((num_nodes + 255) / 256), dim3(256), 0, stream, nodes + 8 * (size_t)node_base, blob + 2 * node_off, kind, num_nodes,
+        (unsigned int)node_off, (unsigned int)test_off);
+  return (int)hipGetLastError();
+}
 
 // waves: 4, 6 or 8 per SIMD (the register budget: 128 / 80 / 64)
 typedef void (*lanes_kernel_t)(const yhd_scene, const yhd_scene*, int, const float*, int*, unsigned int*, int, int*, int*, float*, float*);

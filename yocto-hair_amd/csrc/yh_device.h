@@ -48,8 +48,11 @@ typedef struct yhd_object {
   // safety margin: a ray that misses it by that much cannot hit anything in the object, so ENTER
   // and the root fetch are skipped for it (dev_trace.h)
   float wbox_min[4], wbox_max[4];  // wbox_min[3] / wbox_max[3] = (int bits) first 8-wide / 16-wide node of the shape in yhd_scene::nodes8 / nodes16
+  // the shape's place in yhd_scene::lane_blob (the one-lane kernels' copy of the trees, dev_lane.h), in 32-byte units:
+  // its root node and its first test record
+  int   lane_root, lane_test, lane_pad0, lane_pad1;
 } yhd_object;
-#define YH_OBJECT_F4 10 /* sizeof(yhd_object) / 16 */
+#define YH_OBJECT_F4 11 /* sizeof(yhd_object) / 16 */
 
 // ptr::material + everything of hair_brdf that depends on the material only
 // (ext.cpp:131-172), computed ONCE on the host at upload.
@@ -179,6 +182,17 @@ typedef struct yhd_scene {
   const yhd_float4* nodes16;
   int               num_nodes16_total;
   int               stack_entries16;
+  // The one-lane kernels' copy of the shape trees (k_stream, k_intersect_lanes; dev_lane.h), ONE array addressed in
+  // 32-byte units so that whatever a lane holds — node or leaf — is fetched from lane_blob + 32 * offset with the same
+  // eight 16-byte loads:
+  //   test records  a hair segment = 32 B {p0.xyz, r0} {p1.xyz, r1} (the ray-test half of its yhd_scene::prims record),
+  //                 a triangle = 64 B {p0}{p1}{p2}{-}; both in the shape's leaf order
+  //   nodes         the 4-wide nodes of yhd_scene::nodes (128 B, same boxes, same axes word + a bit per occupied slot in
+  //                 bits 8-11) with ABSOLUTE references: a child node's offset in the blob, or
+  //                 YH_TAG_LEAF | count << 27 | offset of the leaf's first test record
+  // Built on the device from nodes / prims at the first launch that needs it (host/context.cpp: ensure_lane_blob).
+  const yhd_float4* lane_blob;
+  long long         lane_blob_units;
 } yhd_scene;
 #ifndef YH_LDS_NODELETS
 #define YH_LDS_NODELETS 0 /* developer switch: stage the top wide nodes of the dominant hair shape in LDS (YHAIR_LDS_NODES=n); measured twice without gain */

@@ -13,6 +13,9 @@
 // There is no CPU fallback: without a GPU yh_create returns NULL.
 #include <hip/hip_runtime_api.h>
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <rccl/rccl.h>  // types only: the library is opened on first use (yh_gather_framebuffer)
 
 #include <algorithm>
@@ -34,6 +37,7 @@
 
 #include "../csrc/yh_device.h"
 #include "bvh_build.h"
+#include "build_id.h"  // YH_BUILD_ID: a hash of the device and host sources, written by the Makefile
 #include "yhair.h"
 
 // launchers in csrc/kernels.hip
@@ -55,6 +59,8 @@ int yhk_wavefront_lds_bytes(int stack_entries, int tables_f4, int k);
 int yhk_wavefront_occupancy(int lds_bytes, int general, int k);
 #endif
 int yhk_stream(const yhd_scene*, const yhd_scene* sc_dev, const yhd_state*, int, const yhd_stream*, int grid_blocks, hipStream_t);
+int yhk_lane_blob_shape(const yhd_float4* nodes, const yhd_float4* prims, yhd_float4* blob, int kind, int node_base, int num_nodes, int prim_base,
+    int num_prims, long long node_off, long long test_off, hipStream_t);
 int yhk_stream_block_threads(void);
 int yhk_stream_lds_bytes(int tables_f4, int slots_per_wave);
 int yhk_stream_occupancy(int lds_bytes, int general);
@@ -281,6 +287,7 @@ struct yh_context {
   int         hy_quad_items = 0, hy_oct_entries = 0;  // layout of the work list for shape 5: [quad items][octet entries]
   std::vector<int> hy_oct_items;                       // ... and the items that run as octets
   int         num_cus = 0;
+  std::string device_name;  // gcnArchName / marketing name / CU count: part of the key of the trial record on disk
   std::string error = "no error";
   // scene
   bool      have_scene = false;
@@ -296,6 +303,12 @@ struct yh_context {
   std::vector<yhh::Tree>   host_trees;    // per shape (emptied once the wide arrays exist)
   std::vector<yhd_object>  host_objects;  // as uploaded; wbox_min[3] / wbox_max[3] = the wide arrays' bases once built
   std::vector<int>         object_shape;  // shape index of every object
+  // the one-lane kernels' copy of the trees (yhd_scene::lane_blob): laid out at upload, filled on the device at the first
+  // launch of k_stream / k_intersect_lanes (ensure_lane_blob)
+  struct LaneShape { int kind, node_base, num_nodes, prim_base, num_prims; long long node_off, test_off; };  // offsets in 32-byte units
+  std::vector<LaneShape>   lane_shapes;
+  long long                lane_units = 0;
+  DevBuf                   d_lane_blob;
   // state
   bool             have_state = false;
   yhd_state        state{};
@@ -324,6 +337,7 @@ struct yh_context {
   double           shape_ms[YH_SHAPES] = {};   // (indexed by launch shape, yhd_state::launch_shape)
   int              shape_trials[YH_SHAPES] = {};  // trial launches behind each shape_ms (the minimum over them counts)
   uint64_t         scene_key = 0;                   // fingerprint of the uploaded scene (key of the process-wide trial record)
+  bool             trials_from_disk = false;        // the record was read from the on-disk cache: complete, no trial runs
   bool             have_costs = false;
   bool             costs_settled = false;   // the item costs come from a launch of at least YH_TRIAL_SPP samples (not from the 1-spp probe)
   bool             planned_settled = false; // ... and the most recent launch was planned from such costs (only then does its time rank a kernel)
@@ -459,6 +473,7 @@ constexpr int YH_TRIAL_SPP = 32;  // shorter launches have flat, noisy costs: th
 // best, both are tried a second time and the minimum of a kernel's trials counts, so that two ranks rendering halves of
 // one image, or two renders of one image, do not settle on different kernels by chance.
 constexpr double YH_TRIAL_TIE  = 1.15;
+constexpr double YH_FINAL_TIE  = 1.05;  // after the trials: candidates this close to the fastest count as tied (pick_launch_shape)
 constexpr int    YH_TRIALS_MAX = 2;
 // The trial results of an image are kept per process under (scene fingerprint, image size, shard, bounces): a new
 // context on the same scene and image (a re-render, the next frame of a caller that re-creates its context) starts
@@ -479,20 +494,101 @@ std::map<TrialKey, TrialRecord> g_trials;
 TrialKey trial_key(const yh_context* ctx) {
   return TrialKey{ctx->scene_key, ctx->state.width, ctx->state.height, ctx->rank, ctx->world, ctx->state.bounces};
 }
+// The same record ON DISK (round 4), so that the kernel an image runs does not depend on a handful of 32-sample launches
+// re-decided by every process (every rank of every run): ~/.cache/yhair/trials_v1.txt (YHAIR_CACHE_DIR, XDG_CACHE_HOME),
+// one line per record, keyed by device, the build's fingerprint (host/build_id.h: a hash of the device and host sources),
+// YHAIR_DEVICE_SHARE and the TrialKey; appended with one O_APPEND write (atomic between the ranks of a run), the last line
+// of a key counts. Only COMPLETE records are written (no candidate still wants a trial) and a loaded one is complete by
+// construction, so a process that finds its image here runs no trial at all. YHAIR_NO_DISK_CACHE (or YHAIR_NO_TRIAL_CACHE,
+// which also forgets the per-process record) switches it off.
+std::string disk_cache_path() {
+  if (getenv("YHAIR_NO_DISK_CACHE") || getenv("YHAIR_NO_TRIAL_CACHE")) return "";
+  std::string dir;
+  if (const char* e = getenv("YHAIR_CACHE_DIR")) dir = e;
+  else if (const char* x = getenv("XDG_CACHE_HOME")) dir = std::string(x) + "/yhair";
+  else if (const char* h = getenv("HOME")) dir = std::string(h) + "/.cache/yhair";
+  else return "";
+  return dir + "/trials_v1.txt";
+}
+std::string disk_key(const yh_context* ctx) {
+  const char* share = getenv("YHAIR_DEVICE_SHARE");
+  char buf[256];
+  snprintf(buf, sizeof(buf), "%s|%s|%s|%016llx|%d|%d|%d|%d|%d", ctx->device_name.c_str(), YH_BUILD_ID, share ? share : "1",
+      (unsigned long long)ctx->scene_key, ctx->state.width, ctx->state.height, ctx->rank, ctx->world, ctx->state.bounces);
+  return buf;
+}
+void mkdirs(const std::string& file) {
+  for (size_t i = 1; i < file.size(); i++)
+    if (file[i] == '/') (void)mkdir(file.substr(0, i).c_str(), 0755);
+}
+void disk_store(const yh_context* ctx, const TrialRecord& r) {
+  const std::string path = disk_cache_path();
+  if (path.empty()) return;
+  mkdirs(path);
+  std::string line = disk_key(ctx) + " =";
+  char        buf[64];
+  for (int k = 0; k < YH_SHAPES; k++) {
+    snprintf(buf, sizeof(buf), " %.9g:%d", std::isinf(r.ms[k]) ? -1.0 : r.ms[k], r.trials[k]);
+    line += buf;
+  }
+  snprintf(buf, sizeof(buf), " ; %d %d %d\n", r.dense, r.chain, r.chain16);
+  line += buf;
+  int fd = open(path.c_str(), O_WRONLY | O_CREAT | O_APPEND, 0644);
+  if (fd < 0) return;
+  (void)!write(fd, line.data(), line.size());
+  close(fd);
+}
+bool disk_load(const yh_context* ctx, TrialRecord& r) {
+  const std::string path = disk_cache_path();
+  if (path.empty()) return false;
+  FILE* f = fopen(path.c_str(), "r");
+  if (!f) return false;
+  const std::string key = disk_key(ctx) + " =";
+  bool  found = false;
+  char  line[2048];
+  while (fgets(line, sizeof(line), f)) {
+    if (strncmp(line, key.c_str(), key.size()) != 0) continue;
+    TrialRecord t{};
+    const char* p  = line + key.size();
+    bool        ok = true;
+    for (int k = 0; k < YH_SHAPES && ok; k++) {
+      int n = 0;
+      ok    = sscanf(p, " %lf:%d%n", &t.ms[k], &t.trials[k], &n) == 2;
+      p += n;
+      if (ok && t.ms[k] < 0) t.ms[k] = std::numeric_limits<double>::infinity();  // a candidate that cannot run on this device
+    }
+    if (ok && sscanf(p, " ; %d %d %d", &t.dense, &t.chain, &t.chain16) == 3) r = t, found = true;  // (the last line of a key counts)
+  }
+  fclose(f);
+  return found;
+}
 void trials_store(const yh_context* ctx) {
   TrialRecord r;
   for (int k = 0; k < YH_SHAPES; k++) r.ms[k] = ctx->shape_ms[k], r.trials[k] = ctx->shape_trials[k];
   r.dense = ctx->dense, r.chain = ctx->chain, r.chain16 = ctx->chain16;
-  std::lock_guard<std::mutex> lock(g_trials_mutex);
-  g_trials[trial_key(ctx)] = r;
+  {
+    std::lock_guard<std::mutex> lock(g_trials_mutex);
+    g_trials[trial_key(ctx)] = r;
+  }
+  if (ctx->costs_settled && !trial_pending(ctx)) disk_store(ctx, r);  // complete: nothing left to try on this image
 }
 void trials_load(yh_context* ctx) {
   if (getenv("YHAIR_NO_TRIAL_CACHE")) return;  // developer switch
-  std::lock_guard<std::mutex> lock(g_trials_mutex);
-  auto it = g_trials.find(trial_key(ctx));
-  if (it == g_trials.end()) return;
-  for (int k = 0; k < YH_SHAPES; k++) ctx->shape_ms[k] = it->second.ms[k], ctx->shape_trials[k] = it->second.trials[k];
-  ctx->dense = it->second.dense, ctx->chain = it->second.chain, ctx->chain16 = it->second.chain16;
+  TrialRecord r{};
+  bool        have = false;
+  {
+    std::lock_guard<std::mutex> lock(g_trials_mutex);
+    auto it = g_trials.find(trial_key(ctx));
+    if (it != g_trials.end()) r = it->second, have = true;
+  }
+  if (!have && disk_load(ctx, r)) {
+    have = true;
+    ctx->trials_from_disk = true;
+    if (getenv("YHAIR_TIMING")) fprintf(stderr, "[yhair] kernel trials of this image: read from %s\n", disk_cache_path().c_str());
+  }
+  if (!have) return;
+  for (int k = 0; k < YH_SHAPES; k++) ctx->shape_ms[k] = r.ms[k], ctx->shape_trials[k] = r.trials[k];
+  ctx->dense = r.dense, ctx->chain = r.chain, ctx->chain16 = r.chain16;
 }
 bool trials_off() {
   static const bool off = getenv("YHAIR_NO_TRIALS") != nullptr;  // developer switch: the cost heuristic only
@@ -553,8 +649,13 @@ bool wants_trial(const yh_context* ctx, const int* cand, int n, int c) {
 // Is a candidate kernel still untimed on this image (so that a long request should start with a short trial)?
 bool trial_pending(const yh_context* ctx) {
   if (!ctx->have_state || !ctx->have_costs || ctx->state.shader != YH_SHADER_PATH || trials_off() || ctx->params.hair_exact) return false;
-  if (!ctx->costs_settled) return true;  // (the first short launch settles the item costs; the trials follow it)
   int cand[6], n = candidates(ctx, cand);
+  if (ctx->trials_from_disk) {  // a record from the disk cache is complete: no settling launch, no trial — unless the candidates have changed
+    bool complete = true;
+    for (int k = 0; k < n; k++) complete = complete && ctx->shape_ms[cand[k]] != 0;
+    if (complete) return false;
+  }
+  if (!ctx->costs_settled) return true;  // (the first short launch settles the item costs; the trials follow it)
   for (int k = 0; k < n; k++)
     if (wants_trial(ctx, cand, n, cand[k])) return true;
   return false;
@@ -567,14 +668,22 @@ int pick_launch_shape(const yh_context* ctx, int nsamples) {
   const int by_costs = ctx->dense > 0 ? 1 : 0;
   if (trials_off()) return by_costs;
   int cand[6], n = candidates(ctx, cand), best = -1;
-  const bool trial_length = ctx->costs_settled && nsamples >= YH_TRIAL_SPP && nsamples < 2 * YH_TRIAL_SPP;
+  const bool trial_length = ctx->costs_settled && nsamples >= YH_TRIAL_SPP && nsamples < 2 * YH_TRIAL_SPP && !(ctx->trials_from_disk && !trial_pending(ctx));
   for (int k = 0; k < n; k++) {
     const int c = cand[k];
     if (trial_length && wants_trial(ctx, cand, n, c)) return c;  // a trial
     if (ctx->shape_ms[c] == 0) continue;
     if (best < 0 || ctx->shape_ms[c] < ctx->shape_ms[best]) best = c;
   }
-  return best >= 0 ? best : by_costs;
+  if (best < 0) return by_costs;
+  // A tie is decided by a FIXED order, not by the noise of the last 32-sample launch: among the candidates within
+  // YH_FINAL_TIE of the fastest the first of k_stream, the dense quad shape, the side-by-side launch, the wide forms
+  // (leaf groups before plain), the plain quad kernel — so that two renders (two ranks, two boxes) of one image run the same kernel.
+  static const int order[YH_SHAPES] = {3, 1, 5, 8, 7, 6, 4, 0, 2};
+  for (int o = 0; o < YH_SHAPES; o++)
+    for (int k = 0; k < n; k++)
+      if (cand[k] == order[o] && ctx->shape_ms[cand[k]] != 0 && ctx->shape_ms[cand[k]] <= YH_FINAL_TIE * ctx->shape_ms[best]) return cand[k];
+  return best;
 }
 void build_work_items(const yh_context* ctx, std::vector<int>& items) {
   // Expensive items first, in decreasing cost (they bound the launch); the cheap
@@ -653,6 +762,9 @@ yh_context* yh_create(int device) {
     return nullptr;
   }
   ctx->num_cus = prop.multiProcessorCount;
+  ctx->device_name = std::string(prop.gcnArchName) + "/" + prop.name + "/" + std::to_string(prop.multiProcessorCount);
+  for (char& c : ctx->device_name)
+    if (c == ' ' || c == '|' || c == '\n') c = '_';
   return ctx;
 }
 
@@ -694,7 +806,7 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
     int node8_base, depth8;  // the same tree collapsed three levels at a time (yhd_scene::nodes8)
     int node16_base, depth16;  // ... and four (yhd_scene::nodes16)
     yhh::Box root;
-    int num_nodes;
+    int num_nodes, num_prims;
   };
   std::vector<ShapeInfo>  info(sd->num_shapes);
   std::vector<yhd_float4> nodes, prims, vpos;
@@ -780,7 +892,7 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
       I.depth8 = 1 + deepest / 3, I.depth16 = 1 + deepest / 4;
       I.node8_base = I.node16_base = 0;
     }
-    I.root = tree.nodes[0].bbox, I.num_nodes = (int)wide.size();
+    I.root = tree.nodes[0].bbox, I.num_nodes = (int)wide.size(), I.num_prims = nel;
     {
       size_t at = nodes.size();
       nodes.resize(at + wide.size() * 8);
@@ -838,6 +950,22 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
     lap("leaf records + vertex arrays");
     ctx->host_trees[(size_t)si] = std::move(tree);
   }
+  // ---- layout of the one-lane kernels' copy of the trees (yh_device.h: lane_blob): test records first, nodes behind ----
+  ctx->lane_shapes.assign((size_t)sd->num_shapes, yh_context::LaneShape{});
+  {
+    long long at = 0;
+    for (int si = 0; si < sd->num_shapes; si++) {
+      auto& L = ctx->lane_shapes[(size_t)si];
+      L.kind = info[si].kind, L.node_base = info[si].node_base, L.num_nodes = info[si].num_nodes, L.prim_base = info[si].prim_base, L.num_prims = info[si].num_prims;
+      L.test_off = at, at += (long long)L.num_prims * (L.kind == YH_KIND_LINES ? 1 : 2);
+    }
+    at = (at + 3) / 4 * 4 + 4;  // (nodes on 128-byte lines; four units of slack behind the last test record: a leaf step reads 64 bytes)
+    if (at >= (1ll << 27)) return fail(ctx, YH_E_INVALID, "scene too large for 27-bit leaf offsets (%lld test-record units)", at);
+    for (int si = 0; si < sd->num_shapes; si++) ctx->lane_shapes[(size_t)si].node_off = at, at += 4ll * info[si].num_nodes;
+    if (at >= (1ll << 30)) return fail(ctx, YH_E_INVALID, "scene too large for 30-bit node offsets (%lld units)", at);
+    ctx->lane_units = at + 4;
+  }
+  ctx->d_lane_blob.reset();
   // ---- objects and the scene-level BVH (pt.cpp:792-814) -------------------
   std::vector<yhd_object> objects(sd->num_objects);
   std::vector<yhh::Box>   obj_boxes(sd->num_objects);
@@ -851,6 +979,7 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
     inverse_frame(o.frame, true, d.inv_frame);
     d.kind = I.kind, d.node_base = I.node_base, d.prim_base = I.prim_base, d.vert_base = I.vert_base;
     d.elem_base = I.elem_base, d.has_normals = I.has_normals, d.material = o.material, d.has_texcoords = sd->shapes[o.shape].texcoords != nullptr;
+    d.lane_root = (int)ctx->lane_shapes[(size_t)o.shape].node_off, d.lane_test = (int)ctx->lane_shapes[(size_t)o.shape].test_off, d.lane_pad0 = d.lane_pad1 = 0;
     // transform_bbox (math.h:3174-3185)
     const yhh::Box& b = I.root;
     float lo[3] = {std::numeric_limits<float>::max(), std::numeric_limits<float>::max(), std::numeric_limits<float>::max()};
@@ -1060,6 +1189,7 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
   sc.stack_entries8 = std::max(8, (ctx->stack_need8 + 7) / 8 * 8);
   sc.nodes16 = nullptr, sc.num_nodes16_total = 0;
   sc.stack_entries16 = std::max(8, (ctx->stack_need16 + 7) / 8 * 8);
+  sc.lane_blob = nullptr, sc.lane_blob_units = 0;  // filled at first use: ensure_lane_blob
   sc.textures = (const yhd_texture*)ctx->d_textures.p, sc.tex_texels = (const yhd_float4*)ctx->d_tex_texels.p;
   sc.vtex = (const float*)ctx->d_vtex.p;
   memcpy(sc.camera.frame, sd->camera.frame, 48);
@@ -1483,6 +1613,24 @@ static int wavefront_impl(yh_context* ctx, int nsamples, bool sync) {
 }
 #endif
 
+// The one-lane kernels' copy of the shape trees (yh_device.h: yhd_scene::lane_blob), made on the device from the node and
+// primitive arrays at the first launch that needs it: an image that never runs k_stream / k_intersect_lanes does not pay
+// the memory (test records 32 B per segment + the nodes once more).
+static int ensure_lane_blob(yh_context* ctx) {
+  if (ctx->scene.lane_blob) return YH_OK;
+  int rc;
+  if ((rc = alloc_zero(ctx, ctx->d_lane_blob, (size_t)ctx->lane_units * 32))) return rc;
+  for (auto& L : ctx->lane_shapes) {
+    int e = yhk_lane_blob_shape(ctx->scene.nodes, ctx->scene.prims, (yhd_float4*)ctx->d_lane_blob.p, L.kind, L.node_base, L.num_nodes, L.prim_base,
+        L.num_prims, L.node_off, L.test_off, ctx->stream);
+    if (e) return fail(ctx, YH_E_DEVICE, "lane blob build: %s", hipGetErrorString((hipError_t)e));
+  }
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->scene.lane_blob = (const yhd_float4*)ctx->d_lane_blob.p, ctx->scene.lane_blob_units = ctx->lane_units;
+  ctx->d_scene_copy.reset();  // (the scene table in device memory is made again at its next use)
+  return YH_OK;
+}
+
 // Launch geometry of the streaming integrator: path slots per wave and workgroups. The pixels of the launch are
 // spread over as many waves as the CUs hold, each wave with a few paths per lane so that its lanes stay full
 // between stages: 128 .. 192 slots (more waves beat fuller batches: measured on C2 / C3, profiles/r02;
@@ -1602,6 +1750,7 @@ static int stream_impl(yh_context* ctx, int nsamples, bool sync) {
     ctx->st_ovf_words = ovf_words, ctx->stream_pool.stack_ovf = (unsigned int*)ctx->d_st_ovf.p;
   }
   ctx->stream_pool.slots_per_wave = P, ctx->stream_pool.ovf_entries = ovf_entries, ctx->stream_pool.total_slots = (long long)ctx->st_slots;
+  if ((rc = ensure_lane_blob(ctx))) return rc;
   const bool prof = getenv("YHAIR_ST_PROF") && atoi(getenv("YHAIR_ST_PROF")) != 0;  // developer switch: per-stage counters on stderr
   if (prof) {
     if ((rc = alloc_zero(ctx, ctx->d_st_prof, 64 * 8))) return rc;
@@ -1787,6 +1936,7 @@ int yh_kernel_trials(const yh_context* ctx, double* ms_per_sample, int* trials, 
   }
   return YH_SHAPES;
 }
+int yh_trials_pending(const yh_context* ctx) { return ctx ? (trial_pending(ctx) ? 1 : 0) : YH_E_INVALID; }
 int yh_last_trace_ms(const yh_context* ctx, float* ms, int* launches) {
   if (!ctx) return YH_E_INVALID;
   if (ms) *ms = ctx->last_ms;
@@ -2272,6 +2422,7 @@ int yh_intersect_batch(yh_context* ctx, int n, const float* rays, int* object, i
     auto         dcur        = (int*)s.out(16);
     auto         dovf        = (unsigned int*)s.out((size_t)grid * 4 * ovf_entries * 64 * 4);
     if (s.rc) return s.rc;
+    if (int rcb = ensure_lane_blob(ctx)) return rcb;
     if (!ctx->d_scene_copy.p) {
       int rc = upload(ctx, ctx->d_scene_copy, &ctx->scene, sizeof(yhd_scene));
       if (rc) return rc;

@@ -150,6 +150,7 @@ _SIGS = {
     "yh_tile_costs": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_int]),
     "yh_item_costs": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_int]),
     "yh_kernel_trials": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_int]),
+    "yh_trials_pending": (C.c_int, [C.c_void_p]),
     "yh_hair_brdf_batch": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Material), c_float_p,
                                      c_float_p, c_float_p, c_float_p]),
     "yh_curves_to_lines": (C.c_int, [C.c_void_p, C.c_int, c_float_p, c_float_p, c_float_p, C.c_int, c_float_p,
@@ -311,6 +312,12 @@ class Context:
         n = self.lib.yh_kernel_trials(self.h, ms, tr, 16)
         self._chk(min(n, 0))
         return {k: (round(ms[k], 5), tr[k]) for k in range(min(n, 16)) if tr[k] or ms[k]}
+
+    def trials_pending(self):
+        """True while a candidate kernel of this image still wants a 32-sample timing trial (include/yhair.h)."""
+        n = self.lib.yh_trials_pending(self.h)
+        self._chk(min(n, 0))
+        return n > 0
 
     def item_costs(self):
         """Per work item (tile * 4 + quadrant) cost of the most recent launch."""
