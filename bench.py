@@ -470,6 +470,36 @@ def main():
     torch.cuda.synchronize()
     gather_ms = (time.perf_counter() - t0) * 1e3
 
+    # ---- N > 1: "pixels do not depend on the shard", checked on the real collective: the ranks render the config's image
+    # once more at a few spp and gather it; rank 0 then renders the WHOLE image alone at the same spp and seed — bitwise equal
+    shard_check = None
+    if world > 1:
+        check_spp = 4
+        pc = yh.TraceParams.default(resolution=res_main)
+        ctx.set_shard(rank, world)
+        ctx.init_state(pc)
+        ctx.trace_samples(check_spp)
+        npix = ctx.shard_pixels(rank, world)
+        pk = torch.zeros((npix, 4), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        ctx.pack_tiles_device(pk.data_ptr(), npix)
+        if cdev == "cpu":
+            pk = pk.cpu()
+        gathered = yhair_dist.gather_framebuffer(pk, width, height, rank, world, ctx=ctx)
+        torch.cuda.synchronize()
+        if rank == 0:
+            ctx.set_shard(0, 1)
+            ctx.init_state(pc)
+            ctx.trace_samples(check_spp)
+            alone = ctx.download()
+            got = gathered.cpu().numpy()
+            diff = int(np.any(got != alone, axis=2).sum())
+            shard_check = {"what": f"the image gathered from {world} ranks against the same image rendered by rank 0 alone, same seed, {check_spp} spp",
+                           "spp": check_spp, "bitwise_equal": diff == 0, "differing_pixels": diff,
+                           "collective_ranks": dist.get_world_size(), "backend": dist.get_backend()}
+        ctx.set_shard(rank, world)
+        dist.barrier()
+
     # ---- N > 1: the other scaling mode, a shorter run, reported next to the main one -------------------
     other = None
     if world > 1:
@@ -479,9 +509,33 @@ def main():
         other = {"mode": "strong" if a.weak else "weak", "image": f"{ow}x{oh}", "steps": k_other,
                  "value": round(ow * oh * sum(step_spp[:k_other]) / oel / 1e6, 2), "unit": "Msamples/s"}
 
+    img = image.cpu().numpy() if rank == 0 else None  # (a copy: the context's buffers are about to be reused)
+    # ---- how closely device paths FOLLOW the reference's on the scene where the default BSDF arithmetic shows most: the
+    # reference's own sphere-hairblock.json (light hair, colour 0.8: eight-bounce paths) against the reference's images of it
+    # (tests/golden/refscenes.npz), with the default arithmetic and with yh_trace_params::hair_exact -------------------
+    follow = None
+    if rank == 0 and world == 1 and headline:
+        try:
+            g = np.load(os.path.join(ROOT, "tests", "golden", "refscenes.npz"))
+            ref8, ref8_other_seed = g["sphere-hairblock|8"], g["sphere-hairblock|8_seed777"]
+            rsf = yh.SceneFile(make_scenes.ensure_scene("ref-sphere-hairblock", scenes_dir, scale=0.05))
+            ctx.upload_scene(rsf.desc)
+            ctx.set_shard(0, 1)
+            relrmse = lambda a, b: float(np.sqrt(np.mean((a[..., :3] - b[..., :3]) ** 2)) / max(1e-12, np.mean(b[..., :3])))
+            floor = relrmse(ref8_other_seed, ref8)
+            follow = {"scene": "the reference's tests/sphere-hairblock/sphere-hairblock.json (hair colour 0.8) with stand-in geometry x 0.05, "
+                               f"{ref8.shape[1]}x{ref8.shape[0]}, 8 spp, against the reference's own image of it (tests/golden/refscenes.npz)",
+                      "rel_rmse_cpu_seed_floor": round(floor, 5), "stated_bar": {"fast_bsdf": 0.75, "exact_bsdf": 0.5}}
+            for key, exact in (("fast_bsdf", False), ("exact_bsdf", True)):
+                ctx.init_state(yh.TraceParams.default(resolution=ref8.shape[0], hair_exact=exact))
+                ctx.trace_samples(8)
+                follow["ratio_to_floor_" + key] = round(relrmse(ctx.download(), ref8) / floor, 4)
+            rsf.close()
+        except Exception as e:  # never at the expense of the reported line
+            follow = {"error": str(e)}
+
     # ---- the other BASELINE configs, after everything the headline line needs has been measured -----------
     main_launches = sum(ctx_launches_main)
-    img = image.cpu().numpy() if rank == 0 else None  # (a copy: the context's buffers are about to be reused)
     others = None
     if rank == 0 and world == 1 and headline and a.other_configs:
         others = {}
@@ -546,6 +600,7 @@ def main():
                                    + ("" if world == 1 else (f" (weak: image side {base_res} * sqrt({world}) -> {width}, {width * height // world} pixels per GPU)"
                                                              if a.weak else " (strong: the config's own image)")),
                        "collective": collective if grouped else "none (one rank: the packed tiles are un-interleaved in place)",
+                       "collective_ranks": dist.get_world_size() if grouped else 1,
                        "upload_s": round(upload_s, 2), "gather_ms": round(gather_ms, 2),
                        "image_mean_rgb": [round(float(x), 5) for x in img[..., :3].mean(axis=(0, 1))]},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -578,6 +633,10 @@ def main():
                 "runs": others}
         if parity is not None:
             out["parity"] = parity
+            if follow is not None:  # the path-following ratio of the DEFAULT arithmetic next to the exact one's: the relaxed 0.75 bar in the record
+                out["parity"]["path_following_light_hair"] = follow
+        elif shard_check is not None:  # N > 1: no CPU leg; the parity statement of this line is the shard invariance on the real collective
+            out["parity"] = shard_check
         if cpu is not None and world == 1:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), file=json_out, flush=True)

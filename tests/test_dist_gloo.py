@@ -48,6 +48,19 @@ def test_gather_framebuffer_gloo(tmp_path, world, w, h):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("w,h", [(720, 720), (1280, 1280)])
+def test_gather_framebuffer_gloo_world_8_at_the_configs_image_sizes(tmp_path, w, h):
+    """The 8-rank gather of BASELINE.json's 8-GPU configs on CPU (gloo): 720^2 has 8 100 tiles — shards of 1 013 and
+    1 012 tiles, so the padded capacity and the per-rank trim are exercised — 1280^2 has 25 600 (equal shards)."""
+    import torch.multiprocessing as mp
+    sizes = [yhair_dist.shard_pixels(w, h, r, 8) for r in range(8)]
+    assert (len(set(sizes)) > 1) == (w == 720)
+    out = str(tmp_path / "img.npy")
+    mp.spawn(_worker, args=(8, _free_port(), w, h, out), nprocs=8, join=True)
+    got, want = np.load(out)
+    assert np.array_equal(got, want)
+
+
 def test_shards_partition_the_image():
     for w, h in ((720, 720), (720, 405), (13, 7)):
         tx, ty = yhair_dist.tiles_xy(w, h)

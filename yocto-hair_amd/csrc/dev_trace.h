@@ -288,6 +288,9 @@ YH_DEV void count_quad(unsigned int& slot) {
 // as soon as no more than `leave_at` lanes are still running, the quads still running keep their state in `rs` and
 // their LDS stack, and the next call picks them up where they stopped (instance-space ray data recomputed: same
 // operations, same bits).
+#ifndef YH_QUAD_BLOB
+#define YH_QUAD_BLOB 1 /* the quad form over 4-wide nodes (YH_MODE_QUAD) reads nodes and leaf test records from yhd_scene::lane_blob (yh_device.h: absolute references, 32-byte test records): one base and one address form instead of two arrays, a record-size select and a node base (round 4); 0: nodes / prims as until round 3 (A/B) */
+#endif
 #ifndef YH_REMAT_Q
 #define YH_REMAT_Q 1 /* dense launch shape (96 registers): lane & 3 recomputed in the node step (two instructions) instead of reloaded from scratch */
 #endif
@@ -335,6 +338,7 @@ template <bool COUNT, int STRIDE, bool EXACT, bool PHASE = false, bool LDS_SCENE
 YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_object, unsigned int* steps_out, bool& redo,
     trav_state* rs = nullptr, int leave_at = 0) {
   static_assert(MODE == YH_MODE_QUAD || !PHASE, "the resumable traversal exists for the 4-wide quad form only");
+  constexpr bool QB = YH_QUAD_BLOB && MODE == YH_MODE_QUAD && !PHASE && !YH_PREFETCH && !YH_LDS_NODELETS;  // nodes and test records from the lane blob
   const yhd_scene&     sc   = *tc.sc;
   const unsigned int   q    = __lane_id() & 3u;
 #if YH_REMAT_Q
@@ -468,12 +472,14 @@ YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_obj
         kind = __float_as_int(d.x), node_base = __float_as_int(d.y), prim_base = __float_as_int(d.z);
         if (MODE == YH_MODE_W8 || YH_IS_OCT(MODE)) node_base = __float_as_int(ob[8].w);  // the shape's first 8-wide node (yhd_object::wbox_min[3])
         if (YH_IS_HEX(MODE)) node_base = __float_as_int(ob[9].w);                          // ... first 16-wide node (wbox_max[3])
+        if (QB) node_base = __float_as_int(ob[10].x);                                      // ... root in the lane blob, 32-byte units (yhd_object::lane_root)
       } else {
         const yhd_object& o = sc.objects[cur_obj];
         inv  = ldframe(o.inv_frame);
         kind = o.kind, node_base = o.node_base, prim_base = o.prim_base;
         if (MODE == YH_MODE_W8 || YH_IS_OCT(MODE)) node_base = __float_as_int(o.wbox_min[3]);
         if (YH_IS_HEX(MODE)) node_base = __float_as_int(o.wbox_max[3]);
+        if (QB) node_base = o.lane_root;
       }
       lo    = transform_point(inv, ray.o);
       ld    = transform_vector(inv, ray.d);
@@ -547,7 +553,8 @@ YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_obj
 #endif
       int  pq         = mine ? (int)q : leaf_num - 1;
       const yhd_float4* addr;
-      if (MODE == YH_MODE_QUAD) addr = is_leaf ? sc.prims + (size_t)prim_base + (size_t)(leaf_start + pq) * rec : sc.nodes + 8 * (size_t)cur + 2 * q;
+      if (QB) addr = sc.lane_blob + 2 * (size_t)(is_leaf ? (unsigned)leaf_start + (unsigned)pq * (kind == YH_KIND_LINES ? 1u : 2u) : cur + q);  // (leaf_start: the leaf's first test record, blob units)
+      else if (MODE == YH_MODE_QUAD) addr = is_leaf ? sc.prims + (size_t)prim_base + (size_t)(leaf_start + pq) * rec : sc.nodes + 8 * (size_t)cur + 2 * q;
       else if (MODE == YH_MODE_W8) addr = is_leaf ? sc.prims + (size_t)prim_base + (size_t)(leaf_start + pq) * rec : sc.nodes8 + 16 * (size_t)cur + 4 * q;
       else if (YH_IS_OCT(MODE)) addr = is_leaf ? sc.prims + (size_t)prim_base + (size_t)(leaf_start + pq) * rec : sc.nodes8 + 16 * (size_t)cur + 2 * (__lane_id() & 7u);
       else addr = is_leaf ? sc.prims + (size_t)prim_base + (size_t)(leaf_start + pq) * rec : sc.nodes16 + 32 * (size_t)cur + 2 * (__lane_id() & 15u);
@@ -647,7 +654,7 @@ YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_obj
         unsigned int ref  = __float_as_uint(s1.z);
         unsigned int axes = __float_as_uint(s1.w);
         h = h && ref != YH_NONE;  // an empty slot's inverted box still passes the min/max slab test
-        if ((ref & YH_TAG_MASK) == 0) ref += (unsigned)node_base;  // child wide nodes are shape-local indices
+        if (!QB && (ref & YH_TAG_MASK) == 0) ref += (unsigned)node_base;  // child wide nodes are shape-local indices (absolute in the lane blob)
         // Visiting order of the four slots (pt.cpp:887-893 applied at both collapsed
         // levels): the pair on the near side of the node's own axis first, and
         // inside each pair the slot on the near side of that child's axis first.
@@ -737,7 +744,7 @@ YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_obj
           }
           sp -= grp;  // the group's leaves came off the stack
         } else if (key_i >= 0) {
-          hit.object = cur_obj, hit.slot = leaf_start + key_i;
+          hit.object = cur_obj, hit.slot = QB ? leaf_start + key_i * (kind == YH_KIND_LINES ? 1 : 2) : leaf_start + key_i;  // (QB: the primitive's test record; made the leaf-order index below)
           hit.u = uu, hit.v = vv, hit.distance = key_t;
           tmax = key_t;
         }
@@ -747,6 +754,16 @@ YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_obj
 #if YH_PREFETCH
   prefetch_drain();
 #endif
+  if (QB && hit.object >= 0) {  // test record in the blob -> leaf-order index of the primitive in its shape (hit_t)
+    int hk, lt;
+    if (in_lds) {
+      const YH_LDS v4f* ob = tc.lds_scene + YH_OBJECT_F4 * hit.object;
+      hk = __float_as_int(ob[6].x), lt = __float_as_int(ob[10].y);
+    } else {
+      hk = sc.objects[hit.object].kind, lt = sc.objects[hit.object].lane_test;
+    }
+    hit.slot = hk == YH_KIND_LINES ? hit.slot - lt : (hit.slot - lt) >> 1;
+  }
   if (COUNT) {
     if (steps_out) *steps_out = n_steps;
     tc.stats->nodes += (unsigned int)n_nodes, tc.stats->seg += (unsigned int)n_seg, tc.stats->tri += (unsigned int)n_tri;

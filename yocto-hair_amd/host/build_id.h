@@ -1,1 +1,1 @@
-#define YH_BUILD_ID "0aa68c0d2020f438"
+#define YH_BUILD_ID "8f51eb1a7e0ff2bf"

@@ -415,6 +415,7 @@ int  choose_launch_shape(const yh_context* ctx);
 void record_launch(yh_context* ctx, int nsamples, bool fresh_costs);
 int  pick_launch_shape(const yh_context* ctx, int nsamples);
 bool trial_pending(const yh_context* ctx);
+bool trials_off();
 
 }  // namespace
 
@@ -570,9 +571,12 @@ void trials_store(const yh_context* ctx) {
     std::lock_guard<std::mutex> lock(g_trials_mutex);
     g_trials[trial_key(ctx)] = r;
   }
-  if (ctx->costs_settled && !trial_pending(ctx)) disk_store(ctx, r);  // complete: nothing left to try on this image
+  // on disk only what a later process may rely on: the choice was made by the trials (no forced shape, no heuristic-only
+  // mode), dense / sparse is known, and nothing is left to try on this image
+  if (!trials_off() && ctx->dense >= 0 && ctx->costs_settled && !trial_pending(ctx)) disk_store(ctx, r);
 }
 void trials_load(yh_context* ctx) {
+  ctx->trials_from_disk = false;
   if (getenv("YHAIR_NO_TRIAL_CACHE")) return;  // developer switch
   TrialRecord r{};
   bool        have = false;
@@ -581,7 +585,7 @@ void trials_load(yh_context* ctx) {
     auto it = g_trials.find(trial_key(ctx));
     if (it != g_trials.end()) r = it->second, have = true;
   }
-  if (!have && disk_load(ctx, r)) {
+  if (!have && !trials_off() && disk_load(ctx, r)) {
     have = true;
     ctx->trials_from_disk = true;
     if (getenv("YHAIR_TIMING")) fprintf(stderr, "[yhair] kernel trials of this image: read from %s\n", disk_cache_path().c_str());
@@ -616,7 +620,8 @@ int candidates(const yh_context* ctx, int cand[6]) {
 void record_launch(yh_context* ctx, int nsamples, bool fresh_costs) {
   const int last = ctx->last_shape;
   bool trial = false;
-  if (nsamples >= YH_TRIAL_SPP && nsamples < 2 * YH_TRIAL_SPP && ctx->planned_settled && !ctx->last_counted && !ctx->params.hair_exact && last >= 0 && last < YH_SHAPES && ctx->last_ms > 0) {
+  static const bool prof_build = getenv("YHAIR_ST_PROF") && atoi(getenv("YHAIR_ST_PROF")) != 0;  // the instrumented k_stream: its times rank nothing
+  if (!prof_build && nsamples >= YH_TRIAL_SPP && nsamples < 2 * YH_TRIAL_SPP && ctx->planned_settled && !ctx->last_counted && !ctx->params.hair_exact && last >= 0 && last < YH_SHAPES && ctx->last_ms > 0) {
     const double ms = (double)ctx->last_ms / nsamples;
     ctx->shape_ms[last] = ctx->shape_trials[last] > 0 ? std::min(ctx->shape_ms[last], ms) : ms;
     ctx->shape_trials[last]++;
@@ -731,6 +736,7 @@ static void split_items_for_hex(std::vector<int>& items) {
 }
 static void split_items_side_by_side(yh_context* ctx, std::vector<int>& items);
 static int  ensure_wide_nodes(yh_context* ctx);
+static int  ensure_lane_blob(yh_context* ctx);
 static void wide_build_join(yh_context* ctx);
 static void wide_build_start(yh_context* ctx);
 static void lay_out_first_round(const yh_context* ctx, std::vector<int>& items, int shape);
@@ -1251,7 +1257,10 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
   for (double& t : ctx->shape_ms) t = 0;
   for (int& t : ctx->shape_trials) t = 0;
   wide_build_start(ctx);  // the wide collapses in the background: ready by the time a kernel that needs them is tried
-  return YH_OK;
+  ctx->trials_from_disk = false;
+  // the kernels over 4-wide nodes — quads and one lane per path alike — read the trees from the lane blob (yh_device.h): made
+  // here, on the device, from the arrays just uploaded (two streaming kernels per shape, about a millisecond)
+  return ensure_lane_blob(ctx);
 }
 
 int yh_set_shard(yh_context* ctx, int rank, int world) {
@@ -2011,6 +2020,8 @@ struct RcclApi {
   void* lib = nullptr;
   ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   ncclResult_t (*Gather)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -2028,11 +2039,14 @@ RcclApi* rccl_api(const char** why = nullptr) {
     if (api.lib) {
       api.CommInitAll    = (decltype(api.CommInitAll))dlsym(api.lib, "ncclCommInitAll");
       api.CommDestroy    = (decltype(api.CommDestroy))dlsym(api.lib, "ncclCommDestroy");
+      api.CommCount      = (decltype(api.CommCount))dlsym(api.lib, "ncclCommCount");
+      api.CommUserRank   = (decltype(api.CommUserRank))dlsym(api.lib, "ncclCommUserRank");
       api.GroupStart     = (decltype(api.GroupStart))dlsym(api.lib, "ncclGroupStart");
       api.GroupEnd       = (decltype(api.GroupEnd))dlsym(api.lib, "ncclGroupEnd");
       api.Gather         = (decltype(api.Gather))dlsym(api.lib, "ncclGather");
       api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.lib, "ncclGetErrorString");
-      if (!api.CommInitAll || !api.CommDestroy || !api.GroupStart || !api.GroupEnd || !api.Gather || !api.GetErrorString) api.lib = nullptr;
+      if (!api.CommInitAll || !api.CommDestroy || !api.CommCount || !api.CommUserRank || !api.GroupStart || !api.GroupEnd || !api.Gather || !api.GetErrorString)
+        api.lib = nullptr;
     } else if (const char* why = dlerror()) {
       api.open_error = why;
     }
@@ -2101,6 +2115,16 @@ int yh_gather_framebuffer(yh_context** ctxs, int n, float* rgba) {
       if (r != ncclSuccess) {
         root->comms.clear();
         return fail(root, YH_E_DEVICE, "ncclCommInitAll: %s", api->GetErrorString(r));
+      }
+      // what RCCL made must be what was asked for: n ranks, communicator i = rank i (the gather's root is rank 0 and
+      // un-interleaves shard r from the r-th block of the receive buffer)
+      for (int i = 0; i < n; i++) {
+        int count = -1, urank = -1;
+        ncclResult_t rc1 = api->CommCount(root->comms[i], &count), rc2 = api->CommUserRank(root->comms[i], &urank);
+        if (rc1 != ncclSuccess || rc2 != ncclSuccess || count != n || urank != i) {
+          destroy_communicators(root);
+          return fail(root, YH_E_DEVICE, "ncclCommInitAll made communicator %d with %d ranks as rank %d (wanted %d ranks, rank %d)", i, count, urank, n, i);
+        }
       }
       root->comm_devices = devs;
     }
