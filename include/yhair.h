@@ -290,7 +290,7 @@ int yh_kernel_trials(const yh_context* ctx, double* ms_per_sample, int* trials, 
  * more will start with a 32-sample launch of it — else 0: a caller that times its launches (bench.py) keeps warming up
  * until this is 0. The record of an image is kept per process and in ~/.cache/yhair/trials_v1.txt (YHAIR_CACHE_DIR;
  * YHAIR_NO_DISK_CACHE switches the file off), keyed by device, build, scene, image size, shard and bounces: an image
- * found there runs no trial. Replaces nothing in the reference (host/context.cpp: pick_launch_shape).              */
+ * found there runs no trial. Replaces nothing in the reference (host/launch_plan.cpp: pick_launch_shape).              */
 int yh_trials_pending(const yh_context* ctx);
 
 /* Load-balance telemetry: for every tile id (row-major over ceil(W/8) x

@@ -734,7 +734,7 @@ def test_launch_shapes_and_kernels_render_identical_pixels(ctx, yh, name, kw, mo
                          ids=["sphere-hairblock", "straight-hair"])
 def test_kernel_trials_are_cut_off_a_long_request(ctx, yh, name, kw, monkeypatch):
     """yh_trace_samples starts a long request with 32-sample launches of the kernels the image has not timed yet
-    (host/context.cpp: pick_launch_shape). The samples count like any others: one 150-sample request renders the bits of
+    (host/launch_plan.cpp: pick_launch_shape). The samples count like any others: one 150-sample request renders the bits of
     a single launch of one kernel, in more than one launch; once every candidate is timed a request is one launch again."""
     sf = yh.SceneFile(scene_path(name, **kw))
     ctx.upload_scene(sf.desc)

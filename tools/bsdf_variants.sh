@@ -13,7 +13,7 @@ wait
 for v in "$@"; do
   name=${v%%:*}
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o /tmp/yh_sweep/libyhair_$name.so /tmp/yh_sweep/k_$name.o $(ls $R/yocto-hair_amd/csrc/*.o | grep -v kernels.o) \
-      $R/yocto-hair_amd/host/context.o $R/yocto-hair_amd/host/bvh_build.o $R/yocto-hair_amd/host/scene_io.o -lpthread -lz
+      $R/yocto-hair_amd/host/*.o -lpthread -lz
   echo "== $name" | tee -a "$out/summary.txt"
   YHAIR_LIB=/tmp/yh_sweep/libyhair_$name.so python3 $R/oracle/divergence_report.py 2>&1 | tee "$out/div_$name.txt" | grep -E "ref-sphere|ref-straight|zoom|curly" | tee -a "$out/summary.txt"
 done

@@ -16,6 +16,6 @@ for v in "$@"; do
   name=${v%%:*}
   others=""; for o in kernels exact stream bvh_gpu; do [ "$o" != "$SRC" ] && others="$others $P/csrc/$o.o"; done
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/tools/_ab/libyhair_$name.so /tmp/yh_var/${SRC}_$name.o $others \
-      $P/host/context.o $P/host/bvh_build.o $P/host/scene_io.o -lpthread -lz -ldl
+      $P/host/*.o -lpthread -lz -ldl
   echo "built tools/_ab/libyhair_$name.so"
 done

@@ -76,7 +76,7 @@ YH_DEV void trace_items(const yhd_scene& sc, const yhd_state& st, int nsamples, 
   // others come from the cursor, which starts behind those positions. The four wave slots of a SIMD do not run at the same
   // speed (slot 0: 10.4 ms for the kind of item that takes 13.3 ms in slot 3 on C1, profiles/r03/where_items_ran.txt) and a
   // wave's slot follows from the dispatch order of its workgroup, so the host lays the head of the list out by position: the
-  // most expensive items on the fastest slots, none on the slowest (host/context.cpp: lay_out_first_round). Any list is
+  // most expensive items on the fastest slots, none on the slowest (host/launch_plan.cpp: lay_out_first_round). Any list is
   // rendered correctly — every entry is taken exactly once, by position or through the cursor; the layout is a matter of time.
 #ifndef YH_FIRST_BY_POSITION
 #define YH_FIRST_BY_POSITION 1

@@ -39,7 +39,7 @@ typedef struct yhd_object {
   int   kind;           // YH_KIND_*
   int   node_base;      // first BVH node of the shape in `nodes`
   int   prim_base;      // first leaf-ordered record of the shape (float4 units)
-  int   vert_base;      // first vertex in vpos / vtex (shapes that need them, host/context.cpp)
+  int   vert_base;      // first vertex in vpos / vtex (shapes that need them, host/scene_upload.cpp)
   int   elem_base;      // first element in elems
   int   has_normals;
   int   material;
@@ -190,7 +190,7 @@ typedef struct yhd_scene {
   //   nodes         the 4-wide nodes of yhd_scene::nodes (128 B, same boxes, same axes word + a bit per occupied slot in
   //                 bits 8-11) with ABSOLUTE references: a child node's offset in the blob, or
   //                 YH_TAG_LEAF | count << 27 | offset of the leaf's first test record
-  // Built on the device from nodes / prims at the first launch that needs it (host/context.cpp: ensure_lane_blob).
+  // Built on the device from nodes / prims at the first launch that needs it (host/scene_upload.cpp: ensure_lane_blob, at yh_upload_scene).
   const yhd_float4* lane_blob;
   long long         lane_blob_units;
 } yhd_scene;
@@ -229,7 +229,7 @@ typedef struct yhd_state {
   int         shard_rank, shard_world;  // tile ids owned: rank, rank + world, ...
   // (k_trace hands the first grid x waves-per-workgroup entries of `tiles` out BY POSITION — wave w of workgroup b starts
   // with entry b * (waves per workgroup) + w, the rest go through the cursor — and the host lays that head of the list out by
-  // hardware wave slot, host/context.cpp: lay_out_first_round. This field is not read any more.)
+  // hardware wave slot, host/launch_plan.cpp: lay_out_first_round. This field is not read any more.)
   int         static_items;
   // k_trace: the waves that take one of the first `prio_items` entries of `tiles` (the most expensive items: the list is
   // cost-sorted) run at raised issue priority (s_setprio); 0: off
