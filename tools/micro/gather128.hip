@@ -9,6 +9,9 @@
 //           record back from LDS (8 x ds_read_b128, XOR-swizzled so that the reads are conflict-free)
 //   mode 5  as 4 with plain loads + ds_write_b128 (register staging)
 //   mode 6  64-byte records, cooperatively: four lanes per record, four instructions (LDS-DMA)
+//   mode 7  k_stream's mix: 5 of 8 lanes fetch 128 bytes (a wide node), 3 of 8 fetch 64 (a leaf's two segments), per-lane loads
+//   mode 8  every lane 64 bytes of a 64-byte record (what 64-byte nodes would make of mode 7), per-lane loads
+//   mode 9  5 of 8 lanes 64 bytes, 3 of 8 lanes 96 (64-byte nodes + leaves with a 32-byte header), per-lane loads
 //
 // Every lane runs a dependent chain (the next index comes out of the record), `filler` independent v_fma per step stand
 // for the step's arithmetic, `active` lanes of each wave take part (the others idle, as in k_stream's trace stage).
@@ -39,7 +42,15 @@ __global__ __launch_bounds__(256, MINW) void gather(const v4f* __restrict__ recs
     v4f r[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) r[k] = v4f{0, 0, 0, 0};
-    if (MODE <= 3) {
+    if (MODE >= 7) {
+      if (on) {
+        const bool    nodey = (lane & 7) < 5;
+        const v4f*    a = MODE == 7 ? recs + (size_t)idx * 8 : recs + (size_t)(idx * 2u + (lane & 1)) * 4;  // (modes 8, 9: 64-byte records, twice as many)
+        r[0] = a[0], r[1] = a[1], r[2] = a[2], r[3] = a[3];
+        if (MODE == 7 && nodey) r[4] = a[4], r[5] = a[5], r[6] = a[6], r[7] = a[7];
+        if (MODE == 9 && !nodey) r[4] = a[4], r[5] = a[5];
+      }
+    } else if (MODE <= 3) {
       if (on) {
         const v4f*    a = recs + (size_t)idx * 8;
         constexpr int N = MODE == 0 ? 8 : MODE == 1 ? 4 : MODE == 2 ? 2 : 1;
@@ -120,12 +131,12 @@ int main(int argc, char** argv) {
   hipMemcpy(d, h.data(), nrec * 128, hipMemcpyHostToDevice);
   hipDeviceProp_t prop; hipGetDeviceProperties(&prop, 0);
   int blocks = prop.multiProcessorCount * wps;  // 256-thread blocks: wps waves per SIMD
-  kern_t ks[7] = {gather<0>, gather<1>, gather<2>, gather<3>, gather<4>, gather<5>, gather<6>};
-  const char* names[7] = {"8 x dwordx4 per lane", "4 x dwordx4 per lane", "2 x dwordx4 per lane", "1 x dwordx4 per lane", "whole lines by LDS-DMA", "whole lines, register staged", "64-B records by LDS-DMA"};
+  kern_t ks[10] = {gather<0>, gather<1>, gather<2>, gather<3>, gather<4>, gather<5>, gather<6>, gather<7>, gather<8>, gather<9>};
+  const char* names[10] = {"8 x dwordx4 per lane", "4 x dwordx4 per lane", "2 x dwordx4 per lane", "1 x dwordx4 per lane", "whole lines by LDS-DMA", "whole lines, register staged", "64-B records by LDS-DMA", "mix: 5/8 lanes 128 B, 3/8 64 B", "every lane 64 B of a 64-B record", "mix: 5/8 lanes 64 B, 3/8 96 B"};
   printf("# table %zu MB, %d steps, filler %d fma, %d active lanes, %d waves per SIMD (%d blocks)\n", mb, steps, filler, active, wps, blocks);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int m = 0; m < 7; m++) {
-    size_t ldsb = m >= 4 ? 32768 : 0;
+  for (int m = 0; m < 10; m++) {
+    size_t ldsb = (m >= 4 && m <= 6) ? 32768 : 0;
     float best = 1e30f;
     for (int rep = 0; rep < 3; rep++) {
       hipEventRecord(e0);

@@ -51,7 +51,7 @@ int yhk_trace_sbs_lds_bytes(const yhd_scene* sc);
 int yhk_trace_sbs_occupancy(int lds_bytes, int general);
 int yhk_trace_lds_bytes(const yhd_scene* sc, int shape);
 int yhk_stack_entries(void);
-#ifdef YH_LAB_WAVEFRONT  // developer build (make WAVEFRONT=1): the workgroup-staged kernel of csrc/lab/, YHAIR_SHAPE=2
+#ifdef YH_LAB_WAVEFRONT  // developer build (make WAVEFRONT=1): the workgroup-staged kernel of tools/lab/, YHAIR_SHAPE=2
 int yhk_wavefront(const yhd_scene*, const yhd_state*, int, const yhd_pool*, int k, int grid_blocks, hipStream_t);
 int yhk_wavefront_slots(int k);
 int yhk_wavefront_lds_bytes(int stack_entries, int tables_f4, int k);

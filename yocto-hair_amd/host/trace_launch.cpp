@@ -101,7 +101,7 @@ int yh_init_state(yh_context* ctx, const yh_trace_params* params) {
 }
 
 #ifdef YH_LAB_WAVEFRONT
-// One launch of the wavefront integrator (csrc/lab/wavefront.hip): persistent workgroups, one path pool each.
+// One launch of the wavefront integrator (tools/lab/wavefront.hip): persistent workgroups, one path pool each.
 int wavefront_impl(yh_context* ctx, int nsamples, bool sync) {
   int k = 1;
   if (const char* env = getenv("YHAIR_WF_SLOTS")) k = atoi(env) >= 2 ? 2 : 1;  // path slots per thread (developer switch)
