@@ -527,7 +527,7 @@ def main():
                                f"{ref8.shape[1]}x{ref8.shape[0]}, 8 spp, against the reference's own image of it (tests/golden/refscenes.npz)",
                       "rel_rmse_cpu_seed_floor": round(floor, 5), "stated_bar": {"fast_bsdf": 0.75, "exact_bsdf": 0.5}}
             for key, exact in (("fast_bsdf", False), ("exact_bsdf", True)):
-                ctx.init_state(yh.TraceParams.default(resolution=ref8.shape[0], hair_exact=exact))
+                ctx.init_state(yh.TraceParams.default(resolution=max(ref8.shape[0], ref8.shape[1]), hair_exact=exact))
                 ctx.trace_samples(8)
                 follow["ratio_to_floor_" + key] = round(relrmse(ctx.download(), ref8) / floor, 4)
             rsf.close()
