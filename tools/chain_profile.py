@@ -26,4 +26,4 @@ for shape in shapes:
     ws = max(1, wc["wave_steps"])
     print(f"{name} {res}^2 shape {shape}: 64 spp {min(ms):.2f} ms (instrumented {ctx.last_trace_ms()[0]:.2f}) | per wave iteration: trace {wc['cyc_trace'] / wi:.0f} cyc, "
           f"shade {wc['cyc_shade'] / wi:.0f} cyc, trips {ws / wi:.2f}, cycles per trip {wc['cyc_trace'] / ws:.0f}, wave iterations {wi} | steps ran in share of trips: "
-          + ", ".join(f"{nm} {wc['trips_' + nm] / ws:.2f}" for nm in ("node", "line", "tri", "enter", "scene")), flush=True)
+          + ", ".join(f"{nm} {wc['trips_' + nm] / ws:.2f} ({wc['lanes_' + nm] / max(1, wc['trips_' + nm]):.1f} lanes)" for nm in ("node", "line", "tri", "enter", "scene")), flush=True)

@@ -1,1 +1,1 @@
-#define YH_BUILD_ID "e9045830d20b3d52"
+#define YH_BUILD_ID "717889fabcd758ef"

@@ -270,6 +270,7 @@ struct yh_context {
   int              shape_trials[YH_SHAPES] = {};  // trial launches behind each shape_ms (the minimum over them counts)
   uint64_t         scene_key = 0;                   // fingerprint of the uploaded scene (key of the process-wide trial record)
   bool             trials_from_disk = false;        // the record was read from the on-disk cache: complete, no trial runs
+  bool             trials_on_disk = false;          // ... or has been written there by this context (once per image)
   bool             have_costs = false;
   bool             costs_settled = false;   // the item costs come from a launch of at least YH_TRIAL_SPP samples (not from the 1-spp probe)
   bool             planned_settled = false; // ... and the most recent launch was planned from such costs (only then does its time rank a kernel)

@@ -153,10 +153,14 @@ static void trials_store(const yh_context* ctx) {
   }
   // on disk only what a later process may rely on: the choice was made by the trials (no forced shape, no heuristic-only
   // mode), dense / sparse is known, and nothing is left to try on this image
-  if (!trials_off() && ctx->dense >= 0 && ctx->costs_settled && !trial_pending(ctx)) disk_store(ctx, r);
+  // — and once per image and context: later trial-length launches refine the times in memory, they do not grow the file
+  if (!ctx->trials_on_disk && !trials_off() && ctx->dense >= 0 && ctx->costs_settled && !trial_pending(ctx)) {
+    disk_store(ctx, r);
+    const_cast<yh_context*>(ctx)->trials_on_disk = true;
+  }
 }
 void trials_load(yh_context* ctx) {
-  ctx->trials_from_disk = false;
+  ctx->trials_from_disk = false, ctx->trials_on_disk = false;
   if (getenv("YHAIR_NO_TRIAL_CACHE")) return;  // developer switch
   TrialRecord r{};
   bool        have = false;
@@ -167,7 +171,7 @@ void trials_load(yh_context* ctx) {
   }
   if (!have && !trials_off() && disk_load(ctx, r)) {
     have = true;
-    ctx->trials_from_disk = true;
+    ctx->trials_from_disk = true, ctx->trials_on_disk = true;
     if (getenv("YHAIR_TIMING")) fprintf(stderr, "[yhair] kernel trials of this image: read from %s\n", disk_cache_path().c_str());
   }
   if (!have) return;
