@@ -20,7 +20,7 @@ done
 wait
 for v in "${variants[@]}"; do
   name=${v%%:*}
-  [ -f /tmp/yh_sweep/libyhair_$name.so ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o /tmp/yh_sweep/libyhair_$name.so /tmp/yh_sweep/k_$name.o $R/yocto-hair_amd/csrc/exact.o $R/yocto-hair_amd/csrc/stream.o $R/yocto-hair_amd/csrc/bvh_gpu.o \
+  [ -f /tmp/yh_sweep/libyhair_$name.so ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o /tmp/yh_sweep/libyhair_$name.so /tmp/yh_sweep/k_$name.o $R/yocto-hair_amd/csrc/wide.o $R/yocto-hair_amd/csrc/exact.o $R/yocto-hair_amd/csrc/stream.o $R/yocto-hair_amd/csrc/bvh_gpu.o \
       $R/yocto-hair_amd/host/*.o -lpthread -lz -ldl
 done
 [ -n "${AB_PREBUILT:-}" ] && cp "$AB_PREBUILT" /tmp/yh_sweep/libyhair_prebuilt.so && variants+=("prebuilt:")   # e.g. AB_PREBUILT=tools/_ab/libyhair_<commit>.so

@@ -2,7 +2,7 @@
 # Developer tool (build container, no GPU): builds variants of ONE device source with extra -D flags and links each into
 # tools/_ab/libyhair_<name>.so next to the product's other objects (git-ignored, travels to the GPU box with the snapshot),
 # so that a gpurun call spends its minutes measuring, not compiling. Time them with YHAIR_LIB=tools/_ab/libyhair_<name>.so.
-# usage: [SRC=stream|kernels] [HOSTFLAGS="-DX"] tools/build_variants.sh "name:-DFLAG=1 -DOTHER" ...
+# usage: [SRC=stream|kernels|wide] [HOSTFLAGS="-DX"] tools/build_variants.sh "name:-DFLAG=1 -DOTHER" ...
 #        HOSTFLAGS: the host sources are compiled once more with these flags (into /tmp/yh_var/host) and linked instead of host/*.o
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd); P=$R/yocto-hair_amd; SRC=${SRC:-stream}
@@ -23,7 +23,7 @@ if [ -n "${HOSTFLAGS:-}" ]; then
 fi
 for v in "$@"; do
   name=${v%%:*}
-  others=""; for o in kernels exact stream bvh_gpu; do [ "$o" != "$SRC" ] && others="$others $P/csrc/$o.o"; done
+  others=""; for o in kernels wide exact stream bvh_gpu; do [ "$o" != "$SRC" ] && others="$others $P/csrc/$o.o"; done
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/tools/_ab/libyhair_$name.so /tmp/yh_var/${SRC}_$name.o $others \
       $HOSTOBJ -lpthread -lz -ldl
   echo "built tools/_ab/libyhair_$name.so"

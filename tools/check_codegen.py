@@ -107,7 +107,7 @@ def kernels(src):
 
 if __name__ == "__main__":
     bad = 0
-    for src, pat in (("kernels.hip", r"k_traceILb0ELb[01]E|k_trace_sbsILb[01]E"), ("exact.hip", r"k_trace_exact"), ("stream.hip", r"k_streamILb[01]ELi\dELb0")):
+    for src, pat in (("kernels.hip", r"k_traceILb0ELb[01]E"), ("wide.hip", r"k_trace_sbsILb[01]E"), ("exact.hip", r"k_trace_exact"), ("stream.hip", r"k_streamILb[01]ELi\dELb0")):
         for name, k in sorted(kernels(src).items()):
             if not re.search(pat, name):
                 continue

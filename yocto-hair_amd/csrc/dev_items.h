@@ -227,4 +227,33 @@ YH_DEV void trace_items(const yhd_scene& sc, const yhd_state& st, int nsamples, 
     }
   }
 }
+// ---------------------------------------------------------------------------
+// The sample-loop kernels (instantiated by csrc/kernels.hip: quads over 4-wide nodes, the other shaders; csrc/wide.hip: octets,
+// sixteen lanes per path, side by side; csrc/exact.hip has its own)
+// ---------------------------------------------------------------------------
+typedef void (*trace_kernel_t)(const yhd_scene, const yhd_state, int, yhd_counters*);
+#define YH_OCT_BLOCK 256 /* workgroup of the wide forms (launch shapes 4, 6, 7, 8) */
+template <bool COUNT, bool GENERAL, int BLOCK, int WAVES, int MODE = YH_MODE_QUAD>
+__global__ __launch_bounds__(BLOCK, WAVES) void k_trace(const yhd_scene sc, const yhd_state st,
+    int nsamples, yhd_counters* counters) {
+  trace_items<COUNT, GENERAL, BLOCK, YH_SHADER_PATH, MODE>(sc, st, nsamples, counters);
+}
+// SIDE BY SIDE in one launch (launch shape 5): the first `oct_blocks` workgroups run the octet form over the second part of
+// the work list (`oct_entries` half-quadrant entries behind the `quad_items` quad entries, its own cursor), the others the
+// quad form over the first part. The first workgroups of a launch get the fastest wave slots of their CUs (dev_items.h), so
+// the few items whose chain bounds the launch run with eight lanes per path AND in the best slots; same workgroup size, so
+// the two forms pack on a CU like one kernel's workgroups.
+template <bool GENERAL>
+__global__ __launch_bounds__(YH_BLOCK, YH_MIN_WAVES) void k_trace_sbs(const yhd_scene sc, const yhd_state st, int nsamples, int oct_blocks,
+    int quad_items, int oct_entries) {
+  if ((int)blockIdx.x < oct_blocks) {
+    yhd_state so   = st;
+    so.tiles       = st.tiles + quad_items, so.num_tiles = oct_entries, so.tile_cursor = st.tile_cursor + 16;
+    trace_items<false, GENERAL, YH_BLOCK, YH_SHADER_PATH, YH_MODE_OCT>(sc, so, nsamples, nullptr, blockIdx.x, (unsigned)oct_blocks);
+  } else {
+    yhd_state sq = st;
+    sq.num_tiles = quad_items;
+    trace_items<false, GENERAL, YH_BLOCK, YH_SHADER_PATH, YH_MODE_QUAD>(sc, sq, nsamples, nullptr, blockIdx.x - (unsigned)oct_blocks, gridDim.x - (unsigned)oct_blocks);
+  }
+}
 #endif

@@ -26,29 +26,6 @@
 #include "yhair.h"
 #include "dev_items.h"
 
-template <bool COUNT, bool GENERAL, int BLOCK, int WAVES, int MODE = YH_MODE_QUAD>
-__global__ __launch_bounds__(BLOCK, WAVES) void k_trace(const yhd_scene sc, const yhd_state st,
-    int nsamples, yhd_counters* counters) {
-  trace_items<COUNT, GENERAL, BLOCK, YH_SHADER_PATH, MODE>(sc, st, nsamples, counters);
-}
-// SIDE BY SIDE in one launch (launch shape 5): the first `oct_blocks` workgroups run the octet form over the second part of
-// the work list (`oct_entries` half-quadrant entries behind the `quad_items` quad entries, its own cursor), the others the
-// quad form over the first part. The first workgroups of a launch get the fastest wave slots of their CUs (dev_items.h), so
-// the few items whose chain bounds the launch run with eight lanes per path AND in the best slots; same workgroup size, so
-// the two forms pack on a CU like one kernel's workgroups.
-template <bool GENERAL>
-__global__ __launch_bounds__(YH_BLOCK, YH_MIN_WAVES) void k_trace_sbs(const yhd_scene sc, const yhd_state st, int nsamples, int oct_blocks,
-    int quad_items, int oct_entries) {
-  if ((int)blockIdx.x < oct_blocks) {
-    yhd_state so   = st;
-    so.tiles       = st.tiles + quad_items, so.num_tiles = oct_entries, so.tile_cursor = st.tile_cursor + 16;
-    trace_items<false, GENERAL, YH_BLOCK, YH_SHADER_PATH, YH_MODE_OCT>(sc, so, nsamples, nullptr, blockIdx.x, (unsigned)oct_blocks);
-  } else {
-    yhd_state sq = st;
-    sq.num_tiles = quad_items;
-    trace_items<false, GENERAL, YH_BLOCK, YH_SHADER_PATH, YH_MODE_QUAD>(sc, sq, nsamples, nullptr, blockIdx.x - (unsigned)oct_blocks, gridDim.x - (unsigned)oct_blocks);
-  }
-}
 template <int SHADER>
 __global__ __launch_bounds__(YH_BLOCK, YH_MIN_WAVES) void k_trace_shader(const yhd_scene sc, const yhd_state st,
     int nsamples, yhd_counters* counters) {
@@ -443,7 +420,7 @@ __global__ void k_curves_to_lines(int n, const float* P, const float* width0, co
 
 extern "C" {
 
-typedef void (*trace_kernel_t)(const yhd_scene, const yhd_state, int, yhd_counters*);
+trace_kernel_t yhk_wide_kernel(int counted, int general, int shape);  // csrc/wide.hip: launch shapes 4, 6, 7, 8
 #ifndef YH_DENSE_WAVES
 #define YH_DENSE_WAVES 5 /* 96 VGPRs: at 6 (80 VGPRs) the traversal loop itself spills and the kernel is at the mercy of the register allocator (measured 0.6-0.75x after an unrelated change of the shading code, profiles/r02) */
 #endif
@@ -451,7 +428,6 @@ typedef void (*trace_kernel_t)(const yhd_scene, const yhd_state, int, yhd_counte
 // shape 2 = 512 x 4, quads over 8-wide nodes (YH_MODE_W8); shape 4 = 256 x 4, octets over 8-wide nodes (YH_MODE_OCT);
 // shape 6 = 256 x 4, sixteen lanes per path over 16-wide nodes (YH_MODE_HEX); shape 7 = shape 4 with leaf pairs (YH_MODE_OCTP). (3 is k_stream, csrc/stream.hip; 5 the host's
 // side-by-side launch of shapes 0 and 4.) shape 8 = shape 6 with leaf groups (YH_MODE_HEXP).
-#define YH_OCT_BLOCK 256
 static bool shape_oct(int shape) { return shape == 4 || shape == 7; }
 static bool shape_hex(int shape) { return shape == 6 || shape == 8; }
 static int shape_block(int shape) { return shape == 1 ? 256 : (shape_oct(shape) || shape_hex(shape)) ? YH_OCT_BLOCK : YH_BLOCK; }
@@ -465,13 +441,8 @@ static trace_kernel_t trace_kernel(bool counted, bool general, int shape, int sh
   if (shape == 2 && counted && !general) return k_trace<true, false, YH_BLOCK, YH_MIN_WAVES, YH_MODE_W8>;
   if (shape == 2 && !counted) return general ? k_trace<false, true, YH_BLOCK, YH_MIN_WAVES, YH_MODE_W8> : k_trace<false, false, YH_BLOCK, YH_MIN_WAVES, YH_MODE_W8>;
 #endif
-  if (shape == 4 && counted && !general) return k_trace<true, false, YH_OCT_BLOCK, YH_MIN_WAVES, YH_MODE_OCT>;
-  if (shape == 4 && !counted) return general ? k_trace<false, true, YH_OCT_BLOCK, YH_MIN_WAVES, YH_MODE_OCT> : k_trace<false, false, YH_OCT_BLOCK, YH_MIN_WAVES, YH_MODE_OCT>;
-  if (shape == 6 && !counted) return general ? k_trace<false, true, YH_OCT_BLOCK, YH_MIN_WAVES, YH_MODE_HEX> : k_trace<false, false, YH_OCT_BLOCK, YH_MIN_WAVES, YH_MODE_HEX>;
-  if (shape == 6 && counted && !general) return k_trace<true, false, YH_OCT_BLOCK, YH_MIN_WAVES, YH_MODE_HEX>;
-  if (shape == 7 && !counted) return general ? k_trace<false, true, YH_OCT_BLOCK, YH_MIN_WAVES, YH_MODE_OCTP> : k_trace<false, false, YH_OCT_BLOCK, YH_MIN_WAVES, YH_MODE_OCTP>;
-  if (shape == 8 && !counted) return general ? k_trace<false, true, YH_OCT_BLOCK, YH_MIN_WAVES, YH_MODE_HEXP> : k_trace<false, false, YH_OCT_BLOCK, YH_MIN_WAVES, YH_MODE_HEXP>;
-  if (shape == 2 || shape_oct(shape) || shape_hex(shape)) return nullptr;
+  if (shape_oct(shape) || shape_hex(shape)) return yhk_wide_kernel(counted ? 1 : 0, general ? 1 : 0, shape);  // csrc/wide.hip
+  if (shape == 2) return nullptr;
   // The GENERAL variants carry the surface lobes, volumes, textures and the through-memory light code. The dense shape
   // spilled 184 registers at the plain variant's 96 (7 scratch instructions inside its traversal loops): it runs at 256 x 4
   // (128 registers, 49 spilled, none in the traversal loops; lobes / volumes +15-20 %, profiles/r03/general_waves_ab.txt).
@@ -506,30 +477,6 @@ int yhk_trace(const yhd_scene* sc, const yhd_state* st, int nsamples, yhd_counte
     if (e != hipSuccess) return (int)e;
   }
   hipLaunchKernelGGL(k, dim3(grid_blocks), dim3(shape_block(shape)), lds, stream, *sc, *st, nsamples, counters);
-  return (int)hipGetLastError();
-}
-// (side by side: both forms at YH_BLOCK threads; the LDS of the larger layout)
-static size_t sbs_lds(const yhd_scene* sc) {
-  const size_t stacks = (size_t)std::max(sc->stack_entries * (YH_BLOCK / 4), sc->stack_entries8 * (YH_BLOCK / 8)) * 4;
-  return (size_t)sc->lds_node_count * 128 + stacks + (size_t)YHD_LDS_TABLES_F4(sc) * 16 + (YH_PREFETCH ? 256 : 0);
-}
-int yhk_trace_sbs_lds_bytes(const yhd_scene* sc) { return (int)sbs_lds(sc); }
-int yhk_trace_sbs_occupancy(int lds_bytes, int general) {
-  int  blocks = 0;
-  auto k      = general ? k_trace_sbs<true> : k_trace_sbs<false>;
-  if (lds_bytes > 64 * 1024 && hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess) return 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k, YH_BLOCK, lds_bytes) != hipSuccess) return 1;
-  return blocks < 1 ? 0 : blocks;
-}
-int yhk_trace_sbs(const yhd_scene* sc, const yhd_state* st, int nsamples, int oct_blocks, int quad_items, int oct_entries, int grid_blocks,
-    hipStream_t stream) {
-  const size_t lds = sbs_lds(sc);
-  auto         k   = sc->general_materials ? k_trace_sbs<true> : k_trace_sbs<false>;
-  if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-  }
-  hipLaunchKernelGGL(k, dim3(grid_blocks), dim3(YH_BLOCK), lds, stream, *sc, *st, nsamples, oct_blocks, quad_items, oct_entries);
   return (int)hipGetLastError();
 }
 int yhk_block_threads(int shape) { return shape_block(shape); }
