@@ -450,7 +450,9 @@ def main():
                 pw, ph, pel, _, _ = timed_run(res_main, step_spp, 3)  # (three warm-up steps: the shard's kernel trials — and the wide BVH nodes the octet kernels build at their first launch — stay out of the timed steps, as the run's own warm-up keeps them out of a rank's)
                 projected.append({"n_gpus": n_proj, "shard": f"0 of {n_proj}", "seconds": round(pel, 4),
                                   "value_if_every_gpu_takes_this_long": round(pw * ph * spp_total / pel / 1e6, 1),
-                                  "kernel": KERNELS.get(ctx.launch_shape(), "?")})
+                                  "kernel": KERNELS.get(ctx.launch_shape(), "?"),
+                                  "launches_in_timed_steps": sum(ctx_launches),  # = the steps: every trial of the shard's (up to five) candidates ran before them
+                                  "kernel_trials": {KERNELS.get(k, str(k)): v[1] for k, v in ctx.kernel_trials().items()}})
         except Exception as e:  # never at the expense of the reported line
             projected.append({"error": str(e)})
         ctx.set_shard(0, 1)
