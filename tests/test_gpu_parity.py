@@ -778,7 +778,10 @@ def test_baseline_configs_at_full_size(ctx, oracle, yh, tag, name, kw, res):
     """BASELINE.json configs[1..4] with their full geometry (1.6 M / 3.2 M / 4 x 1.0 M segments): (1) at the
     config's resolution, the size-independent properties of test_full_size_properties; (2) the same
     geometry at 96 x 96 against the oracle with ALL THREE image bars of the golden scenes: 1 spp within 1e-3,
-    16 spp relRMSE <= 0.5 x the seed-to-seed floor, 16 spp per-pixel error within K_SIGMA standard errors."""
+    16 spp relRMSE <= 0.5 x the seed-to-seed floor, 16 spp per-pixel error within K_SIGMA standard errors;
+    (3) (round 4) the oracle AT THE CONFIG'S OWN RESOLUTION — the very camera rays of the config: 720^2 / 1280^2 —
+    all three bars again: 1 spp within 1e-3 with identical alpha, 8 spp relRMSE <= 0.5 x the floor, 8 spp per-pixel error
+    within K_SIGMA standard errors over four seeds (the oracle on the box's host threads: seconds per render)."""
     sf = yh.SceneFile(scene_path(name, **kw))
     d = sf.desc.contents
     segments = sum(d.shapes[i].num_lines for i in range(d.num_shapes))
@@ -818,6 +821,21 @@ def test_baseline_configs_at_full_size(ctx, oracle, yh, tag, name, kw, res):
     assert err <= 0.5 * floor, f"{tag}: relRMSE {err:.4f} vs seed floor {floor:.4f}"
     share, _ = _k_sigma_share(ctx, osc, yh, 96, 16, r16, seeds=(961748941, 12345, 777, 31337))
     assert share >= 0.99, f"{tag}: {share:.4f} of pixels within {K_SIGMA} sigma at 16 spp"
+    # (3) the config's own image size against the oracle
+    ctx.init_state(p)
+    ctx.trace_samples(1)
+    g1, r1 = ctx.download(), osc.render(p, 1)
+    assert np.array_equal(g1[..., 3], r1[..., 3]), f"{tag}: primary visibility differs at {res}^2"
+    close = _rel(g1[..., :3], r1[..., :3]).max(axis=2) < 1e-3
+    assert close.mean() >= BAR_1SPP, f"{tag}: only {close.mean():.3f} of the {res}^2 pixels within rel 1e-3 at 1 spp"
+    ctx.init_state(p)
+    ctx.trace_samples(8)
+    g8, r8 = ctx.download(), osc.render(p, 8)
+    other8 = osc.render(yh.TraceParams.default(resolution=res, seed=12345), 8)
+    err, floor = _relrmse(g8, r8), _relrmse(other8, r8)
+    assert err <= 0.5 * floor, f"{tag} at {res}^2: relRMSE {err:.4f} vs seed floor {floor:.4f}"
+    share, _ = _k_sigma_share(ctx, osc, yh, res, 8, r8, seeds=(961748941, 12345, 777, 31337))
+    assert share >= 0.99, f"{tag} at {res}^2: {share:.4f} of pixels within {K_SIGMA} sigma at 8 spp"
     osc.close(), sf.close()
 
 
