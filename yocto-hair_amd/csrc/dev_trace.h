@@ -288,6 +288,9 @@ YH_DEV void count_quad(unsigned int& slot) {
 // as soon as no more than `leave_at` lanes are still running, the quads still running keep their state in `rs` and
 // their LDS stack, and the next call picks them up where they stopped (instance-space ray data recomputed: same
 // operations, same bits).
+#ifndef YH_WIDE_BLOB
+#define YH_WIDE_BLOB 1 /* ... and so do the octet and sixteen-lane forms over the 8- / 16-wide nodes, which join the blob in ensure_wide_nodes (host/scene_upload.cpp); 0: nodes8 / nodes16 + prims (A/B) */
+#endif
 #ifndef YH_QUAD_BLOB
 #define YH_QUAD_BLOB 1 /* the quad form over 4-wide nodes (YH_MODE_QUAD) reads nodes and leaf test records from yhd_scene::lane_blob (yh_device.h: absolute references, 32-byte test records): one base and one address form instead of two arrays, a record-size select and a node base (round 4); 0: nodes / prims as until round 3 (A/B) */
 #endif
@@ -339,6 +342,8 @@ YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_obj
     trav_state* rs = nullptr, int leave_at = 0) {
   static_assert(MODE == YH_MODE_QUAD || !PHASE, "the resumable traversal exists for the 4-wide quad form only");
   constexpr bool QB = YH_QUAD_BLOB && MODE == YH_MODE_QUAD && !PHASE && !YH_PREFETCH && !YH_LDS_NODELETS;  // nodes and test records from the lane blob
+  constexpr bool QW = YH_QUAD_BLOB && YH_WIDE_BLOB && (YH_IS_OCT(MODE) || YH_IS_HEX(MODE)) && !YH_PREFETCH;  // ... the 8- / 16-wide nodes too (they join the blob in ensure_wide_nodes)
+  constexpr bool QX = QB || QW;
   const yhd_scene&     sc   = *tc.sc;
   const unsigned int   q    = __lane_id() & 3u;
 #if YH_REMAT_Q
@@ -473,6 +478,7 @@ YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_obj
         if (MODE == YH_MODE_W8 || YH_IS_OCT(MODE)) node_base = __float_as_int(ob[8].w);  // the shape's first 8-wide node (yhd_object::wbox_min[3])
         if (YH_IS_HEX(MODE)) node_base = __float_as_int(ob[9].w);                          // ... first 16-wide node (wbox_max[3])
         if (QB) node_base = __float_as_int(ob[10].x);                                      // ... root in the lane blob, 32-byte units (yhd_object::lane_root)
+        if (QW) node_base = __float_as_int(YH_IS_HEX(MODE) ? ob[10].w : ob[10].z);         // ... (lane_root16 / lane_root8)
       } else {
         const yhd_object& o = sc.objects[cur_obj];
         inv  = ldframe(o.inv_frame);
@@ -480,6 +486,7 @@ YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_obj
         if (MODE == YH_MODE_W8 || YH_IS_OCT(MODE)) node_base = __float_as_int(o.wbox_min[3]);
         if (YH_IS_HEX(MODE)) node_base = __float_as_int(o.wbox_max[3]);
         if (QB) node_base = o.lane_root;
+        if (QW) node_base = YH_IS_HEX(MODE) ? o.lane_root16 : o.lane_root8;
       }
       lo    = transform_point(inv, ray.o);
       ld    = transform_vector(inv, ray.d);
@@ -554,6 +561,7 @@ YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_obj
       int  pq         = mine ? (int)q : leaf_num - 1;
       const yhd_float4* addr;
       if (QB) addr = sc.lane_blob + 2 * (size_t)(is_leaf ? (unsigned)leaf_start + (unsigned)pq * (kind == YH_KIND_LINES ? 1u : 2u) : cur + q);  // (leaf_start: the leaf's first test record, blob units)
+      else if (QW) addr = sc.lane_blob + 2 * (size_t)(is_leaf ? (unsigned)leaf_start + (unsigned)pq * (kind == YH_KIND_LINES ? 1u : 2u) : cur + (__lane_id() & (YH_IS_HEX(MODE) ? 15u : 7u)));
       else if (MODE == YH_MODE_QUAD) addr = is_leaf ? sc.prims + (size_t)prim_base + (size_t)(leaf_start + pq) * rec : sc.nodes + 8 * (size_t)cur + 2 * q;
       else if (MODE == YH_MODE_W8) addr = is_leaf ? sc.prims + (size_t)prim_base + (size_t)(leaf_start + pq) * rec : sc.nodes8 + 16 * (size_t)cur + 4 * q;
       else if (YH_IS_OCT(MODE)) addr = is_leaf ? sc.prims + (size_t)prim_base + (size_t)(leaf_start + pq) * rec : sc.nodes8 + 16 * (size_t)cur + 2 * (__lane_id() & 7u);
@@ -582,7 +590,7 @@ YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_obj
         const unsigned int rank = (((o >> 3) ^ n0) << 3) | ((((o >> 2) & 1) ^ n1) << 2) | ((((o >> 1) & 1) ^ n2) << 1) | ((o & 1) ^ n3);
         unsigned int ref = __float_as_uint(s1.z);
         const bool   h   = box_test(lo, ldinv, ray.tmin, tmax, f3{s0.x, s0.y, s0.z}, f3{s0.w, s1.x, s1.y}) && ref != YH_NONE;
-        if ((ref & YH_TAG_MASK) == 0) ref += (unsigned)node_base;  // child wide nodes are shape-local indices
+        if (!QW && (ref & YH_TAG_MASK) == 0) ref += (unsigned)node_base;  // child wide nodes are shape-local indices (absolute in the lane blob)
         unsigned int bits = h ? (1u << rank) : 0u;
         unsigned int M    = bits | (unsigned int)dpp_i<YH_QUAD_XOR1>((int)bits);
         M |= (unsigned int)dpp_i<YH_QUAD_XOR2>((int)M);
@@ -626,7 +634,7 @@ YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_obj
           ref_a  = __float_as_uint(s1.z);
           h_a    = box_test(lo, ldinv, ray.tmin, tmax, f3{s0.x, s0.y, s0.z}, f3{s0.w, s1.x, s1.y}) && ref_a != YH_NONE;
         }
-        if ((ref_a & YH_TAG_MASK) == 0) ref_a += (unsigned)node_base;  // child wide nodes are shape-local indices
+        if (!QW && (ref_a & YH_TAG_MASK) == 0) ref_a += (unsigned)node_base;  // child wide nodes are shape-local indices (absolute in the lane blob)
         if (MODE == YH_MODE_W8 && (ref_b & YH_TAG_MASK) == 0) ref_b += (unsigned)node_base;
         unsigned int bits = (h_a ? (1u << rank_a) : 0u) | (h_b ? (1u << rank_b) : 0u);
         unsigned int M    = bits | (unsigned int)dpp_i<YH_QUAD_XOR1>((int)bits);
@@ -726,7 +734,7 @@ YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_obj
           // The reference meets the group's leaves one after the other, each against the ray shortened by the hits before
           // it: the survivor is the accepted primitive of minimum t, the LATER one among equal t (math.h:3450) — the same
           // rule as inside a leaf, so the merge simply goes on across the quads with the leaf's place in the key.
-          int slot = leaf_start + (key_i & 3);
+          int slot = QW ? leaf_start + (key_i & 3) * (kind == YH_KIND_LINES ? 1 : 2) : leaf_start + (key_i & 3);
 #define YH_GROUP_MERGE(CTRL)                                                               \
   {                                                                                        \
     int   oi = dpp_i<CTRL>(key_i), os = dpp_i<CTRL>(slot);                                 \
@@ -744,7 +752,7 @@ YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_obj
           }
           sp -= grp;  // the group's leaves came off the stack
         } else if (key_i >= 0) {
-          hit.object = cur_obj, hit.slot = QB ? leaf_start + key_i * (kind == YH_KIND_LINES ? 1 : 2) : leaf_start + key_i;  // (QB: the primitive's test record; made the leaf-order index below)
+          hit.object = cur_obj, hit.slot = QX ? leaf_start + key_i * (kind == YH_KIND_LINES ? 1 : 2) : leaf_start + key_i;  // (QB: the primitive's test record; made the leaf-order index below)
           hit.u = uu, hit.v = vv, hit.distance = key_t;
           tmax = key_t;
         }
@@ -754,7 +762,7 @@ YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_obj
 #if YH_PREFETCH
   prefetch_drain();
 #endif
-  if (QB && hit.object >= 0) {  // test record in the blob -> leaf-order index of the primitive in its shape (hit_t)
+  if (QX && hit.object >= 0) {  // test record in the blob -> leaf-order index of the primitive in its shape (hit_t)
     int hk, lt;
     if (in_lds) {
       const YH_LDS v4f* ob = tc.lds_scene + YH_OBJECT_F4 * hit.object;

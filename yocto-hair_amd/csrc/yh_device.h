@@ -50,7 +50,8 @@ typedef struct yhd_object {
   float wbox_min[4], wbox_max[4];  // wbox_min[3] / wbox_max[3] = (int bits) first 8-wide / 16-wide node of the shape in yhd_scene::nodes8 / nodes16
   // the shape's place in yhd_scene::lane_blob (the one-lane kernels' copy of the trees, dev_lane.h), in 32-byte units:
   // its root node and its first test record
-  int   lane_root, lane_test, lane_pad0, lane_pad1;
+  int   lane_root, lane_test;
+  int   lane_root8, lane_root16;  // ... and the roots of its 8- / 16-wide trees there, once those exist (ensure_wide_nodes)
 } yhd_object;
 #define YH_OBJECT_F4 11 /* sizeof(yhd_object) / 16 */
 
@@ -190,7 +191,9 @@ typedef struct yhd_scene {
   //   nodes         the 4-wide nodes of yhd_scene::nodes (128 B, same boxes, same axes word + a bit per occupied slot in
   //                 bits 8-11) with ABSOLUTE references: a child node's offset in the blob, or
   //                 YH_TAG_LEAF | count << 27 | offset of the leaf's first test record
-  // Built on the device from nodes / prims at the first launch that needs it (host/scene_upload.cpp: ensure_lane_blob, at yh_upload_scene).
+  // Built on the device from nodes / prims (host/scene_upload.cpp: ensure_lane_blob, at yh_upload_scene). When the 8- / 16-wide
+  // nodes are made (ensure_wide_nodes) they join the array behind the 4-wide ones (256 / 512 B each, same slot format, absolute
+  // references too), so that the octet and sixteen-lane forms address nodes and leaves like the quad form does.
   const yhd_float4* lane_blob;
   long long         lane_blob_units;
 } yhd_scene;

@@ -266,7 +266,7 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
     inverse_frame(o.frame, true, d.inv_frame);
     d.kind = I.kind, d.node_base = I.node_base, d.prim_base = I.prim_base, d.vert_base = I.vert_base;
     d.elem_base = I.elem_base, d.has_normals = I.has_normals, d.material = o.material, d.has_texcoords = sd->shapes[o.shape].texcoords != nullptr;
-    d.lane_root = (int)ctx->lane_shapes[(size_t)o.shape].node_off, d.lane_test = (int)ctx->lane_shapes[(size_t)o.shape].test_off, d.lane_pad0 = d.lane_pad1 = 0;
+    d.lane_root = (int)ctx->lane_shapes[(size_t)o.shape].node_off, d.lane_test = (int)ctx->lane_shapes[(size_t)o.shape].test_off, d.lane_root8 = d.lane_root16 = 0;
     // transform_bbox (math.h:3174-3185)
     const yhh::Box& b = I.root;
     float lo[3] = {std::numeric_limits<float>::max(), std::numeric_limits<float>::max(), std::numeric_limits<float>::max()};
@@ -604,6 +604,40 @@ int ensure_wide_nodes(yh_context* ctx) {
     const size_t si = (size_t)ctx->object_shape[oi];
     memcpy(&ctx->host_objects[oi].wbox_min[3], &base8[si], 4);
     memcpy(&ctx->host_objects[oi].wbox_max[3], &base16[si], 4);
+  }
+  {
+    // The wide nodes join the lane blob (yh_device.h) behind what it holds, with ABSOLUTE references: a child node's offset in
+    // the blob (32-byte units: 8 per 8-wide node, 16 per 16-wide one), a leaf's first test record. The blob is made anew with
+    // room for them (device-to-device copy of the old one); d_nodes8 / d_nodes16 above stay for the developer builds.
+    const long long U8 = (ctx->lane_units + 3) / 4 * 4, U16 = U8 + (long long)(nodes8.size() / 2), total = U16 + (long long)(nodes16.size() / 2) + 4;
+    if (total >= (1ll << 30)) return fail(ctx, YH_E_INVALID, "scene too large for 30-bit node offsets with its wide nodes (%lld units)", total);
+    auto rewrite = [&](std::vector<yhd_float4>& nodes, const std::vector<int>& base, long long U, int slots) {
+      for (size_t si = 0; si < ns; si++) {
+        const auto&  L   = ctx->lane_shapes[si];
+        const size_t n0  = (size_t)base[si], n1 = si + 1 < ns ? (size_t)base[si + 1] : nodes.size() / (2 * (size_t)slots);
+        for (size_t n = n0; n < n1; n++)
+          for (int q = 0; q < slots; q++) {
+            unsigned ref;
+            memcpy(&ref, &nodes[(n * (size_t)slots + (size_t)q) * 2 + 1].z, 4);
+            if (ref == 0xFFFFFFFFu) continue;
+            if ((ref & 0xC0000000u) == 0xC0000000u) ref = (ref & 0xF8000000u) | (unsigned)(L.test_off + (long long)(ref & 0x07FFFFFFu) * (L.kind == YH_KIND_LINES ? 1 : 2));
+            else ref = (unsigned)(U + (long long)slots * ((long long)base[si] + (long long)ref));
+            memcpy(&nodes[(n * (size_t)slots + (size_t)q) * 2 + 1].z, &ref, 4);
+          }
+      }
+    };
+    rewrite(nodes8, base8, U8, 8), rewrite(nodes16, base16, U16, 16);
+    DevBuf bigger;
+    if ((rc = alloc_zero(ctx, bigger, (size_t)total * 32))) return rc;
+    HIPCHK(ctx, hipMemcpy(bigger.p, ctx->d_lane_blob.p, (size_t)ctx->lane_units * 32, hipMemcpyDeviceToDevice));
+    if (!nodes8.empty()) HIPCHK(ctx, hipMemcpy((char*)bigger.p + (size_t)U8 * 32, nodes8.data(), nodes8.size() * 16, hipMemcpyHostToDevice));
+    if (!nodes16.empty()) HIPCHK(ctx, hipMemcpy((char*)bigger.p + (size_t)U16 * 32, nodes16.data(), nodes16.size() * 16, hipMemcpyHostToDevice));
+    std::swap(ctx->d_lane_blob.p, bigger.p), std::swap(ctx->d_lane_blob.bytes, bigger.bytes);
+    ctx->scene.lane_blob = (const yhd_float4*)ctx->d_lane_blob.p, ctx->scene.lane_blob_units = total;
+    for (size_t oi = 0; oi < ctx->host_objects.size(); oi++) {
+      const size_t si = (size_t)ctx->object_shape[oi];
+      ctx->host_objects[oi].lane_root8 = (int)(U8 + 8ll * base8[si]), ctx->host_objects[oi].lane_root16 = (int)(U16 + 16ll * base16[si]);
+    }
   }
   HIPCHK(ctx, hipMemcpy(ctx->d_objects.p, ctx->host_objects.data(), ctx->host_objects.size() * sizeof(yhd_object), hipMemcpyHostToDevice));
   ctx->scene.nodes8 = (const yhd_float4*)ctx->d_nodes8.p, ctx->scene.num_nodes8_total = (int)(nodes8.size() / 16);
