@@ -527,7 +527,7 @@ def main():
             floor = relrmse(ref8_other_seed, ref8)
             follow = {"scene": "the reference's tests/sphere-hairblock/sphere-hairblock.json (hair colour 0.8) with stand-in geometry x 0.05, "
                                f"{ref8.shape[1]}x{ref8.shape[0]}, 8 spp, against the reference's own image of it (tests/golden/refscenes.npz)",
-                      "rel_rmse_cpu_seed_floor": round(floor, 5), "stated_bar": {"fast_bsdf": 0.75, "exact_bsdf": 0.5}}
+                      "rel_rmse_cpu_seed_floor": round(floor, 5), "stated_bar": {"fast_bsdf": 0.5, "exact_bsdf": 0.5}}
             for key, exact in (("fast_bsdf", False), ("exact_bsdf", True)):
                 ctx.init_state(yh.TraceParams.default(resolution=max(ref8.shape[0], ref8.shape[1]), hair_exact=exact))
                 ctx.trace_samples(8)
@@ -635,7 +635,7 @@ def main():
                 "runs": others}
         if parity is not None:
             out["parity"] = parity
-            if follow is not None:  # the path-following ratio of the DEFAULT arithmetic next to the exact one's: the relaxed 0.75 bar in the record
+            if follow is not None:  # the path-following ratio of the DEFAULT arithmetic next to the exact one's (one bar, 0.5, for both since round 4)
                 out["parity"]["path_following_light_hair"] = follow
         elif shard_check is not None:  # N > 1: no CPU leg; the parity statement of this line is the shard invariance on the real collective
             out["parity"] = shard_check

@@ -400,15 +400,15 @@ def test_reference_scene_files_render_like_the_reference(ctx, yh, which, exact):
     assert np.mean(img[..., 3] == ref1[..., 3]) > 0.995
     close = _rel(img[..., :3], ref1[..., :3]).max(axis=2) < 1e-3
     assert close.mean() >= BAR_1SPP, f"only {close.mean():.3f} of pixels within rel 1e-3 at 1 spp"
-    # 8 spp against the seed-to-seed floor (0.5 x floor). The exact arithmetic meets it on every
-    # file (measured 0.00-0.23). The default arithmetic has the STATED bar 0.75 here: the reference's sphere-hairblock
-    # material is light hair (colour 0.8: eight-bounce paths, each bounce a chance to leave the reference's path),
-    # measured 0.52-0.62 there and 0.00-0.43 on the others (oracle/divergence_report.py,
-    # profiles/r02/bsdf_arithmetic_variants.txt)
+    # 8 spp against the seed-to-seed floor (0.5 x floor), the SAME bar for both arithmetics. Until round 4
+    # the default arithmetic had a relaxed bar of 0.75 (measured 0.52-0.62 on the reference's sphere-hairblock: light hair,
+    # colour 0.8, eight-bounce paths, each bounce a chance to leave the reference's path). Since the chain that ends in the
+    # SAMPLED DIRECTION is kept in the exact forms (csrc/dev_hair.h: YH_DIR_EXACT; only the lobes' values stay fast) it
+    # measures 0.21 there, as the exact arithmetic does (0.23): profiles/r04/direction_chain_ab.txt
     ctx.init_state(p)
     ctx.trace_samples(8)
     assert ctx.launch_shape() == 0 or not exact
-    bar = 0.5 if exact else 0.75
+    bar = 0.5
     err, floor = _relrmse(ctx.download(), ref8), _relrmse(other, ref8)
     assert err <= bar * floor, f"{which}: relRMSE {err:.4f} vs {bar} x seed floor {floor:.4f}"
     sf.close()

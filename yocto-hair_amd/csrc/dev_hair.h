@@ -90,6 +90,23 @@ YH_DEV f3    h_normalize(f3 a) {
 YH_DEV f3 h_div(f3 a, float b) { float r = h_rcp(b); return YH_FAST_DIV ? a * r : a / b; }
 YH_DEV f3 h_transform_direction(const frame& a, f3 b) { return h_normalize(transform_vector(a, b)); }
 
+// The chain that ends in the SAMPLED DIRECTION (gamma_t of the transmitted ray, the longitudinal / azimuthal sampling formulas, the
+// rotation into world space): a last-place difference there sends the path to another fibre within a few bounces, one in the
+// lobes' VALUES only scales the weight. YH_DIR_EXACT = 1 keeps that chain in the exact forms while the values stay fast.
+#ifndef YH_DIR_EXACT
+#define YH_DIR_EXACT 1 /* 0: the sampled direction in the fast forms too, as until round 4 (A/B: profiles/r04/direction_chain_ab.txt) */
+#endif
+constexpr bool dir_fast_div = YH_FAST_DIV && !YH_DIR_EXACT, dir_fast_log = YH_FAST_LOG && !YH_DIR_EXACT, dir_fast_trig = YH_FAST_TRIG && !YH_DIR_EXACT;
+YH_DEV float d_rcp(float x) { return dir_fast_div ? __builtin_amdgcn_rcpf(x) : 1 / x; }
+YH_DEV float d_div(float a, float b) { return dir_fast_div ? a * __builtin_amdgcn_rcpf(b) : a / b; }
+YH_DEV float d_sqrt(float x) { return dir_fast_div ? __builtin_amdgcn_sqrtf(x) : sqrtf(x); }
+YH_DEV float d_safe_sqrt(float x) { return d_sqrt(fmax_(0.0f, x)); }
+YH_DEV float d_log(float x) { return dir_fast_log ? __builtin_amdgcn_logf(x) * 0.693147181f : logf(x); }
+YH_DEV float d_sin(float x) { return dir_fast_trig ? __builtin_amdgcn_sinf(x * 0.159154943f) : sinf(x); }
+YH_DEV float d_cos(float x) { return dir_fast_trig ? __builtin_amdgcn_cosf(x * 0.159154943f) : cosf(x); }
+YH_DEV float d_cos_turns(float t) { return dir_fast_trig ? __builtin_amdgcn_cosf(t) : cosf(2 * pif * t); }
+YH_DEV f3    d_transform_direction(const frame& a, f3 b) { return dir_fast_div ? h_normalize(transform_vector(a, b)) : normalize(transform_vector(a, b)); }
+
 YH_DEV float sqr(float v) { return v * v; }
 YH_DEV float safe_asin(float x) { return h_asin(fclamp(x, -1.0f, 1.0f)); }
 YH_DEV float safe_sqrt(float x) { return h_sqrt(fmax_(0.0f, x)); }
@@ -191,8 +208,8 @@ YH_DEV f3 transmittance(const yhd_material& m, float h, float sin_theta_o, float
     float& gamma_t) {
   float sin_theta_t = h_div(sin_theta_o, m.eta);
   float cos_theta_t = safe_sqrt(1 - sqr(sin_theta_t));
-  float etap        = h_div(h_sqrt(m.eta * m.eta - sqr(sin_theta_o)), cos_theta_o);
-  float sin_gamma_t = h_div(h, etap);
+  float etap        = d_div(d_sqrt(m.eta * m.eta - sqr(sin_theta_o)), cos_theta_o);  // (gamma_t: part of the sampled azimuth)
+  float sin_gamma_t = d_div(h, etap);
   float cos_gamma_t = safe_sqrt(1 - sqr(sin_gamma_t));
   gamma_t           = safe_asin(sin_gamma_t);
   float k           = h_div_n(2 * cos_gamma_t, cos_theta_t);
@@ -439,23 +456,23 @@ YH_DEV f3 hair_sample(const yhd_material& m, const hair_hit& hh, const hair_out&
   // select without dynamic indexing into the struct
   vp   = p == 0 ? m.v[0] : p == 1 ? m.v[1] : m.v[2];  // v[3] == v[2]
   em2v = p == 0 ? m.exp_m2_inv_v[0] : p == 1 ? m.exp_m2_inv_v[1] : m.exp_m2_inv_v[2];
-  float cos_theta   = 1 + vp * h_log(u10 + (1 - u10) * em2v);
-  float sin_theta   = safe_sqrt(1 - sqr(cos_theta));
-  float cos_phi     = h_cos_turns(u11);
+  float cos_theta   = 1 + vp * d_log(u10 + (1 - u10) * em2v);
+  float sin_theta   = d_safe_sqrt(1 - sqr(cos_theta));
+  float cos_phi     = d_cos_turns(u11);
   float sin_theta_i = -cos_theta * sin_theta_op + sin_theta * cos_phi * cos_theta_op;
-  float cos_theta_i = safe_sqrt(1 - sqr(sin_theta_i));
+  float cos_theta_i = d_safe_sqrt(1 - sqr(sin_theta_i));
   // gamma_t (ext.cpp:463-465) is the same expression as in eval: ho.gamma_t
   float dphi;
   if (p < p_max) {
     // sample_trimmed_logistic (ext.cpp:359-363)
-    float x = -m.s * h_log(h_rcp(u01 * m.tl_norm + m.tl_cdf_a) - 1);
+    float x = -m.s * d_log(d_rcp(u01 * m.tl_norm + m.tl_cdf_a) - 1);
     dphi    = phi_fn(p, hh.gamma_o, ho.gamma_t) + fclamp(x, -pif, pif);
   } else {
     dphi = 2 * pif * u01;
   }
   float phi_i    = phi_o + dphi;
-  f3    incoming = f3{sin_theta_i, cos_theta_i * h_cos(phi_i), cos_theta_i * h_sin(phi_i)};
-  return h_transform_direction(transpose_rot(hh.w2b), incoming);
+  f3    incoming = f3{sin_theta_i, cos_theta_i * d_cos(phi_i), cos_theta_i * d_sin(phi_i)};
+  return d_transform_direction(transpose_rot(hh.w2b), incoming);
 }
 YH_DEV f3 hair_sample(const yhd_material& m, const hair_hit& hh, f3 outgoing_, float rnx, float rny) {
   hair_out ho = hair_prepare(m, hh, outgoing_);

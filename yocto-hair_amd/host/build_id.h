@@ -1,1 +1,1 @@
-#define YH_BUILD_ID "6a71656123d0c3c4"
+#define YH_BUILD_ID "fd4ef95e6bb8406d"
