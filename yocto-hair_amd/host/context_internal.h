@@ -36,7 +36,6 @@
 
 #include "../csrc/yh_device.h"
 #include "bvh_build.h"
-#include "build_id.h"  // YH_BUILD_ID: a hash of the device and host sources, written by the Makefile
 #include "yhair.h"
 
 // launchers in csrc/kernels.hip
