@@ -204,14 +204,14 @@ YH_DEV void ap(float cos_theta_o, float eta, float h, f3 T, f3 out[p_max + 1]) {
   out[3]  = f3{h_div(num.x, den.x), h_div(num.y, den.y), h_div(num.z, den.z)};
 }
 // T for a given (sin_theta_o, cos_theta_o) (ext.cpp:281-291 / 375-384)
-// (DIR: the caller uses gamma_t — part of the sampled azimuth, YH_DIR_EXACT — and not just T)
-template <bool DIR = true>
+// (etap and sin_gamma_t in the exact forms, YH_DIR_EXACT: gamma_t is part of the sampled azimuth. Also where only T is used —
+// the lobe pdfs — so that the one-lane and the quad forms, which share this code differently, keep computing the same bits)
 YH_DEV f3 transmittance(const yhd_material& m, float h, float sin_theta_o, float cos_theta_o,
     float& gamma_t) {
   float sin_theta_t = h_div(sin_theta_o, m.eta);
   float cos_theta_t = safe_sqrt(1 - sqr(sin_theta_t));
-  float etap        = DIR ? d_div(d_sqrt(m.eta * m.eta - sqr(sin_theta_o)), cos_theta_o) : h_div(h_sqrt(m.eta * m.eta - sqr(sin_theta_o)), cos_theta_o);
-  float sin_gamma_t = DIR ? d_div(h, etap) : h_div(h, etap);
+  float etap        = d_div(d_sqrt(m.eta * m.eta - sqr(sin_theta_o)), cos_theta_o);
+  float sin_gamma_t = d_div(h, etap);
   float cos_gamma_t = safe_sqrt(1 - sqr(sin_gamma_t));
   gamma_t           = safe_asin(sin_gamma_t);
   float k           = h_div_n(2 * cos_gamma_t, cos_theta_t);
@@ -252,7 +252,7 @@ YH_DEV void compute_ap_pdf(const yhd_material& m, float h, float cos_theta_o,
     float ap_pdf[p_max + 1]) {
   float sin_theta_o = safe_sqrt(1 - cos_theta_o * cos_theta_o);
   float gamma_t;
-  f3    T = transmittance<false>(m, h, sin_theta_o, cos_theta_o, gamma_t);
+  f3    T = transmittance(m, h, sin_theta_o, cos_theta_o, gamma_t);
   f3    apv[p_max + 1];
   ap(cos_theta_o, m.eta, h, T, apv);
   float sum_y = 0.0f;
