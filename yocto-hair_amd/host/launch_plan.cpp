@@ -319,16 +319,6 @@ int upload_work_items(yh_context* ctx) {
   ctx->state.num_groups = 1, ctx->state.group_begin[0] = 0, ctx->state.group_begin[1] = (int)tiles.size();
   ctx->state.static_items = 0;
   ctx->state.prio_items   = getenv("YHAIR_PRIO_ITEMS") ? atoi(getenv("YHAIR_PRIO_ITEMS")) : 0;  // developer A/B switch (a library built with -DYH_LAB_PRIO)
-  if (const char* dp = getenv("YHAIR_DYN_PRIO")) {  // developer A/B switch (a library built with -DYH_DYN_PRIO): ticks per sample above which a wave raises its priority
-    std::vector<unsigned int> heavy;                //   = that percentile of the expensive items' cost per sample in the last launch
-    for (int t : tiles) heavy.push_back(ctx->item_cost[(size_t)t]);
-    std::sort(heavy.begin(), heavy.end());
-    const size_t n_exp = std::min(heavy.size(), (size_t)std::max(1, expensive_items(ctx, tiles)));
-    const double pct = std::max(1.0, std::min(100.0, atof(dp)));
-    const unsigned int at = heavy.empty() ? 0u : heavy[heavy.size() - 1 - (size_t)((100.0 - pct) / 100.0 * (double)(n_exp - 1))];
-    ctx->state.prio_items = ctx->last_nsamples > 0 ? (int)std::max<unsigned int>(1u, at / (unsigned int)ctx->last_nsamples) : 0;
-    if (getenv("YHAIR_TIMING")) fprintf(stderr, "[yhair] dynamic priority above %d ticks per sample (%zu expensive items)\n", ctx->state.prio_items, n_exp);
-  }
   if (ctx->state.shader == YH_SHADER_PATH && ctx->state.launch_shape == 3) deal_items_for_stream(ctx, tiles);
   if (ctx->state.shader == YH_SHADER_PATH && (ctx->state.launch_shape == 4 || ctx->state.launch_shape == 7)) split_items_for_octets(tiles);
   if (ctx->state.shader == YH_SHADER_PATH && ctx->state.launch_shape == 5) split_items_side_by_side(ctx, tiles);
