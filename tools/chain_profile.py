@@ -25,5 +25,7 @@ for shape in shapes:
     wi = max(1, wc["wave_iters"])
     ws = max(1, wc["wave_steps"])
     print(f"{name} {res}^2 shape {shape}: 64 spp {min(ms):.2f} ms (instrumented {ctx.last_trace_ms()[0]:.2f}) | per wave iteration: trace {wc['cyc_trace'] / wi:.0f} cyc, "
-          f"shade {wc['cyc_shade'] / wi:.0f} cyc, trips {ws / wi:.2f}, cycles per trip {wc['cyc_trace'] / ws:.0f}, wave iterations {wi} | steps ran in share of trips: "
+          f"shade {wc['cyc_shade'] / wi:.0f} cyc, trips {ws / wi:.2f}, cycles per trip {wc['cyc_trace'] / ws:.0f}, wave iterations {wi} | "
+          f"quad trips {wc['lane_steps']}, wave trips {ws}, quad idle trips 1 - quad / (16 x wave) = {1 - wc['lane_steps'] / (16.0 * ws):.3f}, "
+          f"live quads per wave iteration {wc['lane_iters'] / wi:.2f}, trips per ray {wc['lane_steps'] / max(1, wc['lane_iters']):.1f} | steps ran in share of trips: "
           + ", ".join(f"{nm} {wc['trips_' + nm] / ws:.2f} ({wc['lanes_' + nm] / max(1, wc['trips_' + nm]):.1f} lanes)" for nm in ("node", "line", "tri", "enter", "scene")), flush=True)
