@@ -67,10 +67,12 @@ KERNELS = {0: "k_trace<512 x 4>", 1: "k_trace<256 x 5>", 2: "k_trace<512 x 4, 8-
            8: "k_trace<256 x 4, 16 lanes per path, leaf groups>"}
 
 
-def cpu_leg(scene_json, resolution, budget_s, force_spp=0):
+def cpu_leg(scene_json, resolution, budget_s, force_spp=0, full_spp=0, full_budget_s=0.0, want_counts=True):
     """The CPU path on this host (test infrastructure, used here only as the reported baseline and as
     the checker of the `parity` field): two renders of the same scene at equal spp, seeds A and B.
-    Returns (cpu_baseline dict, image A, image B, spp, seed B, work counts of the reference algorithm)."""
+    spp = force_spp if given; else full_spp (the config's own sample count) when one seed of it fits full_budget_s on this
+    host (judged from a 1-spp render); else what budget_s allows, at most 256.
+    Returns (cpu_baseline dict, image A, image B, spp, seed B, work counts of the reference algorithm or None)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_capi as oc
     import yhair_capi as yh
@@ -95,7 +97,12 @@ def cpu_leg(scene_json, resolution, budget_s, force_spp=0):
     t0 = time.time()
     render(pa, 1)
     t1 = time.time() - t0
-    spp = force_spp if force_spp > 0 else int(max(1, min(256, budget_s / max(t1, 1e-3))))
+    if force_spp > 0:
+        spp = force_spp
+    elif full_spp > 0 and full_spp * t1 <= full_budget_s:
+        spp = full_spp
+    else:
+        spp = int(max(1, min(256, budget_s / max(t1, 1e-3))))
     t0 = time.time()
     img_a = render(pa, spp)
     dt = time.time() - t0
@@ -103,7 +110,7 @@ def cpu_leg(scene_json, resolution, budget_s, force_spp=0):
     n = img_a.shape[0] * img_a.shape[1] * spp
     # work counts of the REFERENCE algorithm (binary BVH, <= 4 primitives per leaf) on this scene:
     # the N_* of SURVEY.md 8(d)'s algorithmic-bytes formula
-    _, wc = osc.render(pa, 2, nthreads=threads, want_counts=True)
+    wc = osc.render(pa, 2, nthreads=threads, want_counts=True)[1] if want_counts else None
     osc.close()
     if rsc is not None:
         rsc.close()
@@ -112,6 +119,64 @@ def cpu_leg(scene_json, resolution, budget_s, force_spp=0):
             "sample": f"{img_a.shape[1]}x{img_a.shape[0]} x {spp} spp of the same scene, {dt:.1f} s, {what} "
                       f"(scene load and BVH build {build_s:.1f} s not counted)"}
     return base, img_a, img_b, spp, seed_b, wc
+
+
+def end_to_end(scene_json, resolution, spp, cpu_rate_msamples):
+    """BASELINE's metric times the sample loop only; this is the rest of the job next to it (SURVEY.md 8 f3's reason to exist): the wall-clock
+    of the command line a user runs — yocto-hair_amd/yscenetrace scene -r R -s SPP -o out.pfm — on a COLD kernel-trial record (the first run
+    on a machine: the trials are cut off the front of the render) and on a WARM one, split by phase (--timing), next to the reference's own
+    command line (oracle/_ref/yscenetrace_ref, built from /root/reference where that exists) on the same scene file at a stated reduced spp."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "yocto-hair_amd", "yscenetrace")
+    work = tempfile.mkdtemp(prefix="yhair_e2e_")
+    out = {"command": f"yocto-hair_amd/yscenetrace {os.path.basename(os.path.dirname(scene_json))}/scene.json -r {resolution} -s {spp} -o out.pfm --timing",
+           "what": "wall-clock seconds of the whole command by phase: load_scene = JSON + PLY + HDR parse; bvh_and_upload = flatten + yh_upload_scene (reference-order BVH on "
+                   "the device, leaf-ordered records, H2D copies); init_state_and_probe = pixel RNG streams + the 1-spp probe launch; sample_loop = every launch incl. the kernel "
+                   "trials of a cold record; download_or_gather; save = .pfm write; process start to exit in total_wall_s"}
+    try:
+        env = dict(os.environ, YHAIR_CACHE_DIR=os.path.join(work, "cache"))
+        env.pop("YHAIR_NO_DISK_CACHE", None), env.pop("YHAIR_SHAPE", None)
+        for key in ("cold_trial_record", "warm_trial_record"):
+            t0 = time.time()
+            r = subprocess.run([exe, scene_json, "-r", str(resolution), "-s", str(spp), "-o", os.path.join(work, "out.pfm"), "--timing"], env=env, capture_output=True, text=True, timeout=300)
+            wall = time.time() - t0
+            if r.returncode != 0:
+                raise RuntimeError(f"yscenetrace exited {r.returncode}: {(r.stdout + r.stderr)[-300:]}")
+            t = json.loads(re.search(r"^timing: (\{.*\})$", r.stdout, re.M).group(1))
+            t["total_wall_s"] = round(wall, 3)
+            t["msamples_per_s_whole_command"] = round(t["width"] * t["height"] * t["samples"] / wall / 1e6, 1)
+            out[key] = t
+        warm = out["warm_trial_record"]
+        shares = {k: warm[k] for k in ("load_scene_s", "convert_s", "bvh_and_upload_s", "lights_s", "init_state_and_probe_s", "download_or_gather_s", "save_s")}
+        big = max(shares, key=shares.get)
+        out["largest_non_render_phase"] = {"phase": big, "seconds": shares[big], "share_of_total": round(shares[big] / warm["total_s"], 3),
+                                           "sample_loop_share_of_total": round(warm["sample_loop_s"] / warm["total_s"], 3)}
+        ref = os.path.join(ROOT, "oracle", "_ref", "yscenetrace_ref")
+        if os.path.exists(ref):
+            rspp = int(max(2, min(256, 8.0 * cpu_rate_msamples * 1e6 / (resolution * resolution)))) if cpu_rate_msamples else 16
+            walls = {}
+            for n in (1, rspp):
+                t0 = time.time()
+                r = subprocess.run([ref, scene_json, "-r", str(resolution), "-s", str(n), "-o", os.path.join(work, "ref.pfm")], capture_output=True, text=True, timeout=300)
+                if r.returncode != 0:
+                    raise RuntimeError(f"yscenetrace_ref exited {r.returncode}: {(r.stdout + r.stderr)[-300:]}")
+                walls[n] = time.time() - t0
+            per_spp = (walls[rspp] - walls[1]) / (rspp - 1)
+            out["reference_cli"] = {"command": f"oracle/_ref/yscenetrace_ref scene.json -r {resolution} -s N -o ref.pfm", "spp": rspp, "total_wall_s": round(walls[rspp], 3),
+                                    "total_wall_s_at_1_spp": round(walls[1], 3), "seconds_per_spp": round(per_spp, 4), "threads": os.cpu_count(),
+                                    "fixed_part_s": round(walls[1] - per_spp, 3),
+                                    "projected_total_wall_s_at_full_spp": round(walls[1] - per_spp + per_spp * spp, 1),
+                                    "note": "the reference's own command line (load, init_bvh, init_lights, sample loop over this host's threads, save); "
+                                            "its full-spp time is projected from two runs (time is linear in spp)"}
+            out["speedup_whole_command_vs_reference_projected"] = round(out["reference_cli"]["projected_total_wall_s_at_full_spp"] / warm["total_wall_s"], 1)
+    except Exception as e:  # never at the expense of the reported line
+        out["error"] = str(e)
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    return out
 
 
 def parity_field(np, gpu_a, gpu_b, cpu_a, cpu_b, spp):
@@ -205,7 +270,11 @@ def valu_block(pmc):
     return {"bound": "valu", "issue_fraction": issue, "lane_utilisation": lanes,
             "achieved": round(issue * lanes, 4) if issue and lanes else None, "peak": 1.0, "unit": "share of vector lane-cycles doing work",
             "simd_busy": pmc.get("valu_simd_busy_at_2GHz"),
-            "wait_fraction": pmc.get("wait_any_fraction"), "l2_hit_rate": pmc.get("l2_hit_rate"), "source": pmc.get("source")}
+            "wait_fraction": pmc.get("wait_any_fraction"), "l2_hit_rate": pmc.get("l2_hit_rate"),
+            "mem_unit_busy": pmc.get("mem_unit_busy"), "achieved_waves_per_simd": pmc.get("achieved_waves_per_simd"),
+            "l2_read_requests_to_dram_share": pmc.get("l2_read_requests_to_dram_share"),
+            "mall_hit_rate": pmc.get("mall_hit_rate"), "mall_note": "no counter of this rocprofv3 build separates Infinity-Cache hits (FETCH_SIZE counts what leaves the L2s)",
+            "source": pmc.get("source")}
 
 
 def spawn_ranks(n):
@@ -251,8 +320,13 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0, help="hair strand-count multiplier (1.0 = the config's scene)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=10.0, help="seconds of CPU rendering per seed (two seeds)")
-    ap.add_argument("--cpu-spp", type=int, default=0, help="samples of the CPU leg and of the parity field (default: what --cpu-budget allows, at most 256); "
-                                                           "1536 = the metric's own sample count on C1, about 40 s per seed on 256 threads")
+    ap.add_argument("--cpu-spp", type=int, default=0, help="samples of the CPU leg and of the parity field (default: the config's OWN sample count when one seed of it "
+                                                           "fits --cpu-full-budget on this host — C1's 1536 spp take about 40 s per seed on 256 threads — else what --cpu-budget allows, at most 256)")
+    ap.add_argument("--cpu-full-budget", type=float, default=75.0, help="seconds one seed of the CPU leg may take at the config's own sample count (two seeds are rendered)")
+    ap.add_argument("--other-cpu-budget", type=float, default=6.0, help="seconds of CPU rendering per seed for the parity / cpu_baseline of each of config.other_configs")
+    ap.add_argument("--no-end-to-end", dest="end_to_end", action="store_false",
+                    help="headline run at N = 1: skip config.end_to_end (the yscenetrace command line on the config's scene file, cold and warm trial record, next to the reference's)")
+    ap.add_argument("--no-trial-cache", action="store_true", help="do not keep the kernel-trial record on disk (yh_set_trial_cache_dir; the environment's YHAIR_NO_DISK_CACHE does the same)")
     ap.add_argument("--save", default="", help="write the final image (.pfm/.hdr) on rank 0")
     ap.add_argument("--weak", action="store_true", help="N > 1: report the weak-scaling run (image side x sqrt(N))")
     ap.add_argument("--strong", action="store_true", help="(default for N > 1; kept for compatibility)")
@@ -276,6 +350,10 @@ def main():
     import make_scenes
     import yhair_capi as yh
     import yhair_dist
+
+    # the kernel-trial record on disk is opt-in for library callers (include/yhair.h: yh_set_trial_cache_dir); the bench opts in like the
+    # command lines do, so that the ranks of a run and the runs on a node settle on one kernel per image
+    trial_cache = None if a.no_trial_cache else yh.set_trial_cache_dir(default=True)
 
     cfg = dict(CONFIGS[a.config])
     scene_name = a.scene or cfg["scene"]
@@ -406,13 +484,28 @@ def main():
             achieved = bps * w * h * spp_launch / launch_s / 1e9
             pmc, why = committed_counters(c["scene"], kw, c["resolution"], 1.0, 1, shape)
             traffic = round((pmc["hbm_fetch_bytes_per_launch"] + pmc["hbm_write_bytes_per_launch"]) * spp_launch / pmc["spp_per_launch"] / 1e9, 3) if pmc else None
+            # the config's own parity statement and CPU baseline: the reference on this host's threads at the config's resolution, at the
+            # spp a few seconds per seed allow (stated), and the device at that spp and both seeds
+            o_parity = o_cpu = None
+            if not a.no_cpu_baseline:
+                try:
+                    o_cpu, ca, cb, ospp, oseed_b, _ = cpu_leg(path, c["resolution"], a.other_cpu_budget, want_counts=False)
+                    oimgs = []
+                    for sd in (None, oseed_b):
+                        ctx.init_state(yh.TraceParams.default(resolution=c["resolution"]) if sd is None else yh.TraceParams.default(resolution=c["resolution"], seed=sd))
+                        ctx.trace_samples(ospp)
+                        oimgs.append(ctx.download())
+                    o_parity = parity_field(np, oimgs[0], oimgs[1], ca, cb, ospp)
+                except Exception as e:  # never at the expense of the throughput numbers
+                    o_parity = {"error": str(e)}
             return {"workload": f"{name}: {c['scene']} {w}x{h} x {c['spp']} spp" + "".join(f" {k} {v:g}" for k, v in kw.items()),
                     "value": round(w * h * c["spp"] / el / 1e6, 2), "unit": "Msamples/s", "steps": steps, "ms_per_step": round(el * 1e3 / steps, 3),
                     "kernel": KERNELS.get(shape, "?"), "launch_shape": shape, "launches_in_timed_steps": launches,
                     "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                                  "traffic": traffic, "traffic_unit": "GB per launch", "traffic_source": pmc["source"] if pmc else why,
                                  "avg_launch_ms": round(launch_s * 1e3, 3), "algorithmic_bytes_per_sample": round(bps, 1), "work_counts_from": src,
-                                 "valu": valu_block(pmc)}}
+                                 "valu": valu_block(pmc)},
+                    "parity": o_parity, "cpu_baseline": o_cpu}
         finally:
             osf.close()
 
@@ -424,7 +517,8 @@ def main():
                       for i in range(sf.desc.contents.num_materials))  # (label only: the GENERAL dense shape runs at 256 x 4)
     cpu = ref_wc = parity = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        cpu, cpu_a, cpu_b, cpu_spp, seed_b, ref_wc = cpu_leg(scene_json, base_res, a.cpu_budget, a.cpu_spp)
+        cpu, cpu_a, cpu_b, cpu_spp, seed_b, ref_wc = cpu_leg(scene_json, base_res, a.cpu_budget, a.cpu_spp, full_spp=spp_total if headline else 0,
+                                                             full_budget_s=a.cpu_full_budget)
         imgs = []
         for sd in (None, seed_b):  # the device at the CPU leg's spp, both seeds (untimed)
             p = yh.TraceParams.default(resolution=base_res) if sd is None else yh.TraceParams.default(resolution=base_res, seed=sd)
@@ -547,6 +641,10 @@ def main():
             except Exception as e:  # never at the expense of the reported line
                 others[oname] = {"error": str(e)}
 
+    e2e = None
+    if rank == 0 and world == 1 and headline and a.end_to_end:
+        e2e = end_to_end(scene_json, base_res, spp_total, cpu["value"] if cpu else None)
+
     if rank == 0:
         if a.save:
             err = C.create_string_buffer(256)
@@ -633,6 +731,9 @@ def main():
                 "what": "BASELINE.json configs[2..4] on this GPU after the headline run, each at its FULL sample count in 8 launches with its own "
                         "warm-up (three 96-sample launches: the kernel trials); roofline as for the headline (committed work counts / counter passes)",
                 "runs": others}
+        if e2e:
+            out["config"]["end_to_end"] = e2e
+        out["config"]["trial_cache_dir"] = trial_cache  # where the kernel-trial record is kept (opt-in; None: nowhere)
         if parity is not None:
             out["parity"] = parity
             if follow is not None:  # the path-following ratio of the DEFAULT arithmetic next to the exact one's (one bar, 0.5, for both since round 4)

@@ -288,10 +288,17 @@ int yh_launch_shape(const yh_context* ctx);
 int yh_kernel_trials(const yh_context* ctx, double* ms_per_sample, int* trials, int count);
 /* 1 while a candidate kernel of the current image still wants a timing trial — the next yh_trace_samples of 64 samples or
  * more will start with a 32-sample launch of it — else 0: a caller that times its launches (bench.py) keeps warming up
- * until this is 0. The record of an image is kept per process and in ~/.cache/yhair/trials_v1.txt (YHAIR_CACHE_DIR;
- * YHAIR_NO_DISK_CACHE switches the file off), keyed by device, build, scene, image size, shard and bounces: an image
- * found there runs no trial. Replaces nothing in the reference (host/launch_plan.cpp: pick_launch_shape).              */
+ * until this is 0. The record of an image is kept per process and, when the caller opted in (yh_set_trial_cache_dir), on disk.
+ * Replaces nothing in the reference (host/launch_plan.cpp: pick_launch_shape).                                          */
 int yh_trials_pending(const yh_context* ctx);
+/* The kernel-trial record ON DISK (process-wide, opt-in: a library call writes no file unless asked to). `dir` = a directory
+ * (created when needed) that holds trials_v2.txt, one appended line per image, keyed by device, the loaded library's
+ * fingerprint, scene, image size, shard and bounces: an image found there runs no trial at all, so two processes (two
+ * ranks, two runs) render one image with one kernel. NULL or "" = no file (the default). yscenetrace / ysceneitraces /
+ * bench.py pass yh_default_trial_cache_dir() = $XDG_CACHE_HOME/yhair or ~/.cache/yhair. The environment's YHAIR_CACHE_DIR
+ * names a directory too (and wins); YHAIR_NO_DISK_CACHE switches the file off whatever was set. No reference counterpart. */
+int         yh_set_trial_cache_dir(const char* dir);
+const char* yh_default_trial_cache_dir(void);
 
 /* Load-balance telemetry: for every tile id (row-major over ceil(W/8) x
  * ceil(H/8) tiles) the time its wavefront spent on it in the most recent

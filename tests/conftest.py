@@ -12,6 +12,10 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 sys.path.insert(0, os.path.join(ROOT, "yocto-hair_amd", "python"))
 GOLD = os.path.join(ROOT, "tests", "golden")
 SCENES = os.environ.get("YHAIR_SCENES", "/tmp/yhair_test_scenes")
+# The kernel-trial record on disk is opt-in (yh_set_trial_cache_dir / YHAIR_CACHE_DIR) and bench.py opts in: keep every process this
+# suite starts off it, so that no test depends on what an earlier run left behind and the suite leaves nothing behind for the bench
+# (ADVICE r04). test_kernel_trials_persist_on_disk drops the variable for its own subprocesses and names its own directory.
+os.environ.setdefault("YHAIR_NO_DISK_CACHE", "1")
 
 
 def pytest_configure(config):

@@ -264,6 +264,18 @@ def test_leaf_group_merge_is_the_sequential_rule():
         assert merged == best
 
 
+def test_launch_deadline_logic(tmp_path):
+    """The bounded wait behind yh_trace_samples / yh_synchronize (yocto-hair_amd/host/deadline.h), compiled
+    with a mocked event query and a fake clock: an event that never signals ends the wait AT the deadline (not before, at most
+    one 2 ms sleep after), one that signals ends it at once, a query error is passed on, the sleeps back off from 50 us to 2 ms,
+    and YHAIR_LAUNCH_TIMEOUT_S is parsed with the default for anything that is not a positive number."""
+    exe = str(tmp_path / "test_deadline")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I" + os.path.join(ROOT, "yocto-hair_amd", "host"),
+                           os.path.join(ROOT, "tests", "cpp", "test_deadline.cpp"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0 and "all checks passed" in out.stdout, out.stdout + out.stderr
+
+
 def test_traversal_loops_do_not_spill():
     """The traversal loop of the product kernels (plain k_trace in both launch shapes, plain k_stream) must not contain
     scratch instructions: a spill reload there stalls every step of every ray (0.75-0.8x on the dense configs), and

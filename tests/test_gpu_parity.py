@@ -974,8 +974,8 @@ def test_kernel_choice_is_stable_on_the_baseline_configs(yh, tag, name, kw, res,
 
 
 def test_kernel_trials_persist_on_disk(yh, tmp_path, monkeypatch):
-    """The trial record of an image is kept in YHAIR_CACHE_DIR/trials_v1.txt (default ~/.cache/yhair), keyed by device,
-    build, scene, image size, shard and bounces: a second PROCESS that renders the same image runs no trial at all —
+    """The trial record of an image is kept in YHAIR_CACHE_DIR/trials_v2.txt — for callers that opted in (YHAIR_CACHE_DIR or
+    yh_set_trial_cache_dir: a library call writes no file unasked) — keyed by device, build, scene, image size, shard and bounces: a second PROCESS that renders the same image runs no trial at all —
     its first request is one launch of the kernel the first process settled on — and renders the same pixels."""
     import json
     import subprocess
@@ -998,7 +998,7 @@ def test_kernel_trials_persist_on_disk(yh, tmp_path, monkeypatch):
         assert out.returncode == 0, out.stderr[-2000:]
         runs.append(json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]))
     a, b = runs
-    assert os.path.exists(tmp_path / "trials_v1.txt")
+    assert os.path.exists(tmp_path / "trials_v2.txt")
     assert a["first_launches"] > 1 and not a["pending"]        # the first process ran its trials inside the first request
     assert not b["pending0"] and b["first_launches"] == 1       # the second found the record: no trial, one launch
     assert b["shape"] == a["shape"] and b["trials"] == a["trials"] and b["md5"] == a["md5"]
@@ -1008,6 +1008,19 @@ def test_kernel_trials_persist_on_disk(yh, tmp_path, monkeypatch):
     assert out.returncode == 0 and not os.path.exists(tmp_path / "unused")
     c = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert c["first_launches"] > 1 and c["md5"] == a["md5"]
+    # OPT-IN (round 5): a library caller that names no directory gets no file, wherever HOME points
+    home = tmp_path / "home"
+    home.mkdir()
+    env3 = {k: v for k, v in env.items() if k not in ("YHAIR_CACHE_DIR", "XDG_CACHE_HOME")}
+    env3["HOME"] = str(home)
+    out = subprocess.run([sys.executable, "-c", code], env=env3, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["first_launches"] > 1 and d["md5"] == a["md5"] and not any(f for _, _, fs in os.walk(home) for f in fs if f.startswith("trials_"))
+    # ... and yh_set_trial_cache_dir is the call that opts in (what the command lines and bench.py do)
+    code2 = code.replace("c = yh.Context(0)", "yh.set_trial_cache_dir(%r); c = yh.Context(0)" % str(tmp_path / "api"))
+    out = subprocess.run([sys.executable, "-c", code2], env=env3, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and os.path.exists(tmp_path / "api" / "trials_v2.txt"), out.stderr[-2000:]
 
 
 def test_blocking_launch_after_an_async_one_across_a_kernel_switch(ctx, yh, monkeypatch):
@@ -1028,6 +1041,33 @@ def test_blocking_launch_after_an_async_one_across_a_kernel_switch(ctx, yh, monk
         ctx.trace_samples(10)
         ctx.synchronize()
         assert np.array_equal(ctx.download(), want[0]) and np.array_equal(ctx.download_rng(), want[1]), (first, second)
+    sf.close()
+
+
+def test_launch_deadline_poisons_the_context(yh, monkeypatch):
+    """yh_trace_samples waits for its launch with a deadline (YHAIR_LAUNCH_TIMEOUT_S; host/deadline.h). With a
+    deadline no real launch can meet, the call returns YH_E_DEVICE with a message instead of blocking, and the context refuses
+    every further launch — init_state, trace, download; a fresh context is unaffected. (The wait logic itself, with an event
+    that never signals, is tests/test_abi.py::test_launch_deadline_logic on the CPU.)"""
+    sf = yh.SceneFile(scene_path("straight-hair", scale=0.05))
+    c = yh.Context(0)
+    c.upload_scene(sf.desc)
+    c.init_state(yh.TraceParams.default(resolution=256))
+    c.trace_samples(2)
+    monkeypatch.setenv("YHAIR_LAUNCH_TIMEOUT_S", "1e-9")
+    with pytest.raises(yh.YhError, match="did not complete within"):
+        c.trace_samples(64)
+    monkeypatch.delenv("YHAIR_LAUNCH_TIMEOUT_S")
+    for call in (lambda: c.trace_samples(1), lambda: c.init_state(yh.TraceParams.default(resolution=64)), c.download, c.synchronize):
+        with pytest.raises(yh.YhError, match="exceeded its deadline"):
+            call()
+    c.close()  # frees nothing (the device may still be running the launch), returns at once
+    c2 = yh.Context(0)
+    c2.upload_scene(sf.desc)
+    c2.init_state(yh.TraceParams.default(resolution=64))
+    c2.trace_samples(4)
+    assert c2.download()[..., 3].max() > 0
+    c2.close()
     sf.close()
 
 

@@ -9,7 +9,7 @@ from the layout: the block placement may put a loop's latch above its header.
 usage: tools/check_codegen.py [--strict] [--loops]
   --strict: exit 1 when a traversal loop of a product kernel touches scratch
   --loops:  list every other loop of >= 100 vector instructions too
-  env YH_EXTRA_FLAGS="-DYH_SUSPEND=8": look at a developer variant"""
+  env YH_EXTRA_FLAGS="-D...": look at a developer variant"""
 import os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "yocto-hair_amd", "csrc")

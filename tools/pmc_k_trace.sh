@@ -11,7 +11,8 @@ mkdir -p "$OUT"
 i=0
 for grp in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES" \
            "SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_FLAT SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" \
-           "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"; do
+           "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" \
+           "GRBM_GUI_ACTIVE TA_BUSY_avr TA_BUSY_max" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum TCC_EA0_RDREQ_32B_sum"; do   # (round 5: MemUnitBusy = TA busy / GPU active, occupancy = wave cycles / GPU active; where the L2's read requests go)
   i=$((i+1))
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc $grp -d "$OUT/p$i" -o run -- python3 "$ROOT/bench.py" --no-cpu-baseline ${PMC_ARGS:-} --steps 4 --warmup ${PMC_WARMUP:-1} > "$OUT/p$i.log" 2>&1)
 done

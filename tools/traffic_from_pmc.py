@@ -16,6 +16,7 @@ CONFIGS = {"C1": ("sphere-hairblock", 720, 64), "C2": ("straight-hair", 720, 64)
            "lobes": ("lobes", 720, 64), "volumes": ("volumes", 720, 64), "textured": ("textured", 720, 64)}
 SCENE_KW = {"C2b": {"beta_m": 0.25}}  # scene overrides of a config name (C2b = C2 at beta_m 0.25: bench.py's config.other_configs)
 CONFIGS["C2b"] = CONFIGS["C2"]
+XCCS = 8  # GRBM_GUI_ACTIVE comes summed over the eight XCCs
 SIMDS, CLOCK = 1024, 2.0e9  # 256 CUs x 4 SIMDs; a vector instruction of a 64-wide wave holds its SIMD for 2 cycles at full rate
 
 
@@ -50,7 +51,16 @@ def main():
             "valu_lane_utilisation": p["SQ_THREAD_CYCLES_VALU"] / (64 * p["SQ_ACTIVE_INST_VALU"]),
             "valu_instructions_per_launch": p["SQ_INSTS_VALU"], "salu_instructions_per_launch": p["SQ_INSTS_SALU"],
             "kernel_avg_ms": avg_ms, "kernel_launches_averaged": len(full),
-            "valu_simd_busy_at_2GHz": 2 * p["SQ_INSTS_VALU"] / (SIMDS * CLOCK * avg_ms / 1e3)})
+            "valu_simd_busy_at_2GHz": 2 * p["SQ_INSTS_VALU"] / (SIMDS * CLOCK * avg_ms / 1e3),
+            # round 5 (SURVEY.md 8d asks for them next to VALUBusy): MemUnitBusy = the texture-addresser's busy cycles over the GPU's active cycles (rocprof's
+            # classic definition; GRBM_GUI_ACTIVE is per XCC, TA_BUSY_avr the mean over the TA instances); achieved occupancy = resident waves per SIMD =
+            # OccupancyPercent's expression (400 * SQ_WAVE_CYCLES / GRBM_GUI_ACTIVE / CU_NUM / 32, in per cent of 8 waves per SIMD) x 8 / 100; the share of the
+            # L2's read requests that go to DRAM's side of the fabric (the Infinity Cache sits behind that interface: no counter of this rocprofv3 build separates its hits)
+            "mem_unit_busy": (p["TA_BUSY_avr"] / (p["GRBM_GUI_ACTIVE"] / XCCS)) if p.get("GRBM_GUI_ACTIVE") else None,
+            "mem_unit_busy_max": (p["TA_BUSY_max"] / (p["GRBM_GUI_ACTIVE"] / XCCS)) if p.get("GRBM_GUI_ACTIVE") else None,
+            "achieved_waves_per_simd": (4 * p["SQ_WAVE_CYCLES"] / (p["GRBM_GUI_ACTIVE"] / XCCS) / 256 / 4) if p.get("GRBM_GUI_ACTIVE") else None,
+            "l2_read_requests_to_dram_share": (p["TCC_EA0_RDREQ_DRAM_sum"] / p["TCC_EA0_RDREQ_sum"]) if p.get("TCC_EA0_RDREQ_sum") else None,
+            "mall_hit_rate": None})
         print(cfg, kern, f"{avg_ms:.3f} ms over {len(full)} launches, VALU {p['SQ_INSTS_VALU']:.3g}, lanes {entries[-1]['valu_lane_utilisation']:.3f}, "
               f"issue {entries[-1]['valu_issue_fraction']:.3f}, wait {entries[-1]['wait_any_fraction']:.3f}, L2 hit {entries[-1]['l2_hit_rate']:.3f}, "
               f"fetch {entries[-1]['hbm_fetch_bytes_per_launch'] / 1e9:.2f} GB")

@@ -44,23 +44,14 @@ struct hair_hit {
 // is 1e-4 of the result. Geometry — traversal, intersection, positions, camera rays, the surface
 // lobes — stays exact throughout.
 #ifndef YH_HAIR_FAST
-#define YH_HAIR_FAST 1
+#define YH_HAIR_FAST 1 /* 0: the exact arithmetic (csrc/exact.hip compiles the sample loop a second time with it: yh_trace_params::hair_exact) */
 #endif
-#ifndef YH_FAST_DIV
+// (what YH_HAIR_FAST stands for; the per-function A/Bs of round 2 are closed: profiles/r02/bsdf_arithmetic_variants.txt)
 #define YH_FAST_DIV YH_HAIR_FAST
-#endif
-#ifndef YH_FAST_EXP
 #define YH_FAST_EXP 0
-#endif
-#ifndef YH_FAST_LOG
 #define YH_FAST_LOG YH_HAIR_FAST
-#endif
-#ifndef YH_FAST_TRIG
 #define YH_FAST_TRIG YH_HAIR_FAST
-#endif
-#ifndef YH_FAST_ASIN
 #define YH_FAST_ASIN YH_HAIR_FAST
-#endif
 YH_DEV float h_rcp(float x) { return YH_FAST_DIV ? __builtin_amdgcn_rcpf(x) : 1 / x; }
 YH_DEV float h_div(float a, float b) { return YH_FAST_DIV ? a * __builtin_amdgcn_rcpf(b) : a / b; }
 // quotient that feeds an exponential: one Newton step on the reciprocal (0.5 ulp), so that the
@@ -91,21 +82,18 @@ YH_DEV f3 h_div(f3 a, float b) { float r = h_rcp(b); return YH_FAST_DIV ? a * r 
 YH_DEV f3 h_transform_direction(const frame& a, f3 b) { return h_normalize(transform_vector(a, b)); }
 
 // The chain that ends in the SAMPLED DIRECTION (gamma_t of the transmitted ray, the longitudinal / azimuthal sampling formulas, the
-// rotation into world space): a last-place difference there sends the path to another fibre within a few bounces, one in the
-// lobes' VALUES only scales the weight. YH_DIR_EXACT = 1 keeps that chain in the exact forms while the values stay fast.
-#ifndef YH_DIR_EXACT
-#define YH_DIR_EXACT 1 /* 0: the sampled direction in the fast forms too, as until round 4 (A/B: profiles/r04/direction_chain_ab.txt) */
-#endif
-constexpr bool dir_fast_div = YH_FAST_DIV && !YH_DIR_EXACT, dir_fast_log = YH_FAST_LOG && !YH_DIR_EXACT, dir_fast_trig = YH_FAST_TRIG && !YH_DIR_EXACT;
-YH_DEV float d_rcp(float x) { return dir_fast_div ? __builtin_amdgcn_rcpf(x) : 1 / x; }
-YH_DEV float d_div(float a, float b) { return dir_fast_div ? a * __builtin_amdgcn_rcpf(b) : a / b; }
-YH_DEV float d_sqrt(float x) { return dir_fast_div ? __builtin_amdgcn_sqrtf(x) : sqrtf(x); }
+// rotation into world space) is ALWAYS in the exact forms: a last-place difference there sends the path to another fibre within a
+// few bounces, one in the lobes' VALUES only scales the weight (round 4: path following on light hair 0.52 -> 0.21 of the seed floor
+// for 1.5-2 % of C1's throughput, profiles/r04/direction_chain_ab.txt; the all-fast A/B half is gone with round 5).
+YH_DEV float d_rcp(float x) { return 1 / x; }
+YH_DEV float d_div(float a, float b) { return a / b; }
+YH_DEV float d_sqrt(float x) { return sqrtf(x); }
 YH_DEV float d_safe_sqrt(float x) { return d_sqrt(fmax_(0.0f, x)); }
-YH_DEV float d_log(float x) { return dir_fast_log ? __builtin_amdgcn_logf(x) * 0.693147181f : logf(x); }
-YH_DEV float d_sin(float x) { return dir_fast_trig ? __builtin_amdgcn_sinf(x * 0.159154943f) : sinf(x); }
-YH_DEV float d_cos(float x) { return dir_fast_trig ? __builtin_amdgcn_cosf(x * 0.159154943f) : cosf(x); }
-YH_DEV float d_cos_turns(float t) { return dir_fast_trig ? __builtin_amdgcn_cosf(t) : cosf(2 * pif * t); }
-YH_DEV f3    d_transform_direction(const frame& a, f3 b) { return dir_fast_div ? h_normalize(transform_vector(a, b)) : normalize(transform_vector(a, b)); }
+YH_DEV float d_log(float x) { return logf(x); }
+YH_DEV float d_sin(float x) { return sinf(x); }
+YH_DEV float d_cos(float x) { return cosf(x); }
+YH_DEV float d_cos_turns(float t) { return cosf(2 * pif * t); }
+YH_DEV f3    d_transform_direction(const frame& a, f3 b) { return normalize(transform_vector(a, b)); }
 
 YH_DEV float sqr(float v) { return v * v; }
 YH_DEV float safe_asin(float x) { return h_asin(fclamp(x, -1.0f, 1.0f)); }
@@ -204,7 +192,7 @@ YH_DEV void ap(float cos_theta_o, float eta, float h, f3 T, f3 out[p_max + 1]) {
   out[3]  = f3{h_div(num.x, den.x), h_div(num.y, den.y), h_div(num.z, den.z)};
 }
 // T for a given (sin_theta_o, cos_theta_o) (ext.cpp:281-291 / 375-384)
-// (etap and sin_gamma_t in the exact forms, YH_DIR_EXACT: gamma_t is part of the sampled azimuth. Also where only T is used —
+// (etap and sin_gamma_t in the exact forms: gamma_t is part of the sampled azimuth. Also where only T is used —
 // the lobe pdfs — so that the one-lane and the quad forms, which share this code differently, keep computing the same bits)
 YH_DEV f3 transmittance(const yhd_material& m, float h, float sin_theta_o, float cos_theta_o,
     float& gamma_t) {
@@ -310,9 +298,6 @@ struct hair_out {
   f3    ap0, ap1, ap2, ap3;      // Ap for f: T from sin_theta_o = outgoing.x (ext.cpp:281-295)
   float pdf0, pdf1, pdf2, pdf3;  // lobe pdfs: T from sin_theta_o = sqrt(1 - cos^2) (ext.cpp:372)
 };
-#ifndef YH_QUAD_AP
-#define YH_QUAD_AP 1  /* A/B switch (tools/ab_sweep.sh) */
-#endif
 template <bool QUAD = false>
 YH_DEV hair_out hair_prepare(const yhd_material& m, const hair_hit& hh, f3 outgoing_) {
   hair_out o;
@@ -320,7 +305,7 @@ YH_DEV hair_out hair_prepare(const yhd_material& m, const hair_hit& hh, f3 outgo
   o.sin_theta_o = outgoing.x;
   o.cos_theta_o = exact_safe_sqrt(1 - sqr(o.sin_theta_o));
   o.phi_o       = atan2f(outgoing.z, outgoing.y);
-  if (QUAD && YH_QUAD_AP) {
+  if (QUAD) {
     // The reference evaluates the transmittance and Ap twice, with sin_theta_o = outgoing.x for f
     // (ext.cpp:281-295) and with sqrt(1 - cos^2) for the lobe pdfs (ext.cpp:372-397): lanes 0-1 of
     // the quad take the first, lanes 2-3 the second, in one pass over the same code.

@@ -6,12 +6,8 @@
 
 using namespace yhd;
 
-#ifndef YH_BLOCK
 #define YH_BLOCK 512
-#endif
-#ifndef YH_MIN_WAVES
 #define YH_MIN_WAVES 4 /* waves per SIMD the register allocator must allow */
-#endif
 
 // ---------------------------------------------------------------------------
 // The sample loop
@@ -35,7 +31,7 @@ using namespace yhd;
 // when many pixels are expensive (dense hair: +5-10 %, profiles/r01, r02); the host picks by measurement.
 // SHADER = the reference's shader_type (YH_SHADER_*): trace_path is the product path (k_trace), the
 // preview / debug shaders (naive, eyelight, normal) share everything but the bounce step (k_trace_shader).
-// MODE (dev_trace.h): YH_MODE_QUAD, YH_MODE_W8 = a quad per path as above, over 4-wide or 8-wide nodes;
+// MODE (dev_trace.h): YH_MODE_QUAD = a quad per path as above, over 4-wide nodes;
 // YH_MODE_OCT = EIGHT lanes per path (two quads that run the same path and share the box tests of an 8-wide node): a
 // wave holds 8 pixels, a work-list entry is HALF a quadrant (entry = item << 1 | half: rows 2 half, 2 half + 1 of the
 // 4x4 block) — half the paths per wave, twice the waves, for launches bound by the chain of one path.
@@ -47,15 +43,10 @@ YH_DEV void trace_items(const yhd_scene& sc, const yhd_state& st, int nsamples, 
   constexpr int LPP    = YH_IS_HEX(MODE) ? 16 : YH_IS_OCT(MODE) ? 8 : 4;  // lanes per path
   constexpr int GROUPS = BLOCK / LPP;                   // paths per block = columns of the LDS stack
   extern __shared__ v4f lds_dyn[];
-  // LDS carve-out: [nodelets: 8 * lds_node_count float4][stacks: stack entries x GROUPS uint]
-  //                [tables: scene level | camera | small area lights | environment cdf index] (dev_trace.h: stage_tables)
-  YH_LDS v4f*          lds_nodes = (YH_LDS v4f*)lds_dyn;
-  YH_LDS unsigned int* lds_stack = (YH_LDS unsigned int*)(lds_nodes + 8 * sc.lds_node_count);
-  YH_LDS v4f*          lds_tabs  = (YH_LDS v4f*)(lds_stack + (MODE == YH_MODE_QUAD ? sc.stack_entries : YH_IS_HEX(MODE) ? sc.stack_entries16 : sc.stack_entries8) * GROUPS);
-  // stage the nodelets: the first lds_node_count wide nodes (breadth-first =
-  // top levels) of the dominant hair shape, 128 B each, coalesced dwordx4 loads
-  if (YH_LDS_NODELETS)
-    for (int i = threadIdx.x; i < 8 * sc.lds_node_count; i += blockDim.x) lds_nodes[i] = ldg4(sc.nodes + 8 * (size_t)sc.lds_node_base + i);
+  // LDS carve-out: [stacks: stack entries x GROUPS uint][tables: scene level | camera | small area lights | environment cdf index | materials]
+  // (dev_trace.h: stage_tables)
+  YH_LDS unsigned int* lds_stack = (YH_LDS unsigned int*)lds_dyn;
+  YH_LDS v4f*          lds_tabs  = (YH_LDS v4f*)(lds_stack + ((MODE == YH_MODE_QUAD ? sc.stack_entries : YH_IS_HEX(MODE) ? sc.stack_entries16 : sc.stack_entries8) + YH_HITROWS) * GROUPS);
   trace_ctx tc;
   tc.sc = &sc;
   tc.ls = nullptr, tc.sc_dev = nullptr;
@@ -63,10 +54,6 @@ YH_DEV void trace_items(const yhd_scene& sc, const yhd_state& st, int nsamples, 
   stage_tables(sc, lds_tabs, threadIdx.x, blockDim.x, tc, lds_cam);
   __syncthreads();
 
-  tc.lds_nodes = sc.lds_node_count ? lds_nodes : nullptr;
-#if YH_PREFETCH
-  tc.lds_pf = (unsigned int)(size_t)(lds_tabs + YHD_LDS_TABLES_F4(&sc));  // (kernels.hip: trace_lds adds the row)
-#endif
   tc.lds_stack = lds_stack + (threadIdx.x / LPP);
   stats_t stats = {};
   tc.stats = COUNT ? &stats : nullptr;
@@ -78,11 +65,8 @@ YH_DEV void trace_items(const yhd_scene& sc, const yhd_state& st, int nsamples, 
   // wave's slot follows from the dispatch order of its workgroup, so the host lays the head of the list out by position: the
   // most expensive items on the fastest slots, none on the slowest (host/launch_plan.cpp: lay_out_first_round). Any list is
   // rendered correctly — every entry is taken exactly once, by position or through the cursor; the layout is a matter of time.
-#ifndef YH_FIRST_BY_POSITION
-#define YH_FIRST_BY_POSITION 1
-#endif
-  const int by_position = YH_FIRST_BY_POSITION ? (int)(blocks * (BLOCK / 64)) : 0;
-  int       t_first     = YH_FIRST_BY_POSITION ? __builtin_amdgcn_readfirstlane((int)(block * (BLOCK / 64) + (threadIdx.x >> 6))) : -1;
+  const int by_position = (int)(blocks * (BLOCK / 64));
+  int       t_first     = __builtin_amdgcn_readfirstlane((int)(block * (BLOCK / 64) + (threadIdx.x >> 6)));
   while (true) {
     int t = t_first;
     if (t < 0) {
@@ -91,12 +75,6 @@ YH_DEV void trace_items(const yhd_scene& sc, const yhd_state& st, int nsamples, 
     }
     t_first = -1;
     if (t >= st.num_tiles) break;
-#ifdef YH_LAB_PRIO /* developer experiment (YHAIR_PRIO_ITEMS), measured without effect: compiled out */
-    if (st.prio_items > 0) {  // issue priority for the waves that hold the most expensive items (the head of the cost-sorted list)
-      if (t < st.prio_items) __builtin_amdgcn_s_setprio(3);
-      else __builtin_amdgcn_s_setprio(0);
-    }
-#endif
     unsigned long long t0 = wall_clock64();
     int  item  = st.tiles[t];
     int  half  = 0;  // which half (octets) / quarter (sixteen lanes per path) of the quadrant this entry is
@@ -116,9 +94,6 @@ YH_DEV void trace_items(const yhd_scene& sc, const yhd_state& st, int nsamples, 
     bool   alive   = false;
     path_t ps;
     ps.bounce = 0, ps.hit = false;
-    bool       running = false;  // YH_SUSPEND: this quad's ray is suspended mid-traversal
-    trav_state rs;
-    rs.cur = YH_NONE, rs.sp = 0, rs.cur_obj = -1, rs.hit = hit_t{};
     unsigned long long cyc_trace = 0, cyc_shade = 0;
     unsigned int       w_iters = 0, w_steps = 0, l_steps = 0, l_iters = 0;
     while (true) {
@@ -135,27 +110,6 @@ YH_DEV void trace_items(const yhd_scene& sc, const yhd_state& st, int nsamples, 
       unsigned int       steps = 0;
       if (COUNT) c0 = clock64(), l_iters += (alive && (lane & 3) == 0) ? 1 : 0, w_iters++;
       hit_t isec;
-#ifdef YH_SUSPEND /* developer experiment: resumable traversal, the wave shades once YH_SUSPEND / 16 of its live quads are left running */
-      if constexpr (!COUNT && SHADER == YH_SHADER_PATH) {
-        if (alive && !running) {
-          rs.cur = sc.num_scene_nodes ? (YH_TAG_SCENE | 0u) : YH_NONE, rs.sp = 0, rs.cur_obj = -1;
-          rs.hit.object = -1, rs.hit.slot = -1, rs.hit.u = 0, rs.hit.v = 0, rs.hit.distance = 0;
-        }
-        if (alive) {
-          int  live = __popcll(__ballot(1)) >> 2;
-          bool redo = false;
-          trace_ray_loop<false, (BLOCK / 4), false, true, !GENERAL>(tc, ps.ray, -1, nullptr, redo, &rs, ((live * YH_SUSPEND) >> 4) << 2);
-          if (__any(redo)) {
-            if (redo) {
-              rs.hit = trace_ray_loop<false, (BLOCK / 4), true>(tc, ps.ray, -1, nullptr, redo);
-              rs.cur = YH_NONE, rs.sp = 0;
-            }
-          }
-          running = !(rs.cur == YH_NONE && rs.sp == 0);
-          isec    = rs.hit;
-        }
-      } else
-#endif
       if (alive) {
         if (COUNT) count_quad<COUNT>(stats.rays);
         isec = trace_ray<COUNT, GROUPS, !GENERAL, MODE>(tc, ps.ray, -1, &steps);
@@ -166,7 +120,7 @@ YH_DEV void trace_items(const yhd_scene& sc, const yhd_state& st, int nsamples, 
         for (int off = 32; off > 0; off >>= 1) smax = max(smax, (unsigned int)__shfl_xor((int)smax, off, 64));
         w_steps += smax, l_steps += (lane & 3) == 0 ? steps : 0;
       }
-      if (alive && !running) {
+      if (alive) {
         if constexpr (SHADER == YH_SHADER_PATH) alive = path_step<COUNT, GROUPS, GENERAL>(tc, ps, isec, rng, st.bounces);
         else alive = shade_step<COUNT, GROUPS, SHADER>(tc, ps, isec, rng, st.bounces);
         if (!alive) {
@@ -211,16 +165,6 @@ YH_DEV void trace_items(const yhd_scene& sc, const yhd_state& st, int nsamples, 
     }
     if (lane == 0) {
       unsigned int dt = (unsigned int)(wall_clock64() - t0);
-#ifdef YH_LAB_WHERE /* developer experiment (tools/where_items_ran.py): the low 13 bits of the cost say where the wave ran — XCC, SE, SH, CU, SIMD */
-      {
-        const unsigned int hw = __builtin_amdgcn_s_getreg(63492), xcc = __builtin_amdgcn_s_getreg(63508);  // HW_REG_HW_ID, HW_REG_XCC_ID
-#ifdef YH_LAB_WHERE_SLOT /* ... or XCC, second half of the grid, wave of the workgroup, hardware wave slot, SIMD */
-        dt = (dt & ~0x1FFFu) | ((xcc & 7u) << 10) | ((blockIdx.x * 2 >= gridDim.x ? 1u : 0u) << 9) | (((threadIdx.x >> 6) & 7u) << 6) | ((hw & 15u) << 2) | ((hw >> 4) & 3u);
-#else
-        dt = (dt & ~0x1FFFu) | ((xcc & 7u) << 10) | (((hw >> 13) & 7u) << 7) | (((hw >> 12) & 1u) << 6) | (((hw >> 8) & 15u) << 2) | ((hw >> 4) & 3u);
-#endif
-      }
-#endif
       if (YH_IS_OCT(MODE) || YH_IS_HEX(MODE)) atomicAdd(&st.tile_cost[item], dt);  // the halves / quarters of a quadrant add up (zeroed before the launch)
       else st.tile_cost[item] = dt;
       if (COUNT) atomicAdd(&counters->cyc_tile, (unsigned long long)dt);

@@ -31,15 +31,7 @@
 
 namespace yhd {
 
-#ifndef YH_LANE_LEAF4
-#define YH_LANE_LEAF4 0 /* A/B switch: a line leaf's third and fourth segment in the same step as the first two. Bit-identical; the trace-only batch kernel +4 %, k_stream 0 to -3 % (its step loop grows from 1018 to 1259 vector instructions and spills five registers more): off (profiles/r03/lane_leaf4_ab.txt) */
-#endif
-#ifndef YH_LANE_BLOB
-#define YH_LANE_BLOB 1 /* 1: nodes and leaf test records from yhd_scene::lane_blob (one base, one address form: round 4); 0: from yhd_scene::nodes / prims as until round 3 (A/B) */
-#endif
-#ifndef YH_LSTACK
 #define YH_LSTACK 16 /* LDS stack window per lane, entries (power of two) */
-#endif
 // Developer instrumentation of a step, both compiled out of the product kernels:
 //   YH_ISA_MARKS   comment lines in the assembly at the start of every branch of lane_step (tools/isa_blocks.py --marks
 //                  counts the instructions between them: the static half of profiles/r04/k_stream_branch_budget.txt)
@@ -85,10 +77,10 @@ struct lane_trav {
   f3           ro, rd, wdinv;  // world-space ray, 1 / d
   f3           lo, ld, ldinv;  // the ray in the space of the object it is in
   int          wsign, lsign;   // sign bits of 1 / d (x | y << 1 | z << 2)
-  int          cur_obj, kind, node_base, prim_base;
+  int          cur_obj, kind;
   unsigned int cur;            // the entry being visited (YH_NONE: pop the next one)
   float        tmax;
-  // YH_LANE_BLOB: while the ray is in flight the hit is kept RAW — hit.slot = the primitive's test record (32-byte units of
+  // While the ray is in flight the hit is kept RAW — hit.slot = the primitive's test record (32-byte units of
   // lane_blob) and, on a line, hit.v = the squared distance d2 with hit_r = the radius there: the reference's
   // uv.y = sqrt(d2) / r (math.h:3465) is evaluated once, for the ray's final hit (lane_hit), not at every accepted test
   hit_t        hit;
@@ -106,7 +98,7 @@ YH_DEV void lane_begin(const yhd_scene& sc, lane_trav& t, f3 ro, f3 rd, int firs
   t.wsign  = (t.wdinv.x < 0 ? 1 : 0) | (t.wdinv.y < 0 ? 2 : 0) | (t.wdinv.z < 0 ? 4 : 0);
   t.wnonan = finite3(t.wdinv) && finite3(ro);
   t.lo = ro, t.ld = rd, t.ldinv = t.wdinv, t.lsign = t.wsign;
-  t.cur_obj = -1, t.kind = 0, t.node_base = 0, t.prim_base = 0;
+  t.cur_obj = -1, t.kind = 0;
   t.tmax = flt_max, t.steps = 0;
   t.hit.object = -1, t.hit.slot = -1, t.hit.u = 0, t.hit.v = 0, t.hit.distance = 0;
   t.hit_lines = false, t.hit_r = 1.0f, t.ld2 = dot(rd, rd);
@@ -139,7 +131,6 @@ YH_DEV bool intersect_line_raw(f3 ro, f3 rd, float a, float tmin, float tmax, f3
 // The finished ray's hit as the rest of the code knows it (hit_t of dev_trace.h: slot = leaf-order index of the primitive
 // in its shape, uv as the reference's intersect_line / intersect_triangle return them) from the raw form above.
 YH_DEV hit_t lane_hit(const trace_ctx& tc, hit_t raw, bool hit_lines, float hit_r) {
-#if YH_LANE_BLOB
   if (raw.object >= 0) {
     int lane_test;
     if (tc.lds_scene) lane_test = __float_as_int(tc.lds_scene[YH_OBJECT_F4 * raw.object + 10].y);
@@ -147,7 +138,6 @@ YH_DEV hit_t lane_hit(const trace_ctx& tc, hit_t raw, bool hit_lines, float hit_
     raw.slot = hit_lines ? raw.slot - lane_test : (raw.slot - lane_test) >> 1;
     if (hit_lines) raw.v = sqrtf(raw.v) / hit_r;
   }
-#endif
   return raw;
 }
 
@@ -228,11 +218,11 @@ YH_DEV bool lane_step(const trace_ctx& tc, lane_trav& t, lane_stack& s, int sp0,
         const YH_LDS v4f* ob = tc.lds_scene + YH_OBJECT_F4 * t.cur_obj;
         v4f a = ob[3], b = ob[4], c = ob[5], d = ob[6];
         inv.x = {a.x, a.y, a.z}, inv.y = {a.w, b.x, b.y}, inv.z = {b.z, b.w, c.x}, inv.o = {c.y, c.z, c.w};
-        t.kind = __float_as_int(d.x), t.node_base = __float_as_int(d.y), t.prim_base = __float_as_int(d.z);
+        t.kind = __float_as_int(d.x);
       } else {
         const yhd_object& o = sc.objects[t.cur_obj];
         inv    = ldframe(o.inv_frame);
-        t.kind = o.kind, t.node_base = o.node_base, t.prim_base = o.prim_base;
+        t.kind = o.kind;
       }
       t.lo    = transform_point(inv, t.ro);
       t.ld    = transform_vector(inv, t.rd);
@@ -242,7 +232,6 @@ YH_DEV bool lane_step(const trace_ctx& tc, lane_trav& t, lane_stack& s, int sp0,
         redo = true;
         return true;
       }
-#if YH_LANE_BLOB
       {  // the shape's root in the blob (yhd_object::lane_root): fetched in this same step
         int root;
         if (tc.lds_scene) root = __float_as_int(tc.lds_scene[YH_OBJECT_F4 * t.cur_obj + 10].x);
@@ -250,14 +239,10 @@ YH_DEV bool lane_step(const trace_ctx& tc, lane_trav& t, lane_stack& s, int sp0,
         t.cur = (unsigned)root;
         t.ld2 = dot(t.ld, t.ld);
       }
-#else
-      t.cur = YH_TAG_SHAPE | (unsigned)t.node_base;  // the shape's root: fetched in this same step
-#endif
       tag   = YH_TAG_SHAPE;
     }
   }
   YH_MARK("after_enter");
-#if YH_LANE_BLOB
   if (!skip) {
     YH_MARK("fetch");
     YH_LPROF(LP_FETCH)
@@ -267,13 +252,13 @@ YH_DEV bool lane_step(const trace_ctx& tc, lane_trav& t, lane_stack& s, int sp0,
     const unsigned int off      = t.cur & (is_leaf ? 0x07FFFFFFu : 0x3FFFFFFFu);  // 32-byte units into the blob
     // Whatever the lane holds, its record is at lane_blob + 32 * off:
     //   wide node      slot q = {A_q, B_q}
-    //   line leaf      segment i = {p0 r0, p1 r1} = {A_i, B_i}   (two per step; YH_LANE_LEAF4: up to four)
+    //   line leaf      segment i = {p0 r0, p1 r1} = {A_i, B_i}   (two per step)
     //   triangle leaf  triangle i = {p0}{p1}{p2}{-} = {A_2i, B_2i, A_2i+1}   (two per step)
     // ONE round trip, one 64-bit address; the second 64 bytes are fetched only by the lanes that use them.
     const yhd_float4* a = sc.lane_blob + 2 * (size_t)off;
     const v4f A0 = ldg4(a), B0 = ldg4(a + 1), A1 = ldg4(a + 2), B1 = ldg4(a + 3);
     v4f       A2, B2, A3, B3;
-    if (!is_leaf || (lines ? (YH_LANE_LEAF4 && leaf_num > 2) : leaf_num > 1)) A2 = ldg4(a + 4), B2 = ldg4(a + 5), A3 = ldg4(a + 6), B3 = ldg4(a + 7);
+    if (!is_leaf || (!lines && leaf_num > 1)) A2 = ldg4(a + 4), B2 = ldg4(a + 5), A3 = ldg4(a + 6), B3 = ldg4(a + 7);
     if (!is_leaf) {
       YH_MARK("node");
       YH_LPROF(LP_NODE)
@@ -310,8 +295,7 @@ YH_DEV bool lane_step(const trace_ctx& tc, lane_trav& t, lane_stack& s, int sp0,
     } else {
       YH_MARK("leaf");
       // ---- leaf: its primitives in leaf order, tmax shrinking after each accepted hit (pt.cpp:905-923) ----
-      const int per_step = lines ? (YH_LANE_LEAF4 ? 4 : 2) : 2;
-      t.cur = leaf_num > per_step ? (YH_TAG_LEAF | ((unsigned)(leaf_num - per_step) << 27) | (off + (unsigned)(lines ? per_step : 2 * per_step))) : YH_NONE;
+      t.cur = leaf_num > 2 ? (YH_TAG_LEAF | ((unsigned)(leaf_num - 2) << 27) | (off + (lines ? 2u : 4u))) : YH_NONE;  // two primitives per step
 #define YH_LANE_ACCEPT_LINE(I)                                          \
   if (ok && I < leaf_num) {                                             \
     t.hit.object = t.cur_obj, t.hit.slot = (int)off + I;                \
@@ -331,18 +315,6 @@ YH_DEV bool lane_step(const trace_ctx& tc, lane_trav& t, lane_stack& s, int sp0,
           float ss, d2, rr, dist;
           bool  ok = intersect_line_raw(t.lo, t.ld, t.ld2, ray_eps, t.tmax, xyz(A1), xyz(B1), A1.w, B1.w, ss, d2, rr, dist);
           YH_LANE_ACCEPT_LINE(1)
-        }
-        if (YH_LANE_LEAF4 && leaf_num > 2) {
-          {
-            float ss, d2, rr, dist;
-            bool  ok = intersect_line_raw(t.lo, t.ld, t.ld2, ray_eps, t.tmax, xyz(A2), xyz(B2), A2.w, B2.w, ss, d2, rr, dist);
-            YH_LANE_ACCEPT_LINE(2)
-          }
-          {
-            float ss, d2, rr, dist;
-            bool  ok = intersect_line_raw(t.lo, t.ld, t.ld2, ray_eps, t.tmax, xyz(A3), xyz(B3), A3.w, B3.w, ss, d2, rr, dist);
-            YH_LANE_ACCEPT_LINE(3)
-          }
         }
       } else {
         YH_MARK("tri_leaf");
@@ -368,119 +340,6 @@ YH_DEV bool lane_step(const trace_ctx& tc, lane_trav& t, lane_stack& s, int sp0,
 #undef YH_LANE_ACCEPT_LINE
     }
   }
-#else
-  if (!skip) {
-    YH_MARK("fetch");
-    YH_LPROF(LP_FETCH)
-    const bool is_leaf    = tag == YH_TAG_LEAF;
-    const bool lines      = t.kind == YH_KIND_LINES;
-    const int  leaf_start = (int)(t.cur & 0x07FFFFFFu), leaf_num = (int)((t.cur >> 27) & 7u);
-    const int  rec        = lines ? 4 : 6;
-    // Eight 16-byte loads, ONE round trip, whatever the lane holds:
-    //   wide node      slot q = {A_q, B_q} at a + 2 q
-    //   line leaf      primitive i < 2 = {p0 r0, p1 r1} = {A_i, B_i} at a + 4 i   (A2, A3: not used)
-    //   triangle leaf  primitive i < 2 = {p0, p1} = {A_i, B_i} at a + 6 i, its p2 = A_(2 + i)
-    // (a leaf of one primitive re-reads it as the second; a leaf longer than two takes another step)
-    //   line leaf, YH_LANE_LEAF4: all (up to four) primitives of the leaf in this one step: A2 B2 / A3 B3 = primitives 2 / 3
-    //   (the loads are issued anyway); a leaf of three or four segments costs one round trip instead of two
-    const yhd_float4* a  = is_leaf ? sc.prims + (size_t)t.prim_base + (size_t)leaf_start * rec : sc.nodes + 8 * (size_t)t.cur;
-    const int         o1 = is_leaf ? (leaf_num > 1 ? rec : 0) : 2;
-    const int         o2 = is_leaf ? (lines ? ((YH_LANE_LEAF4 && leaf_num > 2) ? 2 * rec : 0) : 2) : 4;
-    const int         o3 = is_leaf ? (lines ? ((YH_LANE_LEAF4 && leaf_num > 3) ? 3 * rec : 0) : o1 + 2) : 6;
-    const v4f A0 = ldg4(a), B0 = ldg4(a + 1), A1 = ldg4(a + o1), B1 = ldg4(a + o1 + 1);
-#ifdef YH_LANE_SPLIT_LOADS /* developer A/B switch: the second half only where it is used */
-    v4f A2 = A0, B2 = B0, A3 = A0, B3 = B0;
-    if (!is_leaf || !lines) A2 = ldg4(a + o2), B2 = ldg4(a + o2 + 1), A3 = ldg4(a + o3), B3 = ldg4(a + o3 + 1);
-#else
-    const v4f A2 = ldg4(a + o2), B2 = ldg4(a + o2 + 1), A3 = ldg4(a + o3), B3 = ldg4(a + o3 + 1);
-#endif
-    if (!is_leaf) {
-      YH_MARK("node");
-      YH_LPROF(LP_NODE)
-      // ---- wide node: the four slots {min.xyz, max.x} {max.yz, ref, axes} ----
-      const unsigned int axes = __float_as_uint(B0.w);
-      unsigned int r0 = __float_as_uint(B0.z), r1 = __float_as_uint(B1.z), r2 = __float_as_uint(B2.z), r3 = __float_as_uint(B3.z);
-      unsigned int hm = 0;
-      hm |= (box_test(t.lo, t.ldinv, ray_eps, t.tmax, f3{A0.x, A0.y, A0.z}, f3{A0.w, B0.x, B0.y}) && r0 != YH_NONE) ? 1u : 0u;
-      hm |= (box_test(t.lo, t.ldinv, ray_eps, t.tmax, f3{A1.x, A1.y, A1.z}, f3{A1.w, B1.x, B1.y}) && r1 != YH_NONE) ? 2u : 0u;
-      hm |= (box_test(t.lo, t.ldinv, ray_eps, t.tmax, f3{A2.x, A2.y, A2.z}, f3{A2.w, B2.x, B2.y}) && r2 != YH_NONE) ? 4u : 0u;
-      hm |= (box_test(t.lo, t.ldinv, ray_eps, t.tmax, f3{A3.x, A3.y, A3.z}, f3{A3.w, B3.x, B3.y}) && r3 != YH_NONE) ? 8u : 0u;
-      // Visiting order of the slots (pt.cpp:887-893 at both collapsed levels, dev_trace.h): the pair
-      // on the near side of the node's axis first, inside a pair the slot on the near side of that
-      // child's axis. Slots are taken in REVERSE visiting order: each hit pushes the one found
-      // before it, so the first in visiting order ends up in `cur` and the others pop in order.
-      const unsigned int s0  = ((unsigned)t.lsign >> (axes & 3)) & 1;
-      const unsigned int sg0 = ((unsigned)t.lsign >> ((axes >> 2) & 3)) & 1, sg1 = ((unsigned)t.lsign >> ((axes >> 4) & 3)) & 1;
-      t.cur = YH_NONE;
-      YH_MARK("node_order");
-#pragma unroll
-      for (int r = 3; r >= 0; r--) {
-        const unsigned int pair = ((unsigned)r >> 1) ^ s0;
-        const unsigned int q    = (pair << 1) | (((unsigned)r & 1) ^ (pair ? sg1 : sg0));
-        if ((hm >> q) & 1) {
-          unsigned int ref = (q & 2) ? ((q & 1) ? r3 : r2) : ((q & 1) ? r1 : r0);
-          if ((ref & YH_TAG_MASK) == 0) ref += (unsigned)t.node_base;  // child wide nodes are shape-local indices
-          if (t.cur != YH_NONE) {
-            YH_LPROF(LP_PUSH)
-            lane_push(s, t.cur);
-          }
-          t.cur = ref;
-        }
-      }
-    } else {
-      YH_MARK("leaf");
-      // ---- leaf: its primitives in leaf order, tmax shrinking after each accepted hit (pt.cpp:905-923) ----
-      t.cur = (leaf_num > 2 && !(YH_LANE_LEAF4 && lines)) ? (YH_TAG_LEAF | ((unsigned)(leaf_num - 2) << 27) | (unsigned)(leaf_start + 2)) : YH_NONE;
-#define YH_LANE_ACCEPT(I, LINES)                          \
-  if (ok && I < leaf_num) {                               \
-    t.hit.object = t.cur_obj, t.hit.slot = leaf_start + I; \
-    t.hit.u = uu, t.hit.v = vv, t.hit.distance = dist;    \
-    t.tmax = dist, t.hit_lines = LINES;                   \
-  }
-      if (lines) {
-        YH_MARK("line_leaf");
-        YH_LPROF(LP_LINE_LEAF)
-        if (PROF && leaf_num > 1) { YH_LPROF(LP_SEGS) }  // lanes whose second test of the step is a real segment
-        {
-          float uu = 0, vv = 0, dist = 0;
-          bool  ok = intersect_line<true>(t.lo, t.ld, ray_eps, t.tmax, xyz(A0), xyz(B0), A0.w, B0.w, uu, vv, dist);
-          YH_LANE_ACCEPT(0, true)
-        }
-        {
-          float uu = 0, vv = 0, dist = 0;
-          bool  ok = intersect_line<true>(t.lo, t.ld, ray_eps, t.tmax, xyz(A1), xyz(B1), A1.w, B1.w, uu, vv, dist);
-          YH_LANE_ACCEPT(1, true)
-        }
-        if (YH_LANE_LEAF4 && leaf_num > 2) {
-          {
-            float uu = 0, vv = 0, dist = 0;
-            bool  ok = intersect_line<true>(t.lo, t.ld, ray_eps, t.tmax, xyz(A2), xyz(B2), A2.w, B2.w, uu, vv, dist);
-            YH_LANE_ACCEPT(2, true)
-          }
-          {
-            float uu = 0, vv = 0, dist = 0;
-            bool  ok = intersect_line<true>(t.lo, t.ld, ray_eps, t.tmax, xyz(A3), xyz(B3), A3.w, B3.w, uu, vv, dist);
-            YH_LANE_ACCEPT(3, true)
-          }
-        }
-      } else {
-        YH_MARK("tri_leaf");
-        YH_LPROF(LP_TRI_LEAF)
-        {
-          float uu = 0, vv = 0, dist = 0;
-          bool  ok = intersect_triangle(t.lo, t.ld, ray_eps, t.tmax, xyz(A0), xyz(B0), xyz(A2), uu, vv, dist);
-          YH_LANE_ACCEPT(0, false)
-        }
-        if (leaf_num > 1) {
-          float uu = 0, vv = 0, dist = 0;
-          bool  ok = intersect_triangle(t.lo, t.ld, ray_eps, t.tmax, xyz(A1), xyz(B1), xyz(A3), uu, vv, dist);
-          YH_LANE_ACCEPT(1, false)
-        }
-      }
-#undef YH_LANE_ACCEPT
-    }
-  }
-#endif
   YH_MARK("step_end");
   return t.cur == YH_NONE && s.sp == sp0;
 }
@@ -497,7 +356,7 @@ struct lane_exact_result {
 __device__ __attribute__((noinline)) lane_exact_result lane_trace_exact(const yhd_scene* sc, const YH_LDS v4f* lds_scene,
     YH_LDS unsigned int* lds, unsigned int* ovf, int sp, int base, f3 ro, f3 rd, int first_object) {
   trace_ctx tc;
-  tc.sc = sc, tc.lds_nodes = nullptr, tc.lds_stack = nullptr, tc.lds_scene = lds_scene, tc.stats = nullptr, tc.ls = nullptr, tc.sc_dev = sc;
+  tc.sc = sc, tc.lds_stack = nullptr, tc.lds_scene = lds_scene, tc.stats = nullptr, tc.ls = nullptr, tc.sc_dev = sc;
   tc.lds_lights = nullptr, tc.lds_envtab = nullptr, tc.lds_mats = nullptr;
   lane_stack s;
   s.lds = lds, s.ovf = ovf, s.sp = sp, s.base = base;

@@ -113,11 +113,8 @@ YH_DEV f3 quad_spread(float r) { return f3{quad_bcast_f<0>(r), quad_bcast_f<1>(r
 #ifndef YH_LANE
 #define YH_LANE 0
 #endif
-#ifndef YH_QUAD_DIV
-#define YH_QUAD_DIV (!YH_LANE)  /* 0: every lane divides all three components (also an A/B switch, tools/ab_sweep.sh) */
-#endif
-YH_DEV f3 quad_div(f3 a, float b) { return YH_QUAD_DIV ? quad_spread(quad_pick(a) / b) : a / b; }
-YH_DEV f3 quad_rcp(f3 b) { return YH_QUAD_DIV ? quad_spread(1 / quad_pick(b)) : f3{1 / b.x, 1 / b.y, 1 / b.z}; }
+YH_DEV f3 quad_div(f3 a, float b) { return !YH_LANE ? quad_spread(quad_pick(a) / b) : a / b; }
+YH_DEV f3 quad_rcp(f3 b) { return !YH_LANE ? quad_spread(1 / quad_pick(b)) : f3{1 / b.x, 1 / b.y, 1 / b.z}; }
 YH_DEV f3 quad_normalize(f3 a) {  // normalize (math.h:2036-2039)
   float l = length(a);
   return (l != 0) ? quad_div(a, l) : a;

@@ -454,12 +454,9 @@ YH_DEV bool path_step(const trace_ctx& tc, path_t& ps, const hit_t& isec, rng_t&
   // The object and material records of the hit: the plain kernel variants (GENERAL = false: the host guarantees
   // that the scene-level table and the material table are staged in LDS) read them there, so that shading a hit
   // starts with ONE dependent fetch (the leaf record) instead of object -> record and object -> material chains.
-#ifndef YH_LDS_RECORDS
-#define YH_LDS_RECORDS 1 /* developer A/B switch */
-#endif
   // (not in the 256-thread k_trace shape, STRIDE 64 quads: there the LDS form happens to put spill reloads into
   // the traversal loop, 0.8x on C2 / C4 — tools/check_codegen.py watches for that; k_stream is YH_LANE)
-  constexpr bool from_lds = YH_LDS_RECORDS && !GENERAL && (YH_LANE || STRIDE != 64);
+  constexpr bool from_lds = !GENERAL && (YH_LANE || STRIDE != 64);
   const yhd_object&   o   = !from_lds ? sc.objects[isec.object] : *(const yhd_object*)(const YH_LDS yhd_object*)(tc.lds_scene + YH_OBJECT_F4 * isec.object);
   const yhd_material& mat = !from_lds ? sc.materials[o.material] : *(const yhd_material*)(const YH_LDS yhd_material*)(tc.lds_mats + YH_MATERIAL_F4 * o.material);
   hit_geom hg = eval_hit(sc, o, isec.slot, isec.u, isec.v);

@@ -24,8 +24,7 @@
 //   * the stack lives in LDS, one column per quad; inverse object frames are
 //     precomputed at upload (pt.cpp:1012-1013 recomputes a 3x3 adjugate
 //     inverse per ray per object); leaf primitives are 16-byte-aligned records
-//     in leaf order (yh_device.h); the top of the dominant hair tree is read
-//     from LDS ("nodelets").
+//     in leaf order (yh_device.h).
 #ifndef YH_DEV_TRACE_H_
 #define YH_DEV_TRACE_H_
 #include "dev_math.h"
@@ -79,11 +78,14 @@ struct hit_t {
 // shape: +2 % on C2); in C1 leaf steps run with a few lanes and the returns do skip (-3 %), so
 // the 512-thread shape keeps them. A zero det makes t and s inf or NaN and every comparison false,
 // as the first return would.
-template <bool STRAIGHT = false>
+// RAW (the traversal loop below): `a` = dot(rd, rd) is handed in (the same for every segment a ray meets inside one object) and an
+// accepted hit returns vv = d2 and rr = r instead of vv = sqrt(d2) / r — the loop evaluates that once, for the hit that survives
+// (same operands, same operations: same bits).
+template <bool STRAIGHT = false, bool RAW = false>
 YH_DEV bool intersect_line(f3 ro, f3 rd, float tmin, float tmax, f3 p0, f3 p1, float r0,
-    float r1, float& uu, float& vv, float& dist) {
+    float r1, float& uu, float& vv, float& dist, float a_in = 0.0f, float* rr = nullptr) {
   f3    u = rd, v = p1 - p0, w = ro - p0;
-  float a = dot(u, u), b = dot(u, v), c = dot(v, v), d = dot(u, w), e = dot(v, w);
+  float a = RAW ? a_in : dot(u, u), b = dot(u, v), c = dot(v, v), d = dot(u, w), e = dot(v, w);
   float det = a * c - b * b;
   if (STRAIGHT) {
     float t   = (b * e - c * d) / det;
@@ -96,6 +98,10 @@ YH_DEV bool intersect_line(f3 ro, f3 rd, float tmin, float tmax, f3 p0, f3 p1, f
     float d2  = dot(prl, prl);
     float r   = r0 * (1 - s) + r1 * s;
     ok        = ok && !(d2 > r * r);
+    if (RAW) {
+      uu = s, vv = d2, *rr = r, dist = t;
+      return ok;
+    }
     if (ok) uu = s, vv = sqrtf(d2) / r, dist = t;
     return ok;
   }
@@ -110,7 +116,8 @@ YH_DEV bool intersect_line(f3 ro, f3 rd, float tmin, float tmax, f3 p0, f3 p1, f
   float d2  = dot(prl, prl);
   float r   = r0 * (1 - s) + r1 * s;
   if (d2 > r * r) return false;
-  uu = s, vv = sqrtf(d2) / r;
+  if (RAW) uu = s, vv = d2, *rr = r;
+  else uu = s, vv = sqrtf(d2) / r;
   dist = t;
   return true;
 }
@@ -173,19 +180,25 @@ YH_DEV bool intersect_bbox_nonan(f3 ro, f3 dinv, float tmin_, float tmax_, f3 bm
 #define YH_TAG_MASK 0xC0000000u
 #define YH_NONE 0xFFFFFFFFu
 
-// Traversal stack: YH_QSTACK entries per quad in LDS, column `quad` of a
-// [depth][quads] array (conflict-free; the four lanes of a quad read / write
-// the same word). yh_upload_scene refuses scenes whose trees could need more.
-#ifndef YH_QSTACK
+// Traversal stack: at most YH_QSTACK entries per quad in LDS (the kernels reserve what the scene's trees need,
+// yhd_scene::stack_entries), column `quad` of a [depth][quads] array (conflict-free; the four lanes of a quad
+// read / write the same word). yh_upload_scene refuses scenes whose trees could need more.
 #define YH_QSTACK 96
-#endif
+// THE HIT RECORD (round 5). A leaf step reduces its lanes' hits to the survivor with DPP exchanges; until round 4 the survivor's u, v
+// travelled along (four more exchanges and four more selects per merge stage) and v = sqrt(d2) / r of a line was evaluated by every
+// accepted test. Now only the KEY (t, place in the leaf) is merged, the lane that holds the survivor writes its u, raw v (d2 on a
+// line) and r into the first YH_HITROWS rows of the path's stack column, and the loop reads them back once, when the ray ends:
+// ~24 vector instructions less in every leaf step with a hit (line leaves run in 34 % of C1's and 75 % of hair-curls' trips).
+// The traversal stack proper starts YH_HITROWS rows into the column; every launcher reserves entries + YH_HITROWS rows.
+// Measured, interleaved on one box (profiles/r05/hit_record_ab.txt): hair-curls (k_trace<256 x 5>) 443 -> 462 Msamples/s (+4.2 %), straight-hair with
+// quads +3 %, C1 side by side 13.4 -> 13.0 ms per 64 spp (+2 %); bit-identical.
+#define YH_HITROWS 4
 #define YH_LDS __attribute__((address_space(3)))
 typedef float v4f __attribute__((ext_vector_type(4)));
 
 struct lane_stack;  // dev_lane.h
 struct trace_ctx {
   const yhd_scene*      sc;
-  const YH_LDS v4f*     lds_nodes;  // LDS copy of nodes[lds_node_base ..+count), or nullptr
   YH_LDS unsigned int*  lds_stack;  // this quad's LDS stack column
   // LDS copy of the scene-level tables (k_trace stages them per block when they fit;
   // NULL: read sc.objects / sc.scene_nodes / sc.scene_prims from memory):
@@ -198,9 +211,6 @@ struct trace_ctx {
   lane_stack*           ls;         // one lane per path (YH_LANE, dev_lane.h): this lane's stack, else unused
   const yhd_scene*      sc_dev;     // YH_LANE: a copy of *sc in device memory, for out-of-line callees (the kernel
                                     // argument itself must not have its address escape: it would be copied to scratch)
-#if YH_PREFETCH
-  unsigned int          lds_pf;     // byte address of the block's 256-byte LDS row that the prefetch loads land in
-#endif
 };
 // Stages the tables every kernel keeps in LDS — the scene level (objects, scene BVH nodes and primitives; when it
 // fits), the camera, the small area lights and the environment cdf index — at `at` (YHD_LDS_TABLES_F4 float4) and
@@ -283,48 +293,21 @@ YH_DEV void count_quad(unsigned int& slot) {
 // reports `redo`, and trace_ray repeats that ray with EXACT = true, the reference's compare +
 // select form throughout. Results are identical either way; only axis-parallel rays take the
 // second pass.
-// PHASE = true (developer experiment YH_SUSPEND, kernels.hip): the traversal is resumable. `rs` holds what cannot be
-// recomputed from the ray (current entry, stack depth, entered object, closest hit so far); the wave leaves the loop
-// as soon as no more than `leave_at` lanes are still running, the quads still running keep their state in `rs` and
-// their LDS stack, and the next call picks them up where they stopped (instance-space ray data recomputed: same
-// operations, same bits).
-#ifndef YH_WIDE_BLOB
-#define YH_WIDE_BLOB 1 /* ... and so do the octet and sixteen-lane forms over the 8- / 16-wide nodes, which join the blob in ensure_wide_nodes (host/scene_upload.cpp); 0: nodes8 / nodes16 + prims (A/B) */
-#endif
-#ifndef YH_QUAD_BLOB
-#define YH_QUAD_BLOB 1 /* the quad form over 4-wide nodes (YH_MODE_QUAD) reads nodes and leaf test records from yhd_scene::lane_blob (yh_device.h: absolute references, 32-byte test records): one base and one address form instead of two arrays, a record-size select and a node base (round 4); 0: nodes / prims as until round 3 (A/B) */
-#endif
-#ifndef YH_REMAT_Q
-#define YH_REMAT_Q 1 /* dense launch shape (96 registers): lane & 3 recomputed in the node step (two instructions) instead of reloaded from scratch */
-#endif
-struct trav_state {
-  unsigned int cur;
-  int          sp, cur_obj;
-  hit_t        hit;
-};
+// Nodes and leaf test records are read from yhd_scene::lane_blob (yh_device.h: ONE array in 32-byte units with absolute references —
+// the 4-wide nodes, and the 8- / 16-wide ones once ensure_wide_nodes has appended them): one base and one address form for
+// whatever a quad, an octet or a group of sixteen holds. (Until round 4 the kernels read `nodes` / `nodes8` / `nodes16` + `prims`;
+// the A/B halves, the resumable PHASE form, the cache-line touches of pushed children and the quad form over 8-wide nodes are
+// closed experiments: profiles/r05/pruned_experiments.patch holds their code, profiles/r02-r04 their numbers.)
 // LDS_SCENE = true: the caller knows the scene-level table is in LDS (the plain kernel variants: the host selects the
 // GENERAL ones when it does not fit), so the loop carries no second code path for reading it from memory.
 // MODE: how many lanes own the ray and how many binary levels a node step covers.
 //   YH_MODE_QUAD  four lanes, 4-wide nodes (two levels): lane q tests slot q.
-//   YH_MODE_W8    four lanes, 8-wide nodes (three levels, host/bvh_build.h: WideNode8): lane q tests slots 2q and
-//                 2q + 1 — a third fewer node steps per ray for a node step that costs half as much again.
 //   YH_MODE_OCT   EIGHT lanes, 8-wide nodes: lane o tests slot o; the two quads of the octet hold the same path and run
 //                 everything else (scene level, ENTER, leaves, shading) twice over. Eight paths share a wave instead of
 //                 sixteen: for launches bound by the chain of steps of ONE path (few expensive pixels per GPU).
 // The children of a wide node are visited in the reference's order in every mode (ranks below), so closest hits,
 // `tmax` and exact-t ties are the same.
-#ifndef YH_PREFETCH
-#define YH_PREFETCH 0 /* developer switch, bit mask by lanes per path (1: quads, 2: octets, 4: sixteen): a lane that pushes a child touches the child's cache lines */
-#endif
-// A load whose result nobody reads: the line is on its way into the L1 / L2 while the traversal is busy with the children
-// visited first (every pushed entry is popped and fetched later). An LDS-DMA load (the dword lands in a 256-byte scratch
-// row of the block's LDS, trace_ctx::lds_pf), so no register waits for data that arrives whenever it arrives; inline
-// assembly, so that the compiler neither waits for it nor counts it (its own s_waitcnt values stay correct: loads return in
-// order, more outstanding loads only make a count-based wait wait longer). M0 is not used by the compiled kernels.
-YH_DEV void prefetch_line(const void* p, unsigned int lds_row) { asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" ::"s"(lds_row), "v"(p)); }  // (s_nop: one wait state between a write of M0 and the LDS-DMA that reads it)
-YH_DEV void prefetch_drain() { asm volatile("s_waitcnt vmcnt(0)"); }
 #define YH_MODE_QUAD 0
-#define YH_MODE_W8 1
 #define YH_MODE_OCT 2
 #define YH_MODE_HEX 3 /* SIXTEEN lanes, 16-wide nodes (four levels, host/bvh_build.h: WideNode16): lane o tests slot o; the four quads hold the same path */
 #define YH_ROW_HALF_MIRROR 0x141 /* DPP: lane i of every eight reads lane 7 - i */
@@ -337,28 +320,22 @@ YH_DEV void prefetch_drain() { asm volatile("s_waitcnt vmcnt(0)"); }
                           on the stack); the merge keeps the reference's order. C1 at 180^2 +5-8 %, hair-curls at 320^2 1.47 x over YH_MODE_HEX, `textured` equal
                           (profiles/r03/hex_leaf_groups_ab.txt). Its own launch shape (8), the trials decide */
 #define YH_IS_HEX(MODE) ((MODE) == YH_MODE_HEX || (MODE) == YH_MODE_HEXP)
-template <bool COUNT, int STRIDE, bool EXACT, bool PHASE = false, bool LDS_SCENE = false, int MODE = YH_MODE_QUAD>
-YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_object, unsigned int* steps_out, bool& redo,
-    trav_state* rs = nullptr, int leave_at = 0) {
-  static_assert(MODE == YH_MODE_QUAD || !PHASE, "the resumable traversal exists for the 4-wide quad form only");
-  constexpr bool QB = YH_QUAD_BLOB && MODE == YH_MODE_QUAD && !PHASE && !YH_PREFETCH && !YH_LDS_NODELETS;  // nodes and test records from the lane blob
-  constexpr bool QW = YH_QUAD_BLOB && YH_WIDE_BLOB && (YH_IS_OCT(MODE) || YH_IS_HEX(MODE)) && !YH_PREFETCH;  // ... the 8- / 16-wide nodes too (they join the blob in ensure_wide_nodes)
-  constexpr bool QX = QB || QW;
+template <bool COUNT, int STRIDE, bool EXACT, bool LDS_SCENE = false, int MODE = YH_MODE_QUAD>
+YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_object, unsigned int* steps_out, bool& redo) {
   const yhd_scene&     sc   = *tc.sc;
   const unsigned int   q    = __lane_id() & 3u;
-#if YH_REMAT_Q
   const unsigned int   q_   = q;
-#endif
   int                  sp   = 0;
-  YH_LDS unsigned int* lstk = tc.lds_stack;
-  auto push = [&](unsigned int v) { lstk[sp * STRIDE] = v, sp++; };
-  auto pop  = [&]() -> unsigned int { sp--; return lstk[sp * STRIDE]; };
+  YH_LDS unsigned int* hrec = tc.lds_stack;  // rows 0-2 of the column: the surviving hit's u, v (raw), r; the stack proper starts at row YH_HITROWS
+#define YH_STK(i) hrec[((i) + YH_HITROWS) * STRIDE] /* (one base pointer for both: the row offset folds into the LDS instruction) */
+  auto push = [&](unsigned int v) { YH_STK(sp) = v, sp++; };
+  auto pop  = [&]() -> unsigned int { sp--; return YH_STK(sp); };
   hit_t hit;
   hit.object = -1, hit.slot = -1, hit.u = 0, hit.v = 0, hit.distance = 0;
   float tmax = ray.tmax;
   // world-space ray data for the scene level
   f3  wdinv = quad_rcp(ray.d);  // one division per lane of the quad (dev_math.h)
-  int wsign = (wdinv.x < 0 ? 1 : 0) | (wdinv.y < 0 ? 2 : 0) | (wdinv.z < 0 ? 4 : 0);
+  const int wsign = (wdinv.x < 0 ? 1 : 0) | (wdinv.y < 0 ? 2 : 0) | (wdinv.z < 0 ? 4 : 0);
   const bool wnonan = finite3(wdinv) && finite3(ray.o);
   auto box_test = [](f3 o, f3 dinv, float t0, float t1, f3 bmin, f3 bmax) {
     return EXACT ? intersect_bbox(o, dinv, t0, t1, bmin, bmax) : intersect_bbox_nonan(o, dinv, t0, t1, bmin, bmax);
@@ -368,8 +345,14 @@ YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_obj
     return hit;
   }
   // instance-space ray data
-  f3  lo = ray.o, ld = ray.d, ldinv = wdinv;
-  int lsign = wsign, cur_obj = -1, kind = 0, node_base = 0, prim_base = 0;
+  f3    lo = ray.o, ld = ray.d, ldinv = wdinv;
+  // dot(ld, ld): the `a` of every line test inside the entered object (math.h:3437), set at ENTER — except in the dense shape (96
+  // registers: one more live value puts a spill reload into the loop, tools/check_codegen.py), which computes it per test
+  constexpr bool HOIST_A = STRIDE != 64;
+  float ld2 = 0.0f;
+  // sign bits of 1 / d (x | y << 1 | z << 2) of the ray in the entered object's space in bits 0-2 and of the world-space ray in bits
+  // 4-6 of ONE register (a split axis is 0, 1 or 2, so `(lsign >> axis) & 1` reads the right bit either way)
+  int   lsign = wsign | (wsign << 4), cur_obj = -1, kind = 0, node_base = 0;
   unsigned long long n_nodes = 0, n_seg = 0, n_tri = 0;
   unsigned int       n_steps = 0;
 
@@ -380,26 +363,7 @@ YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_obj
     return sc.scene_prims[i];
   };
   unsigned int cur;
-  if (PHASE) {
-    cur = rs->cur, sp = rs->sp, cur_obj = rs->cur_obj, hit = rs->hit;
-    if (hit.object >= 0) tmax = hit.distance;
-    if (cur_obj >= 0) {  // resumed inside an object: the ENTER arithmetic again
-      frame inv;
-      if (in_lds) {
-        const YH_LDS v4f* ob = tc.lds_scene + YH_OBJECT_F4 * cur_obj;
-        v4f a = ob[3], b = ob[4], c = ob[5], d = ob[6];
-        inv.x = {a.x, a.y, a.z}, inv.y = {a.w, b.x, b.y}, inv.z = {b.z, b.w, c.x}, inv.o = {c.y, c.z, c.w};
-        kind = __float_as_int(d.x), node_base = __float_as_int(d.y), prim_base = __float_as_int(d.z);
-      } else {
-        const yhd_object& o = sc.objects[cur_obj];
-        inv  = ldframe(o.inv_frame);
-        kind = o.kind, node_base = o.node_base, prim_base = o.prim_base;
-      }
-      lo = transform_point(inv, ray.o), ld = transform_vector(inv, ray.d);
-      ldinv = quad_rcp(ld);
-      lsign = (ldinv.x < 0 ? 1 : 0) | (ldinv.y < 0 ? 2 : 0) | (ldinv.z < 0 ? 4 : 0);
-    }
-  } else if (first_object >= 0) {
+  if (first_object >= 0) {
     cur = YH_TAG_ENTER | (unsigned)first_object;
   } else {
     if (sc.num_scene_nodes == 0) return hit;
@@ -416,7 +380,6 @@ YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_obj
       if (sp == 0) break;
       cur = pop();
     }
-    if (PHASE && __popcll(__ballot(1)) <= leave_at) break;  // few enough quads left: the wave goes shading, these resume later
     unsigned int tag = cur & YH_TAG_MASK;
     // The scene level costs no trip of its own: a scene node (read from the LDS copy
     // of the tiny scene BVH), the ENTER it leads to and the root fetch of the entered
@@ -435,12 +398,16 @@ YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_obj
         int start = __float_as_int(n0.w), meta = __float_as_int(n1.w);
         if (meta & 0x10000) {  // internal
           int axis = (meta >> 24) & 3;
-          int near = (wsign >> axis) & 1;  // dsign set: visit start+1 first
+          int near = (lsign >> (4 + axis)) & 1;  // dsign set: visit start+1 first
           push(YH_TAG_SCENE | (unsigned)(start + 1 - near));
           cur = YH_TAG_SCENE | (unsigned)(start + near);
         } else {
+          // a leaf of the scene BVH: its objects are entered in order, i.e. pushed in reverse behind the first (pt.cpp:1005-1023). A
+          // leaf of the reference's tree holds at most four (pt.cpp:598), so lane q of the quad pushes object q — one predicated
+          // LDS write, no loop
           int num = meta & 0xffff;
-          for (int i = num - 1; i >= 1; i--) push(YH_TAG_ENTER | (unsigned)scene_prim(start + i));
+          if ((int)q >= 1 && (int)q < num) YH_STK(sp + (num - 1 - (int)q)) = YH_TAG_ENTER | (unsigned)scene_prim(start + (int)q);
+          sp += num > 1 ? num - 1 : 0;
           if (num > 0) cur = YH_TAG_ENTER | (unsigned)scene_prim(start);
         }
       }
@@ -470,32 +437,28 @@ YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_obj
         }
       }
       frame inv;
-      if (in_lds) {  // yhd_object: frame[12] inv_frame[12] kind node_base prim_base ... (10 float4)
+      if (in_lds) {  // yhd_object: frame[12] inv_frame[12] kind ... lane_root lane_test lane_root8 lane_root16 (11 float4)
         const YH_LDS v4f* ob = tc.lds_scene + YH_OBJECT_F4 * cur_obj;
         v4f a = ob[3], b = ob[4], c = ob[5], d = ob[6];
         inv.x = {a.x, a.y, a.z}, inv.y = {a.w, b.x, b.y}, inv.z = {b.z, b.w, c.x}, inv.o = {c.y, c.z, c.w};
-        kind = __float_as_int(d.x), node_base = __float_as_int(d.y), prim_base = __float_as_int(d.z);
-        if (MODE == YH_MODE_W8 || YH_IS_OCT(MODE)) node_base = __float_as_int(ob[8].w);  // the shape's first 8-wide node (yhd_object::wbox_min[3])
-        if (YH_IS_HEX(MODE)) node_base = __float_as_int(ob[9].w);                          // ... first 16-wide node (wbox_max[3])
-        if (QB) node_base = __float_as_int(ob[10].x);                                      // ... root in the lane blob, 32-byte units (yhd_object::lane_root)
-        if (QW) node_base = __float_as_int(YH_IS_HEX(MODE) ? ob[10].w : ob[10].z);         // ... (lane_root16 / lane_root8)
+        kind = __float_as_int(d.x);
+        // the shape's root in the lane blob, 32-byte units: yhd_object::lane_root / lane_root8 / lane_root16
+        node_base = __float_as_int(YH_IS_HEX(MODE) ? ob[10].w : YH_IS_OCT(MODE) ? ob[10].z : ob[10].x);
       } else {
         const yhd_object& o = sc.objects[cur_obj];
-        inv  = ldframe(o.inv_frame);
-        kind = o.kind, node_base = o.node_base, prim_base = o.prim_base;
-        if (MODE == YH_MODE_W8 || YH_IS_OCT(MODE)) node_base = __float_as_int(o.wbox_min[3]);
-        if (YH_IS_HEX(MODE)) node_base = __float_as_int(o.wbox_max[3]);
-        if (QB) node_base = o.lane_root;
-        if (QW) node_base = YH_IS_HEX(MODE) ? o.lane_root16 : o.lane_root8;
+        inv       = ldframe(o.inv_frame);
+        kind      = o.kind;
+        node_base = YH_IS_HEX(MODE) ? o.lane_root16 : YH_IS_OCT(MODE) ? o.lane_root8 : o.lane_root;
       }
       lo    = transform_point(inv, ray.o);
       ld    = transform_vector(inv, ray.d);
       ldinv = quad_rcp(ld);
-      lsign = (ldinv.x < 0 ? 1 : 0) | (ldinv.y < 0 ? 2 : 0) | (ldinv.z < 0 ? 4 : 0);
+      lsign = (lsign & 0x70) | (ldinv.x < 0 ? 1 : 0) | (ldinv.y < 0 ? 2 : 0) | (ldinv.z < 0 ? 4 : 0);
       if (!EXACT && !(finite3(ldinv) && finite3(lo))) {  // a slab of this object could hold a NaN: second pass
         redo = true;
         break;
       }
+      if (HOIST_A) ld2 = dot(ld, ld);
       cur = YH_TAG_SHAPE | (unsigned)node_base;  // shape root: fetched in this same iteration
       tag = YH_TAG_SHAPE;
     }
@@ -514,7 +477,7 @@ YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_obj
       unsigned int       mycur  = cur;    // the leaf this lane's quad tests
       if (GROUPS) {
         const bool   look = is_leaf && qj > 0 && sp >= (int)qj;  // (YH_NONE itself carries the leaf tag: an empty stack must not read as a leaf)
-        unsigned int pk   = look ? lstk[(sp - (int)qj) * STRIDE] : 0u;
+        unsigned int pk   = look ? YH_STK(sp - (int)qj) : 0u;
         unsigned int lb   = (look && (pk & YH_TAG_MASK) == YH_TAG_LEAF) ? (1u << qj) : 0u;
         lb |= (unsigned int)dpp_i<YH_ROW_HALF_MIRROR>((int)lb);
         if (MODE == YH_MODE_HEXP) lb |= (unsigned int)dpp_i<YH_ROW_MIRROR>((int)lb);
@@ -523,59 +486,13 @@ YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_obj
         mycur = (qj > 0 && !idle) ? pk : cur;
       }
       int  leaf_start = (int)(mycur & 0x07FFFFFFu), leaf_num = (int)((mycur >> 27) & 7u);
-      int  rec        = kind == YH_KIND_LINES ? 4 : 6;  // float4 per leaf record
-#if YH_PREFETCH
-      constexpr bool PF = (YH_PREFETCH & (YH_IS_HEX(MODE) ? 4 : YH_IS_OCT(MODE) ? 2 : MODE == YH_MODE_QUAD ? 1 : 0)) != 0;
-      auto prefetch_entry = [&](unsigned int ref) {  // (YH_PREFETCH) the cache lines of a pushed child: a wide node, or a leaf's records
-        if ((ref & YH_TAG_MASK) == YH_TAG_LEAF) {
-          const char* a     = (const char*)(sc.prims + (size_t)prim_base + (size_t)(ref & 0x07FFFFFFu) * rec);
-          const int   bytes = (int)((ref >> 27) & 7u) * rec * 16;
-          prefetch_line(a, tc.lds_pf);
-          if (bytes > 128) prefetch_line(a + 128, tc.lds_pf);
-          if (bytes > 256) prefetch_line(a + 256, tc.lds_pf);
-        } else {
-          const char* a = MODE == YH_MODE_QUAD ? (const char*)(sc.nodes + 8 * (size_t)ref)
-                          : YH_IS_HEX(MODE)    ? (const char*)(sc.nodes16 + 32 * (size_t)ref)
-                                               : (const char*)(sc.nodes8 + 16 * (size_t)ref);
-          prefetch_line(a, tc.lds_pf);
-          if (MODE != YH_MODE_QUAD) prefetch_line(a + 128, tc.lds_pf);
-          if (YH_IS_HEX(MODE)) prefetch_line(a + 256, tc.lds_pf), prefetch_line(a + 384, tc.lds_pf);
-        }
-      };
-#else
-      constexpr bool PF = false;
-      auto prefetch_entry = [](unsigned int) {};
-#endif
       bool mine       = !is_leaf || (int)q < leaf_num;  // lanes beyond the leaf's count re-read its last record
-#ifdef YH_DEBUG_BOUNDS
-      {
-        bool bad = is_leaf ? (leaf_num < 1 || leaf_num > 4 || (size_t)prim_base + (size_t)(leaf_start + leaf_num) * rec > (size_t)sc.num_prim_f4)
-                           : (cur >= (unsigned)sc.num_nodes_total);
-        if (bad) {
-          printf("BAD entry %08x leaf %d sp %d obj %d lane %d steps %u\n", cur, (int)is_leaf, sp, cur_obj, (int)__lane_id(), n_steps);
-          break;
-        }
-        if (sp < 0 || sp > YH_QSTACK - 4) { printf("BAD sp %d\n", sp); break; }
-      }
-#endif
       int  pq         = mine ? (int)q : leaf_num - 1;
-      const yhd_float4* addr;
-      if (QB) addr = sc.lane_blob + 2 * (size_t)(is_leaf ? (unsigned)leaf_start + (unsigned)pq * (kind == YH_KIND_LINES ? 1u : 2u) : cur + q);  // (leaf_start: the leaf's first test record, blob units)
-      else if (QW) addr = sc.lane_blob + 2 * (size_t)(is_leaf ? (unsigned)leaf_start + (unsigned)pq * (kind == YH_KIND_LINES ? 1u : 2u) : cur + (__lane_id() & (YH_IS_HEX(MODE) ? 15u : 7u)));
-      else if (MODE == YH_MODE_QUAD) addr = is_leaf ? sc.prims + (size_t)prim_base + (size_t)(leaf_start + pq) * rec : sc.nodes + 8 * (size_t)cur + 2 * q;
-      else if (MODE == YH_MODE_W8) addr = is_leaf ? sc.prims + (size_t)prim_base + (size_t)(leaf_start + pq) * rec : sc.nodes8 + 16 * (size_t)cur + 4 * q;
-      else if (YH_IS_OCT(MODE)) addr = is_leaf ? sc.prims + (size_t)prim_base + (size_t)(leaf_start + pq) * rec : sc.nodes8 + 16 * (size_t)cur + 2 * (__lane_id() & 7u);
-      else addr = is_leaf ? sc.prims + (size_t)prim_base + (size_t)(leaf_start + pq) * rec : sc.nodes16 + 32 * (size_t)cur + 2 * (__lane_id() & 15u);
+      // the lane's 32 bytes in the blob: slot (lane of the group) of the node, or the test record of primitive pq of the leaf (leaf_start: its first test record)
+      const unsigned int nslot = MODE == YH_MODE_QUAD ? q : (__lane_id() & (YH_IS_HEX(MODE) ? 15u : 7u));
+      const yhd_float4*  addr  = sc.lane_blob + 2 * (size_t)(is_leaf ? (unsigned)leaf_start + (unsigned)pq * (kind == YH_KIND_LINES ? 1u : 2u) : cur + nslot);
       if (GROUPS) mine = mine && !idle;
-      v4f s0, s1, s2w, s3w;  // (s2w, s3w: the lane's second slot in YH_MODE_W8; of a leaf record they are the rest of its 64 bytes)
-      int rel = (int)cur - sc.lds_node_base;
-      if (MODE == YH_MODE_QUAD && YH_LDS_NODELETS && tc.lds_nodes && !is_leaf && rel >= 0 && rel < sc.lds_node_count) {
-        const YH_LDS v4f* n = tc.lds_nodes + 8 * rel + 2 * q;  // optional nodelets (YHAIR_LDS_NODES), off by default
-        s0 = n[0], s1 = n[1];
-      } else {
-        s0 = ldg4(addr), s1 = ldg4(addr + 1);
-        if (MODE == YH_MODE_W8) s2w = ldg4(addr + 2), s3w = ldg4(addr + 3);
-      }
+      const v4f s0 = ldg4(addr), s1 = ldg4(addr + 1);
       if (YH_IS_HEX(MODE) && !is_leaf) {
         // ---- 16-wide node: slot o = s1 << 3 | s2 << 2 | s3 << 1 | s4, one per lane of the sixteen; the rank of a slot in the
         // reference's visiting order is the four near / far decisions of pt.cpp:887-893 at the four collapsed levels.
@@ -590,17 +507,13 @@ YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_obj
         const unsigned int rank = (((o >> 3) ^ n0) << 3) | ((((o >> 2) & 1) ^ n1) << 2) | ((((o >> 1) & 1) ^ n2) << 1) | ((o & 1) ^ n3);
         unsigned int ref = __float_as_uint(s1.z);
         const bool   h   = box_test(lo, ldinv, ray.tmin, tmax, f3{s0.x, s0.y, s0.z}, f3{s0.w, s1.x, s1.y}) && ref != YH_NONE;
-        if (!QW && (ref & YH_TAG_MASK) == 0) ref += (unsigned)node_base;  // child wide nodes are shape-local indices (absolute in the lane blob)
         unsigned int bits = h ? (1u << rank) : 0u;
         unsigned int M    = bits | (unsigned int)dpp_i<YH_QUAD_XOR1>((int)bits);
         M |= (unsigned int)dpp_i<YH_QUAD_XOR2>((int)M);
         M |= (unsigned int)dpp_i<YH_ROW_HALF_MIRROR>((int)M);
         M |= (unsigned int)dpp_i<YH_ROW_MIRROR>((int)M);  // hits in visiting order, bit k = k-th visited
         const bool first = h && (1u << rank) == (M & (0u - M));
-        if (h && !first) {
-          lstk[(sp + (int)__popc(M >> (rank + 1))) * STRIDE] = ref;
-          if (PF) prefetch_entry(ref);
-        }
+        if (h && !first) YH_STK(sp + (int)__popc(M >> (rank + 1))) = ref;
         unsigned int mine = first ? ref : 0u;
         mine |= (unsigned int)dpp_i<YH_QUAD_XOR1>((int)mine);
         mine |= (unsigned int)dpp_i<YH_QUAD_XOR2>((int)mine);
@@ -610,47 +523,30 @@ YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_obj
         sp += nh > 0 ? nh - 1 : 0;
         cur = nh > 0 ? mine : YH_NONE;
       } else if (MODE != YH_MODE_QUAD && !is_leaf) {
-        // ---- 8-wide node: slot o = s1 << 2 | s2 << 1 | s3 (host/bvh_build.h). The visiting order applies pt.cpp:887-893
-        // at the three collapsed levels: rank bit 2 = side of the node's own axis, bit 1 = side of the child's, bit 0 =
+        // ---- 8-wide node: slot o = s1 << 2 | s2 << 1 | s3 (host/bvh_build.h), one per lane of the octet. The visiting order applies
+        // pt.cpp:887-893 at the three collapsed levels: rank bit 2 = side of the node's own axis, bit 1 = side of the child's, bit 0 =
         // side of the grandchild's, each flipped when the ray runs against that axis. Every hit slot pushes itself so
         // that the stack pops in visiting order; the first visited becomes `cur`.
         if (q == 0) n_nodes++;
         if (COUNT) count_branch<COUNT>(tc.stats->t_node, tc.stats->l_node);
         const unsigned int axes = __float_as_uint(s1.w);
-        const unsigned int g    = MODE == YH_MODE_W8 ? q : ((__lane_id() & 7u) >> 1);  // this lane's grandchild: 2 * s1 + s2
+        const unsigned int g    = (__lane_id() & 7u) >> 1;  // this lane's grandchild: 2 * s1 + s2
         const unsigned int n0   = (lsign >> (axes & 3)) & 1;
         const unsigned int n1   = (lsign >> ((axes >> (2 + 2 * (g >> 1))) & 3)) & 1;
         const unsigned int n2   = (lsign >> ((axes >> (6 + 2 * g)) & 3)) & 1;
-        const unsigned int base = ((((g >> 1) ^ n0) << 2) | (((g & 1) ^ n1) << 1));
-        unsigned int rank_a, rank_b = 0, ref_a, ref_b = YH_NONE;
-        bool         h_a, h_b = false;
-        if (MODE == YH_MODE_W8) {
-          rank_a = base | n2, rank_b = base | (1u ^ n2);  // slots 2q (s3 = 0) and 2q + 1 (s3 = 1)
-          ref_a = __float_as_uint(s1.z), ref_b = __float_as_uint(s3w.z);
-          h_a = box_test(lo, ldinv, ray.tmin, tmax, f3{s0.x, s0.y, s0.z}, f3{s0.w, s1.x, s1.y}) && ref_a != YH_NONE;
-          h_b = box_test(lo, ldinv, ray.tmin, tmax, f3{s2w.x, s2w.y, s2w.z}, f3{s2w.w, s3w.x, s3w.y}) && ref_b != YH_NONE;
-        } else {
-          rank_a = base | ((__lane_id() & 1u) ^ n2);
-          ref_a  = __float_as_uint(s1.z);
-          h_a    = box_test(lo, ldinv, ray.tmin, tmax, f3{s0.x, s0.y, s0.z}, f3{s0.w, s1.x, s1.y}) && ref_a != YH_NONE;
-        }
-        if (!QW && (ref_a & YH_TAG_MASK) == 0) ref_a += (unsigned)node_base;  // child wide nodes are shape-local indices (absolute in the lane blob)
-        if (MODE == YH_MODE_W8 && (ref_b & YH_TAG_MASK) == 0) ref_b += (unsigned)node_base;
-        unsigned int bits = (h_a ? (1u << rank_a) : 0u) | (h_b ? (1u << rank_b) : 0u);
+        const unsigned int rank = ((((g >> 1) ^ n0) << 2) | (((g & 1) ^ n1) << 1)) | ((__lane_id() & 1u) ^ n2);
+        const unsigned int ref  = __float_as_uint(s1.z);
+        const bool         h    = box_test(lo, ldinv, ray.tmin, tmax, f3{s0.x, s0.y, s0.z}, f3{s0.w, s1.x, s1.y}) && ref != YH_NONE;
+        unsigned int bits = h ? (1u << rank) : 0u;
         unsigned int M    = bits | (unsigned int)dpp_i<YH_QUAD_XOR1>((int)bits);
         M |= (unsigned int)dpp_i<YH_QUAD_XOR2>((int)M);
-        if (YH_IS_OCT(MODE)) M |= (unsigned int)dpp_i<YH_ROW_HALF_MIRROR>((int)M);  // hits in visiting order, bit k = k-th visited
-        const unsigned int low     = M & (0u - M);                                      // the first visited hit slot
-        const bool         first_a = h_a && (1u << rank_a) == low, first_b = h_b && (1u << rank_b) == low;
-        if (h_a && !first_a) {
-          lstk[(sp + (int)__popc(M >> (rank_a + 1))) * STRIDE] = ref_a;
-          if (PF) prefetch_entry(ref_a);
-        }
-        if (MODE == YH_MODE_W8 && h_b && !first_b) lstk[(sp + (int)__popc(M >> (rank_b + 1))) * STRIDE] = ref_b;
-        unsigned int mine = first_a ? ref_a : (first_b ? ref_b : 0u);  // child refs are never 0 (node 0 is a root)
+        M |= (unsigned int)dpp_i<YH_ROW_HALF_MIRROR>((int)M);  // hits in visiting order, bit k = k-th visited
+        const bool first = h && (1u << rank) == (M & (0u - M));  // the first visited hit slot
+        if (h && !first) YH_STK(sp + (int)__popc(M >> (rank + 1))) = ref;
+        unsigned int mine = first ? ref : 0u;  // child refs are never 0 (a node's offset lies behind the test records)
         mine |= (unsigned int)dpp_i<YH_QUAD_XOR1>((int)mine);
         mine |= (unsigned int)dpp_i<YH_QUAD_XOR2>((int)mine);
-        if (YH_IS_OCT(MODE)) mine |= (unsigned int)dpp_i<YH_ROW_HALF_MIRROR>((int)mine);
+        mine |= (unsigned int)dpp_i<YH_ROW_HALF_MIRROR>((int)mine);
         int nh = __popc(M);
         sp += nh > 0 ? nh - 1 : 0;
         cur = nh > 0 ? mine : YH_NONE;
@@ -662,21 +558,18 @@ YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_obj
         unsigned int ref  = __float_as_uint(s1.z);
         unsigned int axes = __float_as_uint(s1.w);
         h = h && ref != YH_NONE;  // an empty slot's inverted box still passes the min/max slab test
-        if (!QB && (ref & YH_TAG_MASK) == 0) ref += (unsigned)node_base;  // child wide nodes are shape-local indices (absolute in the lane blob)
         // Visiting order of the four slots (pt.cpp:887-893 applied at both collapsed
         // levels): the pair on the near side of the node's own axis first, and
         // inside each pair the slot on the near side of that child's axis first.
         // Each lane computes the RANK of its own slot in that order; the hit lanes
         // then push themselves in one parallel step: the first hit in visiting order
         // becomes `cur`, the others go on the stack so that they pop in visiting order.
-#if YH_REMAT_Q
         unsigned int q = q_;
-        if (STRIDE == 64) {  // dense shape, 96 registers: two instructions here instead of a lane constant that the allocator reloads from scratch
+        if (STRIDE == 64) {  // dense shape, 96 registers: lane & 3 recomputed here (two instructions) instead of a lane constant that the allocator reloads from scratch
           unsigned int x;
           asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(x));
           q = x & 3u;
         }
-#endif
         unsigned int pair = q >> 1;
         unsigned int sgn  = (lsign >> ((axes >> (2 + 2 * pair)) & 3)) & 1;   // near side of this pair's own axis
         unsigned int s0_  = (lsign >> (axes & 3)) & 1;                      // near side of the node's axis
@@ -686,10 +579,7 @@ YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_obj
         M |= (unsigned int)dpp_i<YH_QUAD_XOR2>((int)M);                     // hits in visiting order, bit k = k-th visited
         bool         first = h && (M & (bit - 1)) == 0;
         unsigned int after = (unsigned int)__popc(M >> (rank + 1));         // hit slots visited after this one
-        if (h && !first) {
-          lstk[(sp + (int)after) * STRIDE] = ref;
-          if (PF) prefetch_entry(ref);
-        }
+        if (h && !first) YH_STK(sp + (int)after) = ref;
         unsigned int mine = first ? ref : 0u;                                // child refs are never 0 (node 0 is a root)
         mine |= (unsigned int)dpp_i<YH_QUAD_XOR1>((int)mine);
         mine |= (unsigned int)dpp_i<YH_QUAD_XOR2>((int)mine);
@@ -700,16 +590,16 @@ YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_obj
         // ---- leaf: lane q tests primitive q, in leaf order (pt.cpp:905-923) ---------
         cur = YH_NONE;
         bool  ok = false;
-        float uu = 0, vv = 0, dist = 0;
+        float uu = 0, vv = 0, dist = 0, rr = 1.0f;
         if (kind == YH_KIND_LINES) {
           if (COUNT) count_branch<COUNT>(tc.stats->t_line, tc.stats->l_line);
           if (mine) {
             n_seg++;
-            ok = intersect_line<(STRIDE == 64)>(lo, ld, ray.tmin, tmax, xyz(s0), xyz(s1), s0.w, s1.w, uu, vv, dist);  // dense shape: 256 threads = 64 quads
+            ok = intersect_line<(STRIDE == 64), true>(lo, ld, ray.tmin, tmax, xyz(s0), xyz(s1), s0.w, s1.w, uu, vv, dist, HOIST_A ? ld2 : dot(ld, ld), &rr);  // dense shape: 256 threads = 64 quads
           }
         } else {
           if (COUNT) count_branch<COUNT>(tc.stats->t_tri, tc.stats->l_tri);
-          v4f s2 = MODE == YH_MODE_W8 ? s2w : ldg4(addr + 2);
+          v4f s2 = ldg4(addr + 2);
           if (mine) {
             n_tri++;
             ok = intersect_triangle(lo, ld, ray.tmin, tmax, xyz(s0), xyz(s1), xyz(s2), uu, vv, dist);
@@ -718,51 +608,45 @@ YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_obj
         // The reference tests the leaf's primitives in order, shrinking tmax after
         // each accepted hit: the survivor is the accepted primitive of minimum t,
         // the LATER one among equal t. Same result as a quad min-reduction.
-        int   key_i = ok ? (int)(4 * qj + q) : -1;  // (qj: the quad's place in a leaf group, 0 in the modes without)
-        float key_t = dist;
-#define YH_QUAD_MERGE(CTRL)                                                                \
+        const int my_i  = (int)(4 * qj + q);  // (qj: the quad's place in a leaf group, 0 in the modes without)
+        int       key_i = ok ? my_i : -1;
+        float     key_t = dist;
+        int       slot  = leaf_start + (int)q * (kind == YH_KIND_LINES ? 1 : 2);  // this lane's primitive: its test record in the blob
+#define YH_KEY_MERGE(CTRL, WITH_SLOT)                                                      \
   {                                                                                        \
     int   oi = dpp_i<CTRL>(key_i);                                                         \
-    float ot = dpp_f<CTRL>(key_t), ou = dpp_f<CTRL>(uu), ov = dpp_f<CTRL>(vv);             \
+    float ot = dpp_f<CTRL>(key_t);                                                         \
     bool  take = (oi >= 0) & ((key_i < 0) | (ot < key_t) | ((ot == key_t) & (oi > key_i))); /* no short circuits: selects, not branches */ \
-    key_i = take ? oi : key_i, key_t = take ? ot : key_t, uu = take ? ou : uu, vv = take ? ov : vv; \
+    if (WITH_SLOT) {                                                                       \
+      int os = dpp_i<CTRL>(slot);                                                          \
+      slot   = take ? os : slot;                                                           \
+    }                                                                                      \
+    key_i = take ? oi : key_i, key_t = take ? ot : key_t;                                  \
   }
-        YH_QUAD_MERGE(YH_QUAD_XOR1)
-        YH_QUAD_MERGE(YH_QUAD_XOR2)
-#undef YH_QUAD_MERGE
+        YH_KEY_MERGE(YH_QUAD_XOR1, false)
+        YH_KEY_MERGE(YH_QUAD_XOR2, false)
         if (GROUPS) {
           // The reference meets the group's leaves one after the other, each against the ray shortened by the hits before
           // it: the survivor is the accepted primitive of minimum t, the LATER one among equal t (math.h:3450) — the same
           // rule as inside a leaf, so the merge simply goes on across the quads with the leaf's place in the key.
-          int slot = QW ? leaf_start + (key_i & 3) * (kind == YH_KIND_LINES ? 1 : 2) : leaf_start + (key_i & 3);
-#define YH_GROUP_MERGE(CTRL)                                                               \
-  {                                                                                        \
-    int   oi = dpp_i<CTRL>(key_i), os = dpp_i<CTRL>(slot);                                 \
-    float ot = dpp_f<CTRL>(key_t), ou = dpp_f<CTRL>(uu), ov = dpp_f<CTRL>(vv);             \
-    bool  take = (oi >= 0) & ((key_i < 0) | (ot < key_t) | ((ot == key_t) & (oi > key_i))); \
-    key_i = take ? oi : key_i, key_t = take ? ot : key_t, uu = take ? ou : uu, vv = take ? ov : vv, slot = take ? os : slot; \
-  }
-          YH_GROUP_MERGE(YH_ROW_HALF_MIRROR)
-          if (MODE == YH_MODE_HEXP) YH_GROUP_MERGE(YH_ROW_MIRROR)
-#undef YH_GROUP_MERGE
-          if (key_i >= 0) {
-            hit.object = cur_obj, hit.slot = slot;
-            hit.u = uu, hit.v = vv, hit.distance = key_t;
-            tmax = key_t;
-          }
+          slot = leaf_start + (key_i & 3) * (kind == YH_KIND_LINES ? 1 : 2);
+          YH_KEY_MERGE(YH_ROW_HALF_MIRROR, true)
+          if (MODE == YH_MODE_HEXP) YH_KEY_MERGE(YH_ROW_MIRROR, true)
           sp -= grp;  // the group's leaves came off the stack
-        } else if (key_i >= 0) {
-          hit.object = cur_obj, hit.slot = QX ? leaf_start + key_i * (kind == YH_KIND_LINES ? 1 : 2) : leaf_start + key_i;  // (QB: the primitive's test record; made the leaf-order index below)
-          hit.u = uu, hit.v = vv, hit.distance = key_t;
+        } else {
+          slot = leaf_start + (key_i & 3) * (kind == YH_KIND_LINES ? 1 : 2);
+        }
+#undef YH_KEY_MERGE
+        if (key_i >= 0) {
+          hit.object = cur_obj, hit.slot = slot;  // (the primitive's test record; made the leaf-order index below)
+          hit.distance = key_t;
           tmax = key_t;
+          if (key_i == my_i) hrec[0] = __float_as_uint(uu), hrec[STRIDE] = __float_as_uint(vv), hrec[2 * STRIDE] = __float_as_uint(rr);  // the survivor's lane (the octet / sixteen forms run the same path in every quad: any one of the identical writers)
         }
       }
     }
   }
-#if YH_PREFETCH
-  prefetch_drain();
-#endif
-  if (QX && hit.object >= 0) {  // test record in the blob -> leaf-order index of the primitive in its shape (hit_t)
+  if (hit.object >= 0) {  // test record in the blob -> leaf-order index of the primitive in its shape (hit_t)
     int hk, lt;
     if (in_lds) {
       const YH_LDS v4f* ob = tc.lds_scene + YH_OBJECT_F4 * hit.object;
@@ -771,21 +655,25 @@ YH_DEV hit_t trace_ray_loop(const trace_ctx& tc, const ray_t& ray, int first_obj
       hk = sc.objects[hit.object].kind, lt = sc.objects[hit.object].lane_test;
     }
     hit.slot = hk == YH_KIND_LINES ? hit.slot - lt : (hit.slot - lt) >> 1;
+    {  // the survivor's u, v from the hit record; uv.y = sqrt(d2) / r of a line (math.h:3465) evaluated here, once
+      const float hu = __uint_as_float(hrec[0]), hv = __uint_as_float(hrec[STRIDE]), hr = __uint_as_float(hrec[2 * STRIDE]);
+      hit.u = hu, hit.v = hk == YH_KIND_LINES ? sqrtf(hv) / hr : hv;
+    }
   }
   if (COUNT) {
     if (steps_out) *steps_out = n_steps;
     tc.stats->nodes += (unsigned int)n_nodes, tc.stats->seg += (unsigned int)n_seg, tc.stats->tri += (unsigned int)n_tri;
   }
-  if (PHASE) rs->cur = cur, rs->sp = sp, rs->cur_obj = cur_obj, rs->hit = hit;
   return hit;
 }
+#undef YH_STK
 
 template <bool COUNT, int STRIDE, bool LDS_SCENE = false, int MODE = YH_MODE_QUAD>
 YH_DEV hit_t trace_ray(const trace_ctx& tc, const ray_t& ray, int first_object, unsigned int* steps_out = nullptr) {
   bool  redo = false;
-  hit_t hit  = trace_ray_loop<COUNT, STRIDE, false, false, LDS_SCENE, MODE>(tc, ray, first_object, steps_out, redo);
+  hit_t hit  = trace_ray_loop<COUNT, STRIDE, false, LDS_SCENE, MODE>(tc, ray, first_object, steps_out, redo);
   if (__any(redo)) {
-    if (redo) hit = trace_ray_loop<COUNT, STRIDE, true, false, LDS_SCENE, MODE>(tc, ray, first_object, steps_out, redo);
+    if (redo) hit = trace_ray_loop<COUNT, STRIDE, true, LDS_SCENE, MODE>(tc, ray, first_object, steps_out, redo);
   }
   return hit;
 }

@@ -5,10 +5,9 @@
 //                    pixel / one path (its PCG32 stream is sequential) and split BVH steps and hair lobes over
 //                    their lanes. In LDS: the traversal stacks (one column per quad, sized by the scene's
 //                    need) and the tables of dev_trace.h: stage_tables — scene level, camera, small area
-//                    lights, the index of the environment cdf, the material table (nodelets optional,
-//                    YHAIR_LDS_NODES). Two launch shapes: 512 threads x 4 waves per SIMD, 256 x 5.
-//                    The other sample-loop kernels: csrc/stream.hip (k_stream, one lane per path),
-//                    csrc/wavefront.hip (k_wavefront, staged per workgroup); the host picks per launch.
+//                    lights, the index of the environment cdf, the material table. Two launch shapes: 512 threads
+//                    x 4 waves per SIMD, 256 x 5. The other sample-loop kernels: csrc/wide.hip (more lanes per
+//                    path), csrc/stream.hip (k_stream, one lane per path); the host picks per launch by measurement.
 //   k_hair_*         unit-level batches of the four yocto::extension functions
 //   k_intersect      unit-level closest-hit batch
 //   k_selftest       the four Monte-Carlo self-tests (ext.cpp:555-693), made
@@ -175,17 +174,13 @@ __global__ void k_hair_sample(int n, const float* brdf, const float* wo, const f
 // four threads (one quad) per ray; block of 256 threads = 64 quads
 __global__ __launch_bounds__(256) void k_intersect(const yhd_scene sc, int n, const float* rays, int* object,
     int* element, float* uv, float* dist) {
-  __shared__ unsigned int stacks[YH_QSTACK * 64];
+  __shared__ unsigned int stacks[(YH_QSTACK + YH_HITROWS) * 64];
   int  i     = (blockIdx.x * blockDim.x + threadIdx.x) >> 2;
   bool valid = i < n;
   if (!valid) i = n - 1;  // whole quads stay converged; surplus quads redo the last ray
   trace_ctx tc;
-  tc.sc = &sc, tc.lds_nodes = nullptr, tc.stats = nullptr, tc.lds_scene = nullptr, tc.ls = nullptr, tc.sc_dev = nullptr, tc.lds_lights = nullptr, tc.lds_envtab = nullptr, tc.lds_mats = nullptr;
+  tc.sc = &sc, tc.stats = nullptr, tc.lds_scene = nullptr, tc.ls = nullptr, tc.sc_dev = nullptr, tc.lds_lights = nullptr, tc.lds_envtab = nullptr, tc.lds_mats = nullptr;
   tc.lds_stack   = (YH_LDS unsigned int*)stacks + (threadIdx.x >> 2);
-#if YH_PREFETCH
-  __shared__ unsigned int pf_row[64];
-  tc.lds_pf = (unsigned int)(size_t)(YH_LDS unsigned int*)pf_row;
-#endif
   const float* r = rays + 8 * (size_t)i;
   ray_t ray      = ray_t{ld3(r), ld3(r + 3), r[6], r[7]};
   hit_t h        = trace_ray<false, 64>(tc, ray, -1);
@@ -421,11 +416,9 @@ __global__ void k_curves_to_lines(int n, const float* P, const float* width0, co
 extern "C" {
 
 trace_kernel_t yhk_wide_kernel(int counted, int general, int shape);  // csrc/wide.hip: launch shapes 4, 6, 7, 8
-#ifndef YH_DENSE_WAVES
 #define YH_DENSE_WAVES 5 /* 96 VGPRs: at 6 (80 VGPRs) the traversal loop itself spills and the kernel is at the mercy of the register allocator (measured 0.6-0.75x after an unrelated change of the shading code, profiles/r02) */
-#endif
 // shape 0 = 512 threads x 4 waves per SIMD, shape 1 = 256 threads x YH_DENSE_WAVES (5) waves per SIMD: quads over 4-wide nodes;
-// shape 2 = 512 x 4, quads over 8-wide nodes (YH_MODE_W8); shape 4 = 256 x 4, octets over 8-wide nodes (YH_MODE_OCT);
+// (shape 2 was the quad form over 8-wide nodes, a closed experiment: never chosen, not built;) shape 4 = 256 x 4, octets over 8-wide nodes (YH_MODE_OCT);
 // shape 6 = 256 x 4, sixteen lanes per path over 16-wide nodes (YH_MODE_HEX); shape 7 = shape 4 with leaf pairs (YH_MODE_OCTP). (3 is k_stream, csrc/stream.hip; 5 the host's
 // side-by-side launch of shapes 0 and 4.) shape 8 = shape 6 with leaf groups (YH_MODE_HEXP).
 static bool shape_oct(int shape) { return shape == 4 || shape == 7; }
@@ -437,10 +430,6 @@ static trace_kernel_t trace_kernel(bool counted, bool general, int shape, int sh
   if (shader == YH_SHADER_EYELIGHT) return k_trace_shader<YH_SHADER_EYELIGHT>;
   if (shader == YH_SHADER_NORMAL) return k_trace_shader<YH_SHADER_NORMAL>;
   // (instrumented builds of the 8-wide forms: plain scenes only; their per-quad counters count an octet twice, the wave-level ones hold)
-#ifdef YH_LAB_W8  // developer build (make W8=1): quads over 8-wide nodes, measured without gain (profiles/r03/w8_oct_ab.txt): not in the product library
-  if (shape == 2 && counted && !general) return k_trace<true, false, YH_BLOCK, YH_MIN_WAVES, YH_MODE_W8>;
-  if (shape == 2 && !counted) return general ? k_trace<false, true, YH_BLOCK, YH_MIN_WAVES, YH_MODE_W8> : k_trace<false, false, YH_BLOCK, YH_MIN_WAVES, YH_MODE_W8>;
-#endif
   if (shape_oct(shape) || shape_hex(shape)) return yhk_wide_kernel(counted ? 1 : 0, general ? 1 : 0, shape);  // csrc/wide.hip
   if (shape == 2) return nullptr;
   // The GENERAL variants carry the surface lobes, volumes, textures and the through-memory light code. The dense shape
@@ -448,9 +437,7 @@ static trace_kernel_t trace_kernel(bool counted, bool general, int shape, int sh
   // (128 registers, 49 spilled, none in the traversal loops; lobes / volumes +15-20 %, profiles/r03/general_waves_ab.txt).
   // The 512-thread shape stays at 4 waves per SIMD (68 spilled, none in the traversal loops): at 3 (168 registers, 2
   // spilled) its expensive items no longer fit the resident waves and it loses a third.
-  // YHAIR_GENERAL_WAVES=hi: the plain variants' budget for the dense shape too (developer A/B switch).
-  static const bool general_hi = getenv("YHAIR_GENERAL_WAVES") && !strcmp(getenv("YHAIR_GENERAL_WAVES"), "hi");
-  if (general && !counted && !general_hi && shape == 1) return k_trace<false, true, 256, YH_DENSE_WAVES - 1>;
+  if (general && !counted && shape == 1) return k_trace<false, true, 256, YH_DENSE_WAVES - 1>;
   if (shape == 1)
     return counted ? (general ? k_trace<true, true, 256, YH_DENSE_WAVES> : k_trace<true, false, 256, YH_DENSE_WAVES>)
                    : (general ? k_trace<false, true, 256, YH_DENSE_WAVES> : k_trace<false, false, 256, YH_DENSE_WAVES>);
@@ -458,10 +445,10 @@ static trace_kernel_t trace_kernel(bool counted, bool general, int shape, int sh
                  : (general ? k_trace<false, true, YH_BLOCK, YH_MIN_WAVES> : k_trace<false, false, YH_BLOCK, YH_MIN_WAVES>);
 }
 static size_t trace_lds(const yhd_scene* sc, int shape) {
-  const int entries = shape_hex(shape) ? sc->stack_entries16 : (shape == 2 || shape_oct(shape)) ? sc->stack_entries8 : sc->stack_entries;
-  return (size_t)sc->lds_node_count * 128 + (size_t)entries * shape_groups(shape) * 4 + (size_t)YHD_LDS_TABLES_F4(sc) * 16 + (YH_PREFETCH ? 256 : 0);
+  const int entries = shape_hex(shape) ? sc->stack_entries16 : shape_oct(shape) ? sc->stack_entries8 : sc->stack_entries;
+  return (size_t)(entries + YH_HITROWS) * shape_groups(shape) * 4 + (size_t)YHD_LDS_TABLES_F4(sc) * 16;
 }
-// `shape`: 0, 1, 2 or 4 (above); the caller built the work list for it (shape 4: half-quadrant entries)
+// `shape`: 0, 1, 4, 6, 7 or 8 (above); the caller built the work list for it (shape 4: half-quadrant entries)
 int yhk_trace(const yhd_scene* sc, const yhd_state* st, int nsamples, yhd_counters* counters, int shape,
     int grid_blocks, hipStream_t stream) {
   const bool path  = st->shader == YH_SHADER_PATH;

@@ -33,35 +33,15 @@
 
 using namespace yhd;
 
-#ifndef YH_ST_BLOCK
 #define YH_ST_BLOCK 256
-#endif
-#ifndef YH_ST_WAVES
-#define YH_ST_WAVES 4 /* waves per SIMD the register allocator must allow */
-#endif
-#ifndef YH_REFILL_LANES
-#define YH_REFILL_LANES 16 /* idle lanes of a wave before the (divergent) refill code runs */
-#endif
-#ifndef YH_ST_POLICY
-#define YH_ST_POLICY 0 /* developer A/B switch: 0 = every stage in batches of 64 or flushed, trace left only when few lanes are busy */
-#endif
-#ifndef YH_ST_TAKE
-#define YH_ST_TAKE 64 /* free slots of a wave before it takes new work items: 64 = four items at a time; 16 = one or more (developer A/B switch) */
-#endif
-#ifndef YH_SUSPEND_LANES
-#define YH_SUSPEND_LANES 16 /* ray list dry and at most this many lanes busy: go shading */
-#endif
+#define YH_ST_WAVES 4        /* waves per SIMD the register allocator must allow */
+#define YH_REFILL_LANES 16   /* idle lanes of a wave before the (divergent) refill code runs */
+#define YH_SUSPEND_LANES 16  /* ray list dry and at most this many lanes busy: go shading */
+// (tuned in rounds 2 and 4, profiles/r02/k_stream_sweep_slots_suspend.txt, profiles/r04/k_stream_tuning_after_blob.txt; the other
+// scheduling policy, items taken sixteen slots at a time and the field-by-field pool layout are closed A/Bs of the same records)
 
-// Fields of a path slot (yh_device.h: yhd_path_slot, seven 16-byte fields). YH_ST_SOA = 1 lays the pool out
-// field by field instead (developer A/B switch).
-#ifndef YH_ST_SOA
-#define YH_ST_SOA 0
-#endif
-#if YH_ST_SOA
-#define SLOT_F4(pl, g, k) (((yhd_float4*)(pl).slots)[(size_t)(k) * (pl).total_slots + (g)])
-#else
+// Fields of a path slot (yh_device.h: yhd_path_slot, eight 16-byte fields in one 128-byte line).
 #define SLOT_F4(pl, g, k) (((yhd_float4*)&(pl).slots[g])[k])
-#endif
 #define SLOT_RAY_O(pl, g) SLOT_F4(pl, g, 0)
 #define SLOT_RAY_D(pl, g) SLOT_F4(pl, g, 1)
 #define SLOT_WEIGHT(pl, g) SLOT_F4(pl, g, 2)
@@ -122,7 +102,7 @@ __global__ __launch_bounds__(YH_ST_BLOCK, WAVES) void k_stream(const yhd_scene s
   const size_t base    = wave_id * (size_t)P;  // this wave's first slot
 
   trace_ctx tc;
-  tc.sc = &sc, tc.sc_dev = sc_dev, tc.lds_nodes = nullptr, tc.lds_stack = nullptr, tc.stats = nullptr;
+  tc.sc = &sc, tc.sc_dev = sc_dev, tc.lds_stack = nullptr, tc.stats = nullptr;
   YH_LDS float* lds_cam;
   stage_tables(sc, lds_tabs, threadIdx.x, YH_ST_BLOCK, tc, lds_cam);  // shared by the block's waves
   for (int s = lane; s < P; s += 64) l_free[s] = (unsigned short)s;
@@ -133,7 +113,6 @@ __global__ __launch_bounds__(YH_ST_BLOCK, WAVES) void k_stream(const yhd_scene s
   tc.ls   = &stk;
   // lists (wave-uniform counts) and the ray this lane holds
   int       n_ray = 0, n_done = 0, n_hair = 0, n_surf = 0, n_fin = 0, n_free = P;
-  int       n_hair_done = 0;  // hair hits among the entries of the done list
   int       my_group = (int)(blockIdx.x % (unsigned)st.num_groups), groups_done = 0;  // item group being taken from (yh_device.h)
   bool      nomore = false;
   bool      have = false;
@@ -150,23 +129,13 @@ __global__ __launch_bounds__(YH_ST_BLOCK, WAVES) void k_stream(const yhd_scene s
     // and finishing are a few hundred instructions: whatever has gathered since the last trace stage, so that no
     // path waits long for company. Finishing comes after shading (which ends paths) and runs once per round.
     int act;
-#if YH_ST_POLICY == 0
     const bool flush = n_ray + nact < 64;
-    if (!nomore && n_free >= YH_ST_TAKE) act = A_ITEMS;
+    if (!nomore && n_free >= 64) act = A_ITEMS;
     else if (n_done > 0) act = A_SORT;
     else if (n_fin >= 64 || (flush && n_fin > 0)) act = A_FINISH;
     else if (n_hair >= 64 || (flush && n_hair > 0)) act = A_HAIR;
     else if (n_surf >= 64 || (flush && n_surf > 0)) act = A_SURF;
     else if (n_ray > 0 || nact > 0) act = A_TRACE;
-#else
-    const bool flush = n_ray + nact + n_fin < 64;
-    if (!nomore && n_free >= 64) act = A_ITEMS;
-    else if (n_done > 0) act = A_SORT;
-    else if (n_surf > 0) act = A_SURF;
-    else if (n_hair >= 64 || (flush && n_hair > 0)) act = A_HAIR;
-    else if (n_fin > 0) act = A_FINISH;
-    else if (n_ray > 0 || nact > 0) act = A_TRACE;
-#endif
     else break;  // every slot is free and the work items are used up
     unsigned long long pc0 = 0, p_steps = 0, p_busy = 0, p_batch = 0;
     if (PROF) pc0 = clock64();
@@ -175,7 +144,7 @@ __global__ __launch_bounds__(YH_ST_BLOCK, WAVES) void k_stream(const yhd_scene s
       // ---- items: free slots take the pixels of the next work items (4 items = 64 pixels) ------------------
       // the next items of this workgroup's group (its XCD's image region); a group that is used up hands over to the next
       int       t0 = 0, got = 0;
-      const int want = YH_ST_TAKE >= 64 ? 4 : min(4, n_free >> 4);
+      const int want = 4;
       while (true) {
         int c = 0;
         if (lane == 0) c = atomicAdd(st.tile_cursor + 16 * my_group, want);
@@ -228,7 +197,7 @@ __global__ __launch_bounds__(YH_ST_BLOCK, WAVES) void k_stream(const yhd_scene s
         n_surf = list_push(l_surf, n_surf, kd == K_SURF, sl);
         n_fin  = list_push(l_fin, n_fin, kd == K_MISS, sl);
       }
-      n_done = 0, n_hair_done = 0;
+      n_done = 0;
     } else if (act == A_FINISH) {
       // ---- finish: account the sample that ended, start the pixel's next one ---------------------------------
       const int  cnt = min(n_fin, 64);
@@ -354,7 +323,7 @@ __global__ __launch_bounds__(YH_ST_BLOCK, WAVES) void k_stream(const yhd_scene s
         if (busy == 0) break;
         // Leave for the shading stages when the ray list is dry and either a full batch of hair hits has gathered
         // or few lanes are busy; the unfinished rays stay in their lanes.
-        if (n_ray == 0 && ((YH_ST_POLICY != 0 && n_hair + n_hair_done >= 64) || (busy <= YH_SUSPEND_LANES && (n_done | n_hair | n_surf | n_fin) != 0))) break;
+        if (n_ray == 0 && busy <= YH_SUSPEND_LANES && (n_done | n_hair | n_surf | n_fin) != 0) break;
         if (PROF) p_steps++, p_busy += (unsigned long long)busy;
         bool fin  = false;
         int  kind = 0;
@@ -372,10 +341,7 @@ __global__ __launch_bounds__(YH_ST_BLOCK, WAVES) void k_stream(const yhd_scene s
           }
         }
         YH_MARK("trace_lists");
-        if (__ballot(fin) != 0) {
-          n_done = list_push(l_done, n_done, fin, slot | (kind << 12));
-          n_hair_done += (int)__popcll(__ballot(fin && kind == K_HAIR));
-        }
+        if (__ballot(fin) != 0) n_done = list_push(l_done, n_done, fin, slot | (kind << 12));
         YH_MARK("trace_loop_end");
       }
       if (PROF) {
@@ -409,7 +375,7 @@ __global__ __launch_bounds__(256, WAVES) void k_intersect_lanes(const yhd_scene 
   const int   lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
   YH_LDS unsigned int* w_stack = (YH_LDS unsigned int*)(lds_tabs + YHD_LDS_TABLES_F4(&sc)) + wib * 64 * YH_LSTACK;
   trace_ctx tc;
-  tc.sc = &sc, tc.sc_dev = sc_dev, tc.lds_nodes = nullptr, tc.lds_stack = nullptr, tc.stats = nullptr;
+  tc.sc = &sc, tc.sc_dev = sc_dev, tc.lds_stack = nullptr, tc.stats = nullptr;
   YH_LDS float* lds_cam;
   stage_tables(sc, lds_tabs, threadIdx.x, 256, tc, lds_cam);
   __syncthreads();

@@ -25,8 +25,8 @@ trace_kernel_t yhk_wide_kernel(int counted, int general, int shape) {
 
 // (side by side: both forms at YH_BLOCK threads; the LDS of the larger layout)
 static size_t sbs_lds(const yhd_scene* sc) {
-  const size_t stacks = (size_t)std::max(sc->stack_entries * (YH_BLOCK / 4), sc->stack_entries8 * (YH_BLOCK / 8)) * 4;
-  return (size_t)sc->lds_node_count * 128 + stacks + (size_t)YHD_LDS_TABLES_F4(sc) * 16 + (YH_PREFETCH ? 256 : 0);
+  const size_t stacks = (size_t)std::max((sc->stack_entries + YH_HITROWS) * (YH_BLOCK / 4), (sc->stack_entries8 + YH_HITROWS) * (YH_BLOCK / 8)) * 4;
+  return stacks + (size_t)YHD_LDS_TABLES_F4(sc) * 16;
 }
 int yhk_trace_sbs_lds_bytes(const yhd_scene* sc) { return (int)sbs_lds(sc); }
 int yhk_trace_sbs_occupancy(int lds_bytes, int general) {

@@ -7,8 +7,7 @@
 //     (pt.cpp:557-650) with two levels collapsed into a 4-wide node, SoA over
 //     the four slots: minx[4] miny[4] minz[4] maxx[4] maxy[4] maxz[4] ref[4]
 //     {axes,0,0,0} (host/bvh_build.h: WideNode; WideNode8 = three levels, 256 B). Wide nodes are numbered
-//     breadth-first, so the first K nodes are the top of the tree (the
-//     "nodelets" staged in LDS).
+//     breadth-first, so the first K nodes are the top of the tree.
 //   * scene-level node (32 B): {min.xyz, start} {max.xyz, meta}; meta = num |
 //     internal << 16 | axis << 24 — the reference's bvh_node (pt.h:243-249).
 //   * hair segment (64 B), stored in BVH LEAF ORDER (no primitives[] / lines[]
@@ -47,7 +46,7 @@ typedef struct yhd_object {
   // world-space box of the object (transform_bbox of the shape's root box, pt.cpp:806) grown by a
   // safety margin: a ray that misses it by that much cannot hit anything in the object, so ENTER
   // and the root fetch are skipped for it (dev_trace.h)
-  float wbox_min[4], wbox_max[4];  // wbox_min[3] / wbox_max[3] = (int bits) first 8-wide / 16-wide node of the shape in yhd_scene::nodes8 / nodes16
+  float wbox_min[4], wbox_max[4];  // ([3]: unused)
   // the shape's place in yhd_scene::lane_blob (the one-lane kernels' copy of the trees, dev_lane.h), in 32-byte units:
   // its root node and its first test record
   int   lane_root, lane_test;
@@ -134,7 +133,7 @@ typedef struct yhd_camera {
 
 typedef struct yhd_scene {
   // geometry
-  const yhd_float4* nodes;      // 8 float4 per 4-wide node
+  const yhd_float4* nodes;      // 8 float4 per 4-wide node, shape-local references: the source of the lane blob below (freed once that is made: NULL)
   const yhd_float4* prims;      // leaf-ordered records (4 or 6 float4 each)
   const yhd_float4* vpos;       // per vertex {pos, radius}
   const yhd_int4*   elems;      // per element vertex indices (shape-local)
@@ -156,13 +155,10 @@ typedef struct yhd_scene {
   const yhd_float4* tex_texels;
   const float*      vtex;        // per vertex texture coordinates (2 floats), indexed like vpos
   yhd_camera        camera;
-  // number of leading nodes of the largest line shape staged in LDS
-  int               num_nodes_total; // wide nodes in `nodes` (bounds checks of the debug build)
+  int               num_nodes_total; // wide nodes the 4-wide trees hold
   int               num_prim_f4;     // float4 in `prims`
   int               lds_scene_f4;       // float4 count of the scene-level LDS table (0: scene too big, read from memory)
   int               general_materials;  // some material has lobes beyond diffuse / hair, or some area light is not a small one: the GENERAL kernel variants
-  int               lds_node_base;   // global index of that shape's root (nodelets: builds with -DYH_LDS_NODELETS=1 only)
-  int               lds_node_count;
   int               stack_entries;   // traversal stack depth per ray the kernels reserve in LDS (>= the trees' need)
   // tables the kernels stage in LDS next to the scene-level table (dev_trace.h: stage_tables)
   const yhd_float4* light_table;     // small area lights, YH_SMALL_LIGHT_F4 float4 each
@@ -174,14 +170,10 @@ typedef struct yhd_scene {
   int               env_tab_light;   // index into lights[], -1: none
   int               env_tab_k, env_tab_stride;
   int               lds_materials;   // materials staged in LDS (all of them, or 0 when they are too many)
-  // the same trees with THREE binary levels per node (host/bvh_build.h: WideNode8, 16 float4 each): a node step of the
-  // kernels in YH_MODE_W8 / YH_MODE_OCT (dev_trace.h) covers three levels of the reference's tree
-  const yhd_float4* nodes8;
-  int               num_nodes8_total;
-  int               stack_entries8;  // traversal stack depth per ray over the 8-wide trees (up to seven pushes per node)
-  // ... and FOUR levels per node (WideNode16, 32 float4 each): YH_MODE_HEX
-  const yhd_float4* nodes16;
-  int               num_nodes16_total;
+  // the same trees with THREE binary levels per node (host/bvh_build.h: WideNode8, 256 B: YH_MODE_OCT, dev_trace.h) and with FOUR
+  // (WideNode16, 512 B: YH_MODE_HEX) live in the lane blob below, behind the 4-wide nodes, once a kernel that reads them is about
+  // to run (host/scene_upload.cpp: ensure_wide_nodes); traversal stack depths per ray over them (up to 7 / 15 pushes per node):
+  int               stack_entries8;
   int               stack_entries16;
   // The one-lane kernels' copy of the shape trees (k_stream, k_intersect_lanes; dev_lane.h), ONE array addressed in
   // 32-byte units so that whatever a lane holds — node or leaf — is fetched from lane_blob + 32 * offset with the same
@@ -197,9 +189,6 @@ typedef struct yhd_scene {
   const yhd_float4* lane_blob;
   long long         lane_blob_units;
 } yhd_scene;
-#ifndef YH_LDS_NODELETS
-#define YH_LDS_NODELETS 0 /* developer switch: stage the top wide nodes of the dominant hair shape in LDS (YHAIR_LDS_NODES=n); measured twice without gain */
-#endif
 #define YH_MATERIAL_F4 17 /* sizeof(yhd_material) / 16 */
 // float4 the kernels reserve in LDS for the tables: scene level | camera (5) | small lights | env cdf index | materials
 #define YHD_LDS_TABLES_F4(sc) ((sc)->lds_scene_f4 + 5 + (sc)->light_table_f4 + ((sc)->env_tab_k + 3) / 4 + YH_MATERIAL_F4 * (sc)->lds_materials)
@@ -223,7 +212,7 @@ typedef struct yhd_state {
   unsigned int* tile_cost;  // per item: wall-clock ticks (100 MHz) its last launch took
   int         num_tiles;  // number of work items in `tiles`
   int         shader;        // YH_SHADER_* (yhair.h): path is the product path, the others preview / debug
-  int         launch_shape;  // 0: k_trace 512 threads x 4 waves per SIMD; 1: k_trace 256 x 5 (dense scenes); 2: k_wavefront; 3: k_stream
+  int         launch_shape;  // 0: k_trace 512 threads x 4 waves per SIMD; 1: k_trace 256 x 5 (dense scenes); 3: k_stream; 4-8: the wide forms (host/context_internal.h)
   int         width, height;
   int         tiles_x;
   int         samples_done;
@@ -232,28 +221,8 @@ typedef struct yhd_state {
   int         shard_rank, shard_world;  // tile ids owned: rank, rank + world, ...
   // (k_trace hands the first grid x waves-per-workgroup entries of `tiles` out BY POSITION — wave w of workgroup b starts
   // with entry b * (waves per workgroup) + w, the rest go through the cursor — and the host lays that head of the list out by
-  // hardware wave slot, host/launch_plan.cpp: lay_out_first_round. This field is not read any more.)
-  int         static_items;
-  // k_trace: the waves that take one of the first `prio_items` entries of `tiles` (the most expensive items: the list is
-  // cost-sorted) run at raised issue priority (s_setprio); 0: off
-  int         prio_items;
+  // hardware wave slot, host/launch_plan.cpp: lay_out_first_round.)
 } yhd_state;
-
-// Path pool of the wavefront integrator (csrc/wavefront.hip): SoA ray / hit / path-state buffers in
-// HBM, `slots_per_block` consecutive slots per workgroup (a block only ever touches its own range, so
-// the records stay in its XCD's L2). One path per slot; a pixel has one path in flight at a time
-// (its PCG32 stream is sequential), so the pixel's RNG state and accumulator are read and written in
-// place in yhd_state.
-typedef struct yhd_pool {
-  yhd_float4* ray_o;     // origin.xyz; w = distance of the closest hit (written by the traversal stage)
-  yhd_float4* ray_d;     // direction.xyz; w = int bits: bounce | hit << 8 | in_medium << 9
-  yhd_float4* weight;    // path weight.xyz
-  yhd_float4* radiance;  // radiance collected so far .xyz
-  yhd_int4*   hit;       // closest hit: object (-1 = miss), leaf slot, u bits, v bits
-  yhd_float4* medium;    // scenes with volumes only, 2 per slot: {density.xyz, anisotropy} {scatter.xyz, 0}
-  int         slots_per_block;
-  int         stack_entries;  // traversal stack depth per quad (LDS), >= the scene's need
-} yhd_pool;
 
 // Path pool of the streaming integrator (csrc/stream.hip): one lane per path, `slots_per_wave` slots owned by
 // each WAVEFRONT (no workgroup-level synchronisation), SoA over the slots.

@@ -21,7 +21,7 @@ struct Staged {
 };
 int finish(yh_context* ctx, int launch_err, void* dst, const void* src, size_t bytes) {
   if (launch_err) return fail(ctx, YH_E_DEVICE, "kernel launch: %s", hipGetErrorString((hipError_t)launch_err));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  YH_WAIT(ctx);
   HIPCHK(ctx, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
   return YH_OK;
 }
@@ -88,7 +88,7 @@ int yh_curves_to_lines(yh_context* ctx, int n, const float* P, const float* widt
   if (s.rc) return s.rc;
   int e = yhk_curves_to_lines(n, dp, d0, d1, base_vertex, op, on, orad, ol, ctx->stream);
   if (e) return fail(ctx, YH_E_DEVICE, "k_curves_to_lines launch: %s", hipGetErrorString((hipError_t)e));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  YH_WAIT(ctx);
   HIPCHK(ctx, hipMemcpy(positions, op, 60 * (size_t)n, hipMemcpyDeviceToHost));
   HIPCHK(ctx, hipMemcpy(normals, on, 60 * (size_t)n, hipMemcpyDeviceToHost));
   HIPCHK(ctx, hipMemcpy(radius, orad, 20 * (size_t)n, hipMemcpyDeviceToHost));
@@ -232,7 +232,7 @@ int yh_intersect_batch(yh_context* ctx, int n, const float* rays, int* object, i
     if (e) return fail(ctx, YH_E_DEVICE, "k_intersect launch: %s", hipGetErrorString((hipError_t)e));
   }
   HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  YH_WAIT(ctx);
   HIPCHK(ctx, hipEventElapsedTime(&ctx->last_ms, ctx->ev0, ctx->ev1));  // (yh_last_trace_ms: the kernel alone, without the copies)
   ctx->last_launches = 1;
   HIPCHK(ctx, hipMemcpy(object, dob, 4 * (size_t)n, hipMemcpyDeviceToHost));
@@ -274,7 +274,7 @@ int yh_selftest(yh_context* ctx, int which, float* worst) {
     HIPCHK(ctx, hipMemsetAsync(wbits.p, 0, 4, ctx->stream));
     int e = yhk_selftest(which, bm, bn, rng.state, rng.inc, count, wo, (double*)sums.p, (unsigned int*)wbits.p, ctx->stream);
     if (e) return fail(ctx, YH_E_DEVICE, "k_selftest launch: %s", hipGetErrorString((hipError_t)e));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    YH_WAIT(ctx);
     HIPCHK(ctx, hipMemcpy(out, sums.p, 6 * sizeof(double), hipMemcpyDeviceToHost));
     unsigned int bits;
     HIPCHK(ctx, hipMemcpy(&bits, wbits.p, 4, hipMemcpyDeviceToHost));

@@ -33,7 +33,7 @@ int alloc_zero(yh_context* ctx, DevBuf& buf, size_t bytes) {
   // ordered against kernels launched on it. Clear on that stream and wait, so the
   // buffer is zero for whoever touches it next (stream kernel or blocking copy).
   HIPCHK(ctx, hipMemsetAsync(buf.p, 0, alloc, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  YH_WAIT(ctx);
   return YH_OK;
 }
 
@@ -84,9 +84,10 @@ yh_context* yh_create(int device) {
 void yh_destroy(yh_context* ctx) {
   if (!ctx) return;
   if (ctx->wide_job && ctx->wide_job->th.joinable()) ctx->wide_job->th.join();
+  if (ctx->poisoned) return;  // a launch exceeded its deadline (wait_for_launch): the device may still be running it — synchronising or freeing would wait for it; the process is expected to end
   destroy_communicators(ctx);
   (void)hipSetDevice(ctx->device);
-  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->stream && wait_for_launch(ctx) != YH_OK) return;  // (a queued launch that never completes: as above)
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -122,7 +123,7 @@ int yh_download(yh_context* ctx, float* rgba) {
   int e = yhk_resolve(&ctx->state, (int)ctx->owned.size(), ctx->state.samples_done, ctx->d_image.p, ctx->stream);
   if (e) return fail(ctx, YH_E_DEVICE, "k_resolve launch: %s", hipGetErrorString((hipError_t)e));
   HIPCHK(ctx, hipMemcpyAsync(rgba, ctx->d_image.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  YH_WAIT(ctx);
   return YH_OK;
 }
 
@@ -132,7 +133,7 @@ int yh_download_rng(yh_context* ctx, uint64_t* state_inc) {
   HIPCHK(ctx, hipSetDevice(ctx->device));
   size_t npix = (size_t)ctx->state.width * ctx->state.height;
   std::vector<uint64_t> st(npix), inc(npix);
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  YH_WAIT(ctx);
   HIPCHK(ctx, hipMemcpy(st.data(), ctx->d_rng_state.p, npix * 8, hipMemcpyDeviceToHost));
   HIPCHK(ctx, hipMemcpy(inc.data(), ctx->d_rng_inc.p, npix * 8, hipMemcpyDeviceToHost));
   for (size_t i = 0; i < npix; i++) state_inc[2 * i] = st[i], state_inc[2 * i + 1] = inc[i];
@@ -144,7 +145,7 @@ int yh_tile_costs(yh_context* ctx, uint32_t* ticks, int count) {
   if (!ctx->have_state) return fail(ctx, YH_E_STATE, "yh_tile_costs before yh_init_state");
   if (count < ctx->num_tiles_total) return fail(ctx, YH_E_INVALID, "buffer holds %d tiles, image has %d", count, ctx->num_tiles_total);
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  YH_WAIT(ctx);
   std::vector<unsigned int> cost((size_t)ctx->num_tiles_total * 4);
   HIPCHK(ctx, hipMemcpy(cost.data(), ctx->d_tile_cost.p, cost.size() * 4, hipMemcpyDeviceToHost));
   for (int t = 0; t < ctx->num_tiles_total; t++)  // a tile is four work items (4x4 quadrants): report their sum
@@ -157,7 +158,7 @@ int yh_item_costs(yh_context* ctx, uint32_t* costs, int count) {
   if (!ctx->have_state) return fail(ctx, YH_E_STATE, "yh_item_costs before yh_init_state");
   if (count < ctx->num_tiles_total * 4) return fail(ctx, YH_E_INVALID, "buffer holds %d items, image has %d", count, ctx->num_tiles_total * 4);
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  YH_WAIT(ctx);
   HIPCHK(ctx, hipMemcpy(costs, ctx->d_tile_cost.p, (size_t)ctx->num_tiles_total * 16, hipMemcpyDeviceToHost));
   return YH_OK;
 }

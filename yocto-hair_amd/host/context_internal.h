@@ -36,6 +36,7 @@
 
 #include "../csrc/yh_device.h"
 #include "bvh_build.h"
+#include "deadline.h"
 #include "yhair.h"
 
 // launchers in csrc/kernels.hip
@@ -50,12 +51,6 @@ int yhk_trace_sbs_lds_bytes(const yhd_scene* sc);
 int yhk_trace_sbs_occupancy(int lds_bytes, int general);
 int yhk_trace_lds_bytes(const yhd_scene* sc, int shape);
 int yhk_stack_entries(void);
-#ifdef YH_LAB_WAVEFRONT  // developer build (make WAVEFRONT=1): the workgroup-staged kernel of tools/lab/, YHAIR_SHAPE=2
-int yhk_wavefront(const yhd_scene*, const yhd_state*, int, const yhd_pool*, int k, int grid_blocks, hipStream_t);
-int yhk_wavefront_slots(int k);
-int yhk_wavefront_lds_bytes(int stack_entries, int tables_f4, int k);
-int yhk_wavefront_occupancy(int lds_bytes, int general, int k);
-#endif
 int yhk_stream(const yhd_scene*, const yhd_scene* sc_dev, const yhd_state*, int, const yhd_stream*, int grid_blocks, hipStream_t);
 int yhk_lane_blob_shape(const yhd_float4* nodes, const yhd_float4* prims, yhd_float4* blob, int kind, int node_base, int num_nodes, int prim_base,
     int num_prims, long long node_off, long long test_off, hipStream_t);
@@ -200,7 +195,7 @@ void parallel_for(int n, F&& fn) {
   for (auto& th : pool) th.join();
 }
 
-constexpr int YH_SHAPES = 9;  // launch shapes: 0, 1 k_trace (4-wide nodes) | 2 k_trace over 8-wide nodes | 3 k_stream | 4 k_trace with octets | 5 quads and octets side by side | 6 k_trace with sixteen lanes per path | 7 octets with leaf pairs | 8 sixteen lanes with leaf groups
+constexpr int YH_SHAPES = 9;  // launch shapes: 0, 1 k_trace (4-wide nodes) | 2 (was: quads over 8-wide nodes; not built) | 3 k_stream | 4 k_trace with octets | 5 quads and octets side by side | 6 k_trace with sixteen lanes per path | 7 octets with leaf pairs | 8 sixteen lanes with leaf groups
 // The 8- and 16-wide collapses of a scene's trees take a tenth of a second of host time for a million-segment hair
 // model; the kernels that need them are chosen after the first launches. yh_upload_scene starts them in the background,
 // ensure_wide_nodes (host/scene_upload.cpp) waits for them — so the first launch of a wide kernel does not pay for them.
@@ -219,10 +214,11 @@ struct yh_context {
   int         num_cus = 0;
   std::string device_name;  // gcnArchName / marketing name / CU count: part of the key of the trial record on disk
   std::string error = "no error";
+  bool        poisoned = false;  // a launch of this context did not complete within its deadline (wait_for_launch): no further launches, nothing is freed
   // scene
   bool      have_scene = false;
   yhd_scene scene{};
-  DevBuf    d_nodes, d_nodes8, d_nodes16, d_prims, d_vpos, d_elems, d_objects, d_materials, d_scene_nodes,
+  DevBuf    d_nodes, d_prims, d_vpos, d_elems, d_objects, d_materials, d_scene_nodes,
       d_scene_prims, d_light_cdf, d_env_texels, d_light_table, d_env_tab;
   int       stack_need = 0, stack_need8 = 0, stack_need16 = 0;
   // The 8- and 16-wide node arrays (launch shapes 4, 6, 7) are built and uploaded at their first use (ensure_wide_nodes):
@@ -277,14 +273,10 @@ struct yh_context {
   int              chain16 = -1; // 1: ... and four times as many: the sixteen-lane form (shape 6) is a candidate too
   int              chain = -1;   // 1: so few expensive items that even twice as many waves would all be resident: the launch is bound by the
                                  // chain of steps of ONE path, and the octet kernel (half the paths per wave, shape 4) is a candidate
-  // path pool of the wavefront integrator (csrc/wavefront.hip), allocated at its first launch
-  DevBuf           d_pool_ray_o, d_pool_ray_d, d_pool_weight, d_pool_radiance, d_pool_hit, d_pool_medium;
   // path pool of the streaming integrator (csrc/stream.hip): per-wave slots, allocated at its first launch
   DevBuf           d_st_slots, d_st_medium, d_st_ovf, d_st_prof, d_scene_copy;
   size_t           st_slots = 0, st_medium_slots = 0, st_ovf_words = 0;
   yhd_stream       stream_pool{};
-  size_t           pool_slots = 0, pool_medium_slots = 0;  // capacity of the per-slot arrays / of the medium array (general scenes only)
-  yhd_pool         pool{};
 };
 
 #pragma GCC visibility push(hidden)  // internal to libyhair.so
@@ -293,6 +285,12 @@ extern std::string g_create_error;  // why yh_create returned NULL
   do {                                                                                                  \
     hipError_t e_ = (call);                                                                             \
     if (e_ != hipSuccess) return fail(ctx, YH_E_DEVICE, "%s: %s", #call, hipGetErrorString(e_));       \
+  } while (0)
+
+// every wait for the context's stream is bounded (wait_for_launch, trace_launch.cpp)
+#define YH_WAIT(ctx)                                      \
+  do {                                                    \
+    if (int wrc_ = wait_for_launch(ctx)) return wrc_;     \
   } while (0)
 
 constexpr int YH_TRIAL_SPP = 32;  // shorter launches have flat, noisy costs: they neither rank kernels nor try new ones
@@ -329,9 +327,9 @@ void wide_build_start(yh_context* ctx);
 int ensure_wide_nodes(yh_context* ctx);
 int ensure_lane_blob(yh_context* ctx);
 int build_bvh_device(yh_context* ctx, const std::vector<yhh::Box>& boxes, yhh::Tree& tree);
-int wavefront_impl(yh_context* ctx, int nsamples, bool sync);
 int stream_impl(yh_context* ctx, int nsamples, bool sync);
 int trace_impl(yh_context* ctx, int nsamples, bool counted, bool sync);
+int wait_for_launch(yh_context* ctx);  // hipStreamSynchronize(ctx->stream) with a deadline (host/deadline.h)
 int side_by_side_impl(yh_context* ctx, int nsamples, bool sync);
 void destroy_communicators(yh_context* ctx);
 inline int tiles_of(int n) { return (n + YH_TILE - 1) / YH_TILE; }

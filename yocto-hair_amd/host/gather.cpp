@@ -14,7 +14,7 @@ int yh_pack_tiles_device(yh_context* ctx, void* device_rgba, int64_t capacity, i
   HIPCHK(ctx, hipSetDevice(ctx->device));
   int e = yhk_pack(&ctx->state, (int)ctx->owned.size(), ctx->state.samples_done, device_rgba, ctx->stream);
   if (e) return fail(ctx, YH_E_DEVICE, "k_pack launch: %s", hipGetErrorString((hipError_t)e));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  YH_WAIT(ctx);
   if (count) *count = need;
   return YH_OK;
 }
@@ -27,7 +27,7 @@ int yh_unpack_tiles_device(yh_context* ctx, const void* device_packed, int src_r
   int e = yhk_unpack(device_packed, src_rank, world, n, ctx->num_tiles_total, ctx->state.tiles_x, ctx->state.width,
       ctx->state.height, device_image, ctx->stream);
   if (e) return fail(ctx, YH_E_DEVICE, "k_unpack launch: %s", hipGetErrorString((hipError_t)e));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  YH_WAIT(ctx);
   return YH_OK;
 }
 
@@ -161,13 +161,13 @@ int yh_gather_framebuffer(yh_context** ctxs, int n, float* rgba) {
     if (r != ncclSuccess) return fail(root, YH_E_DEVICE, "ncclGather: %s", api->GetErrorString(r));
     for (int i = 0; i < n; i++) {
       HIPCHK(root, hipSetDevice(ctxs[i]->device));
-      HIPCHK(root, hipStreamSynchronize(ctxs[i]->stream));
+      if (int wrc = wait_for_launch(ctxs[i])) return ctxs[i] == root ? wrc : fail(root, wrc, "yh_gather_framebuffer: context %d: %s", i, ctxs[i]->error.c_str());
     }
   } else {
     for (int i = 0; i < n; i++) {  // device-to-device copies (contexts sharing a device, or YHAIR_GATHER=peer)
       yh_context* c = ctxs[i];
       HIPCHK(root, hipSetDevice(c->device));
-      HIPCHK(root, hipStreamSynchronize(c->stream));
+      if (int wrc = wait_for_launch(c)) return c == root ? wrc : fail(root, wrc, "yh_gather_framebuffer: context %d: %s", i, c->error.c_str());
       HIPCHK(root, hipSetDevice(root->device));
       void* dst = (char*)root->d_gather_recv.p + (size_t)i * cap_bytes;
       if (c->device == root->device) HIPCHK(root, hipMemcpyAsync(dst, c->d_gather_send.p, cap_bytes, hipMemcpyDeviceToDevice, root->stream));
@@ -185,6 +185,6 @@ int yh_gather_framebuffer(yh_context** ctxs, int n, float* rgba) {
     if (e) return fail(root, YH_E_DEVICE, "k_unpack launch: %s", hipGetErrorString((hipError_t)e));
   }
   HIPCHK(root, hipMemcpyAsync(rgba, root->d_image.p, bytes, hipMemcpyDeviceToHost, root->stream));
-  HIPCHK(root, hipStreamSynchronize(root->stream));
+  YH_WAIT(root);
   return YH_OK;
 }

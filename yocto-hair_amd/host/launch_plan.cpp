@@ -76,25 +76,66 @@ static TrialKey trial_key(const yh_context* ctx) {
   return TrialKey{ctx->scene_key, ctx->state.width, ctx->state.height, ctx->rank, ctx->world, ctx->state.bounces};
 }
 // The same record ON DISK (round 4), so that the kernel an image runs does not depend on a handful of 32-sample launches
-// re-decided by every process (every rank of every run): ~/.cache/yhair/trials_v1.txt (YHAIR_CACHE_DIR, XDG_CACHE_HOME),
-// one line per record, keyed by device, the build's fingerprint (host/build_id.h: a hash of the device and host sources),
-// YHAIR_DEVICE_SHARE and the TrialKey; appended with one O_APPEND write (atomic between the ranks of a run), the last line
-// of a key counts. Only COMPLETE records are written (no candidate still wants a trial) and a loaded one is complete by
-// construction, so a process that finds its image here runs no trial at all. YHAIR_NO_DISK_CACHE (or YHAIR_NO_TRIAL_CACHE,
-// which also forgets the per-process record) switches it off.
+// re-decided by every process (every rank of every run). OPT-IN since round 5 — a library that writes files its host application did
+// not ask for is a side effect: yh_set_trial_cache_dir(dir) (the CLIs and bench.py call it with yh_default_trial_cache_dir() =
+// $XDG_CACHE_HOME/yhair or ~/.cache/yhair) or the environment's YHAIR_CACHE_DIR name the directory; without either nothing is read or
+// written. YHAIR_NO_DISK_CACHE (or YHAIR_NO_TRIAL_CACHE, which also forgets the per-process record) switches it off whatever was set.
+// File: <dir>/trials_v2.txt, one line per record, keyed by device (name + CU count), a fingerprint of the LOADED library file (so that
+// builds with other flags — tools/build_variants.sh — never share records), YHAIR_DEVICE_SHARE and the TrialKey; appended with one
+// O_APPEND write (atomic between the ranks of a run), the last line of a key counts. Only COMPLETE records are written (no candidate
+// still wants a trial) and a loaded one is complete by construction, so a process that finds its image here runs no trial at all.
+static std::mutex  g_cache_dir_mutex;
+static std::string g_cache_dir;  // yh_set_trial_cache_dir
+const char* yh_default_trial_cache_dir(void) {
+  static std::string dir = [] {
+    if (const char* x = getenv("XDG_CACHE_HOME")) return std::string(x) + "/yhair";
+    if (const char* h = getenv("HOME")) return std::string(h) + "/.cache/yhair";
+    return std::string();
+  }();
+  return dir.c_str();
+}
+int yh_set_trial_cache_dir(const char* dir) {
+  std::lock_guard<std::mutex> lock(g_cache_dir_mutex);
+  g_cache_dir = dir ? dir : "";
+  return YH_OK;
+}
 static std::string disk_cache_path() {
   if (getenv("YHAIR_NO_DISK_CACHE") || getenv("YHAIR_NO_TRIAL_CACHE")) return "";
   std::string dir;
   if (const char* e = getenv("YHAIR_CACHE_DIR")) dir = e;
-  else if (const char* x = getenv("XDG_CACHE_HOME")) dir = std::string(x) + "/yhair";
-  else if (const char* h = getenv("HOME")) dir = std::string(h) + "/.cache/yhair";
-  else return "";
-  return dir + "/trials_v1.txt";
+  else {
+    std::lock_guard<std::mutex> lock(g_cache_dir_mutex);
+    dir = g_cache_dir;
+  }
+  if (dir.empty()) return "";
+  return dir + "/trials_v2.txt";
+}
+// FNV-1a over the shared library this code was loaded from (found through dladdr): device code, host code and every -D of the build
+// in one fingerprint. Computed once per process (5 MB: a few milliseconds); the Makefile's source hash when the file cannot be read.
+static const std::string& library_fingerprint() {
+  static const std::string fp = [] {
+    Dl_info info{};
+    if (dladdr((const void*)&yh_set_trial_cache_dir, &info) && info.dli_fname) {
+      if (FILE* f = fopen(info.dli_fname, "rb")) {
+        uint64_t h = 1469598103934665603ull;
+        unsigned char buf[65536];
+        size_t n;
+        while ((n = fread(buf, 1, sizeof(buf), f)) > 0)
+          for (size_t i = 0; i < n; i++) h = (h ^ buf[i]) * 1099511628211ull;
+        fclose(f);
+        char out[32];
+        snprintf(out, sizeof(out), "%016llx", (unsigned long long)h);
+        return std::string(out);
+      }
+    }
+    return std::string(YH_BUILD_ID);
+  }();
+  return fp;
 }
 static std::string disk_key(const yh_context* ctx) {
   const char* share = getenv("YHAIR_DEVICE_SHARE");
-  char buf[256];
-  snprintf(buf, sizeof(buf), "%s|%s|%s|%016llx|%d|%d|%d|%d|%d", ctx->device_name.c_str(), YH_BUILD_ID, share ? share : "1",
+  char buf[320];
+  snprintf(buf, sizeof(buf), "%s|%s|%s|%016llx|%d|%d|%d|%d|%d", ctx->device_name.c_str(), library_fingerprint().c_str(), share ? share : "1",
       (unsigned long long)ctx->scene_key, ctx->state.width, ctx->state.height, ctx->rank, ctx->world, ctx->state.bounces);
   return buf;
 }
@@ -136,7 +177,8 @@ static bool disk_load(const yh_context* ctx, TrialRecord& r) {
       int n = 0;
       ok    = sscanf(p, " %lf:%d%n", &t.ms[k], &t.trials[k], &n) == 2;
       p += n;
-      if (ok && t.ms[k] < 0) t.ms[k] = std::numeric_limits<double>::infinity();  // a candidate that cannot run on this device
+      if (ok && t.ms[k] == -1.0) t.ms[k] = std::numeric_limits<double>::infinity();  // a candidate that cannot run on this device
+      else if (ok && !(std::isfinite(t.ms[k]) && t.ms[k] >= 0 && t.trials[k] >= 0 && (t.ms[k] > 0) == (t.trials[k] > 0))) ok = false;  // a damaged line: not a record
     }
     if (ok && sscanf(p, " ; %d %d %d", &t.dense, &t.chain, &t.chain16) == 3) r = t, found = true;  // (the last line of a key counts)
   }
@@ -317,8 +359,6 @@ int upload_work_items(yh_context* ctx) {
   std::vector<int> tiles;
   build_work_items(ctx, tiles);
   ctx->state.num_groups = 1, ctx->state.group_begin[0] = 0, ctx->state.group_begin[1] = (int)tiles.size();
-  ctx->state.static_items = 0;
-  ctx->state.prio_items   = getenv("YHAIR_PRIO_ITEMS") ? atoi(getenv("YHAIR_PRIO_ITEMS")) : 0;  // developer A/B switch (a library built with -DYH_LAB_PRIO)
   if (ctx->state.shader == YH_SHADER_PATH && ctx->state.launch_shape == 3) deal_items_for_stream(ctx, tiles);
   if (ctx->state.shader == YH_SHADER_PATH && (ctx->state.launch_shape == 4 || ctx->state.launch_shape == 7)) split_items_for_octets(tiles);
   if (ctx->state.shader == YH_SHADER_PATH && ctx->state.launch_shape == 5) split_items_side_by_side(ctx, tiles);

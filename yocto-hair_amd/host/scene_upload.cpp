@@ -100,7 +100,6 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
   wide_build_join(ctx), ctx->wide_job.reset();  // (a previous scene's collapses may still be running on the trees replaced below)
   ctx->wide_built = false;
   ctx->host_trees.assign((size_t)sd->num_shapes, yhh::Tree{});
-  ctx->d_nodes8.reset(), ctx->d_nodes16.reset();
   std::vector<float>      vtex;  // 2 per vertex, zeros for shapes without texture coordinates
   std::vector<yhd_int4>   elems;
   int                     best_lines = -1, best_shape = -1;
@@ -472,40 +471,26 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
   sc.light_table = (const yhd_float4*)ctx->d_light_table.p, sc.light_table_f4 = (int)light_table.size();
   sc.env_tab = (const float*)ctx->d_env_tab.p;
   sc.stack_entries = std::max(8, (ctx->stack_need + 7) / 8 * 8);
-  sc.nodes8 = nullptr, sc.num_nodes8_total = 0;  // built at first use: ensure_wide_nodes
-  sc.stack_entries8 = std::max(8, (ctx->stack_need8 + 7) / 8 * 8);
-  sc.nodes16 = nullptr, sc.num_nodes16_total = 0;
+  sc.stack_entries8 = std::max(8, (ctx->stack_need8 + 7) / 8 * 8);  // (the 8- / 16-wide nodes join the lane blob at their first use: ensure_wide_nodes)
   sc.stack_entries16 = std::max(8, (ctx->stack_need16 + 7) / 8 * 8);
-  sc.lane_blob = nullptr, sc.lane_blob_units = 0;  // filled at first use: ensure_lane_blob
+  sc.lane_blob = nullptr, sc.lane_blob_units = 0;  // made at the end of this function: ensure_lane_blob
   sc.textures = (const yhd_texture*)ctx->d_textures.p, sc.tex_texels = (const yhd_float4*)ctx->d_tex_texels.p;
   sc.vtex = (const float*)ctx->d_vtex.p;
   memcpy(sc.camera.frame, sd->camera.frame, 48);
   sc.camera.lens = sd->camera.lens, sc.camera.film_x = sd->camera.film[0], sc.camera.film_y = sd->camera.film[1];
   sc.camera.focus = sd->camera.focus, sc.camera.aperture = sd->camera.aperture;
   sc.num_nodes_total = (int)(nodes.size() / 8), sc.num_prim_f4 = (int)prims.size();
-  // nodelets: the top (breadth-first prefix) of the largest hair shape's BVH
   sc.general_materials = general_materials;
-  {  // scene-level LDS table: objects (8 float4 each), scene BVH nodes (2 float4 each), primitive ids
+  {  // scene-level LDS table: objects (YH_OBJECT_F4 = 11 float4 each), scene BVH nodes (2 float4 each), primitive ids; up to 10 KB = 46
+     // objects (a scene with more runs the GENERAL kernel variants, which read the table from memory)
     static_assert(sizeof(yhd_object) == 16 * YH_OBJECT_F4, "yhd_object is staged to LDS as float4");
     int f4 = YH_OBJECT_F4 * sd->num_objects + 2 * (int)scene_tree.nodes.size() + (sd->num_objects + 3) / 4;
-    sc.lds_scene_f4 = f4 * 16 <= 8192 ? f4 : 0;
+    sc.lds_scene_f4 = f4 * 16 <= 10240 ? f4 : 0;
   }
   {  // the material table in LDS; the plain kernel variants rely on it and on the scene-level table (dev_path.h)
     static_assert(sizeof(yhd_material) == 16 * YH_MATERIAL_F4, "yhd_material is staged to LDS as float4");
     sc.lds_materials = sd->num_materials <= 24 ? sd->num_materials : 0;
     if (sc.lds_materials == 0 || sc.lds_scene_f4 == 0) sc.general_materials = 1;
-  }
-  sc.lds_node_base = 0, sc.lds_node_count = 0;
-  if (best_shape >= 0) {
-    sc.lds_node_base  = info[best_shape].node_base;
-    int want = 0;  // LDS nodelets are optional (YHAIR_LDS_NODES): measured no gain once a step is a single fetch, see DESIGN.md
-#if YH_LDS_NODELETS
-    if (const char* env = getenv("YHAIR_LDS_NODES")) want = std::max(0, atoi(env));
-#endif
-    // 128 B per nodelet next to the stacks and the scene table of the larger launch shape: stay inside the CU's 160 KB
-    sc.lds_node_count = 0;
-    int room = (160 * 1024 - yhk_trace_lds_bytes(&sc, 0)) / 128;
-    sc.lds_node_count = std::max(0, std::min({info[best_shape].num_nodes, want, room}));
   }
   ctx->scene      = sc;
   {  // fingerprint of the scene for the process-wide trial record: counts, camera, materials, objects, a sample of the geometry
@@ -571,7 +556,7 @@ void wide_build_start(yh_context* ctx) {  // (ctx->host_trees must stay untouche
 // when a kernel that traverses them is about to run for the first time (launch shapes 4, 5, 6, 7).
 int ensure_wide_nodes(yh_context* ctx) {
   if (ctx->wide_built) return YH_OK;
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // (a queued launch may be reading the object records)
+  YH_WAIT(ctx);  // (a queued launch may be reading the object records)
   if (!ctx->wide_job) wide_build_start(ctx);  // (normally started by yh_upload_scene)
   wide_build_join(ctx);
   const size_t ns = ctx->host_trees.size();
@@ -598,17 +583,10 @@ int ensure_wide_nodes(yh_context* ctx) {
   if (nodes8.size() > (size_t)std::numeric_limits<int>::max() || nodes16.size() > (size_t)std::numeric_limits<int>::max())
     return fail(ctx, YH_E_INVALID, "scene too large for 32-bit wide-node offsets");
   int rc;
-  if ((rc = upload(ctx, ctx->d_nodes8, nodes8.data(), nodes8.size() * 16))) return rc;
-  if ((rc = upload(ctx, ctx->d_nodes16, nodes16.data(), nodes16.size() * 16))) return rc;
-  for (size_t oi = 0; oi < ctx->host_objects.size(); oi++) {
-    const size_t si = (size_t)ctx->object_shape[oi];
-    memcpy(&ctx->host_objects[oi].wbox_min[3], &base8[si], 4);
-    memcpy(&ctx->host_objects[oi].wbox_max[3], &base16[si], 4);
-  }
   {
     // The wide nodes join the lane blob (yh_device.h) behind what it holds, with ABSOLUTE references: a child node's offset in
     // the blob (32-byte units: 8 per 8-wide node, 16 per 16-wide one), a leaf's first test record. The blob is made anew with
-    // room for them (device-to-device copy of the old one); d_nodes8 / d_nodes16 above stay for the developer builds.
+    // room for them (device-to-device copy of the old one).
     const long long U8 = (ctx->lane_units + 3) / 4 * 4, U16 = U8 + (long long)(nodes8.size() / 2), total = U16 + (long long)(nodes16.size() / 2) + 4;
     if (total >= (1ll << 30)) return fail(ctx, YH_E_INVALID, "scene too large for 30-bit node offsets with its wide nodes (%lld units)", total);
     auto rewrite = [&](std::vector<yhd_float4>& nodes, const std::vector<int>& base, long long U, int slots) {
@@ -640,8 +618,6 @@ int ensure_wide_nodes(yh_context* ctx) {
     }
   }
   HIPCHK(ctx, hipMemcpy(ctx->d_objects.p, ctx->host_objects.data(), ctx->host_objects.size() * sizeof(yhd_object), hipMemcpyHostToDevice));
-  ctx->scene.nodes8 = (const yhd_float4*)ctx->d_nodes8.p, ctx->scene.num_nodes8_total = (int)(nodes8.size() / 16);
-  ctx->scene.nodes16 = (const yhd_float4*)ctx->d_nodes16.p, ctx->scene.num_nodes16_total = (int)(nodes16.size() / 32);
   ctx->d_scene_copy.reset();  // (the copy of the scene table in device memory is made again at its next use)
   ctx->wide_built = true;
   ctx->wide_job.reset();
@@ -649,9 +625,9 @@ int ensure_wide_nodes(yh_context* ctx) {
   return YH_OK;
 }
 
-// The one-lane kernels' copy of the shape trees (yh_device.h: yhd_scene::lane_blob), made on the device from the node and
-// primitive arrays at the first launch that needs it: an image that never runs k_stream / k_intersect_lanes does not pay
-// the memory (test records 32 B per segment + the nodes once more).
+// The trees as every traversal kernel reads them (yh_device.h: yhd_scene::lane_blob: test records 32 B per segment / 64 B per triangle,
+// then the 4-wide nodes with absolute references), made on the device from the node and primitive arrays at the end of
+// yh_upload_scene; the 4-wide node array it was made from is freed afterwards (no kernel reads it).
 int ensure_lane_blob(yh_context* ctx) {
   if (ctx->scene.lane_blob) return YH_OK;
   int rc;
@@ -661,8 +637,9 @@ int ensure_lane_blob(yh_context* ctx) {
         L.num_prims, L.node_off, L.test_off, ctx->stream);
     if (e) return fail(ctx, YH_E_DEVICE, "lane blob build: %s", hipGetErrorString((hipError_t)e));
   }
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  YH_WAIT(ctx);
   ctx->scene.lane_blob = (const yhd_float4*)ctx->d_lane_blob.p, ctx->scene.lane_blob_units = ctx->lane_units;
+  ctx->d_nodes.reset(), ctx->scene.nodes = nullptr;
   ctx->d_scene_copy.reset();  // (the scene table in device memory is made again at its next use)
   return YH_OK;
 }

@@ -1,8 +1,41 @@
 // trace_launch.cpp — yh_init_state (pt.cpp:1931-1946) and the launches of the sample-loop kernels: yh_trace_samples and friends.
 #include "context_internal.h"
 
+// Waits for everything queued on the context's stream, at most YHAIR_LAUNCH_TIMEOUT_S seconds (host/deadline.h): an event recorded
+// behind the queued work is polled instead of blocking in hipStreamSynchronize, so that a kernel that never completes costs the
+// caller an error, not the process. On expiry the context is POISONED: the device may still be running the kernel, so every later
+// launch is refused and yh_destroy frees nothing (hipFree would wait for the kernel).
+int wait_for_launch(yh_context* ctx) {
+  if (ctx->poisoned) return fail(ctx, YH_E_DEVICE, "a launch of this context exceeded its deadline: the context refuses further work, destroy it");
+  hipEvent_t ev = nullptr;
+  HIPCHK(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  hipError_t e = hipEventRecord(ev, ctx->stream);
+  if (e != hipSuccess) {
+    (void)hipEventDestroy(ev);
+    return fail(ctx, YH_E_DEVICE, "hipEventRecord: %s", hipGetErrorString(e));
+  }
+  hipError_t   qe = hipSuccess;
+  const double timeout = yhh::launch_timeout_s();
+  double       waited  = 0;
+  const int    rc = yhh::wait_until(
+      [&]() {
+        qe = hipEventQuery(ev);
+        return qe == hipSuccess ? yhh::QUERY_READY : (qe == hipErrorNotReady ? yhh::QUERY_NOT_READY : yhh::QUERY_ERROR);
+      },
+      timeout, []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); },
+      [](long us) { usleep((useconds_t)us); }, &waited);
+  if (rc == yhh::WAIT_EXPIRED) {
+    ctx->poisoned = true;  // (the event is not destroyed: it is still pending on the device)
+    return fail(ctx, YH_E_DEVICE, "the launch did not complete within %.3g s (YHAIR_LAUNCH_TIMEOUT_S): the context refuses further launches; destroy it and, to retry, start a fresh process", timeout);
+  }
+  (void)hipEventDestroy(ev);
+  if (rc == yhh::WAIT_ERROR) return fail(ctx, YH_E_DEVICE, "hipEventQuery: %s", hipGetErrorString(qe));
+  return YH_OK;
+}
+
 int yh_init_state(yh_context* ctx, const yh_trace_params* params) {
   if (!ctx) return YH_E_INVALID;
+  if (ctx->poisoned) return fail(ctx, YH_E_DEVICE, "a launch of this context exceeded its deadline: the context refuses further work, destroy it");
   if (!ctx->have_scene) return fail(ctx, YH_E_STATE, "yh_init_state before yh_upload_scene");
   if (!params || params->resolution <= 0 || params->bounces < 0)
     return fail(ctx, YH_E_INVALID, "bad trace params");
@@ -48,7 +81,6 @@ int yh_init_state(yh_context* ctx, const yh_trace_params* params) {
   build_work_items(ctx, tiles);
   const int first_shape = getenv("YHAIR_SHAPE") ? choose_launch_shape(ctx) : ctx->launch_shape;
   ctx->state.tiles_x = tx, ctx->state.num_groups = 1, ctx->state.group_begin[0] = 0, ctx->state.group_begin[1] = (int)tiles.size();
-  ctx->state.static_items = 0;
   if (params->shader == YH_SHADER_PATH && first_shape == 3) deal_items_for_stream(ctx, tiles);
   if (params->shader == YH_SHADER_PATH && (first_shape == 4 || first_shape == 7)) split_items_for_octets(tiles);
   if (params->shader == YH_SHADER_PATH && first_shape == 5) split_items_side_by_side(ctx, tiles);
@@ -93,62 +125,12 @@ int yh_init_state(yh_context* ctx, const yh_trace_params* params) {
     if (prc) return prc;
     HIPCHK(ctx, hipMemcpy(ctx->d_rng_state.p, st.data(), npix * 8, hipMemcpyHostToDevice));
     HIPCHK(ctx, hipMemsetAsync(ctx->d_accum.p, 0, npix * 16, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    YH_WAIT(ctx);
     ctx->state.samples_done = 0, ctx->launches_of_state = 0, ctx->last_shape = -1, ctx->last_ms = 0, ctx->last_launches = 0;
     ctx->have_costs = true;  // the launches that follow are planned: their times rank the kernels
   }
   return YH_OK;
 }
-
-#ifdef YH_LAB_WAVEFRONT
-// One launch of the wavefront integrator (tools/lab/wavefront.hip): persistent workgroups, one path pool each.
-int wavefront_impl(yh_context* ctx, int nsamples, bool sync) {
-  int k = 1;
-  if (const char* env = getenv("YHAIR_WF_SLOTS")) k = atoi(env) >= 2 ? 2 : 1;  // path slots per thread (developer switch)
-  const int P         = yhk_wavefront_slots(k);
-  const int stack     = std::max(8, (ctx->stack_need + 7) / 8 * 8);
-  const int lds_bytes = yhk_wavefront_lds_bytes(stack, YHD_LDS_TABLES_F4(&ctx->scene), k);
-  const int occupancy = yhk_wavefront_occupancy(lds_bytes, ctx->scene.general_materials, k);
-  if (occupancy < 1) return fail(ctx, YH_E_DEVICE, "k_wavefront cannot run with %d bytes of LDS per block", lds_bytes);
-  const int64_t pixels = (int64_t)ctx->state.num_tiles * 16;  // work items are 4x4 pixel quadrants
-  const int     grid   = (int)std::max<int64_t>(1, std::min<int64_t>((pixels + P - 1) / P, (int64_t)ctx->num_cus * occupancy));
-  const size_t  slots  = (size_t)grid * P;
-  if (slots > ctx->pool_slots) {
-    int rc;
-    if ((rc = alloc_zero(ctx, ctx->d_pool_ray_o, slots * 16)) || (rc = alloc_zero(ctx, ctx->d_pool_ray_d, slots * 16)) ||
-        (rc = alloc_zero(ctx, ctx->d_pool_weight, slots * 16)) || (rc = alloc_zero(ctx, ctx->d_pool_radiance, slots * 16)) ||
-        (rc = alloc_zero(ctx, ctx->d_pool_hit, slots * 16)))
-      return rc;
-    ctx->pool_slots = slots;
-    ctx->pool.ray_o = (yhd_float4*)ctx->d_pool_ray_o.p, ctx->pool.ray_d = (yhd_float4*)ctx->d_pool_ray_d.p;
-    ctx->pool.weight = (yhd_float4*)ctx->d_pool_weight.p, ctx->pool.radiance = (yhd_float4*)ctx->d_pool_radiance.p;
-    ctx->pool.hit = (yhd_int4*)ctx->d_pool_hit.p;
-  }
-  // the medium of a path inside a volume: two float4 per slot, general scenes only (a plain scene's kernel never
-  // touches it). Its capacity is tracked on its own: a context that rendered a plain scene first has none yet.
-  if (ctx->scene.general_materials && slots > ctx->pool_medium_slots) {
-    int rc;
-    if ((rc = alloc_zero(ctx, ctx->d_pool_medium, slots * 32))) return rc;
-    ctx->pool_medium_slots = slots;
-    ctx->pool.medium       = (yhd_float4*)ctx->d_pool_medium.p;
-  }
-  ctx->pool.slots_per_block = P, ctx->pool.stack_entries = stack;
-  HIPCHK(ctx, hipMemsetAsync(ctx->d_tile_cursor.p, 0, 8 * 16 * 4, ctx->stream));
-  HIPCHK(ctx, hipMemsetAsync(ctx->d_tile_cost.p, 0, (size_t)ctx->num_tiles_total * 16, ctx->stream));
-  HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-  int e = yhk_wavefront(&ctx->scene, &ctx->state, nsamples, &ctx->pool, k, grid, ctx->stream);
-  if (e) return fail(ctx, YH_E_DEVICE, "k_wavefront launch: %s", hipGetErrorString((hipError_t)e));
-  HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-  ctx->state.samples_done += nsamples;
-  ctx->last_launches = 1;
-  if (sync) {
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    HIPCHK(ctx, hipEventElapsedTime(&ctx->last_ms, ctx->ev0, ctx->ev1));
-    return replan_after_launch(ctx, nsamples);
-  }
-  return YH_OK;
-}
-#endif
 
 // One launch of the streaming integrator (csrc/stream.hip): persistent wavefronts, one path pool each, one lane per path.
 int stream_impl(yh_context* ctx, int nsamples, bool sync) {
@@ -196,7 +178,7 @@ int stream_impl(yh_context* ctx, int nsamples, bool sync) {
   ctx->state.samples_done += nsamples;
   ctx->last_launches = 1;
   if (sync) {
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (int wrc = wait_for_launch(ctx)) return wrc;
     HIPCHK(ctx, hipEventElapsedTime(&ctx->last_ms, ctx->ev0, ctx->ev1));
     if (prof) {
       unsigned long long c[64];
@@ -223,6 +205,7 @@ int stream_impl(yh_context* ctx, int nsamples, bool sync) {
 
 int trace_impl(yh_context* ctx, int nsamples, bool counted, bool sync) {
   if (!ctx) return YH_E_INVALID;
+  if (ctx->poisoned) return fail(ctx, YH_E_DEVICE, "a launch of this context exceeded its deadline: the context refuses further launches, destroy it");
   if (!ctx->have_state) return fail(ctx, YH_E_STATE, "yh_trace_samples before yh_init_state");
   if (nsamples < 0) return fail(ctx, YH_E_INVALID, "negative sample count");
   HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -241,13 +224,13 @@ int trace_impl(yh_context* ctx, int nsamples, bool counted, bool sync) {
       ctx->launch_shape = ctx->state.launch_shape = want;
       // The list is rewritten by a blocking copy on the null stream; the context's stream is non-blocking, so a launch
       // queued by yh_trace_samples_async may still be reading it: wait for it first.
-      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+      if (int wrc = wait_for_launch(ctx)) return wrc;
       if (int rc = upload_work_items(ctx)) return rc;
     }
   }
   if (counted && (ctx->state.launch_shape == 5 || (ctx->state.launch_shape >= 4 && (ctx->scene.general_materials || ctx->state.launch_shape >= 7)))) {  // the octet kernel's list holds half-quadrant entries: the instrumented (quad) build needs its own
     ctx->launch_shape = ctx->state.launch_shape = 0;
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (int wrc = wait_for_launch(ctx)) return wrc;
     if (int rc = upload_work_items(ctx)) return rc;
   }
   int shape = path ? ctx->state.launch_shape : 0;  // the preview shaders have one launch shape
@@ -258,7 +241,7 @@ int trace_impl(yh_context* ctx, int nsamples, bool counted, bool sync) {
       ctx->shape_ms[3] = std::numeric_limits<double>::infinity();
       shape = ctx->dense > 0 ? 1 : 0;
       ctx->launch_shape = ctx->state.launch_shape = shape;
-      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+      if (int wrc = wait_for_launch(ctx)) return wrc;
       if (int rc = upload_work_items(ctx)) return rc;
     }
   }
@@ -267,18 +250,14 @@ int trace_impl(yh_context* ctx, int nsamples, bool counted, bool sync) {
     ctx->shape_ms[shape] = std::numeric_limits<double>::infinity();
     shape = 0;
     ctx->launch_shape = ctx->state.launch_shape = shape;
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (int wrc = wait_for_launch(ctx)) return wrc;
     if (int rc = upload_work_items(ctx)) return rc;
   }
-  if (shape == 2 || shape >= 4)
+  if (shape >= 4)
     if (int rc = ensure_wide_nodes(ctx)) return rc;
   ctx->last_shape = shape, ctx->last_counted = counted, ctx->planned_settled = ctx->costs_settled;
-#ifdef YH_LAB_WAVEFRONT
-  if (path && !counted && getenv("YHAIR_LAB_WAVEFRONT")) return wavefront_impl(ctx, nsamples, sync);  // developer build only (make WAVEFRONT=1)
-#endif
   if (shape == 3) return stream_impl(ctx, nsamples, sync);
-  if (shape == 2 && yhk_trace_occupancy(yhk_trace_lds_bytes(&ctx->scene, 2), ctx->scene.general_materials, 2) < 1)
-    return fail(ctx, YH_E_INVALID, "launch shape 2 (quads over 8-wide nodes) is a developer kernel: build with make W8=1");
+  if (shape == 2) return fail(ctx, YH_E_INVALID, "launch shape 2 (quads over 8-wide nodes) was a developer kernel and is not built (profiles/r03/w8_oct_ab.txt)");
   if (shape == 5 && !counted) return side_by_side_impl(ctx, nsamples, sync);
   if (shape == 5) shape = 0;  // (instrumented: guarded above, the list was rebuilt for the quad kernel)
   int waves_per_block = yhk_block_threads(shape) / 64;  // one work item per wave at a time
@@ -299,7 +278,7 @@ int trace_impl(yh_context* ctx, int nsamples, bool counted, bool sync) {
   ctx->state.samples_done += nsamples;
   ctx->last_launches = 1;
   if (sync) {
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (int wrc = wait_for_launch(ctx)) return wrc;
     HIPCHK(ctx, hipEventElapsedTime(&ctx->last_ms, ctx->ev0, ctx->ev1));
     return replan_after_launch(ctx, nsamples);
   }
@@ -319,7 +298,7 @@ int side_by_side_impl(yh_context* ctx, int nsamples, bool sync) {
   ctx->state.samples_done += nsamples;
   ctx->last_launches = 1;
   if (sync) {
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (int wrc = wait_for_launch(ctx)) return wrc;
     HIPCHK(ctx, hipEventElapsedTime(&ctx->last_ms, ctx->ev0, ctx->ev1));
     return replan_after_launch(ctx, nsamples);
   }
@@ -347,7 +326,7 @@ int yh_trace_samples_async(yh_context* ctx, int nsamples) {
 int yh_synchronize(yh_context* ctx) {
   if (!ctx) return YH_E_INVALID;
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (int wrc = wait_for_launch(ctx)) return wrc;
   if (ctx->async_pending) (void)hipEventElapsedTime(&ctx->last_ms, ctx->ev0, ctx->ev1);  // (a blocking call has its own sum)
   ctx->async_pending = false;
   return YH_OK;

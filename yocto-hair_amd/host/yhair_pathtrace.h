@@ -18,6 +18,7 @@
 #define YHAIR_PATHTRACE_H_
 #include <array>
 #include <atomic>
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -229,6 +230,7 @@ struct scene {
   // set by init_bvh / init_lights, consumed by init_state (which knows the camera)
   mutable bool          bvh_requested = false, lights_requested = false;
   mutable const camera* uploaded_for  = nullptr;
+  mutable double        upload_seconds = 0;  // wall-clock of the last flatten + yh_upload_scene (init_bvh + init_lights of the reference), for the command line's --timing
 };
 struct state {  // pt.h:426-429; `render` is refreshed by trace_samples
   int                width = 0, height = 0, samples = 0;
@@ -408,7 +410,11 @@ inline void init_state(state* st, const scene* sc, const camera* cam, const trac
     throw std::runtime_error("sampler unknown");  // pt.cpp:1669
   if (!sc->bvh_requested || !sc->lights_requested)
     throw std::runtime_error("yhair: init_state before init_bvh / init_lights");
-  if (sc->uploaded_for != cam) upload_scene(sc, cam);
+  if (sc->uploaded_for != cam) {
+    const auto t0 = std::chrono::steady_clock::now();
+    upload_scene(sc, cam);
+    sc->upload_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  }
   st->device_params = yh_trace_params{params.resolution, params.bounces, params.clamp, params.seed, (int)params.shader, params.hair_exact ? 1 : 0};
   detail::for_each_context([&](yh_context* ctx, int i) {
     int rc = yh_set_shard(ctx, i, (int)detail::contexts().size());

@@ -52,6 +52,7 @@ int main(int argc, const char* argv[]) {
     else filename = a;
   }
   if (filename.empty()) print_fatal("missing scene");
+  yh_set_trial_cache_dir(yh_default_trial_cache_dir());  // the command line keeps its kernel-trial record on disk (include/yhair.h); a library caller has to ask
   set_devices(first_device, gpus, device_list);
   bool known = false;
   for (size_t i = 0; i < ptr::shader_names.size(); i++)

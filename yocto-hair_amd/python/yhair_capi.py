@@ -151,6 +151,8 @@ _SIGS = {
     "yh_item_costs": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_int]),
     "yh_kernel_trials": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_int]),
     "yh_trials_pending": (C.c_int, [C.c_void_p]),
+    "yh_set_trial_cache_dir": (C.c_int, [C.c_char_p]),
+    "yh_default_trial_cache_dir": (C.c_char_p, []),
     "yh_hair_brdf_batch": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Material), c_float_p,
                                      c_float_p, c_float_p, c_float_p]),
     "yh_curves_to_lines": (C.c_int, [C.c_void_p, C.c_int, c_float_p, c_float_p, c_float_p, C.c_int, c_float_p,
@@ -203,6 +205,17 @@ def load(path=None):
 
 class YhError(RuntimeError):
     pass
+
+
+def set_trial_cache_dir(path=None, default=False):
+    """yh_set_trial_cache_dir: opt in to the kernel-trial record on disk (process-wide). default=True: the directory the
+    command lines use ($XDG_CACHE_HOME/yhair or ~/.cache/yhair); path=None without default: no file."""
+    lib = load()
+    if not hasattr(lib, "yh_set_trial_cache_dir"):  # an older developer build (YHAIR_LIB)
+        return None
+    d = lib.yh_default_trial_cache_dir() if default else (path.encode() if path else None)
+    lib.yh_set_trial_cache_dir(d)
+    return d.decode() if d else None
 
 
 class SceneFile:
