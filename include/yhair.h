@@ -185,7 +185,11 @@ typedef struct yh_context yh_context;
 /* ------------------------------------------------------------------------ */
 
 /* Creates a context on HIP device `device`. Returns NULL when no usable GPU
- * or the HIP code object is missing: there is NO CPU fallback.              */
+ * or the HIP code object is missing: there is NO CPU fallback.
+ * Every call that waits for the device waits at most YHAIR_LAUNCH_TIMEOUT_S seconds (environment, default 1800): a launch that
+ * does not complete in time returns YH_E_DEVICE, and from then on the context refuses every call that would touch the device
+ * (a hung kernel cannot be recalled); yh_destroy of such a context returns at once and frees nothing. A caller that wants to
+ * retry starts a fresh process. (The reference's trace_samples cannot hang: CPU threads over rows, yocto_pathtrace.cpp:1954-1989.) */
 yh_context* yh_create(int device);
 void        yh_destroy(yh_context* ctx);
 /* Text of the last error on this context (or of the failed yh_create when
@@ -202,7 +206,12 @@ const char* yh_version(void);
  * two-level BVH (reference-identical binary middle-split tree, so that
  * closest-hit results, including exact-t ties, match the reference), the
  * area-light triangle CDFs and the environment texel CDF, precomputes inverse
- * object frames and per-material hair constants, and uploads everything.     */
+ * object frames and per-material hair constants, and uploads everything.
+ * LIMITS (YH_E_INVALID with a message beyond them): a shape holds fewer than 2^27 elements; the traversal kernels address a
+ * scene's trees as one array of 32-byte units with 27-bit leaf references and 30-bit node references — a line segment takes one
+ * unit, a triangle two, a 4-wide node four — i.e. about 134 M segments or 67 M triangles in ALL shapes together (instances share
+ * their shape); at most 4 environments and 16 lights. Scenes of more than ~46 objects or 24 materials run the GENERAL
+ * kernel variants (their tables do not fit the LDS budget): slower, same pixels.                                         */
 int yh_upload_scene(yh_context* ctx, const yh_scene_desc* scene);
 
 /* init_state (yocto_pathtrace.cpp:1931-1946): image size from the camera film

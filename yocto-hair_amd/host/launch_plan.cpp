@@ -363,7 +363,7 @@ int upload_work_items(yh_context* ctx) {
   if (ctx->state.shader == YH_SHADER_PATH && (ctx->state.launch_shape == 4 || ctx->state.launch_shape == 7)) split_items_for_octets(tiles);
   if (ctx->state.shader == YH_SHADER_PATH && ctx->state.launch_shape == 5) split_items_side_by_side(ctx, tiles);
   if (ctx->state.shader == YH_SHADER_PATH && (ctx->state.launch_shape == 6 || ctx->state.launch_shape == 8)) split_items_for_hex(tiles);
-  if (!getenv("YHAIR_NO_LAYOUT")) lay_out_first_round(ctx, tiles, ctx->state.shader == YH_SHADER_PATH ? ctx->state.launch_shape : 0);
+  lay_out_first_round(ctx, tiles, ctx->state.shader == YH_SHADER_PATH ? ctx->state.launch_shape : 0);
   ctx->state.num_tiles = (int)tiles.size();
   HIPCHK(ctx, hipMemcpy(ctx->d_tiles.p, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice));
   return YH_OK;
@@ -398,7 +398,7 @@ bool side_by_side_grids(const yh_context* ctx, int* oct_blocks, int* quad_blocks
   const int lds = yhk_trace_sbs_lds_bytes(&ctx->scene), occ = yhk_trace_sbs_occupancy(lds, ctx->scene.general_materials);
   if (occ < 1) return false;
   const int resident = ctx->num_cus * occ;
-  *oct_blocks  = std::min((ctx->hy_oct_entries + 7) / 8, resident / 2);  // (the quad workgroups keep at least half of the device, whatever YHAIR_HY_OCT says)
+  *oct_blocks  = std::min((ctx->hy_oct_entries + 7) / 8, resident / 2);  // (the quad workgroups keep at least half of the device)
   *quad_blocks = ctx->hy_quad_items > 0 ? std::max(1, std::min((ctx->hy_quad_items + 7) / 8, resident - *oct_blocks)) : 0;
   return true;
 }
@@ -408,7 +408,6 @@ void split_items_side_by_side(yh_context* ctx, std::vector<int>& items) {
   // profiles/r03/side_by_side_fused_ab.txt): a sixty-fourth of the expensive items, sixteen at least.
   const int H = expensive_items(ctx, items);
   int n_oct = std::min(H / 2, std::max(16, std::min(256, H / 64)));
-  if (const char* env = getenv("YHAIR_HY_OCT")) n_oct = std::max(0, std::min((int)items.size(), atoi(env)));  // developer switch
   std::vector<int> out;
   out.reserve(items.size() + n_oct);
   for (size_t i = (size_t)n_oct; i < items.size(); i++) out.push_back(items[i]);                   // quads: the rest, most expensive first
@@ -416,7 +415,7 @@ void split_items_side_by_side(yh_context* ctx, std::vector<int>& items) {
   ctx->hy_quad_items = (int)items.size() - n_oct, ctx->hy_oct_entries = 2 * n_oct;
   ctx->hy_oct_items.assign(items.begin(), items.begin() + n_oct);
   items.swap(out);
-  if (!getenv("YHAIR_NO_LAYOUT")) {  // both lists by wave slot: the octet workgroups are the first of the launch, the quad ones follow (side_by_side_impl)
+  {  // both lists by wave slot: the octet workgroups are the first of the launch, the quad ones follow (side_by_side_impl)
     int G_o = 0, G_q = 0;
     side_by_side_grids(ctx, &G_o, &G_q);
     if (G_o > 0) lay_out_range(ctx, items.data() + ctx->hy_quad_items, (size_t)ctx->hy_oct_entries, 8, G_o, 0);
@@ -518,50 +517,11 @@ void deal_items_for_stream(yh_context* ctx, std::vector<int>& items) {
   ctx->state.num_groups = 1, ctx->state.group_begin[0] = 0, ctx->state.group_begin[1] = (int)items.size();
   if (items.empty() || !stream_geometry(ctx, (int)items.size(), &P, &grid, nullptr)) return;
   const size_t R = (size_t)grid * (yhk_stream_block_threads() / 64) * (size_t)(P / 64);  // takes resident together
-  // Groups: one compact image region per XCD (yh_device.h: yhd_state::group_begin). The items in Morton order of
-  // their tiles, cut into G runs of equal cost; inside a run the dealing above. MEASURED WITHOUT GAIN, so off by
-  // default (G = 1; YHAIR_ST_GROUPS=8 turns it on): C3 296 -> 300 Msamples/s, C2 237 -> 222 (the regions' costs drift
-  // apart during a launch), C4 unchanged (profiles/r02/k_stream_xcd_groups.txt) — after the first bounce the rays of
-  // a region wander through the hair, and 4 MB of L2 hold little of a region's 40 MB anyway.
-  int G = 1;
-  if (const char* env = getenv("YHAIR_ST_GROUPS")) G = std::max(1, std::min(8, atoi(env)));
-  if ((size_t)G * 64 > items.size()) G = 1;
+  // (Groups — one compact image region per XCD, the items in Morton order cut into runs of equal cost — were measured without gain in
+  // round 2, profiles/r02/k_stream_xcd_groups.txt: C3 296 -> 300 Msamples/s, C2 237 -> 222; after the first bounce the rays of a region
+  // wander through the hair, and 4 MB of L2 hold little of a region's 40 MB anyway. The device side still takes groups; the host deals one.)
   std::vector<int> out;
   out.reserve(items.size());
-  if (G == 1) {
-    deal_block(out, items.data(), items.size(), R);
-  } else {
-    auto morton = [&](int item) -> uint64_t {
-      const int tile = item >> 2, tx = tile % ctx->state.tiles_x, ty = tile / ctx->state.tiles_x;
-      const unsigned x = (unsigned)(2 * tx + (item & 1)), y = (unsigned)(2 * ty + ((item >> 1) & 1));  // 4x4-pixel quadrant coordinates
-      uint64_t m = 0;
-      for (int b = 0; b < 16; b++) m |= ((uint64_t)((x >> b) & 1) << (2 * b)) | ((uint64_t)((y >> b) & 1) << (2 * b + 1));
-      return m;
-    };
-    std::vector<std::pair<uint64_t, int>> order;  // (morton, rank in the cost-sorted list)
-    order.reserve(items.size());
-    for (size_t i = 0; i < items.size(); i++) order.push_back({morton(items[i]), (int)i});
-    std::sort(order.begin(), order.end());
-    double total = 0;
-    for (int it : items) total += 1.0 + (double)ctx->item_cost[(size_t)it];
-    size_t at = 0;
-    double acc = 0;
-    for (int g = 0; g < G; g++) {
-      std::vector<int> ranks;  // this group's items, by rank in the cost-sorted list (= most expensive first)
-      const double upto = total * (g + 1) / G;
-      while (at < order.size() && (g == G - 1 || acc < upto)) {
-        acc += 1.0 + (double)ctx->item_cost[(size_t)items[(size_t)order[at].second]];
-        ranks.push_back(order[at].second);
-        at++;
-      }
-      std::sort(ranks.begin(), ranks.end());
-      std::vector<int> grp;
-      grp.reserve(ranks.size());
-      for (int r : ranks) grp.push_back(items[(size_t)r]);
-      ctx->state.group_begin[g] = (int)out.size();
-      deal_block(out, grp.data(), grp.size(), std::max<size_t>(1, R / G));
-    }
-    ctx->state.num_groups = G, ctx->state.group_begin[G] = (int)out.size();
-  }
+  deal_block(out, items.data(), items.size(), R);
   items.swap(out);
 }

@@ -85,7 +85,7 @@ int yh_init_state(yh_context* ctx, const yh_trace_params* params) {
   if (params->shader == YH_SHADER_PATH && (first_shape == 4 || first_shape == 7)) split_items_for_octets(tiles);
   if (params->shader == YH_SHADER_PATH && first_shape == 5) split_items_side_by_side(ctx, tiles);
   if (params->shader == YH_SHADER_PATH && (first_shape == 6 || first_shape == 8)) split_items_for_hex(tiles);
-  if (!getenv("YHAIR_NO_LAYOUT")) lay_out_first_round(ctx, tiles, params->shader == YH_SHADER_PATH ? first_shape : 0);  // (developer switch: the plain cost order)
+  lay_out_first_round(ctx, tiles, params->shader == YH_SHADER_PATH ? first_shape : 0);
   tiles.reserve(4 * (size_t)ctx->num_tiles_total * 4 + 4);  // (the list's buffer holds the octet / sixteen-lane kernels' longer lists too)
   int rc;
   if ((rc = upload(ctx, ctx->d_rng_state, st.data(), npix * 8))) return rc;
