@@ -1118,6 +1118,30 @@ def test_another_shard_is_another_image_for_the_kernel_trials(yh, monkeypatch):
     c.close(), sf.close()
 
 
+@pytest.mark.parametrize("res,shard", [(720, (0, 1)), (733, (0, 1)), (1200, (1, 3))], ids=["720", "733-ragged", "1200-shard-1-of-3"])
+def test_stream_shares_render_the_quad_kernels_pixels(ctx, yh, res, shard, monkeypatch):
+    """Round 5: when the resident waves hold the whole image at once (C2's 720 x 720), k_stream hands every wave its OWN share of
+    the work list, sized by the speed of the wave's hardware slot and corrected launch after launch from the waves' begin / end
+    stamps (host/launch_plan.cpp: deal_shares_by_speed). Which wave renders which pixel must not show: four launches (the
+    hand-out is re-planned after launches 1, 2 and 4, each time from the measured stamps) give the quad kernel's image and RNG
+    states bit for bit — on the config's image, on a size that is not a multiple of the tile, and on a shard of it."""
+    sf = yh.SceneFile(scene_path("straight-hair", scale=0.25))
+    ctx.upload_scene(sf.desc)
+    ctx.set_shard(*shard)
+    got = {}
+    for shape in ("1", "3"):
+        monkeypatch.setenv("YHAIR_SHAPE", shape)
+        ctx.init_state(yh.TraceParams.default(resolution=res))
+        for n in (3, 2, 1, 2, 1):
+            ctx.trace_samples(n)
+        got[shape] = (ctx.download(), ctx.download_rng())
+    monkeypatch.delenv("YHAIR_SHAPE")
+    ctx.set_shard(0, 1)
+    assert got["1"][0][..., 3].max() > 0
+    assert np.array_equal(got["1"][0], got["3"][0]) and np.array_equal(got["1"][1], got["3"][1])
+    sf.close()
+
+
 @pytest.mark.parametrize("res", [100, 61, 7])
 def test_every_launch_shape_on_ragged_image_sizes(ctx, yh, res, monkeypatch):
     """Image sizes that are not multiples of the 8x8 tile, down to less than one tile: every kernel (quads, octets with

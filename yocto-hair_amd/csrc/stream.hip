@@ -108,6 +108,8 @@ __global__ __launch_bounds__(YH_ST_BLOCK, WAVES) void k_stream(const yhd_scene s
   for (int s = lane; s < P; s += 64) l_free[s] = (unsigned short)s;
   __syncthreads();  // the only workgroup barrier: from here on every wave runs on its own
 
+  const unsigned long long wl_begin = pl.wave_log ? wall_clock64() : 0ull;
+  unsigned long long       wl_steps = 0;
   lane_stack stk;
   stk.lds = w_stack + lane, stk.ovf = pl.stack_ovf + wave_id * (size_t)pl.ovf_entries * 64 + lane, stk.sp = 0, stk.base = 0;
   tc.ls   = &stk;
@@ -117,6 +119,8 @@ __global__ __launch_bounds__(YH_ST_BLOCK, WAVES) void k_stream(const yhd_scene s
   bool      nomore = false;
   bool      have = false;
   int       slot = 0;
+  // this wave's own share of the work list, taken before anything from the cursor (yh_device.h: yhd_stream::wave_begin)
+  int       own_next = pl.wave_begin ? pl.wave_begin[wave_id] : 0, own_end = pl.wave_begin ? pl.wave_begin[wave_id + 1] : 0;
   lane_trav t;
   lane_begin(sc, t, mk3(0.0f), mk3(1.0f), -1);
 
@@ -130,7 +134,8 @@ __global__ __launch_bounds__(YH_ST_BLOCK, WAVES) void k_stream(const yhd_scene s
     // path waits long for company. Finishing comes after shading (which ends paths) and runs once per round.
     int act;
     const bool flush = n_ray + nact < 64;
-    if (!nomore && n_free >= 64) act = A_ITEMS;
+    const int  want  = own_next < own_end ? min(4, own_end - own_next) : 4;  // work items of the next take: 4 = 64 pixels, fewer at the end of the wave's own share
+    if ((own_next < own_end || !nomore) && n_free >= 16 * want) act = A_ITEMS;
     else if (n_done > 0) act = A_SORT;
     else if (n_fin >= 64 || (flush && n_fin > 0)) act = A_FINISH;
     else if (n_hair >= 64 || (flush && n_hair > 0)) act = A_HAIR;
@@ -143,18 +148,21 @@ __global__ __launch_bounds__(YH_ST_BLOCK, WAVES) void k_stream(const yhd_scene s
     if (act == A_ITEMS) {
       // ---- items: free slots take the pixels of the next work items (4 items = 64 pixels) ------------------
       // the next items of this workgroup's group (its XCD's image region); a group that is used up hands over to the next
-      int       t0 = 0, got = 0;
-      const int want = 4;
-      while (true) {
-        int c = 0;
-        if (lane == 0) c = atomicAdd(st.tile_cursor + 16 * my_group, want);
-        c   = __builtin_amdgcn_readfirstlane(c);
-        t0  = st.group_begin[my_group] + c;
-        got = max(0, min(want, st.group_begin[my_group + 1] - t0));
-        if (got > 0 || ++groups_done >= st.num_groups) break;
-        my_group = (my_group + 1) % st.num_groups;
+      int t0 = 0, got = 0;
+      if (own_next < own_end) {  // the wave's own share first
+        t0 = own_next, got = want, own_next += want;
+      } else {
+        while (true) {
+          int c = 0;
+          if (lane == 0) c = atomicAdd(st.tile_cursor + 16 * my_group, want);
+          c   = __builtin_amdgcn_readfirstlane(c);
+          t0  = st.group_begin[my_group] + c;
+          got = max(0, min(want, st.group_begin[my_group + 1] - t0));
+          if (got > 0 || ++groups_done >= st.num_groups) break;
+          my_group = (my_group + 1) % st.num_groups;
+        }
+        if (got == 0) nomore = true;
       }
-      if (got == 0) nomore = true;
       int pixel = -1, item = 0;
       if (lane < 16 * got) {
         item     = st.tiles[t0 + (lane >> 4)];
@@ -247,6 +255,7 @@ __global__ __launch_bounds__(YH_ST_BLOCK, WAVES) void k_stream(const yhd_scene s
         } else {  // the pixel has all its samples: hand its stream back, report its work, free the slot
           st.rng_state[p] = rng.state;
           if (work) atomicAdd(&st.tile_cost[mt.z], work);
+          if (pl.wave_log) wl_steps += work;
           freed = true;
         }
       }
@@ -357,6 +366,13 @@ __global__ __launch_bounds__(YH_ST_BLOCK, WAVES) void k_stream(const yhd_scene s
       atomicAdd(&pl.prof[8 + act], 1ull);
       atomicAdd(&pl.prof[16 + act], p_batch);
       if (act == A_TRACE) atomicAdd(&pl.prof[24], p_steps), atomicAdd(&pl.prof[25], p_busy);
+    }
+  }
+  if (pl.wave_log) {  // when this wave's work began and ended, and how much it was (freed is per lane: sum over the wave)
+    for (int o = 32; o > 0; o >>= 1) wl_steps += (unsigned long long)__shfl_xor((long long)wl_steps, o);
+    if (lane == 0) {
+      unsigned long long* w = pl.wave_log + 4 * wave_id;
+      w[0] = wl_begin, w[1] = wall_clock64(), w[2] = wl_steps, w[3] = 0;
     }
   }
 }

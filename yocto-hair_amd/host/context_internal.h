@@ -274,7 +274,15 @@ struct yh_context {
   int              chain = -1;   // 1: so few expensive items that even twice as many waves would all be resident: the launch is bound by the
                                  // chain of steps of ONE path, and the octet kernel (half the paths per wave, shape 4) is a candidate
   // path pool of the streaming integrator (csrc/stream.hip): per-wave slots, allocated at its first launch
-  DevBuf           d_st_slots, d_st_medium, d_st_ovf, d_st_prof, d_scene_copy;
+  DevBuf           d_st_slots, d_st_medium, d_st_ovf, d_st_prof, d_st_wave_log, d_st_wave_begin, d_scene_copy;
+  size_t           st_share_waves = 0;   // waves the per-wave shares of the work list were made for (0: none, everything through the cursor)
+  std::vector<int>    st_share_begin, st_share_items;  // host copy of the shares in effect: offsets per wave, items in list order
+  std::vector<double> st_share_cost;                   // ... and the cost each item was planned with
+  std::vector<unsigned long long> st_last_log;         // the last k_stream launch's stamps per wave {begin, end, steps, -}
+  bool                st_log_fresh = false;            // ... not yet used by a hand-out, and taken on the shares above
+  std::vector<float>  st_wave_speed;                   // per wave of the shares' launch geometry: its speed relative to its dispatch round's (deal_shares_by_speed)
+  std::vector<float>  item_scale;                      // per work item: correction of its reported cost (BVH steps) towards the time it takes (deal_shares_by_speed)
+  std::vector<double> stream_speed = {1.10, 1.045, 0.97, 0.885};  // relative speed of k_stream's waves by dispatch round = hardware wave slot (prior: C2's log; every launch refines it)
   size_t           st_slots = 0, st_medium_slots = 0, st_ovf_words = 0;
   yhd_stream       stream_pool{};
 };
@@ -320,7 +328,8 @@ void split_items_side_by_side(yh_context* ctx, std::vector<int>& items);
 void lay_out_range(const yh_context* ctx, int* items, size_t n, int wpb, int G, int block_offset = 0);
 void lay_out_first_round(const yh_context* ctx, std::vector<int>& items, int shape);
 int replan_after_launch(yh_context* ctx, int nsamples);
-int stream_geometry(const yh_context* ctx, int num_items, int* slots_per_wave, int* grid_blocks, int* lds_out);
+int stream_geometry(const yh_context* ctx, int num_items, int* slots_per_wave, int* grid_blocks, int* lds_out, bool* single_generation = nullptr);
+void note_stream_wave_log(yh_context* ctx, const unsigned long long* log, size_t waves);
 void deal_items_for_stream(yh_context* ctx, std::vector<int>& items);
 void wide_build_join(yh_context* ctx);
 void wide_build_start(yh_context* ctx);

@@ -476,19 +476,36 @@ int replan_after_launch(yh_context* ctx, int nsamples) {
 // spread over as many waves as the CUs hold, each wave with a few paths per lane so that its lanes stay full
 // between stages: 128 .. 192 slots (more waves beat fuller batches: measured on C2 / C3, profiles/r02;
 // YHAIR_ST_SLOTS / YHAIR_ST_WAVES: developer switches). Returns 0 when the kernel cannot run.
-int stream_geometry(const yh_context* ctx, int num_items, int* slots_per_wave, int* grid_blocks, int* lds_out) {
+int stream_geometry(const yh_context* ctx, int num_items, int* slots_per_wave, int* grid_blocks, int* lds_out, bool* single_generation) {
   const int     wpb    = yhk_stream_block_threads() / 64;
   const int64_t pixels = (int64_t)num_items * 16;  // work items are 4x4 pixel quadrants
   int           P      = (int)std::max<int64_t>(128, std::min<int64_t>(192, (pixels / ((int64_t)ctx->num_cus * 16) + 63) / 64 * 64));
-  if (const char* env = getenv("YHAIR_ST_SLOTS")) P = std::max(64, std::min(4096, atoi(env) / 64 * 64));
-  const int lds_bytes = yhk_stream_lds_bytes(YHD_LDS_TABLES_F4(&ctx->scene), P);
-  int       occupancy = yhk_stream_occupancy(lds_bytes, ctx->scene.general_materials);
+  const bool    forced = getenv("YHAIR_ST_SLOTS") != nullptr;
+  if (forced) P = std::max(64, std::min(4096, atoi(getenv("YHAIR_ST_SLOTS")) / 64 * 64));
+  int lds_bytes = yhk_stream_lds_bytes(YHD_LDS_TABLES_F4(&ctx->scene), P);
+  int occupancy = yhk_stream_occupancy(lds_bytes, ctx->scene.general_materials);
   if (occupancy < 1) return 0;
   if (const char* env = getenv("YHAIR_ST_WAVES")) occupancy = std::max(1, std::min(occupancy, (atoi(env) + wpb - 1) / wpb));  // waves per CU
-  const int64_t want = (pixels + (int64_t)P * wpb - 1) / ((int64_t)P * wpb);
-  *slots_per_wave    = P;
-  *grid_blocks       = (int)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)ctx->num_cus * occupancy));
+  int64_t want = (pixels + (int64_t)P * wpb - 1) / ((int64_t)P * wpb);
+  int     grid = (int)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)ctx->num_cus * occupancy));
+  // ONE GENERATION (round 5): when the resident waves hold the whole image at once (C2 at 720^2: 127 pixels per wave) no wave ever takes a
+  // second helping, so nothing evens out that the four hardware wave slots of a SIMD run at different speeds — with equal shares the
+  // slot-0 waves are done at 0.69 of the launch and the slot-3 waves at 0.86-1.0 (profiles/r05/k_stream_wave_shares.txt). Then every
+  // resident wave is used, a wave's share of the pixels follows its slot's speed (deal_items_for_stream), and the pool has room for the
+  // largest share: 1.25 x the average, in 64-slot steps.
+  bool one = false;
+  if (!forced) {
+    const int64_t waves_max = (int64_t)ctx->num_cus * occupancy * wpb, per_wave = (pixels + waves_max - 1) / std::max<int64_t>(1, waves_max);
+    if (pixels >= 64 * waves_max && per_wave <= 204) {
+      const int P1   = (int)std::min<int64_t>(256, (per_wave * 5 / 4 + 63) / 64 * 64);
+      const int lds1 = yhk_stream_lds_bytes(YHD_LDS_TABLES_F4(&ctx->scene), P1);
+      if (P1 >= P && yhk_stream_occupancy(lds1, ctx->scene.general_materials) >= occupancy) P = P1, lds_bytes = lds1, grid = (int)(waves_max / wpb), one = true;
+    }
+  }
+  *slots_per_wave = P;
+  *grid_blocks    = grid;
   if (lds_out) *lds_out = lds_bytes;
+  if (single_generation) *single_generation = one;
   return 1;
 }
 
@@ -512,10 +529,115 @@ static void deal_block(std::vector<int>& out, const int* items, size_t n, size_t
     }
   }
 }
+// SHARES BY WAVE-SLOT SPEED (round 5; stream_geometry's "one generation" case). Wave w of the launch starts with the entries
+// [wave_begin[w], wave_begin[w + 1]) of the list (csrc/stream.hip); the items are dealt out longest-processing-time first — most expensive
+// item to the wave with the largest remaining budget — where a wave's budget is the image's total cost times the relative speed of its
+// hardware wave slot (= the dispatch round of its workgroup: one workgroup per CU and round; yh_context::stream_speed, measured by every
+// k_stream launch from the waves' own begin / end stamps: note_stream_wave_log). Pixel results do not depend on who renders them.
+static bool deal_shares_by_speed(yh_context* ctx, std::vector<int>& items, int P, int grid) {
+  const int    wpb = yhk_stream_block_threads() / 64, cap = P / 16;
+  const size_t waves = (size_t)grid * wpb, n = items.size();
+  if (n > waves * (size_t)cap) return false;
+  auto round_of = [&](size_t w) { return (w / wpb) / (size_t)std::max(1, ctx->num_cus); };
+  if (ctx->item_scale.size() != ctx->item_cost.size()) ctx->item_scale.assign(ctx->item_cost.size(), 1.0f);
+  // FEEDBACK from the last launch that ran on shares (its waves' begin / end stamps, note_stream_wave_log): what a dispatch round gets
+  // through per tick — planned cost over time, blended into stream_speed — and, per wave, how much longer or shorter it took than
+  // its round's rate says: its items' costs are corrected by that ratio (the BVH steps an item reports are not all of its time: the same
+  // waves end late launch after launch while the plan stands, correlation 0.96, and others do after a re-deal).
+  if (ctx->st_log_fresh && ctx->st_share_begin.size() == waves + 1 && ctx->st_last_log.size() == 4 * waves) {
+    const size_t rounds = round_of(waves - 1) + 1;
+    std::vector<double> planned(waves, 0.0), took(waves, 0.0), pr(rounds, 0.0), tr(rounds, 0.0);
+    for (size_t w = 0; w < waves; w++) {
+      for (int k = ctx->st_share_begin[w]; k < ctx->st_share_begin[w + 1]; k++) planned[w] += ctx->st_share_cost[(size_t)k];
+      const unsigned long long* e = &ctx->st_last_log[4 * w];
+      took[w] = e[1] > e[0] ? (double)(e[1] - e[0]) : 0.0;
+      if (took[w] > 0 && planned[w] > 0) pr[round_of(w)] += planned[w], tr[round_of(w)] += took[w];
+    }
+    bool all = true;
+    double mean = 0;
+    for (size_t r = 0; r < rounds; r++) all = all && tr[r] > 0, mean += all ? pr[r] / tr[r] : 0.0;
+    if (all) {
+      mean /= (double)rounds;
+      if (ctx->stream_speed.size() != rounds) ctx->stream_speed.assign(rounds, 1.0);
+      for (size_t r = 0; r < rounds; r++) ctx->stream_speed[r] = 0.5 * ctx->stream_speed[r] + 0.5 * (pr[r] / tr[r]) / mean;
+      if (ctx->st_wave_speed.size() != waves) ctx->st_wave_speed.assign(waves, 1.0f);
+      for (size_t w = 0; w < waves; w++) {
+        if (!(took[w] > 0 && planned[w] > 0)) continue;
+        // what is left after the round's rate and the wave's own factor so far: half of it goes to the wave's items, a third to the wave's
+        // position (a CU or an XCC that runs slower shows up launch after launch whatever it is given; an item's deficit moves with the item)
+        const double expected = planned[w] / ((pr[round_of(w)] / tr[round_of(w)]) * (double)ctx->st_wave_speed[w]);
+        const double ratio    = std::min(1.5, std::max(0.67, took[w] / expected));
+        const float  corr     = (float)std::pow(ratio, 0.5);
+        for (int k = ctx->st_share_begin[w]; k < ctx->st_share_begin[w + 1]; k++) {
+          float& sc = ctx->item_scale[(size_t)ctx->st_share_items[(size_t)k]];
+          sc        = std::min(4.0f, std::max(0.25f, sc * corr));
+        }
+        ctx->st_wave_speed[w] = std::min(1.5f, std::max(0.67f, ctx->st_wave_speed[w] * (float)std::pow(ratio, -0.33)));
+      }
+      if (getenv("YHAIR_TIMING")) {
+        fprintf(stderr, "[yhair] k_stream shares: wave-slot speeds (dispatch rounds)");
+        for (double v : ctx->stream_speed) fprintf(stderr, " %.3f", v);
+        fprintf(stderr, "\n");
+      }
+    }
+  }
+  ctx->st_log_fresh = false;
+  std::vector<std::pair<double, int>> by_cost(n);  // (cost, item), most expensive first
+  double total = 0;
+  for (size_t i = 0; i < n; i++) {
+    by_cost[i] = {((double)ctx->item_cost[(size_t)items[i]] + 1.0) * (double)ctx->item_scale[(size_t)items[i]], items[i]};
+    total += by_cost[i].first;
+  }
+  std::sort(by_cost.begin(), by_cost.end(), [](const auto& a, const auto& b) { return a.first != b.first ? a.first > b.first : a.second < b.second; });
+  double ssum = 0;
+  auto speed_of = [&](size_t w) {
+    return (ctx->stream_speed.empty() ? 1.0 : ctx->stream_speed[std::min(round_of(w), ctx->stream_speed.size() - 1)]) * (ctx->st_wave_speed.size() == waves ? (double)ctx->st_wave_speed[w] : 1.0);
+  };
+  for (size_t w = 0; w < waves; w++) ssum += speed_of(w);
+  struct Share { std::vector<int> items; std::vector<double> cost; };
+  std::vector<Share> share(waves);
+  std::vector<std::pair<double, uint32_t>> heap(waves);  // (remaining budget, wave): max-heap
+  for (size_t w = 0; w < waves; w++) heap[w] = {total * speed_of(w) / ssum, (uint32_t)w};
+  std::make_heap(heap.begin(), heap.end());
+  for (size_t i = 0; i < n; i++) {
+    if (heap.empty()) return false;  // (cannot happen: n <= waves x cap)
+    std::pop_heap(heap.begin(), heap.end());
+    auto top = heap.back();
+    heap.pop_back();
+    share[top.second].items.push_back(by_cost[i].second), share[top.second].cost.push_back(by_cost[i].first);
+    top.first -= by_cost[i].first;
+    if ((int)share[top.second].items.size() < cap) heap.push_back(top), std::push_heap(heap.begin(), heap.end());
+  }
+  std::vector<int> begin(waves + 1, 0), out;
+  std::vector<double> out_cost;
+  out.reserve(n), out_cost.reserve(n);
+  for (size_t w = 0; w < waves; w++) {
+    begin[w] = (int)out.size();
+    out.insert(out.end(), share[w].items.begin(), share[w].items.end());
+    out_cost.insert(out_cost.end(), share[w].cost.begin(), share[w].cost.end());
+  }
+  begin[waves] = (int)out.size();
+  if (upload(ctx, ctx->d_st_wave_begin, begin.data(), begin.size() * 4) != YH_OK) return false;
+  ctx->stream_pool.wave_begin = (const int*)ctx->d_st_wave_begin.p;
+  ctx->st_share_waves         = waves;
+  ctx->st_share_begin = begin, ctx->st_share_items = out, ctx->st_share_cost = out_cost;  // what the next feedback reads the launch against
+  items.swap(out);
+  ctx->state.num_groups = 1, ctx->state.group_begin[0] = (int)items.size(), ctx->state.group_begin[1] = (int)items.size();  // nothing is left for the cursor
+  return true;
+}
+// After a synchronous k_stream launch: keep the waves' stamps for the next hand-out (deal_shares_by_speed reads them once).
+void note_stream_wave_log(yh_context* ctx, const unsigned long long* log, size_t waves) {
+  ctx->st_last_log.assign(log, log + 4 * waves);
+  ctx->st_log_fresh = ctx->stream_pool.wave_begin != nullptr && ctx->st_share_waves == waves;  // (only a launch that ran on shares says something about them)
+}
+
 void deal_items_for_stream(yh_context* ctx, std::vector<int>& items) {
-  int P = 0, grid = 0;
+  int  P = 0, grid = 0;
+  bool one = false;
   ctx->state.num_groups = 1, ctx->state.group_begin[0] = 0, ctx->state.group_begin[1] = (int)items.size();
-  if (items.empty() || !stream_geometry(ctx, (int)items.size(), &P, &grid, nullptr)) return;
+  ctx->stream_pool.wave_begin = nullptr, ctx->st_share_waves = 0;
+  if (items.empty() || !stream_geometry(ctx, (int)items.size(), &P, &grid, nullptr, &one)) return;
+  if (one && deal_shares_by_speed(ctx, items, P, grid)) return;
   const size_t R = (size_t)grid * (yhk_stream_block_threads() / 64) * (size_t)(P / 64);  // takes resident together
   // (Groups — one compact image region per XCD, the items in Morton order cut into runs of equal cost — were measured without gain in
   // round 2, profiles/r02/k_stream_xcd_groups.txt: C3 296 -> 300 Msamples/s, C2 237 -> 222; after the first bounce the rays of a region

@@ -102,7 +102,6 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
   ctx->host_trees.assign((size_t)sd->num_shapes, yhh::Tree{});
   std::vector<float>      vtex;  // 2 per vertex, zeros for shapes without texture coordinates
   std::vector<yhd_int4>   elems;
-  int                     best_lines = -1, best_shape = -1;
   {  // one allocation per array: growing them shape by shape would re-copy the hair every time
     size_t np = 0, nv = 0, ne = 0;
     for (int si = 0; si < sd->num_shapes; si++) {
@@ -232,7 +231,6 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
         });
       }
     }
-    if (lines && s.num_lines > best_lines) best_lines = s.num_lines, best_shape = si;
     lap("leaf records + vertex arrays");
     ctx->host_trees[(size_t)si] = std::move(tree);
   }
