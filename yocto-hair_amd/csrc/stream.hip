@@ -105,22 +105,27 @@ __global__ __launch_bounds__(YH_ST_BLOCK, WAVES) void k_stream(const yhd_scene s
   tc.sc = &sc, tc.sc_dev = sc_dev, tc.lds_stack = nullptr, tc.stats = nullptr;
   YH_LDS float* lds_cam;
   stage_tables(sc, lds_tabs, threadIdx.x, YH_ST_BLOCK, tc, lds_cam);  // shared by the block's waves
-  for (int s = lane; s < P; s += 64) l_free[s] = (unsigned short)s;
+  // slots [0, seeded) of this wave's pool hold pixels already — its own share of the work list, put there by k_stream_seed below —
+  // and start in the finish list (their first camera rays); the others are free
+  // (readfirstlane: the count is the same for the whole wave, and the compiler has to KNOW that — loaded per lane it makes every list count
+  // a vector register and the scheduler's branches divergent: 24 spill reloads in the step loop and 0.7 x on curly-hair, profiles/r05/k_stream_wave_shares.txt)
+  const int seeded = __builtin_amdgcn_readfirstlane(pl.wave_fill ? pl.wave_fill[(size_t)blockIdx.x * WPB + wib] : 0);
+  for (int s = lane; s < P; s += 64) {
+    if (s < seeded) l_fin[s] = (unsigned short)s;
+    else l_free[s - seeded] = (unsigned short)s;
+  }
   __syncthreads();  // the only workgroup barrier: from here on every wave runs on its own
 
-  const unsigned long long wl_begin = pl.wave_log ? wall_clock64() : 0ull;
-  unsigned long long       wl_steps = 0;
+  if (pl.wave_log && lane == 0) pl.wave_log[2 * wave_id] = wall_clock64();  // when this wave's work begins (written now: nothing to keep in a register)
   lane_stack stk;
   stk.lds = w_stack + lane, stk.ovf = pl.stack_ovf + wave_id * (size_t)pl.ovf_entries * 64 + lane, stk.sp = 0, stk.base = 0;
   tc.ls   = &stk;
   // lists (wave-uniform counts) and the ray this lane holds
-  int       n_ray = 0, n_done = 0, n_hair = 0, n_surf = 0, n_fin = 0, n_free = P;
+  int       n_ray = 0, n_done = 0, n_hair = 0, n_surf = 0, n_fin = seeded, n_free = P - seeded;
   int       my_group = (int)(blockIdx.x % (unsigned)st.num_groups), groups_done = 0;  // item group being taken from (yh_device.h)
   bool      nomore = false;
   bool      have = false;
   int       slot = 0;
-  // this wave's own share of the work list, taken before anything from the cursor (yh_device.h: yhd_stream::wave_begin)
-  int       own_next = pl.wave_begin ? pl.wave_begin[wave_id] : 0, own_end = pl.wave_begin ? pl.wave_begin[wave_id + 1] : 0;
   lane_trav t;
   lane_begin(sc, t, mk3(0.0f), mk3(1.0f), -1);
 
@@ -134,8 +139,7 @@ __global__ __launch_bounds__(YH_ST_BLOCK, WAVES) void k_stream(const yhd_scene s
     // path waits long for company. Finishing comes after shading (which ends paths) and runs once per round.
     int act;
     const bool flush = n_ray + nact < 64;
-    const int  want  = own_next < own_end ? min(4, own_end - own_next) : 4;  // work items of the next take: 4 = 64 pixels, fewer at the end of the wave's own share
-    if ((own_next < own_end || !nomore) && n_free >= 16 * want) act = A_ITEMS;
+    if (!nomore && n_free >= 64) act = A_ITEMS;
     else if (n_done > 0) act = A_SORT;
     else if (n_fin >= 64 || (flush && n_fin > 0)) act = A_FINISH;
     else if (n_hair >= 64 || (flush && n_hair > 0)) act = A_HAIR;
@@ -148,21 +152,18 @@ __global__ __launch_bounds__(YH_ST_BLOCK, WAVES) void k_stream(const yhd_scene s
     if (act == A_ITEMS) {
       // ---- items: free slots take the pixels of the next work items (4 items = 64 pixels) ------------------
       // the next items of this workgroup's group (its XCD's image region); a group that is used up hands over to the next
-      int t0 = 0, got = 0;
-      if (own_next < own_end) {  // the wave's own share first
-        t0 = own_next, got = want, own_next += want;
-      } else {
-        while (true) {
-          int c = 0;
-          if (lane == 0) c = atomicAdd(st.tile_cursor + 16 * my_group, want);
-          c   = __builtin_amdgcn_readfirstlane(c);
-          t0  = st.group_begin[my_group] + c;
-          got = max(0, min(want, st.group_begin[my_group + 1] - t0));
-          if (got > 0 || ++groups_done >= st.num_groups) break;
-          my_group = (my_group + 1) % st.num_groups;
-        }
-        if (got == 0) nomore = true;
+      int       t0 = 0, got = 0;
+      const int want = 4;
+      while (true) {
+        int c = 0;
+        if (lane == 0) c = atomicAdd(st.tile_cursor + 16 * my_group, want);
+        c   = __builtin_amdgcn_readfirstlane(c);
+        t0  = st.group_begin[my_group] + c;
+        got = max(0, min(want, st.group_begin[my_group + 1] - t0));
+        if (got > 0 || ++groups_done >= st.num_groups) break;
+        my_group = (my_group + 1) % st.num_groups;
       }
+      if (got == 0) nomore = true;
       int pixel = -1, item = 0;
       if (lane < 16 * got) {
         item     = st.tiles[t0 + (lane >> 4)];
@@ -255,7 +256,6 @@ __global__ __launch_bounds__(YH_ST_BLOCK, WAVES) void k_stream(const yhd_scene s
         } else {  // the pixel has all its samples: hand its stream back, report its work, free the slot
           st.rng_state[p] = rng.state;
           if (work) atomicAdd(&st.tile_cost[mt.z], work);
-          if (pl.wave_log) wl_steps += work;
           freed = true;
         }
       }
@@ -368,13 +368,37 @@ __global__ __launch_bounds__(YH_ST_BLOCK, WAVES) void k_stream(const yhd_scene s
       if (act == A_TRACE) atomicAdd(&pl.prof[24], p_steps), atomicAdd(&pl.prof[25], p_busy);
     }
   }
-  if (pl.wave_log) {  // when this wave's work began and ended, and how much it was (freed is per lane: sum over the wave)
-    for (int o = 32; o > 0; o >>= 1) wl_steps += (unsigned long long)__shfl_xor((long long)wl_steps, o);
-    if (lane == 0) {
-      unsigned long long* w = pl.wave_log + 4 * wave_id;
-      w[0] = wl_begin, w[1] = wall_clock64(), w[2] = wl_steps, w[3] = 0;
+  if (pl.wave_log && lane == 0) pl.wave_log[2 * wave_id + 1] = wall_clock64();  // ... and ends: what the next hand-out sizes the waves' shares by
+}
+
+
+// A WAVE'S OWN SHARE of the work list (yh_device.h: yhd_stream::wave_begin; one-generation images, host/launch_plan.cpp:
+// deal_shares_by_speed): one wavefront here per wavefront of k_stream puts the pixels of the share's entries into the first slots of that
+// wave's pool — what k_stream's items stage does with the entries it takes from the cursor — and says how many (wave_fill). A kernel of
+// its own, launched in front of k_stream: k_stream itself only learns how many of its slots are filled.
+__global__ __launch_bounds__(64) void k_stream_seed(const yhd_state st, int nsamples, const yhd_stream pl, int waves) {
+  const int wave_id = blockIdx.x, lane = threadIdx.x;
+  if (wave_id >= waves) return;
+  const size_t base = (size_t)wave_id * (size_t)pl.slots_per_wave;
+  int          n    = 0;
+  for (int t0 = pl.wave_begin[wave_id], t1 = pl.wave_begin[wave_id + 1]; t0 < t1; t0 += 4) {  // four entries = 64 pixels (padded with -1 = no item)
+    const int item  = st.tiles[t0 + (lane >> 4)];
+    const int tile  = item >> 2, part = item & 3, pq = lane & 15;
+    const int i     = (tile % st.tiles_x) * YH_TILE + (part & 1) * 4 + (pq & 3);
+    const int j     = (tile / st.tiles_x) * YH_TILE + (part >> 1) * 4 + (pq >> 2);
+    const int pixel = (item >= 0 && i < st.width && j < st.height) ? j * st.width + i : -1;
+    const bool               valid = pixel >= 0;
+    const unsigned long long m     = __ballot(valid);
+    if (valid && n + lane_rank(m) < pl.slots_per_wave) {  // (the host sizes the pool for the largest share)
+      const size_t   g  = base + (size_t)(n + lane_rank(m));
+      const uint64_t rs = st.rng_state[pixel], ri = st.rng_inc[pixel];
+      SLOT_META(pl, g)  = yhd_int4{pixel, nsamples, item, 0};
+      SLOT_RNG(pl, g)   = yhd_int4{(int)(unsigned)rs, (int)(unsigned)(rs >> 32), (int)(unsigned)ri, (int)(unsigned)(ri >> 32)};
+      SLOT_HIT(pl, g)   = yhd_int4{H_NEW, 0, 0, 0};
     }
+    n += (int)__popcll(m);
   }
+  if (lane == 0) pl.wave_fill[wave_id] = min(n, pl.slots_per_wave);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -532,6 +556,12 @@ int yhk_stream_occupancy(int lds_bytes, int general) {
 }
 int yhk_stream(const yhd_scene* sc, const yhd_scene* sc_dev, const yhd_state* st, int nsamples, const yhd_stream* pl, int grid_blocks,
     hipStream_t stream) {
+  if (pl->wave_begin && pl->wave_fill) {  // the waves' own shares into their pools first
+    const int waves = grid_blocks * (YH_ST_BLOCK / 64);
+    hipLaunchKernelGGL(k_stream_seed, dim3(waves), dim3(64), 0, stream, *st, nsamples, *pl, waves);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+  }
   int             lds  = yhk_stream_lds_bytes(YHD_LDS_TABLES_F4(sc), pl->slots_per_wave);
   stream_kernel_t kern = stream_kernel(sc->general_materials != 0, pl->prof != nullptr);
   if (lds > 64 * 1024) {

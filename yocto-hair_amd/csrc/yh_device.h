@@ -242,11 +242,13 @@ typedef struct yhd_stream {
   yhd_float4* medium;    // scenes with volumes only, 2 per slot
   unsigned int* stack_ovf;  // per wave: ovf_entries x 64 lanes, what the LDS stack window spills (dev_lane.h)
   unsigned long long* prof;    // developer build (YHAIR_ST_PROF): 32 counters, see stream.hip; else NULL
-  unsigned long long* wave_log;  // per wave {begin, end} of its work in ticks of the 100 MHz wall clock and {steps of its pixels, -}: 4 words; NULL = not kept
+  unsigned long long* wave_log;  // per wave {begin, end} of its work in ticks of the 100 MHz wall clock; NULL = not kept
   // A wave's OWN share of the work list (round 5): wave w starts with the entries [wave_begin[w], wave_begin[w + 1]) of yhd_state::tiles
+  // (a multiple of four entries, padded with -1 = no item: a take is four entries = 64 pixels)
   // — the host sizes the shares by how fast the wave's hardware slot runs (host/launch_plan.cpp: deal_items_for_stream) — and takes from
   // the cursor (the entries behind the shares: yhd_state::group_begin[0]) only after them. NULL: everything through the cursor.
   const int*  wave_begin;
+  int*        wave_fill;   // per wave: slots [0, wave_fill[w]) of its pool hold the pixels of its own share (k_stream_seed writes, k_stream reads); NULL with wave_begin
   int         slots_per_wave;  // multiple of 64, <= 4096
   int         ovf_entries;
   long long   total_slots;     // slots in the pool (all waves)

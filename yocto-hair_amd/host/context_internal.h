@@ -274,11 +274,11 @@ struct yh_context {
   int              chain = -1;   // 1: so few expensive items that even twice as many waves would all be resident: the launch is bound by the
                                  // chain of steps of ONE path, and the octet kernel (half the paths per wave, shape 4) is a candidate
   // path pool of the streaming integrator (csrc/stream.hip): per-wave slots, allocated at its first launch
-  DevBuf           d_st_slots, d_st_medium, d_st_ovf, d_st_prof, d_st_wave_log, d_st_wave_begin, d_scene_copy;
+  DevBuf           d_st_slots, d_st_medium, d_st_ovf, d_st_prof, d_st_wave_log, d_st_wave_begin, d_st_wave_fill, d_scene_copy;
   size_t           st_share_waves = 0;   // waves the per-wave shares of the work list were made for (0: none, everything through the cursor)
   std::vector<int>    st_share_begin, st_share_items;  // host copy of the shares in effect: offsets per wave, items in list order
   std::vector<double> st_share_cost;                   // ... and the cost each item was planned with
-  std::vector<unsigned long long> st_last_log;         // the last k_stream launch's stamps per wave {begin, end, steps, -}
+  std::vector<unsigned long long> st_last_log;         // the last k_stream launch's stamps per wave {begin, end}
   bool                st_log_fresh = false;            // ... not yet used by a hand-out, and taken on the shares above
   std::vector<float>  st_wave_speed;                   // per wave of the shares' launch geometry: its speed relative to its dispatch round's (deal_shares_by_speed)
   std::vector<float>  item_scale;                      // per work item: correction of its reported cost (BVH steps) towards the time it takes (deal_shares_by_speed)

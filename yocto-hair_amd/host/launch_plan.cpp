@@ -544,12 +544,12 @@ static bool deal_shares_by_speed(yh_context* ctx, std::vector<int>& items, int P
   // through per tick — planned cost over time, blended into stream_speed — and, per wave, how much longer or shorter it took than
   // its round's rate says: its items' costs are corrected by that ratio (the BVH steps an item reports are not all of its time: the same
   // waves end late launch after launch while the plan stands, correlation 0.96, and others do after a re-deal).
-  if (ctx->st_log_fresh && ctx->st_share_begin.size() == waves + 1 && ctx->st_last_log.size() == 4 * waves) {
+  if (ctx->st_log_fresh && ctx->st_share_begin.size() == waves + 1 && ctx->st_last_log.size() == 2 * waves) {
     const size_t rounds = round_of(waves - 1) + 1;
     std::vector<double> planned(waves, 0.0), took(waves, 0.0), pr(rounds, 0.0), tr(rounds, 0.0);
     for (size_t w = 0; w < waves; w++) {
       for (int k = ctx->st_share_begin[w]; k < ctx->st_share_begin[w + 1]; k++) planned[w] += ctx->st_share_cost[(size_t)k];
-      const unsigned long long* e = &ctx->st_last_log[4 * w];
+      const unsigned long long* e = &ctx->st_last_log[2 * w];
       took[w] = e[1] > e[0] ? (double)(e[1] - e[0]) : 0.0;
       if (took[w] > 0 && planned[w] > 0) pr[round_of(w)] += planned[w], tr[round_of(w)] += took[w];
     }
@@ -569,6 +569,7 @@ static bool deal_shares_by_speed(yh_context* ctx, std::vector<int>& items, int P
         const double ratio    = std::min(1.5, std::max(0.67, took[w] / expected));
         const float  corr     = (float)std::pow(ratio, 0.5);
         for (int k = ctx->st_share_begin[w]; k < ctx->st_share_begin[w + 1]; k++) {
+          if (ctx->st_share_items[(size_t)k] < 0) continue;  // padding
           float& sc = ctx->item_scale[(size_t)ctx->st_share_items[(size_t)k]];
           sc        = std::min(4.0f, std::max(0.25f, sc * corr));
         }
@@ -615,6 +616,7 @@ static bool deal_shares_by_speed(yh_context* ctx, std::vector<int>& items, int P
     begin[w] = (int)out.size();
     out.insert(out.end(), share[w].items.begin(), share[w].items.end());
     out_cost.insert(out_cost.end(), share[w].cost.begin(), share[w].cost.end());
+    while ((out.size() - (size_t)begin[w]) % 4 != 0) out.push_back(-1), out_cost.push_back(0.0);  // a take is four entries (csrc/stream.hip): -1 = no item
   }
   begin[waves] = (int)out.size();
   if (upload(ctx, ctx->d_st_wave_begin, begin.data(), begin.size() * 4) != YH_OK) return false;
@@ -627,7 +629,7 @@ static bool deal_shares_by_speed(yh_context* ctx, std::vector<int>& items, int P
 }
 // After a synchronous k_stream launch: keep the waves' stamps for the next hand-out (deal_shares_by_speed reads them once).
 void note_stream_wave_log(yh_context* ctx, const unsigned long long* log, size_t waves) {
-  ctx->st_last_log.assign(log, log + 4 * waves);
+  ctx->st_last_log.assign(log, log + 2 * waves);
   ctx->st_log_fresh = ctx->stream_pool.wave_begin != nullptr && ctx->st_share_waves == waves;  // (only a launch that ran on shares says something about them)
 }
 

@@ -170,10 +170,16 @@ int stream_impl(yh_context* ctx, int nsamples, bool sync) {
   // every launch keeps the waves' begin / end stamps and work (32 bytes per wave): the speeds of the hardware wave slots the next
   // hand-out is sized by (launch_plan.cpp: note_stream_wave_log); YHAIR_ST_WAVELOG prints their distribution
   const bool wave_log = getenv("YHAIR_ST_WAVELOG") != nullptr;
-  if (ctx->d_st_wave_log.bytes < waves * 32)
-    if ((rc = alloc_zero(ctx, ctx->d_st_wave_log, waves * 32))) return rc;
+  if (ctx->d_st_wave_log.bytes < waves * 16)
+    if ((rc = alloc_zero(ctx, ctx->d_st_wave_log, waves * 16))) return rc;
   ctx->stream_pool.wave_log = (unsigned long long*)ctx->d_st_wave_log.p;
-  if (ctx->stream_pool.wave_begin && ctx->st_share_waves != waves) ctx->stream_pool.wave_begin = nullptr;  // (shares made for another geometry: the list is then taken through the cursor, which starts behind them — cannot happen while both come from stream_geometry)
+  if (ctx->stream_pool.wave_begin && ctx->st_share_waves != waves) ctx->stream_pool.wave_begin = nullptr;
+  ctx->stream_pool.wave_fill = nullptr;
+  if (ctx->stream_pool.wave_begin) {
+    if (ctx->d_st_wave_fill.bytes < waves * 4)
+      if ((rc = alloc_zero(ctx, ctx->d_st_wave_fill, waves * 4))) return rc;
+    ctx->stream_pool.wave_fill = (int*)ctx->d_st_wave_fill.p;
+  }  // (shares made for another geometry: the list is then taken through the cursor, which starts behind them — cannot happen while both come from stream_geometry)
   if (!ctx->d_scene_copy.p) {  // the scene table in device memory, for the kernel's out-of-line callees
     if ((rc = upload(ctx, ctx->d_scene_copy, &ctx->scene, sizeof(yhd_scene)))) return rc;
   }
@@ -188,22 +194,22 @@ int stream_impl(yh_context* ctx, int nsamples, bool sync) {
   if (sync) {
     if (int wrc = wait_for_launch(ctx)) return wrc;
     HIPCHK(ctx, hipEventElapsedTime(&ctx->last_ms, ctx->ev0, ctx->ev1));
-    std::vector<unsigned long long> w(waves * 4);
+    std::vector<unsigned long long> w(waves * 2);
     HIPCHK(ctx, hipMemcpy(w.data(), ctx->d_st_wave_log.p, w.size() * 8, hipMemcpyDeviceToHost));
     note_stream_wave_log(ctx, w.data(), waves);
     if (wave_log) {
       unsigned long long t0 = ~0ull, t1 = 0;
-      for (size_t i = 0; i < waves; i++) t0 = std::min(t0, w[4 * i]), t1 = std::max(t1, w[4 * i + 1]);
+      for (size_t i = 0; i < waves; i++) t0 = std::min(t0, w[2 * i]), t1 = std::max(t1, w[2 * i + 1]);
       const double span = (double)(t1 - t0);
       // by hardware wave slot (= dispatch round of the wave's workgroup: num_cus workgroups per round) and by XCC (workgroup % 8)
-      double sum_slot[16] = {}, n_slot[16] = {}, sum_x[8] = {}, n_x[8] = {}, work_slot[16] = {}, start_slot[16] = {};
+      double sum_slot[16] = {}, n_slot[16] = {}, sum_x[8] = {}, n_x[8] = {}, start_slot[16] = {};
       std::vector<double> ends;
       double resident = 0;
       for (size_t i = 0; i < waves; i++) {
         const size_t blk = i / wpb;
         const int    sl = (int)std::min<size_t>(15, blk / ctx->num_cus), x = (int)(blk % 8);
-        const double e = (double)(w[4 * i + 1] - t0) / span, b = (double)(w[4 * i] - t0) / span;
-        sum_slot[sl] += e, n_slot[sl] += 1, sum_x[x] += e, n_x[x] += 1, work_slot[sl] += (double)w[4 * i + 2], start_slot[sl] += b;
+        const double e = (double)(w[2 * i + 1] - t0) / span, b = (double)(w[2 * i] - t0) / span;
+        sum_slot[sl] += e, n_slot[sl] += 1, sum_x[x] += e, n_x[x] += 1, start_slot[sl] += b;
         ends.push_back(e), resident += e - b;
       }
       {  // do the same waves end late launch after launch? correlation of the end stamps with the previous launch's (same wave count)
@@ -221,7 +227,7 @@ int stream_impl(yh_context* ctx, int nsamples, bool sync) {
       fprintf(stderr, "[yhair] k_stream wave log: %zu waves, span %.2f ms; a wave is resident %.3f of the span on average; ends at p10 %.3f p50 %.3f p90 %.3f p99 %.3f\n", waves,
           span / 1e5, resident / waves, ends[waves / 10], ends[waves / 2], ends[waves * 9 / 10], ends[waves * 99 / 100]);
       for (int k = 0; k < 16; k++)
-        if (n_slot[k] > 0) fprintf(stderr, "[yhair]   dispatch round %d: %4.0f waves, begin %.3f, mean end %.3f, mean work %.0f steps\n", k, n_slot[k], start_slot[k] / n_slot[k], sum_slot[k] / n_slot[k], work_slot[k] / n_slot[k]);
+        if (n_slot[k] > 0) fprintf(stderr, "[yhair]   dispatch round %d: %4.0f waves, begin %.3f, mean end %.3f\n", k, n_slot[k], start_slot[k] / n_slot[k], sum_slot[k] / n_slot[k]);
       fprintf(stderr, "[yhair]   mean end by XCC:");
       for (int k = 0; k < 8; k++) fprintf(stderr, " %.3f", n_x[k] > 0 ? sum_x[k] / n_x[k] : 0.0);
       fprintf(stderr, "\n");
