@@ -1134,11 +1134,15 @@ def test_stream_shares_render_the_quad_kernels_pixels(ctx, yh, res, shard, monke
         ctx.init_state(yh.TraceParams.default(resolution=res))
         for n in (3, 2, 1, 2, 1):
             ctx.trace_samples(n)
-        got[shape] = (ctx.download(), ctx.download_rng())
+        mid = (ctx.download(), ctx.download_rng())
+        ctx.trace_samples_counted(1)  # the instrumented (quad) launch behind a shared-out k_stream list: it must get a plain list of its own
+        ctx.trace_samples(2)          # ... and k_stream its shares back
+        got[shape] = mid + (ctx.download(), ctx.download_rng())
     monkeypatch.delenv("YHAIR_SHAPE")
     ctx.set_shard(0, 1)
     assert got["1"][0][..., 3].max() > 0
-    assert np.array_equal(got["1"][0], got["3"][0]) and np.array_equal(got["1"][1], got["3"][1])
+    for k in range(4):
+        assert np.array_equal(got["1"][k], got["3"][k]), k
     sf.close()
 
 

@@ -275,6 +275,7 @@ struct yh_context {
                                  // chain of steps of ONE path, and the octet kernel (half the paths per wave, shape 4) is a candidate
   // path pool of the streaming integrator (csrc/stream.hip): per-wave slots, allocated at its first launch
   DevBuf           d_st_slots, d_st_medium, d_st_ovf, d_st_prof, d_st_wave_log, d_st_wave_begin, d_st_wave_fill, d_scene_copy;
+  int              st_items = 0;         // work items of the list k_stream's hand-out was made for (deal_items_for_stream): what its launch geometry follows
   size_t           st_share_waves = 0;   // waves the per-wave shares of the work list were made for (0: none, everything through the cursor)
   std::vector<int>    st_share_begin, st_share_items;  // host copy of the shares in effect: offsets per wave, items in list order
   std::vector<double> st_share_cost;                   // ... and the cost each item was planned with

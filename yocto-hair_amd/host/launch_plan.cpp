@@ -638,6 +638,7 @@ void deal_items_for_stream(yh_context* ctx, std::vector<int>& items) {
   bool one = false;
   ctx->state.num_groups = 1, ctx->state.group_begin[0] = 0, ctx->state.group_begin[1] = (int)items.size();
   ctx->stream_pool.wave_begin = nullptr, ctx->st_share_waves = 0;
+  ctx->st_items = (int)items.size();  // the geometry of k_stream's launches follows the ITEMS of the list, not its entries (a shared-out list is padded)
   if (items.empty() || !stream_geometry(ctx, (int)items.size(), &P, &grid, nullptr, &one)) return;
   if (one && deal_shares_by_speed(ctx, items, P, grid)) return;
   const size_t R = (size_t)grid * (yhk_stream_block_threads() / 64) * (size_t)(P / 64);  // takes resident together

@@ -136,7 +136,7 @@ int yh_init_state(yh_context* ctx, const yh_trace_params* params) {
 // One launch of the streaming integrator (csrc/stream.hip): persistent wavefronts, one path pool each, one lane per path.
 int stream_impl(yh_context* ctx, int nsamples, bool sync) {
   int P = 0, grid = 0, lds_bytes = 0;
-  if (!stream_geometry(ctx, ctx->state.num_tiles, &P, &grid, &lds_bytes))
+  if (!stream_geometry(ctx, ctx->st_items > 0 ? ctx->st_items : ctx->state.num_tiles, &P, &grid, &lds_bytes))
     return fail(ctx, YH_E_DEVICE, "k_stream cannot run with its LDS layout on this device");
   const int     wpb    = yhk_stream_block_threads() / 64;
   const size_t  waves  = (size_t)grid * wpb, slots = waves * P;
@@ -280,6 +280,11 @@ int trace_impl(yh_context* ctx, int nsamples, bool counted, bool sync) {
       if (int rc = upload_work_items(ctx)) return rc;
     }
   }
+  if (counted && ctx->state.launch_shape == 3) {  // k_stream's list may be shared out per wave and padded with -1 (deal_shares_by_speed): the instrumented quad build needs a plain one
+    ctx->launch_shape = ctx->state.launch_shape = ctx->dense > 0 ? 1 : 0;
+    if (int wrc = wait_for_launch(ctx)) return wrc;
+    if (int rc = upload_work_items(ctx)) return rc;
+  }
   if (counted && (ctx->state.launch_shape == 5 || (ctx->state.launch_shape >= 4 && (ctx->scene.general_materials || ctx->state.launch_shape >= 7)))) {  // the octet kernel's list holds half-quadrant entries: the instrumented (quad) build needs its own
     ctx->launch_shape = ctx->state.launch_shape = 0;
     if (int wrc = wait_for_launch(ctx)) return wrc;
@@ -289,7 +294,7 @@ int trace_impl(yh_context* ctx, int nsamples, bool counted, bool sync) {
   if (counted && (shape == 3 || (shape >= 2 && ctx->scene.general_materials))) shape = shape == 3 ? 1 : 0;  // no instrumented build of k_stream, nor of the GENERAL 8-wide forms
   if (shape == 3 && !getenv("YHAIR_SHAPE")) {      // a candidate that cannot run here is dropped, not an error: k_trace renders the same bits
     int P = 0, grid = 0;
-    if (!stream_geometry(ctx, ctx->state.num_tiles, &P, &grid, nullptr)) {
+    if (!stream_geometry(ctx, ctx->st_items > 0 ? ctx->st_items : ctx->state.num_tiles, &P, &grid, nullptr)) {
       ctx->shape_ms[3] = std::numeric_limits<double>::infinity();
       shape = ctx->dense > 0 ? 1 : 0;
       ctx->launch_shape = ctx->state.launch_shape = shape;
