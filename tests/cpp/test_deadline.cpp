@@ -70,6 +70,36 @@ int main() {
     unsetenv("YHAIR_LAUNCH_TIMEOUT_S");
     CHECK(launch_timeout_s() == 1800.0);
   }
+  {  // BoundedCall: a blocking call that returns is DONE with its value, again and again on the same worker
+    BoundedCall bc;
+    int         r = -1, calls = 0;
+    CHECK(bc.run([&] { calls++; return 7; }, 5.0, &r) == WAIT_DONE && r == 7);
+    CHECK(bc.run([&] { calls++; std::this_thread::sleep_for(std::chrono::milliseconds(20)); return 9; }, 5.0, &r) == WAIT_DONE && r == 9);
+    CHECK(calls == 2 && !bc.expired());
+  }  // (the destructor joins the idle worker)
+  {  // ... one that NEVER returns (a kernel that never completes): EXPIRED at the deadline, every later call at once, and the destructor does not wait for it
+    auto t0 = std::chrono::steady_clock::now();
+    auto secs = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
+    {
+      BoundedCall bc;
+      int         r = -1;
+      CHECK(bc.run([] { std::this_thread::sleep_for(std::chrono::hours(1)); return 0; }, 0.2, &r) == WAIT_EXPIRED);
+      CHECK(secs() >= 0.2 && secs() < 1.0 && bc.expired() && r == -1);
+      const double t1 = secs();
+      CHECK(bc.run([] { return 1; }, 5.0, &r) == WAIT_EXPIRED && secs() - t1 < 0.05);
+    }
+    CHECK(secs() < 1.5);
+  }
+  {  // the latency of a wait that is already satisfied: two thread hand-overs, far below a millisecond on average
+    BoundedCall bc;
+    int         r = 0;
+    bc.run([] { return 0; }, 1.0, &r);
+    auto t0 = std::chrono::steady_clock::now();
+    for (int k = 0; k < 200; k++) bc.run([] { return 0; }, 1.0, &r);
+    const double per = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / 200;
+    CHECK(per < 1e-3);
+    printf("BoundedCall round trip: %.1f us\n", per * 1e6);
+  }
   printf(fails ? "deadline: %d checks FAILED\n" : "deadline: all checks passed\n", fails);
   return fails ? 1 : 0;
 }

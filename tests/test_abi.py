@@ -266,11 +266,12 @@ def test_leaf_group_merge_is_the_sequential_rule():
 
 def test_launch_deadline_logic(tmp_path):
     """The bounded wait behind yh_trace_samples / yh_synchronize (yocto-hair_amd/host/deadline.h), compiled
-    with a mocked event query and a fake clock: an event that never signals ends the wait AT the deadline (not before, at most
-    one 2 ms sleep after), one that signals ends it at once, a query error is passed on, the sleeps back off from 50 us to 2 ms,
-    and YHAIR_LAUNCH_TIMEOUT_S is parsed with the default for anything that is not a positive number."""
+    with mocked calls: BoundedCall (what the library uses: the blocking synchronise on a worker thread, the caller waiting with the
+    deadline) — a call that returns is DONE with its value, one that NEVER returns is EXPIRED at the deadline, every later call
+    at once, the destructor does not wait for it, and a satisfied wait costs microseconds; wait_until (the polling form) with a
+    mocked event query and a fake clock; YHAIR_LAUNCH_TIMEOUT_S parsed with the default for anything that is not a positive number."""
     exe = str(tmp_path / "test_deadline")
-    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I" + os.path.join(ROOT, "yocto-hair_amd", "host"),
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-pthread", "-I" + os.path.join(ROOT, "yocto-hair_amd", "host"),
                            os.path.join(ROOT, "tests", "cpp", "test_deadline.cpp"), "-o", exe])
     out = subprocess.run([exe], capture_output=True, text=True, timeout=60)
     assert out.returncode == 0 and "all checks passed" in out.stdout, out.stdout + out.stderr

@@ -1,9 +1,12 @@
 #!/bin/bash
 # The record set of a round (one gpurun call): GPU tests, the bench line (no flags, the driver's flags, under rocprofv3, two ranks), every config with its CPU leg.
-# usage: tools/round_records.sh TAG     (the kernel-trial record on disk: a directory of this run's own, so that no leg sees another process's trials except
+# usage: tools/round_records.sh TAG [a|b|all]    (a: tests + the C1 lines, b: two ranks + C2 / C3 / C4 — the whole set takes about 19 minutes, a gpurun call at most 20;
+# the kernel-trial record on disk: a directory of this run's own, so that no leg sees another process's trials except
 # where that is the point — ADVICE r04)
 cd $GRAFT_REPO_ROOT; out=gpurun_out/${1:-records}; mkdir -p $out; export TMPDIR=/tmp
 export YHAIR_CACHE_DIR=/tmp/yhair_records_cache_$$; rm -rf $YHAIR_CACHE_DIR
+part=${2:-all}
+if [ $part != b ]; then
 (time timeout -k 10 900 python -m pytest tests -m gpu -q --durations=8) > $out/gputests.log 2>&1; tail -4 $out/gputests.log
 grep -q " passed" $out/gputests.log || exit 1
 grep -q " failed" $out/gputests.log && exit 1
@@ -12,9 +15,12 @@ rm -rf $YHAIR_CACHE_DIR   # the driver's run starts on a fresh box: no record
 (time timeout -k 10 900 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench_C1_driver_flags.json 2> $out/bench_C1_driver_flags.err) 2> $out/bench_C1_driver_flags.time || exit 1
 (cd /tmp && timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$out/prof -o run -- python3 $GRAFT_REPO_ROOT/bench.py --gpus 1 --steps 20 --warmup 5 --no-end-to-end > $GRAFT_REPO_ROOT/$out/bench_C1_under_rocprof.json 2> $GRAFT_REPO_ROOT/$out/rocprof.log) || { tail -5 $out/rocprof.log; exit 1; }
 find $out/prof -name "*kernel_stats.csv" -exec cp {} $out/C1_default_cmd_kernel_stats.csv \; ; find $out/prof -name "*kernel_trace.csv" -exec cp {} $out/C1_default_cmd_kernel_trace.csv \; ; rm -rf $out/prof
+fi
+if [ $part != a ]; then
 timeout -k 10 900 python3 bench.py --gpus 2 > $out/bench_gpus2_bare.json 2> $out/bench_gpus2_bare.err || { tail -5 $out/bench_gpus2_bare.err; exit 1; }
 for bm in 0.1 0.25 0.6; do timeout -k 10 900 python3 bench.py --config C2 --beta-m $bm --steps 8 > $out/bench_C2_betam$bm.json 2> $out/bench_C2_betam$bm.err || exit 1; done
 for c in C3 C4; do timeout -k 10 900 python3 bench.py --config $c --steps 8 > $out/bench_$c.json 2> $out/bench_$c.err || exit 1; done
+fi
 rm -rf $YHAIR_CACHE_DIR
 python3 - $out <<'PY'
 import json,sys,glob,os

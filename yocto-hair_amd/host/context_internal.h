@@ -214,6 +214,7 @@ struct yh_context {
   int         num_cus = 0;
   std::string device_name;  // gcnArchName / marketing name / CU count: part of the key of the trial record on disk
   std::string error = "no error";
+  yhh::BoundedCall sync_call;    // the blocking hipStreamSynchronize of this context's stream, on a worker thread with a deadline (wait_for_launch)
   bool        poisoned = false;  // a launch of this context did not complete within its deadline (wait_for_launch): no further launches, nothing is freed
   // scene
   bool      have_scene = false;

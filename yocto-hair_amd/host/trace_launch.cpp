@@ -1,35 +1,27 @@
 // trace_launch.cpp — yh_init_state (pt.cpp:1931-1946) and the launches of the sample-loop kernels: yh_trace_samples and friends.
 #include "context_internal.h"
 
-// Waits for everything queued on the context's stream, at most YHAIR_LAUNCH_TIMEOUT_S seconds (host/deadline.h): an event recorded
-// behind the queued work is polled instead of blocking in hipStreamSynchronize, so that a kernel that never completes costs the
-// caller an error, not the process. On expiry the context is POISONED: the device may still be running the kernel, so every later
-// launch is refused and yh_destroy frees nothing (hipFree would wait for the kernel).
+// Waits for everything queued on the context's stream, at most YHAIR_LAUNCH_TIMEOUT_S seconds (host/deadline.h): the blocking
+// hipStreamSynchronize runs on the context's worker thread and this thread waits for it with the deadline, so that a kernel that never
+// completes costs the caller an error, not the process. On expiry the context is POISONED: the device may still be running the kernel
+// (and the worker is still inside the call), so every later call is refused and yh_destroy frees nothing (hipFree would wait too).
 int wait_for_launch(yh_context* ctx) {
   if (ctx->poisoned) return fail(ctx, YH_E_DEVICE, "a launch of this context exceeded its deadline: the context refuses further work, destroy it");
-  hipEvent_t ev = nullptr;
-  HIPCHK(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-  hipError_t e = hipEventRecord(ev, ctx->stream);
-  if (e != hipSuccess) {
-    (void)hipEventDestroy(ev);
-    return fail(ctx, YH_E_DEVICE, "hipEventRecord: %s", hipGetErrorString(e));
-  }
-  hipError_t   qe = hipSuccess;
   const double timeout = yhh::launch_timeout_s();
-  double       waited  = 0;
-  const int    rc = yhh::wait_until(
-      [&]() {
-        qe = hipEventQuery(ev);
-        return qe == hipSuccess ? yhh::QUERY_READY : (qe == hipErrorNotReady ? yhh::QUERY_NOT_READY : yhh::QUERY_ERROR);
+  const int    device  = ctx->device;
+  hipStream_t  stream  = ctx->stream;
+  int          e       = 0;
+  const int    rc      = ctx->sync_call.run(
+      [device, stream]() {
+        hipError_t se = hipSetDevice(device);
+        return (int)(se != hipSuccess ? se : hipStreamSynchronize(stream));
       },
-      timeout, []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); },
-      [](long us) { usleep((useconds_t)us); }, &waited);
+      timeout, &e);
   if (rc == yhh::WAIT_EXPIRED) {
-    ctx->poisoned = true;  // (the event is not destroyed: it is still pending on the device)
+    ctx->poisoned = true;
     return fail(ctx, YH_E_DEVICE, "the launch did not complete within %.3g s (YHAIR_LAUNCH_TIMEOUT_S): the context refuses further launches; destroy it and, to retry, start a fresh process", timeout);
   }
-  (void)hipEventDestroy(ev);
-  if (rc == yhh::WAIT_ERROR) return fail(ctx, YH_E_DEVICE, "hipEventQuery: %s", hipGetErrorString(qe));
+  if (e != (int)hipSuccess) return fail(ctx, YH_E_DEVICE, "hipStreamSynchronize: %s", hipGetErrorString((hipError_t)e));
   return YH_OK;
 }
 
