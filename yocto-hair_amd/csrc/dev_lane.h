@@ -7,15 +7,16 @@
 //                 repeated four times. Right when rays are scarce (a few expensive pixels bound the
 //                 launch: the chain of one path is what counts).
 //   dev_lane.h    one lane per ray, 64 rays per wavefront: a node step tests the four slots of the
-//                 wide node one after the other, a leaf step tests the leaf's primitives in the
-//                 reference's own sequential form (shrinking tmax after each accepted hit,
-//                 pt.cpp:905-923). Nothing is computed twice, so a ray costs about a third of the
-//                 vector instructions; right when every pixel is expensive (dense hair) and
-//                 throughput is what counts.
+//                 wide node one after the other; a line leaf's segments are tested by the WAVE, one
+//                 per lane, and the leaf's lane applies the reference's sequential accept rule to
+//                 the results (lane_step, COOP); a triangle leaf (and every leaf of the out-of-line
+//                 exact form) is tested by its own lane, two primitives per step, tmax shrinking
+//                 after each accepted hit (pt.cpp:905-923). Nothing is computed twice, so a ray
+//                 costs about a third of the vector instructions; right when every pixel is
+//                 expensive (dense hair) and throughput is what counts.
 //
-// A step is still ONE dependent fetch: whatever a lane holds — a wide node or a leaf — it loads
-// four 32-byte records (the node's slots, or the test halves of the leaf's primitives) with the
-// same eight dwordx4 loads; only the arithmetic diverges.
+// A step is still ONE dependent round trip: a lane loads the four 32-byte slots of its node (or the
+// test halves of its triangle leaf) and the one segment it tests for the wave, back to back.
 //
 // The traversal is a STEP function over explicit state (lane_trav), not a loop, so that the caller
 // can refill finished lanes from a ray list between steps and SUSPEND the unfinished rays of a wave
@@ -144,11 +145,25 @@ YH_DEV hit_t lane_hit(const trace_ctx& tc, hit_t raw, bool hit_lines, float hit_
 // One step of the ray in `t`. Returns true when the ray is finished (closest hit in t.hit), or —
 // EXACT = false only — when it has to be traced again by the EXACT form (`redo` set: a slab of a
 // box test could hold a NaN, dev_trace.h). `sp0` = stack height at which this ray started.
-template <bool EXACT, bool PROF = false>
-YH_DEV bool lane_step(const trace_ctx& tc, lane_trav& t, lane_stack& s, int sp0, bool& redo, float* pc = nullptr) {
+//
+// COOP (k_stream, k_intersect_lanes: every lane of the wave calls the step together, `active` = this lane holds a ray, `cmap` = 64 eight-byte
+// entries of the wave's own LDS): LINE LEAVES ARE TESTED BY THE WAVE, not by the lane that reached them. A leaf of the reference's tree holds
+// 1-4 segments (2.9 on average) and 12-17 of a wave's 64 lanes are at one in a step; tested by their own lanes, two segments one after the
+// other, the line test — the largest block of the step, 205 of 350 vector instructions — ran for a quarter of the lanes and a leaf took 1.67
+// steps. Here the segments of all those leaves are DEALT one per lane over the wave: a leaf lane's first test goes to lane `start` = the
+// number of tests of the leaf lanes below it (three ballots of the count's bits), it writes {itself, which segment, the record's place} for
+// each into cmap[start + i], lane j reads cmap[j], loads that one 32-byte record in the step's one round trip, pulls the ray of its source
+// lane across the wave (ds_bpermute: origin, direction, a, tmax) and runs the test ONCE per step, with ~ 35 lanes busy instead of 16. The
+// source lane pulls the distances of its tests back, applies the reference's sequential accept rule in leaf order (pt.cpp:905-923: a test
+// is accepted when !(t > tmax) with tmax = the last accepted distance — minimum t, the later segment on a tie; a test made with the step's
+// first tmax and re-checked against the running one gives the same answer) and pulls u, d2, r of the survivor. Tests that do not fit the 64
+// lanes stay in the entry for the next step. Triangle leaves and nodes are the lane's own as before.
+template <bool EXACT, bool PROF = false, bool COOP = false>
+YH_DEV bool lane_step(const trace_ctx& tc, lane_trav& t, lane_stack& s, int sp0, bool& redo, float* pc = nullptr, bool active = true,
+    YH_LDS unsigned long long* cmap = nullptr) {
   const yhd_scene& sc = *tc.sc;
   YH_MARK("step_begin");
-  YH_LPROF(LP_STEP)
+  if (!COOP || active) { YH_LPROF(LP_STEP) }
   auto box_test = [](f3 o, f3 dinv, float t0, float t1, f3 bmin, f3 bmax) {
     return EXACT ? intersect_bbox(o, dinv, t0, t1, bmin, bmax) : intersect_bbox_nonan(o, dinv, t0, t1, bmin, bmax);
   };
@@ -157,9 +172,13 @@ YH_DEV bool lane_step(const trace_ctx& tc, lane_trav& t, lane_stack& s, int sp0,
     if (tc.lds_scene) return ((const YH_LDS int*)(lds_snodes + 2 * sc.num_scene_nodes))[i];
     return sc.scene_prims[i];
   };
+  unsigned int tag  = 0;
+  bool         skip = true;
+  // The head of a step — pop, scene level, ENTER: what the lane does before its fetch. false: the ray has to be traced again (redo).
+  auto head = [&]() -> bool {
   if (!EXACT && !t.wnonan) {
     redo = true;
-    return true;
+    return false;
   }
   if (t.cur == YH_NONE && s.sp > sp0) {
     YH_MARK("pop");
@@ -168,8 +187,8 @@ YH_DEV bool lane_step(const trace_ctx& tc, lane_trav& t, lane_stack& s, int sp0,
   }
   YH_MARK("step_head");
   t.steps++;
-  unsigned int tag  = t.cur & YH_TAG_MASK;
-  bool         skip = t.cur == YH_NONE;  // only a scene without objects
+  tag  = t.cur & YH_TAG_MASK;
+  skip = t.cur == YH_NONE;  // only a scene without objects
   if (!skip && tag == YH_TAG_SCENE) {  // scene-level node (binary, the reference's layout)
     YH_MARK("scene");
     YH_LPROF(LP_SCENE)
@@ -230,7 +249,7 @@ YH_DEV bool lane_step(const trace_ctx& tc, lane_trav& t, lane_stack& s, int sp0,
       t.lsign = (t.ldinv.x < 0 ? 1 : 0) | (t.ldinv.y < 0 ? 2 : 0) | (t.ldinv.z < 0 ? 4 : 0);
       if (!EXACT && !(finite3(t.ldinv) && finite3(t.lo))) {
         redo = true;
-        return true;
+        return false;
       }
       {  // the shape's root in the blob (yhd_object::lane_root): fetched in this same step
         int root;
@@ -242,29 +261,25 @@ YH_DEV bool lane_step(const trace_ctx& tc, lane_trav& t, lane_stack& s, int sp0,
       tag   = YH_TAG_SHAPE;
     }
   }
+  return true;
+  };
+  bool aborted = false;
+  if (COOP) {
+    if (active) aborted = !head();
+    if (aborted) skip = true;
+  } else {
+    if (!active) return false;
+    if (!head()) return true;
+  }
   YH_MARK("after_enter");
-  if (!skip) {
-    YH_MARK("fetch");
-    YH_LPROF(LP_FETCH)
-    const bool         is_leaf  = tag == YH_TAG_LEAF;
-    const bool         lines    = t.kind == YH_KIND_LINES;
-    const int          leaf_num = (int)((t.cur >> 27) & 7u);
-    const unsigned int off      = t.cur & (is_leaf ? 0x07FFFFFFu : 0x3FFFFFFFu);  // 32-byte units into the blob
-    // Whatever the lane holds, its record is at lane_blob + 32 * off:
-    //   wide node      slot q = {A_q, B_q}
-    //   line leaf      segment i = {p0 r0, p1 r1} = {A_i, B_i}   (two per step)
-    //   triangle leaf  triangle i = {p0}{p1}{p2}{-} = {A_2i, B_2i, A_2i+1}   (two per step)
-    // ONE round trip, one 64-bit address; the second 64 bytes are fetched only by the lanes that use them.
-    const yhd_float4* a = sc.lane_blob + 2 * (size_t)off;
-    const v4f A0 = ldg4(a), B0 = ldg4(a + 1), A1 = ldg4(a + 2), B1 = ldg4(a + 3);
-    v4f       A2, B2, A3, B3;
-    if (!is_leaf || (!lines && leaf_num > 1)) A2 = ldg4(a + 4), B2 = ldg4(a + 5), A3 = ldg4(a + 6), B3 = ldg4(a + 7);
-    if (!is_leaf) {
+  v4f A0, B0, A1, B1, A2, B2, A3, B3;
+  // ---- wide node: the four slots {min.xyz, max.x} {max.yz, ref, axes}; refs are blob offsets, bits 8-11 of axes = occupied slots ----
+  auto node_code = [&]() {
       YH_MARK("node");
       YH_LPROF(LP_NODE)
-      // ---- wide node: the four slots {min.xyz, max.x} {max.yz, ref, axes}; refs are blob offsets, bits 8-11 of axes = occupied slots ----
       const unsigned int axes = __float_as_uint(B0.w);
       const unsigned int r0 = __float_as_uint(B0.z), r1 = __float_as_uint(B1.z), r2 = __float_as_uint(B2.z), r3 = __float_as_uint(B3.z);
+      if (COOP) asm volatile("" ::"v"(B1.w));
       unsigned int hm = 0;
       hm |= box_test(t.lo, t.ldinv, ray_eps, t.tmax, f3{A0.x, A0.y, A0.z}, f3{A0.w, B0.x, B0.y}) ? 1u : 0u;
       hm |= box_test(t.lo, t.ldinv, ray_eps, t.tmax, f3{A1.x, A1.y, A1.z}, f3{A1.w, B1.x, B1.y}) ? 2u : 0u;
@@ -292,6 +307,149 @@ YH_DEV bool lane_step(const trace_ctx& tc, lane_trav& t, lane_stack& s, int sp0,
           t.cur = ref;
         }
       }
+  };
+  // ---- triangle leaf: two triangles per step in leaf order, tmax shrinking after each accepted hit (pt.cpp:905-923) ----
+  auto tri_code = [&](unsigned int off, int leaf_num) {
+        YH_MARK("tri_leaf");
+        YH_LPROF(LP_TRI_LEAF)
+#define YH_LANE_ACCEPT_TRI(I)                                       \
+  if (ok && I < leaf_num) {                                         \
+    t.hit.object = t.cur_obj, t.hit.slot = (int)off + 2 * I;        \
+    t.hit.u = uu, t.hit.v = vv, t.hit.distance = dist;              \
+    t.tmax = dist, t.hit_lines = false;                             \
+  }
+        {
+          float uu = 0, vv = 0, dist = 0;
+          bool  ok = intersect_triangle(t.lo, t.ld, ray_eps, t.tmax, xyz(A0), xyz(B0), xyz(A1), uu, vv, dist);
+          YH_LANE_ACCEPT_TRI(0)
+        }
+        if (leaf_num > 1) {
+          float uu = 0, vv = 0, dist = 0;
+          bool  ok = intersect_triangle(t.lo, t.ld, ray_eps, t.tmax, xyz(A2), xyz(B2), xyz(A3), uu, vv, dist);
+          YH_LANE_ACCEPT_TRI(1)
+        }
+#undef YH_LANE_ACCEPT_TRI
+  };
+  if (COOP) {
+    const int          lane     = (int)__lane_id();
+    const bool         is_leaf  = !skip && tag == YH_TAG_LEAF;
+    const bool         lines    = t.kind == YH_KIND_LINES;
+    const bool         lf       = is_leaf && lines;
+    const int          leaf_num = (int)((t.cur >> 27) & 7u);
+    const unsigned int off      = t.cur & (is_leaf ? 0x07FFFFFFu : 0x3FFFFFFFu);  // 32-byte units into the blob
+    // ONE round trip for the lane's own node (or triangle leaf) and for the segment it tests for the wave. (The array's address is pinned in
+    // scalar registers here: left to itself the compiler re-reads it from the kernel arguments in front of each of the two groups of loads, and
+    // the wait for that scalar load — s_waitcnt vmcnt(0) lgkmcnt(0) — made the second group wait for the first: two round trips per step.)
+    YH_MARK("fetch");
+    typedef const __attribute__((address_space(1))) v4f* gptr;  // (global, said explicitly: a pointer that went through the asm below would be loaded from as `flat`, and a flat load holds up every LDS wait)
+    gptr blob;
+    {
+      unsigned long long b = (unsigned long long)sc.lane_blob;
+      asm volatile("" : "+s"(b));
+      blob = (gptr)b;
+    }
+    // the tests of the wave's line leaves, dealt over its lanes
+    const int                c  = lf ? min(leaf_num, 4) : 0;
+    const unsigned long long m0 = __ballot((c & 1) != 0), m1 = __ballot((c & 2) != 0), m2 = __ballot((c & 4) != 0);
+    const bool               any_leaf = (m0 | m1 | m2) != 0;  // (wave-uniform)
+    auto below = [](unsigned long long m) { return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)); };
+    int       start = 0, g = 0, total = 0;
+    bool      work  = false;
+    unsigned int w_off = 0, w_src = 0;
+    if (any_leaf) {
+      start = below(m0) + 2 * below(m1) + 4 * below(m2);
+      total = (int)__popcll(m0) + 2 * (int)__popcll(m1) + 4 * (int)__popcll(m2);
+      g     = max(0, min(c, 64 - start));
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+        if (i < g) cmap[start + i] = ((unsigned long long)(off + (unsigned)i) << 32) | (unsigned long long)((unsigned)lane | ((unsigned)i << 8));
+      work = lane < total;
+      if (work) {
+        const unsigned long long e = cmap[lane];
+        w_off = (unsigned int)(e >> 32), w_src = (unsigned int)e & 63u;
+      }
+    }
+    // (every lane loads — the lanes without a test the array's first record: with the loads in straight-line code behind the lane's own the
+    // compiler knows how many are in flight, and the node code waits for the lane's own only)
+    const v4f S0 = blob[2 * (size_t)w_off], S1 = blob[2 * (size_t)w_off + 1];
+    const bool own = !skip && !lf;
+    if (own) {
+      YH_LPROF(LP_FETCH)
+      gptr a = blob + 2 * (size_t)off;
+      // (a triangle leaf's second triangle whether it has one or not: no branch between the loads. The fourth word of slots 1-3' second half
+      // is read by nobody: loaded, its register would be handed to another value while the load is in flight, and that value's write would
+      // wait for the load)
+      typedef const __attribute__((address_space(1))) float* gfptr;
+      gfptr f = (gfptr)a;
+      A0 = a[0], B0 = a[1], A1 = a[2], B1 = a[3], A2 = a[4], A3 = a[6];
+      B2 = v4f{f[20], f[21], f[22], 0.0f}, B3 = v4f{f[28], f[29], f[30], 0.0f};  // (slot 1's comes as four words whatever is asked for: node_code keeps its register until the load is back)
+    }
+    // the source lane's ray, across the wave, while the loads are in flight (every lane takes part in the exchange: a pull reads the registers of
+    // a lane that may itself be idle)
+    auto pull = [](int addr, float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(v))); };
+    f3    wlo = mk3(0.0f), wld = mk3(0.0f);
+    float wa = 0.0f, wtmax = 0.0f;
+    if (any_leaf) {
+      const int sa = (int)(w_src << 2);
+      wlo = f3{pull(sa, t.lo.x), pull(sa, t.lo.y), pull(sa, t.lo.z)}, wld = f3{pull(sa, t.ld.x), pull(sa, t.ld.y), pull(sa, t.ld.z)};
+      wa = pull(sa, t.ld2), wtmax = pull(sa, t.tmax);
+    }
+    if (own && !is_leaf) node_code();
+    if (own && is_leaf) {
+      const unsigned int cur_next = leaf_num > 2 ? (YH_TAG_LEAF | ((unsigned)(leaf_num - 2) << 27) | (off + 4u)) : YH_NONE;
+      tri_code(off, leaf_num);
+      t.cur = cur_next;
+    }
+    if (any_leaf) {
+      YH_MARK("line_leaf");
+      float ss = 0, d2 = 0, rr = 0, key = -1.0f;  // key: the distance of an accepted test, -1 otherwise (an accepted t is >= ray_eps — or a NaN, which the rule below lets through as the reference's comparisons do)
+      if (work) {
+        YH_LPROF(LP_LINE_LEAF)
+        float dist;
+        const bool ok = intersect_line_raw(wlo, wld, wa, ray_eps, wtmax, xyz(S0), xyz(S1), S0.w, S1.w, ss, d2, rr, dist);
+        key = ok ? dist : -1.0f;
+      }
+      // back to the leaf's lane: the reference's accept rule over its tests in leaf order
+      float best = t.tmax;
+      int   win  = -1;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const float ki  = pull(((start + i) & 63) << 2, key);
+        const bool  acc = (i < g) & !(ki < 0.0f) & !(ki > best);
+        best = acc ? ki : best, win = acc ? i : win;
+      }
+      const int   wa2 = ((start + max(win, 0)) & 63) << 2;
+      const float wu = pull(wa2, ss), wv = pull(wa2, d2), wr = pull(wa2, rr);
+      if (lf) {
+        if (win >= 0) {
+          t.hit.object = t.cur_obj, t.hit.slot = (int)off + win;
+          t.hit.u = wu, t.hit.v = wv, t.hit_r = wr, t.hit.distance = best;
+          t.tmax = best, t.hit_lines = true;
+        }
+        const int rest = leaf_num - g;
+        t.cur = rest > 0 ? (YH_TAG_LEAF | ((unsigned)rest << 27) | (off + (unsigned)g)) : YH_NONE;
+      }
+    }
+    YH_MARK("step_end");
+    return active && (aborted || (t.cur == YH_NONE && s.sp == sp0));
+  }
+  if (!skip) {
+    YH_MARK("fetch");
+    YH_LPROF(LP_FETCH)
+    const bool         is_leaf  = tag == YH_TAG_LEAF;
+    const bool         lines    = t.kind == YH_KIND_LINES;
+    const int          leaf_num = (int)((t.cur >> 27) & 7u);
+    const unsigned int off      = t.cur & (is_leaf ? 0x07FFFFFFu : 0x3FFFFFFFu);  // 32-byte units into the blob
+    // Whatever the lane holds, its record is at lane_blob + 32 * off:
+    //   wide node      slot q = {A_q, B_q}
+    //   line leaf      segment i = {p0 r0, p1 r1} = {A_i, B_i}   (two per step)
+    //   triangle leaf  triangle i = {p0}{p1}{p2}{-} = {A_2i, B_2i, A_2i+1}   (two per step)
+    // ONE round trip, one 64-bit address; the second 64 bytes are fetched only by the lanes that use them.
+    const yhd_float4* a = sc.lane_blob + 2 * (size_t)off;
+    A0 = ldg4(a), B0 = ldg4(a + 1), A1 = ldg4(a + 2), B1 = ldg4(a + 3);
+    if (!is_leaf || (!lines && leaf_num > 1)) A2 = ldg4(a + 4), B2 = ldg4(a + 5), A3 = ldg4(a + 6), B3 = ldg4(a + 7);
+    if (!is_leaf) {
+      node_code();
     } else {
       YH_MARK("leaf");
       // ---- leaf: its primitives in leaf order, tmax shrinking after each accepted hit (pt.cpp:905-923) ----
@@ -317,25 +475,7 @@ YH_DEV bool lane_step(const trace_ctx& tc, lane_trav& t, lane_stack& s, int sp0,
           YH_LANE_ACCEPT_LINE(1)
         }
       } else {
-        YH_MARK("tri_leaf");
-        YH_LPROF(LP_TRI_LEAF)
-#define YH_LANE_ACCEPT_TRI(I)                                       \
-  if (ok && I < leaf_num) {                                         \
-    t.hit.object = t.cur_obj, t.hit.slot = (int)off + 2 * I;        \
-    t.hit.u = uu, t.hit.v = vv, t.hit.distance = dist;              \
-    t.tmax = dist, t.hit_lines = false;                             \
-  }
-        {
-          float uu = 0, vv = 0, dist = 0;
-          bool  ok = intersect_triangle(t.lo, t.ld, ray_eps, t.tmax, xyz(A0), xyz(B0), xyz(A1), uu, vv, dist);
-          YH_LANE_ACCEPT_TRI(0)
-        }
-        if (leaf_num > 1) {
-          float uu = 0, vv = 0, dist = 0;
-          bool  ok = intersect_triangle(t.lo, t.ld, ray_eps, t.tmax, xyz(A2), xyz(B2), xyz(A3), uu, vv, dist);
-          YH_LANE_ACCEPT_TRI(1)
-        }
-#undef YH_LANE_ACCEPT_TRI
+        tri_code(off, leaf_num);
       }
 #undef YH_LANE_ACCEPT_LINE
     }

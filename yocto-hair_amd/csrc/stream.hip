@@ -13,7 +13,7 @@
 //   finish   ended samples are clamped and accumulated (trace_sample, pt.cpp:1683-1688), misses look up
 //            the environment first; pixels with samples left get their next camera ray
 //   trace    one ray per lane (dev_lane.h); a lane that finishes its ray takes the next one of the ray
-//            list; when the list is dry and fewer than YH_SUSPEND_LANES lanes are busy the wave goes
+//            list; when the list is dry and at most yhd_stream::suspend_lanes lanes are busy the wave goes
 //            shading and the unfinished rays stay where they are — in registers, their stacks in the
 //            lanes' LDS columns — until the next trace stage
 //   sort     finished rays by what they hit: hair / surface / miss
@@ -35,8 +35,11 @@ using namespace yhd;
 
 #define YH_ST_BLOCK 256
 #define YH_ST_WAVES 4        /* waves per SIMD the register allocator must allow */
+#define YH_ST_WAVE_LDS(P) (64 * YH_LSTACK * 4 + 64 * 8 + 6 * (P) * 2) /* LDS of one wave */
 #define YH_REFILL_LANES 16   /* idle lanes of a wave before the (divergent) refill code runs */
-#define YH_SUSPEND_LANES 16  /* ray list dry and at most this many lanes busy: go shading */
+#define YH_SUSPEND_LANES 16  /* ray list dry and at most this many lanes busy: go shading. The default of yhd_stream::suspend_lanes, which the host sets:
+                                16 for images of several generations, 8 when the resident pools hold the whole image at once (C2: 303-316 -> 330-339 Msamples/s
+                                with the cooperative leaves, C3 349 -> 334-340 the other way: profiles/r05/coop_line_leaves.txt) */
 // (tuned in rounds 2 and 4, profiles/r02/k_stream_sweep_slots_suspend.txt, profiles/r04/k_stream_tuning_after_blob.txt; the other
 // scheduling policy, items taken sixteen slots at a time and the field-by-field pool layout are closed A/Bs of the same records)
 
@@ -50,10 +53,10 @@ using namespace yhd;
 #define SLOT_RNG(pl, g) (*(yhd_int4*)&SLOT_F4(pl, g, 5))
 #define SLOT_META(pl, g) (*(yhd_int4*)&SLOT_F4(pl, g, 6))
 
-// Progress: a trace stage that leaves with rays suspended (<= YH_SUSPEND_LANES busy lanes, something pending) must be
+// Progress: a trace stage that leaves with rays suspended (<= suspend_lanes busy lanes, something pending) must be
 // followed by a stage that consumes what is pending — the scheduler flushes partial batches when fewer than 64 rays are at
 // hand — or the two would hand the wave back and forth forever.
-static_assert(YH_SUSPEND_LANES < 64, "the trace stage's exit condition must imply the scheduler's flush condition");
+static_assert(YH_SUSPEND_LANES < 64, "the trace stage's exit condition must imply the scheduler's flush condition");  // (yhk_stream refuses suspend_lanes >= 64)
 enum { K_HAIR = 0, K_SURF = 1, K_MISS = 2, K_REDO = 3 };  // what a finished ray found (bits 12-13 of a done-list entry)
 enum { H_MISS = -1, H_ENDED = -2, H_NEW = -3 };            // yhd_stream::hit.x of a slot in the finish list
 
@@ -86,13 +89,14 @@ __global__ __launch_bounds__(YH_ST_BLOCK, WAVES) void k_stream(const yhd_scene s
   constexpr int WPB = YH_ST_BLOCK / 64;
   extern __shared__ v4f lds_dyn[];
   const int P = pl.slots_per_wave;
-  // LDS: [tables: scene level | camera | small lights | env cdf index][per wave: stack window 64 x YH_LSTACK | six lists of P slot ids]
+  // LDS: [tables: scene level | camera | small lights | env cdf index][per wave: stack window 64 x YH_LSTACK | who tests which segment (dev_lane.h: COOP) | six lists of P slot ids]
   YH_LDS v4f*   lds_tabs  = (YH_LDS v4f*)lds_dyn;  // dev_trace.h: stage_tables
-  const int     wave_lds  = 64 * YH_LSTACK * 4 + 6 * P * 2;
-  const int     lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+  const int     wave_lds  = YH_ST_WAVE_LDS(P);
+  const int     lane = threadIdx.x & 63, wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // (the wave's index, known to be uniform: the addresses of its lists live in scalar registers)
   YH_LDS unsigned char*  wbase   = (YH_LDS unsigned char*)(lds_tabs + YHD_LDS_TABLES_F4(&sc)) + wib * wave_lds;
   YH_LDS unsigned int*   w_stack = (YH_LDS unsigned int*)wbase;
-  YH_LDS unsigned short* l_ray   = (YH_LDS unsigned short*)(w_stack + 64 * YH_LSTACK);
+  YH_LDS unsigned long long* w_cmap = (YH_LDS unsigned long long*)(w_stack + 64 * YH_LSTACK);
+  YH_LDS unsigned short* l_ray   = (YH_LDS unsigned short*)(w_stack + 64 * YH_LSTACK + 128);
   YH_LDS unsigned short* l_done  = l_ray + P;
   YH_LDS unsigned short* l_hair  = l_done + P;
   YH_LDS unsigned short* l_surf  = l_hair + P;
@@ -332,13 +336,13 @@ __global__ __launch_bounds__(YH_ST_BLOCK, WAVES) void k_stream(const yhd_scene s
         if (busy == 0) break;
         // Leave for the shading stages when the ray list is dry and either a full batch of hair hits has gathered
         // or few lanes are busy; the unfinished rays stay in their lanes.
-        if (n_ray == 0 && busy <= YH_SUSPEND_LANES && (n_done | n_hair | n_surf | n_fin) != 0) break;
+        if (n_ray == 0 && busy <= pl.suspend_lanes && (n_done | n_hair | n_surf | n_fin) != 0) break;
         if (PROF) p_steps++, p_busy += (unsigned long long)busy;
         bool fin  = false;
         int  kind = 0;
-        if (have) {
+        {
           bool redo = false;
-          if (lane_step<false, PROF>(tc, t, stk, 0, redo, pc)) {
+          if (lane_step<false, PROF, true>(tc, t, stk, 0, redo, pc, have, w_cmap)) {  // (every lane: the wave tests its line leaves together)
             YH_MARK("trace_retire");
             have = false, fin = true;
             if (redo) {
@@ -413,7 +417,8 @@ __global__ __launch_bounds__(256, WAVES) void k_intersect_lanes(const yhd_scene 
   extern __shared__ v4f lds_dyn[];
   YH_LDS v4f* lds_tabs = (YH_LDS v4f*)lds_dyn;
   const int   lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
-  YH_LDS unsigned int* w_stack = (YH_LDS unsigned int*)(lds_tabs + YHD_LDS_TABLES_F4(&sc)) + wib * 64 * YH_LSTACK;
+  YH_LDS unsigned int* w_stack = (YH_LDS unsigned int*)(lds_tabs + YHD_LDS_TABLES_F4(&sc)) + wib * (64 * YH_LSTACK + 128);
+  YH_LDS unsigned long long* w_cmap = (YH_LDS unsigned long long*)(size_t)__builtin_amdgcn_readfirstlane((unsigned int)(size_t)(w_stack + 64 * YH_LSTACK));
   trace_ctx tc;
   tc.sc = &sc, tc.sc_dev = sc_dev, tc.lds_stack = nullptr, tc.stats = nullptr;
   YH_LDS float* lds_cam;
@@ -448,9 +453,9 @@ __global__ __launch_bounds__(256, WAVES) void k_intersect_lanes(const yhd_scene 
       if (dry) break;
       continue;
     }
-    if (have) {
+    {
       bool redo = false;
-      if (lane_step<false>(tc, t, stk, 0, redo)) {
+      if (lane_step<false, false, true>(tc, t, stk, 0, redo, nullptr, have, w_cmap)) {
         have = false;
         hit_t h = lane_hit(tc, t.hit, t.hit_lines, t.hit_r);
         if (redo) {  // axis-parallel ray: the reference's compare-and-select box test throughout
@@ -517,7 +522,7 @@ int yhk_lane_blob_shape(const yhd_float4* nodes, const yhd_float4* prims, yhd_fl
 // waves: 4, 6 or 8 per SIMD (the register budget: 128 / 80 / 64)
 typedef void (*lanes_kernel_t)(const yhd_scene, const yhd_scene*, int, const float*, int*, unsigned int*, int, int*, int*, float*, float*);
 static lanes_kernel_t lanes_kernel(int waves) { return waves >= 8 ? k_intersect_lanes<8> : waves >= 6 ? k_intersect_lanes<6> : k_intersect_lanes<4>; }
-int yhk_intersect_lanes_lds(const yhd_scene* sc) { return YHD_LDS_TABLES_F4(sc) * 16 + 4 * 64 * YH_LSTACK * 4; }
+int yhk_intersect_lanes_lds(const yhd_scene* sc) { return YHD_LDS_TABLES_F4(sc) * 16 + 4 * (64 * YH_LSTACK * 4 + 64 * 8); }
 int yhk_intersect_lanes_occupancy(const yhd_scene* sc, int waves) {
   int blocks = 0, lds = yhk_intersect_lanes_lds(sc);
   lanes_kernel_t k = lanes_kernel(waves);
@@ -544,7 +549,7 @@ static stream_kernel_t stream_kernel(bool general, bool prof = false) {
 }
 int yhk_stream_block_threads(void) { return YH_ST_BLOCK; }
 int yhk_stream_lds_bytes(int tables_f4, int slots_per_wave) {
-  return tables_f4 * 16 + (YH_ST_BLOCK / 64) * (64 * YH_LSTACK * 4 + 6 * slots_per_wave * 2);
+  return tables_f4 * 16 + (YH_ST_BLOCK / 64) * YH_ST_WAVE_LDS(slots_per_wave);
 }
 int yhk_stream_occupancy(int lds_bytes, int general) {
   int             blocks = 0;
@@ -556,6 +561,7 @@ int yhk_stream_occupancy(int lds_bytes, int general) {
 }
 int yhk_stream(const yhd_scene* sc, const yhd_scene* sc_dev, const yhd_state* st, int nsamples, const yhd_stream* pl, int grid_blocks,
     hipStream_t stream) {
+  if (pl->suspend_lanes < 0 || pl->suspend_lanes >= 64) return (int)hipErrorInvalidValue;
   if (pl->wave_begin && pl->wave_fill) {  // the waves' own shares into their pools first
     const int waves = grid_blocks * (YH_ST_BLOCK / 64);
     hipLaunchKernelGGL(k_stream_seed, dim3(waves), dim3(64), 0, stream, *st, nsamples, *pl, waves);

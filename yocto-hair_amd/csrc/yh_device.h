@@ -252,6 +252,7 @@ typedef struct yhd_stream {
   int         slots_per_wave;  // multiple of 64, <= 4096
   int         ovf_entries;
   long long   total_slots;     // slots in the pool (all waves)
+  int         suspend_lanes;   // a wave whose ray list is dry leaves the trace stage for the shading stages when at most this many of its lanes are busy (< 64; stream.hip)
 } yhd_stream;
 
 // Work counters (one 64-bit slot each), accumulated with atomics by the

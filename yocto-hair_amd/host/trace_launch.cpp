@@ -127,8 +127,9 @@ int yh_init_state(yh_context* ctx, const yh_trace_params* params) {
 
 // One launch of the streaming integrator (csrc/stream.hip): persistent wavefronts, one path pool each, one lane per path.
 int stream_impl(yh_context* ctx, int nsamples, bool sync) {
-  int P = 0, grid = 0, lds_bytes = 0;
-  if (!stream_geometry(ctx, ctx->st_items > 0 ? ctx->st_items : ctx->state.num_tiles, &P, &grid, &lds_bytes))
+  int  P = 0, grid = 0, lds_bytes = 0;
+  bool one_generation = false;
+  if (!stream_geometry(ctx, ctx->st_items > 0 ? ctx->st_items : ctx->state.num_tiles, &P, &grid, &lds_bytes, &one_generation))
     return fail(ctx, YH_E_DEVICE, "k_stream cannot run with its LDS layout on this device");
   const int     wpb    = yhk_stream_block_threads() / 64;
   const size_t  waves  = (size_t)grid * wpb, slots = waves * P;
@@ -151,6 +152,7 @@ int stream_impl(yh_context* ctx, int nsamples, bool sync) {
     ctx->st_ovf_words = ovf_words, ctx->stream_pool.stack_ovf = (unsigned int*)ctx->d_st_ovf.p;
   }
   ctx->stream_pool.slots_per_wave = P, ctx->stream_pool.ovf_entries = ovf_entries, ctx->stream_pool.total_slots = (long long)ctx->st_slots;
+  ctx->stream_pool.suspend_lanes  = one_generation ? 8 : 16;  // (csrc/stream.hip: YH_SUSPEND_LANES)
   if ((rc = ensure_lane_blob(ctx))) return rc;
   const bool prof = getenv("YHAIR_ST_PROF") && atoi(getenv("YHAIR_ST_PROF")) != 0;  // developer switch: per-stage counters on stderr
   if (prof) {
