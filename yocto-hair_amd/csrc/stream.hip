@@ -34,7 +34,7 @@
 using namespace yhd;
 
 #define YH_ST_BLOCK 256
-#define YH_ST_WAVES 4        /* waves per SIMD the register allocator must allow */
+#define YH_ST_WAVES 4        /* waves per SIMD the register allocator must allow (5 = 96 registers puts 28 spill instructions into the step loop: profiles/r05/coop_line_leaves.txt) */
 #define YH_ST_WAVE_LDS(P) (64 * YH_LSTACK * 4 + 64 * 8 + 6 * (P) * 2) /* LDS of one wave */
 #define YH_REFILL_LANES 16   /* idle lanes of a wave before the (divergent) refill code runs */
 #define YH_SUSPEND_LANES 16  /* ray list dry and at most this many lanes busy: go shading. The default of yhd_stream::suspend_lanes, which the host sets:
