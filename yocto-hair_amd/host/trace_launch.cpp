@@ -11,10 +11,21 @@ int wait_for_launch(yh_context* ctx) {
   const int    device  = ctx->device;
   hipStream_t  stream  = ctx->stream;
   int          e       = 0;
+  // The worker SPINS on the launch's end event for as long as launches of this context have been taking (at most 50 ms), then blocks:
+  // the blocking wait of the HIP runtime sleeps on an interrupt and wakes up tens of microseconds after the kernel has ended — for the
+  // bench's 15 ms launches that is most of what the library adds to a step (profiles/r05/bounded_wait_overhead.txt).
+  hipEvent_t   ev_end  = ctx->ev1;
+  const double spin_s  = getenv("YHAIR_NO_SPIN") ? 0.0 : std::min(0.050, 1.25e-3 * (double)ctx->last_ms + 0.001);
   const int    rc      = ctx->sync_call.run(
-      [device, stream]() {
+      [device, stream, ev_end, spin_s]() {
         hipError_t se = hipSetDevice(device);
-        return (int)(se != hipSuccess ? se : hipStreamSynchronize(stream));
+        if (se != hipSuccess) return (int)se;
+        if (spin_s > 0) {
+          const auto t0 = std::chrono::steady_clock::now();
+          while (hipEventQuery(ev_end) == hipErrorNotReady)
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > spin_s) break;
+        }
+        return (int)hipStreamSynchronize(stream);
       },
       timeout, &e);
   if (rc == yhh::WAIT_EXPIRED) {
