@@ -15,7 +15,7 @@ int wait_for_launch(yh_context* ctx) {
   // the blocking wait of the HIP runtime sleeps on an interrupt and wakes up tens of microseconds after the kernel has ended — for the
   // bench's 15 ms launches that is most of what the library adds to a step (profiles/r05/bounded_wait_overhead.txt).
   hipEvent_t   ev_end  = ctx->ev1;
-  const double spin_s  = getenv("YHAIR_NO_SPIN") ? 0.0 : std::min(0.050, 1.25e-3 * (double)ctx->last_ms + 0.001);
+  const double spin_s  = std::min(0.050, 1.25e-3 * (double)ctx->last_ms + 0.001);
   const int    rc      = ctx->sync_call.run(
       [device, stream, ev_end, spin_s]() {
         hipError_t se = hipSetDevice(device);
