@@ -273,6 +273,37 @@ def test_closest_hits_bit_exact(ctx, oracle, yh, name, kw):
     osc.close(), sf.close()
 
 
+@pytest.mark.parametrize("name,kw", [GOLDEN_SCENES[1], GOLDEN_SCENES[4]], ids=[IDS[1], IDS[4]])
+def test_crowded_waves_test_their_leaves_together(ctx, oracle, yh, name, kw):
+    """The one-lane traversal deals the segments of a wave's line leaves one per lane (csrc/dev_lane.h: lane_step, COOP) and keeps the tests
+    that do not fit the 64 lanes for the next step. Random rays rarely crowd a wave; here every wave's 64 rays are THE SAME ray (or the same
+    up to an ulp of the origin), so all its lanes reach the same leaves in the same steps — up to 256 tests per step for 64 lanes — and every
+    leaf is split over steps. Closest hits must still be the oracle's, bit for bit (and the quad kernel's)."""
+    g = golden(f"scene_{scene_tag(name, kw)}.npz")
+    sf = yh.SceneFile(scene_path(name, **kw))
+    ctx.upload_scene(sf.desc)
+    base = g["rays"][g["object"] >= 0][:1100]
+    assert len(base) >= 64
+    base = np.tile(base, (1100 // len(base) + 1, 1))[:1100]
+    rays = np.repeat(base, 64, axis=0).copy()          # 64 consecutive rays = one wave's lanes (k_intersect_lanes hands rays out in order)
+    odd = np.arange(len(rays)) % 64 >= 48               # a quarter of each wave an ulp off: not all lanes in perfect step
+    rays[odd, 0] = np.nextafter(rays[odd, 0], np.float32(np.inf))
+    assert len(rays) >= 65536                           # the one-lane kernel (host/batch_api.cpp)
+    osc = oracle.scene(sf.desc)
+    ho, hg = osc.intersect(rays), ctx.intersect(rays)
+    for a, b in zip(ho, hg):
+        assert np.array_equal(a, b)
+    assert np.mean(hg[0] >= 0) > 0.9
+    os.environ["YHAIR_INTERSECT"] = "quad"
+    try:
+        hq = ctx.intersect(rays)
+    finally:
+        del os.environ["YHAIR_INTERSECT"]
+    for a, b in zip(hq, hg):
+        assert np.array_equal(a, b)
+    osc.close(), sf.close()
+
+
 @pytest.mark.parametrize("name,kw", GOLDEN_SCENES, ids=IDS)
 def test_images_match_reference_statistically(ctx, yh, name, kw):
     g = golden(f"scene_{scene_tag(name, kw)}.npz")
