@@ -211,7 +211,9 @@ const char* yh_version(void);
  * scene's trees as one array of 32-byte units with 27-bit leaf references and 30-bit node references — a line segment takes one
  * unit, a triangle two, a 4-wide node four — i.e. about 134 M segments or 67 M triangles in ALL shapes together (instances share
  * their shape); at most 4 environments and 16 lights. Scenes of more than ~46 objects or 24 materials run the GENERAL
- * kernel variants (their tables do not fit the LDS budget): slower, same pixels.                                         */
+ * kernel variants (their tables do not fit the LDS budget): slower, same pixels. The one-lane kernels (the streaming integrator
+ * of dense hair, large closest-hit batches) address that array with 32-bit byte offsets: beyond 4 GB of it (about fifty million
+ * segments) they are not candidates and the quad kernels render — same pixels.                                                */
 int yh_upload_scene(yh_context* ctx, const yh_scene_desc* scene);
 
 /* init_state (yocto_pathtrace.cpp:1931-1946): image size from the camera film

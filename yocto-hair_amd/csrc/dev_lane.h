@@ -279,7 +279,7 @@ YH_DEV bool lane_step(const trace_ctx& tc, lane_trav& t, lane_stack& s, int sp0,
       YH_LPROF(LP_NODE)
       const unsigned int axes = __float_as_uint(B0.w);
       const unsigned int r0 = __float_as_uint(B0.z), r1 = __float_as_uint(B1.z), r2 = __float_as_uint(B2.z), r3 = __float_as_uint(B3.z);
-      if (COOP) asm volatile("" ::"v"(B1.w));
+      if (COOP) asm volatile("" ::"v"(B1.w), "v"(B2.w), "v"(B3.w));  // (words nobody reads: their registers stay the loads' until the loads are back — handed to another value, that value's write would wait for the load)
       unsigned int hm = 0;
       hm |= box_test(t.lo, t.ldinv, ray_eps, t.tmax, f3{A0.x, A0.y, A0.z}, f3{A0.w, B0.x, B0.y}) ? 1u : 0u;
       hm |= box_test(t.lo, t.ldinv, ray_eps, t.tmax, f3{A1.x, A1.y, A1.z}, f3{A1.w, B1.x, B1.y}) ? 2u : 0u;
@@ -337,16 +337,23 @@ YH_DEV bool lane_step(const trace_ctx& tc, lane_trav& t, lane_stack& s, int sp0,
     const bool         lf       = is_leaf && lines;
     const int          leaf_num = (int)((t.cur >> 27) & 7u);
     const unsigned int off      = t.cur & (is_leaf ? 0x07FFFFFFu : 0x3FFFFFFFu);  // 32-byte units into the blob
-    // ONE round trip for the lane's own node (or triangle leaf) and for the segment it tests for the wave. (The array's address is pinned in
-    // scalar registers here: left to itself the compiler re-reads it from the kernel arguments in front of each of the two groups of loads, and
-    // the wait for that scalar load — s_waitcnt vmcnt(0) lgkmcnt(0) — made the second group wait for the first: two round trips per step.)
     YH_MARK("fetch");
-    typedef const __attribute__((address_space(1))) v4f* gptr;  // (global, said explicitly: a pointer that went through the asm below would be loaded from as `flat`, and a flat load holds up every LDS wait)
-    gptr blob;
+    // ONE round trip for the lane's own node (or triangle leaf) and for the segment it tests for the wave, through BUFFER LOADS: a lane that
+    // has nothing to fetch hands the load an offset beyond the end of the array — the address unit answers zeros without touching memory — so
+    // every load is unconditional. No branch around any of them: the compiler counts what is in flight exactly (with loads in two arms of a
+    // branch it waits for ALL of them at the join, and the first form of this step made two dependent round trips that way:
+    // profiles/r05/coop_line_leaves.txt), the lane's own node goes out BEFORE the exchange that finds the segments' lanes (its LDS round trip
+    // runs under the memory's), and a lane without a test costs the segment loads nothing. (32-bit offsets: the array has to end below 4 GB,
+    // host/launch_plan.cpp: lane_kernels_can_address.)
+    typedef unsigned int v4u_ __attribute__((ext_vector_type(4)));
+    const unsigned int blob_bytes = (unsigned int)min((long long)sc.lane_blob_units * 32ll, 0xFFFFFE00ll);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)sc.lane_blob, 0, (int)blob_bytes, 0x00020000);
+    auto bload = [&](unsigned int byte_off) { v4u_ r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, 0); return v4f{__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w)}; };
+    const bool own = !skip && !lf;
     {
-      unsigned long long b = (unsigned long long)sc.lane_blob;
-      asm volatile("" : "+s"(b));
-      blob = (gptr)b;
+      const unsigned int o = own ? off * 32u : 0xFFFFFF00u;
+      if (own) { YH_LPROF(LP_FETCH) }
+      A0 = bload(o), B0 = bload(o + 16u), A1 = bload(o + 32u), B1 = bload(o + 48u), A2 = bload(o + 64u), B2 = bload(o + 80u), A3 = bload(o + 96u), B3 = bload(o + 112u);
     }
     // the tests of the wave's line leaves, dealt over its lanes
     const int                c  = lf ? min(leaf_num, 4) : 0;
@@ -369,21 +376,8 @@ YH_DEV bool lane_step(const trace_ctx& tc, lane_trav& t, lane_stack& s, int sp0,
         w_off = (unsigned int)(e >> 32), w_src = (unsigned int)e & 63u;
       }
     }
-    // (every lane loads — the lanes without a test the array's first record: with the loads in straight-line code behind the lane's own the
-    // compiler knows how many are in flight, and the node code waits for the lane's own only)
-    const v4f S0 = blob[2 * (size_t)w_off], S1 = blob[2 * (size_t)w_off + 1];
-    const bool own = !skip && !lf;
-    if (own) {
-      YH_LPROF(LP_FETCH)
-      gptr a = blob + 2 * (size_t)off;
-      // (a triangle leaf's second triangle whether it has one or not: no branch between the loads. The fourth word of slots 1-3' second half
-      // is read by nobody: loaded, its register would be handed to another value while the load is in flight, and that value's write would
-      // wait for the load)
-      typedef const __attribute__((address_space(1))) float* gfptr;
-      gfptr f = (gfptr)a;
-      A0 = a[0], B0 = a[1], A1 = a[2], B1 = a[3], A2 = a[4], A3 = a[6];
-      B2 = v4f{f[20], f[21], f[22], 0.0f}, B3 = v4f{f[28], f[29], f[30], 0.0f};  // (slot 1's comes as four words whatever is asked for: node_code keeps its register until the load is back)
-    }
+    const unsigned int so = work ? w_off * 32u : 0xFFFFFF00u;
+    const v4f S0 = bload(so), S1 = bload(so + 16u);
     // the source lane's ray, across the wave, while the loads are in flight (every lane takes part in the exchange: a pull reads the registers of
     // a lane that may itself be idle)
     auto pull = [](int addr, float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(v))); };

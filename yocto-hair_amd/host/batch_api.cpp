@@ -207,7 +207,7 @@ int yh_intersect_batch(yh_context* ctx, int n, const float* rays, int* object, i
   // YHAIR_INTERSECT=quad | lane4 | lane5 | lane6 | lane8: developer switch (waves per SIMD of the lane kernel).
   const char* mode  = getenv("YHAIR_INTERSECT");
   int         waves = 5;  // 91 registers without a spill: five waves per SIMD (6 and 8 spill 39 / 61 registers, measured slower)
-  bool        lanes = n >= 65536;
+  bool        lanes = n >= 65536 && lane_kernels_can_address(ctx);
   if (mode && !strcmp(mode, "quad")) lanes = false;
   else if (mode && !strncmp(mode, "lane", 4)) lanes = true, waves = std::max(4, std::min(8, atoi(mode + 4)));
   for (int i = 0; lanes && i < n; i++) lanes = rays[8 * (size_t)i + 6] == 1e-4f;

@@ -330,6 +330,7 @@ void split_items_side_by_side(yh_context* ctx, std::vector<int>& items);
 void lay_out_range(const yh_context* ctx, int* items, size_t n, int wpb, int G, int block_offset = 0);
 void lay_out_first_round(const yh_context* ctx, std::vector<int>& items, int shape);
 int replan_after_launch(yh_context* ctx, int nsamples);
+bool lane_kernels_can_address(const yh_context* ctx);  // launch_plan.cpp: the lane blob fits the one-lane kernels' 32-bit offsets
 int stream_geometry(const yh_context* ctx, int num_items, int* slots_per_wave, int* grid_blocks, int* lds_out, bool* single_generation = nullptr);
 void note_stream_wave_log(yh_context* ctx, const unsigned long long* log, size_t waves);
 void deal_items_for_stream(yh_context* ctx, std::vector<int>& items);

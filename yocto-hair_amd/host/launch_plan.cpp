@@ -472,11 +472,16 @@ int replan_after_launch(yh_context* ctx, int nsamples) {
   return upload_work_items(ctx);
 }
 
+// The one-lane kernels (k_stream, k_intersect_lanes) read the lane blob through buffer loads with 32-bit byte offsets (csrc/dev_lane.h): the
+// part of it they read — test records and 4-wide nodes — has to end below 4 GB (about fifty million hair segments; the BASELINE configs hold 0.4-3.2 M).
+bool lane_kernels_can_address(const yh_context* ctx) { return (long long)ctx->lane_units * 32ll <= 0xFFFFFE00ll; }
+
 // Launch geometry of the streaming integrator: path slots per wave and workgroups. The pixels of the launch are
 // spread over as many waves as the CUs hold, each wave with a few paths per lane so that its lanes stay full
 // between stages: 128 .. 192 slots (more waves beat fuller batches: measured on C2 / C3, profiles/r02;
 // YHAIR_ST_SLOTS / YHAIR_ST_WAVES: developer switches). Returns 0 when the kernel cannot run.
 int stream_geometry(const yh_context* ctx, int num_items, int* slots_per_wave, int* grid_blocks, int* lds_out, bool* single_generation) {
+  if (!lane_kernels_can_address(ctx)) return 0;  // (the caller drops the candidate: the quad kernels render the same bits)
   const int     wpb    = yhk_stream_block_threads() / 64;
   const int64_t pixels = (int64_t)num_items * 16;  // work items are 4x4 pixel quadrants
   int           P      = (int)std::max<int64_t>(128, std::min<int64_t>(192, (pixels / ((int64_t)ctx->num_cus * 16) + 63) / 64 * 64));
