@@ -1,6 +1,6 @@
 #!/bin/bash
-# Round 5: interleaved A/B of library variants (tools/_ab/libyhair_<name>.so) on forced launch shapes.
-# usage: r5_ab.sh TAG "name1 name2" "scene res spp shape" ...
+# Interleaved A/B of library variants (tools/_ab/libyhair_<name>.so) on forced launch shapes.
+# usage: variants_ab.sh TAG "name1 name2" "scene res spp shape" ...
 cd $GRAFT_REPO_ROOT; out=gpurun_out/$1; mkdir -p $out; export TMPDIR=/tmp YHAIR_NO_DISK_CACHE=1
 variants=$2; shift 2
 cfgs=("$@")
