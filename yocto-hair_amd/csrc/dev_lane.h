@@ -46,7 +46,7 @@ namespace yhd {
 #endif
 enum { LP_STEP = 0, LP_POP, LP_SCENE, LP_ENTER, LP_FETCH, LP_NODE, LP_LINE_LEAF, LP_TRI_LEAF, LP_PUSH, LP_SEGS, LP_COUNT };  // pc[2 b]: wave steps that ran branch b, pc[2 b + 1]: lanes in them (summed over the lanes)
 #define YH_LPROF(b)                                                                   \
-  if (PROF) {                                                                         \
+  if (PROF && pc) {                                                                   \
     pc[2 * (b)] += 1.0f / (float)__popcll(__ballot(true)), pc[2 * (b) + 1] += 1.0f; \
   }
 
@@ -160,8 +160,19 @@ YH_DEV hit_t lane_hit(const trace_ctx& tc, hit_t raw, bool hit_lines, float hit_
 // lanes stay in the entry for the next step. Triangle leaves and nodes are the lane's own as before.
 template <bool EXACT, bool PROF = false, bool COOP = false>
 YH_DEV bool lane_step(const trace_ctx& tc, lane_trav& t, lane_stack& s, int sp0, bool& redo, float* pc = nullptr, bool active = true,
-    YH_LDS unsigned long long* cmap = nullptr) {
+    YH_LDS unsigned long long* cmap = nullptr, unsigned long long* tacc = nullptr) {
   const yhd_scene& sc = *tc.sc;
+  // PROF + COOP: where a step's time goes — shader-clock stamps at five points of the step, summed per wave in tacc[0..4] (head | exchange and
+  // loads issued | the wait for memory + node code | the wave's line tests | results back and accept); csrc/stream.hip adds them to its counters
+  unsigned long long tp = 0;
+  auto stamp = [&](int k) {
+    if (PROF && COOP && tacc) {
+      const unsigned long long now = (unsigned long long)clock64();
+      if (k >= 0) tacc[k] += now - tp;
+      tp = now;
+    }
+  };
+  stamp(-1);
   YH_MARK("step_begin");
   if (!COOP || active) { YH_LPROF(LP_STEP) }
   auto box_test = [](f3 o, f3 dinv, float t0, float t1, f3 bmin, f3 bmax) {
@@ -337,6 +348,7 @@ YH_DEV bool lane_step(const trace_ctx& tc, lane_trav& t, lane_stack& s, int sp0,
     const bool         lf       = is_leaf && lines;
     const int          leaf_num = (int)((t.cur >> 27) & 7u);
     const unsigned int off      = t.cur & (is_leaf ? 0x07FFFFFFu : 0x3FFFFFFFu);  // 32-byte units into the blob
+    stamp(0);
     YH_MARK("fetch");
     // ONE round trip for the lane's own node (or triangle leaf) and for the segment it tests for the wave, through BUFFER LOADS: a lane that
     // has nothing to fetch hands the load an offset beyond the end of the array — the address unit answers zeros without touching memory — so
@@ -378,6 +390,7 @@ YH_DEV bool lane_step(const trace_ctx& tc, lane_trav& t, lane_stack& s, int sp0,
     }
     const unsigned int so = work ? w_off * 32u : 0xFFFFFF00u;
     const v4f S0 = bload(so), S1 = bload(so + 16u);
+    stamp(1);
     // the source lane's ray, across the wave, while the loads are in flight (every lane takes part in the exchange: a pull reads the registers of
     // a lane that may itself be idle)
     auto pull = [](int addr, float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(v))); };
@@ -394,6 +407,7 @@ YH_DEV bool lane_step(const trace_ctx& tc, lane_trav& t, lane_stack& s, int sp0,
       tri_code(off, leaf_num);
       t.cur = cur_next;
     }
+    stamp(2);
     if (any_leaf) {
       YH_MARK("line_leaf");
       float ss = 0, d2 = 0, rr = 0, key = -1.0f;  // key: the distance of an accepted test, -1 otherwise (an accepted t is >= ray_eps — or a NaN, which the rule below lets through as the reference's comparisons do)
@@ -403,6 +417,7 @@ YH_DEV bool lane_step(const trace_ctx& tc, lane_trav& t, lane_stack& s, int sp0,
         const bool ok = intersect_line_raw(wlo, wld, wa, ray_eps, wtmax, xyz(S0), xyz(S1), S0.w, S1.w, ss, d2, rr, dist);
         key = ok ? dist : -1.0f;
       }
+      stamp(3);
       // back to the leaf's lane: the reference's accept rule over its tests in leaf order
       float best = t.tmax;
       int   win  = -1;
@@ -424,6 +439,7 @@ YH_DEV bool lane_step(const trace_ctx& tc, lane_trav& t, lane_stack& s, int sp0,
         t.cur = rest > 0 ? (YH_TAG_LEAF | ((unsigned)rest << 27) | (off + (unsigned)g)) : YH_NONE;
       }
     }
+    stamp(4);
     YH_MARK("step_end");
     return active && (aborted || (t.cur == YH_NONE && s.sp == sp0));
   }

@@ -315,6 +315,7 @@ __global__ __launch_bounds__(YH_ST_BLOCK, WAVES) void k_stream(const yhd_scene s
       n_fin = list_push(l_fin, n_fin, on && !alive, sl);
     } else {
       // ---- trace: one ray per lane; finished lanes refill from the ray list; leaves with rays suspended ---------
+      unsigned long long tacc[5] = {};  // PROF: shader-clock cycles of the five parts of a step (dev_lane.h), this wave's sums
       float pc[2 * LP_COUNT] = {};  // PROF: per branch of lane_step, this lane's share of the wave steps that ran it and of the lanes in them
       while (true) {
         YH_MARK("trace_refill");
@@ -342,7 +343,7 @@ __global__ __launch_bounds__(YH_ST_BLOCK, WAVES) void k_stream(const yhd_scene s
         int  kind = 0;
         {
           bool redo = false;
-          if (lane_step<false, PROF, true>(tc, t, stk, 0, redo, pc, have, w_cmap)) {  // (every lane: the wave tests its line leaves together)
+          if (lane_step<false, PROF, true>(tc, t, stk, 0, redo, PROF && pl.prof_parts_only ? nullptr : pc, have, w_cmap, PROF ? tacc : nullptr)) {  // (every lane: the wave tests its line leaves together)
             YH_MARK("trace_retire");
             have = false, fin = true;
             if (redo) {
@@ -358,6 +359,8 @@ __global__ __launch_bounds__(YH_ST_BLOCK, WAVES) void k_stream(const yhd_scene s
         YH_MARK("trace_loop_end");
       }
       if (PROF) {
+        if (lane == 0)
+          for (int k = 0; k < 5; k++) atomicAdd(&pl.prof[52 + k], tacc[k]);
         for (int k = 0; k < 2 * LP_COUNT; k++) {
           float v = pc[k];
           for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

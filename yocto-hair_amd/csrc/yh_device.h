@@ -252,6 +252,7 @@ typedef struct yhd_stream {
   int         slots_per_wave;  // multiple of 64, <= 4096
   int         ovf_entries;
   long long   total_slots;     // slots in the pool (all waves)
+  int         prof_parts_only;  // developer build (YHAIR_ST_PROF=2): only the five time stamps per step, none of the per-branch counters (they lengthen the step they measure)
   int         suspend_lanes;   // a wave whose ray list is dry leaves the trace stage for the shading stages when at most this many of its lanes are busy (< 64; stream.hip)
 } yhd_stream;
 

@@ -169,6 +169,7 @@ int stream_impl(yh_context* ctx, int nsamples, bool sync) {
   if (prof) {
     if ((rc = alloc_zero(ctx, ctx->d_st_prof, 64 * 8))) return rc;
     ctx->stream_pool.prof = (unsigned long long*)ctx->d_st_prof.p;
+    ctx->stream_pool.prof_parts_only = atoi(getenv("YHAIR_ST_PROF")) == 2;
   } else {
     ctx->stream_pool.prof = nullptr;
   }
@@ -249,6 +250,14 @@ int stream_impl(yh_context* ctx, int nsamples, bool sync) {
             c[8 + k], c[8 + k] ? (double)c[16 + k] / (double)c[8 + k] : 0.0);
       fprintf(stderr, "[yhair]   trace: %llu wave steps, %.1f lanes busy on average, %.0f cycles per step\n", c[24],
           c[24] ? (double)c[25] / (double)c[24] : 0.0, c[24] ? (double)c[5] / (double)c[24] : 0.0);
+      {  // the five parts of a step (csrc/dev_lane.h: stamp), shader-clock cycles per wave step
+        const char* part[5] = {"head (pop, scene level, ENTER)", "own loads, exchange, segment loads issued", "ray pulls, the wait for memory, node code", "the wave's line tests",
+            "results back, accept"};
+        double      sum = 0;
+        for (int k = 0; k < 5; k++) sum += (double)c[52 + k];
+        for (int k = 0; k < 5 && c[24]; k++)
+          fprintf(stderr, "[yhair]   step part %d %-46s %7.0f cycles per step (%4.1f %% of the stamped step)\n", k, part[k], (double)c[52 + k] / (double)c[24], sum > 0 ? 100.0 * (double)c[52 + k] / sum : 0.0);
+      }
       // per branch of lane_step (csrc/dev_lane.h: LP_*): the share of the wave steps that ran it, and the lanes in it when it ran
       const char* br[10] = {"step", "pop", "scene", "enter", "fetch", "node", "line-leaf", "tri-leaf", "push", "2nd-seg"};
       for (int b = 0; b < 10; b++)
