@@ -142,6 +142,30 @@ YH_DEV hit_t lane_hit(const trace_ctx& tc, hit_t raw, bool hit_lines, float hit_
   return raw;
 }
 
+// ... and when the traversal kept NOTHING of a line hit but its place and distance (the cooperative leaves of lane_step: the segment was tested
+// in another lane, and u, d2, r are not carried back per step): the final hit's uv from the test itself, once per ray — the ray into the
+// object's space as ENTER takes it there, the segment's record, the same arithmetic (intersect_line_raw): same operands, same bits.
+YH_DEV hit_t lane_hit_retest(const trace_ctx& tc, hit_t raw, bool hit_lines, f3 ro, f3 rd) {
+  if (raw.object >= 0 && hit_lines) {
+    frame inv;
+    if (tc.lds_scene) {
+      const YH_LDS v4f* ob = tc.lds_scene + YH_OBJECT_F4 * raw.object;
+      v4f a = ob[3], b = ob[4], c = ob[5];
+      inv.x = {a.x, a.y, a.z}, inv.y = {a.w, b.x, b.y}, inv.z = {b.z, b.w, c.x}, inv.o = {c.y, c.z, c.w};
+    } else {
+      inv = ldframe(tc.sc->objects[raw.object].inv_frame);
+    }
+    const f3          lo = transform_point(inv, ro), ld = transform_vector(inv, rd);
+    const yhd_float4* a  = tc.sc->lane_blob + 2 * (size_t)raw.slot;
+    const v4f         A = ldg4(a), B = ldg4(a + 1);
+    float ss, d2, rr, dist;
+    (void)intersect_line_raw(lo, ld, dot(ld, ld), ray_eps, flt_max, xyz(A), xyz(B), A.w, B.w, ss, d2, rr, dist);
+    raw.u = ss, raw.v = d2;
+    return lane_hit(tc, raw, true, rr);
+  }
+  return lane_hit(tc, raw, hit_lines, 1.0f);
+}
+
 // One step of the ray in `t`. Returns true when the ray is finished (closest hit in t.hit), or —
 // EXACT = false only — when it has to be traced again by the EXACT form (`redo` set: a slab of a
 // box test could hold a NaN, dev_trace.h). `sp0` = stack height at which this ray started.
@@ -391,8 +415,15 @@ YH_DEV bool lane_step(const trace_ctx& tc, lane_trav& t, lane_stack& s, int sp0,
     const unsigned int so = work ? w_off * 32u : 0xFFFFFF00u;
     const v4f S0 = bload(so), S1 = bload(so + 16u);
     stamp(1);
-    // the source lane's ray, across the wave, while the loads are in flight (every lane takes part in the exchange: a pull reads the registers of
-    // a lane that may itself be idle)
+    if (own && !is_leaf) node_code();
+    if (own && is_leaf) {
+      const unsigned int cur_next = leaf_num > 2 ? (YH_TAG_LEAF | ((unsigned)(leaf_num - 2) << 27) | (off + 4u)) : YH_NONE;
+      tri_code(off, leaf_num);
+      t.cur = cur_next;
+    }
+    // the source lane's ray, across the wave (every lane takes part in the exchange: a pull reads the registers of a lane that may itself be
+    // idle). Behind the node code, not in front of it: eight more values alive across it put spill reloads into the test, and an LDS round trip
+    // is not what a step waits for (profiles/r05/coop_line_leaves.txt)
     auto pull = [](int addr, float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(v))); };
     f3    wlo = mk3(0.0f), wld = mk3(0.0f);
     float wa = 0.0f, wtmax = 0.0f;
@@ -401,19 +432,13 @@ YH_DEV bool lane_step(const trace_ctx& tc, lane_trav& t, lane_stack& s, int sp0,
       wlo = f3{pull(sa, t.lo.x), pull(sa, t.lo.y), pull(sa, t.lo.z)}, wld = f3{pull(sa, t.ld.x), pull(sa, t.ld.y), pull(sa, t.ld.z)};
       wa = pull(sa, t.ld2), wtmax = pull(sa, t.tmax);
     }
-    if (own && !is_leaf) node_code();
-    if (own && is_leaf) {
-      const unsigned int cur_next = leaf_num > 2 ? (YH_TAG_LEAF | ((unsigned)(leaf_num - 2) << 27) | (off + 4u)) : YH_NONE;
-      tri_code(off, leaf_num);
-      t.cur = cur_next;
-    }
     stamp(2);
     if (any_leaf) {
       YH_MARK("line_leaf");
-      float ss = 0, d2 = 0, rr = 0, key = -1.0f;  // key: the distance of an accepted test, -1 otherwise (an accepted t is >= ray_eps — or a NaN, which the rule below lets through as the reference's comparisons do)
+      float key = -1.0f;  // key: the distance of an accepted test, -1 otherwise (an accepted t is >= ray_eps — or a NaN, which the rule below lets through as the reference's comparisons do)
       if (work) {
         YH_LPROF(LP_LINE_LEAF)
-        float dist;
+        float ss, d2, rr, dist;
         const bool ok = intersect_line_raw(wlo, wld, wa, ray_eps, wtmax, xyz(S0), xyz(S1), S0.w, S1.w, ss, d2, rr, dist);
         key = ok ? dist : -1.0f;
       }
@@ -427,13 +452,10 @@ YH_DEV bool lane_step(const trace_ctx& tc, lane_trav& t, lane_stack& s, int sp0,
         const bool  acc = (i < g) & !(ki < 0.0f) & !(ki > best);
         best = acc ? ki : best, win = acc ? i : win;
       }
-      const int   wa2 = ((start + max(win, 0)) & 63) << 2;
-      const float wu = pull(wa2, ss), wv = pull(wa2, d2), wr = pull(wa2, rr);
       if (lf) {
-        if (win >= 0) {
+        if (win >= 0) {  // (place and distance only: u, d2, r of the ray's FINAL hit come from lane_hit_retest, once per ray)
           t.hit.object = t.cur_obj, t.hit.slot = (int)off + win;
-          t.hit.u = wu, t.hit.v = wv, t.hit_r = wr, t.hit.distance = best;
-          t.tmax = best, t.hit_lines = true;
+          t.hit.distance = best, t.tmax = best, t.hit_lines = true;
         }
         const int rest = leaf_num - g;
         t.cur = rest > 0 ? (YH_TAG_LEAF | ((unsigned)rest << 27) | (off + (unsigned)g)) : YH_NONE;

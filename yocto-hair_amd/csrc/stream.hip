@@ -71,10 +71,9 @@ YH_DEV int list_push(YH_LDS unsigned short* list, int n, bool pred, int value) {
 }
 // Closest hit of a finished ray into its slot, RAW as the traversal keeps it (dev_lane.h: the shading stage applies lane_hit
 // to the batch it shades, once per hit instead of in every step that retires a ray); returns what it hit.
-YH_DEV int publish(const yhd_stream& pl, size_t g, const hit_t& hit, bool hit_lines, float hit_r, unsigned int steps) {
+YH_DEV int publish(const yhd_stream& pl, size_t g, const hit_t& hit, bool hit_lines, unsigned int steps) {
   SLOT_HIT(pl, g)                 = yhd_int4{hit.object, hit.slot, __float_as_int(hit.u), __float_as_int(hit.v)};
   ((float*)&SLOT_RAY_O(pl, g))[3] = hit.distance;
-  ((float*)&SLOT_F4(pl, g, 7))[1] = hit_r;
   // steps of this ray: a scheduling hint of the pixel's work item, added to the pixel's total by the stage that
   // takes the path next (NOT an atomic add here: device-scope atomics execute at the memory side and drop the
   // slot's line from L2 — measured 1.6x on the whole kernel)
@@ -203,7 +202,7 @@ __global__ __launch_bounds__(YH_ST_BLOCK, WAVES) void k_stream(const yhd_scene s
             lane_exact_result r = lane_trace_exact(sc_dev, tc.lds_scene, stk.lds, stk.ovf, stk.sp, stk.base, f3{o.x, o.y, o.z},
                 f3{d.x, d.y, d.z}, -1);
             stk.base = r.base;
-            kd       = publish(pl, base + sl, r.hit, r.hit_lines != 0, r.hit_r, 1u);
+            kd       = publish(pl, base + sl, r.hit, r.hit_lines != 0, 1u);
           }
         }
         n_hair = list_push(l_hair, n_hair, kd == K_HAIR, sl);
@@ -291,7 +290,7 @@ __global__ __launch_bounds__(YH_ST_BLOCK, WAVES) void k_stream(const yhd_scene s
         }
         hit_t isec;
         isec.object = h.x, isec.slot = h.y, isec.u = __int_as_float(h.z), isec.v = __int_as_float(h.w), isec.distance = o.w;
-        isec = lane_hit(tc, isec, act == A_HAIR, ((const float*)&SLOT_F4(pl, g, 7))[1]);  // (hair batches hold the hits on lines)
+        isec = lane_hit_retest(tc, isec, act == A_HAIR, ps.ray.o, ps.ray.d);  // (hair batches hold the hits on lines: their uv from the test itself, dev_lane.h)
         rng_t rng;
         rng.state = (uint64_t)(unsigned)r4.x | ((uint64_t)(unsigned)r4.y << 32);
         rng.inc   = (uint64_t)(unsigned)r4.z | ((uint64_t)(unsigned)r4.w << 32);
@@ -350,7 +349,7 @@ __global__ __launch_bounds__(YH_ST_BLOCK, WAVES) void k_stream(const yhd_scene s
               kind   = K_REDO;  // traced again by the exact form in the sort stage
               stk.sp = 0, stk.base = 0;
             } else {
-              kind = publish(pl, base + slot, t.hit, t.hit_lines, t.hit_r, t.steps);
+              kind = publish(pl, base + slot, t.hit, t.hit_lines, t.steps);
             }
           }
         }
@@ -460,13 +459,13 @@ __global__ __launch_bounds__(256, WAVES) void k_intersect_lanes(const yhd_scene 
       bool redo = false;
       if (lane_step<false, false, true>(tc, t, stk, 0, redo, nullptr, have, w_cmap)) {
         have = false;
-        hit_t h = lane_hit(tc, t.hit, t.hit_lines, t.hit_r);
+        hit_t h = lane_hit_retest(tc, t.hit, t.hit_lines, t.ro, t.rd);
         if (redo) {  // axis-parallel ray: the reference's compare-and-select box test throughout
           stk.sp = 0, stk.base = 0;
           const float*      r = rays + 8 * (size_t)ray;
           lane_exact_result e = lane_trace_exact(sc_dev, tc.lds_scene, stk.lds, stk.ovf, 0, 0, ld3(r), ld3(r + 3), -1);
           stk.base = e.base;
-          h        = lane_hit(tc, e.hit, e.hit_lines != 0, e.hit_r);
+          h        = lane_hit_retest(tc, e.hit, e.hit_lines != 0, ld3(r), ld3(r + 3));
           if (h.object >= 0 && h.distance > r[7]) h.object = -1, h.slot = -1, h.u = 0, h.v = 0, h.distance = 0;  // (the exact form starts from tmax = flt_max)
         }
         object[ray] = h.object, element[ray] = hit_element(sc, h);
