@@ -405,11 +405,11 @@ YH_DEV bool lane_step(const trace_ctx& tc, lane_trav& t, lane_stack& s, int sp0,
       g     = max(0, min(c, 64 - start));
 #pragma unroll
       for (int i = 0; i < 4; i++)
-        if (i < g) cmap[start + i] = ((unsigned long long)(off + (unsigned)i) << 32) | (unsigned long long)((unsigned)lane | ((unsigned)i << 8));
+        if (i < g) cmap[start + i] = ((unsigned long long)(off + (unsigned)i) << 32) | (unsigned long long)(unsigned)lane;  // {the record's place, this lane}
       work = lane < total;
       if (work) {
         const unsigned long long e = cmap[lane];
-        w_off = (unsigned int)(e >> 32), w_src = (unsigned int)e & 63u;
+        w_off = (unsigned int)(e >> 32), w_src = (unsigned int)e;
       }
     }
     const unsigned int so = work ? w_off * 32u : 0xFFFFFF00u;
@@ -448,7 +448,7 @@ YH_DEV bool lane_step(const trace_ctx& tc, lane_trav& t, lane_stack& s, int sp0,
       int   win  = -1;
 #pragma unroll
       for (int i = 0; i < 4; i++) {
-        const float ki  = pull(((start + i) & 63) << 2, key);
+        const float ki  = pull((start + i) << 2, key);  // (start + i < 64 wherever i < g; the others' answers are not looked at)
         const bool  acc = (i < g) & !(ki < 0.0f) & !(ki > best);
         best = acc ? ki : best, win = acc ? i : win;
       }
