@@ -322,26 +322,36 @@ YH_DEV bool lane_step(const trace_ctx& tc, lane_trav& t, lane_stack& s, int sp0,
       hm |= box_test(t.lo, t.ldinv, ray_eps, t.tmax, f3{A3.x, A3.y, A3.z}, f3{A3.w, B3.x, B3.y}) ? 8u : 0u;
       hm &= axes >> 8;
       // Visiting order of the slots (pt.cpp:887-893 at both collapsed levels, dev_trace.h): the pair on the near side of
-      // the node's axis first, inside a pair the slot on the near side of that child's axis. Slots are taken in REVERSE
-      // visiting order: each hit pushes the one found before it, so the first in visiting order ends up in `cur` and
-      // the others pop in order.
+      // the node's axis first, inside a pair the slot on the near side of that child's axis. The first hit slot in that order
+      // becomes `cur`, the others go on the stack so that they pop in order: the k-th visited hit (k >= 1) lands n - 1 - k
+      // entries above the old top, n = the hits. NO BRANCH per slot: the rank of a hit among the hits visited before it
+      // places it, three predicated stores do the pushes (round 5: the loop that pushed one entry per hit behind two nested
+      // branches ran all of its three bodies in nearly every step, some forty vector and thirty scalar instructions).
       const unsigned int s0  = ((unsigned)t.lsign >> (axes & 3)) & 1;
       const unsigned int sg0 = ((unsigned)t.lsign >> ((axes >> 2) & 3)) & 1, sg1 = ((unsigned)t.lsign >> ((axes >> 4) & 3)) & 1;
-      t.cur = YH_NONE;
       YH_MARK("node_order");
+      unsigned int vq[4], vh[4], vref[4];  // by visiting order r: the slot, whether it is hit, its reference
 #pragma unroll
-      for (int r = 3; r >= 0; r--) {
+      for (int r = 0; r < 4; r++) {
         const unsigned int pair = ((unsigned)r >> 1) ^ s0;
-        const unsigned int q    = (pair << 1) | (((unsigned)r & 1) ^ (pair ? sg1 : sg0));
-        if ((hm >> q) & 1) {
-          const unsigned int ref = (q & 2) ? ((q & 1) ? r3 : r2) : ((q & 1) ? r1 : r0);
-          if (t.cur != YH_NONE) {
-            YH_LPROF(LP_PUSH)
-            lane_push(s, t.cur);
-          }
-          t.cur = ref;
-        }
+        vq[r]   = (pair << 1) | (((unsigned)r & 1) ^ (pair ? sg1 : sg0));
+        vh[r]   = (hm >> vq[r]) & 1u;
+        vref[r] = (vq[r] & 2) ? ((vq[r] & 1) ? r3 : r2) : ((vq[r] & 1) ? r1 : r0);
       }
+      const int np = max((int)(vh[0] + vh[1] + vh[2] + vh[3]) - 1, 0);  // entries to push
+      if (np > 0) { YH_LPROF(LP_PUSH) }
+      while (s.sp - s.base + np > YH_LSTACK) {  // (rare: the window's oldest entries go to memory, lane_push's rule)
+        s.ovf[(size_t)s.base * 64] = s.lds[(s.base & (YH_LSTACK - 1)) * 64];
+        s.base++;
+      }
+      t.cur = vh[0] ? vref[0] : vh[1] ? vref[1] : vh[2] ? vref[2] : vh[3] ? vref[3] : YH_NONE;
+      unsigned int before = vh[0];  // hits visited before slot r
+#pragma unroll
+      for (int r = 1; r < 4; r++) {
+        if (vh[r] && before >= 1) s.lds[((s.sp + np - (int)before) & (YH_LSTACK - 1)) * 64] = vref[r];
+        before += vh[r];
+      }
+      s.sp += np;
   };
   // ---- triangle leaf: two triangles per step in leaf order, tmax shrinking after each accepted hit (pt.cpp:905-923) ----
   auto tri_code = [&](unsigned int off, int leaf_num) {
