@@ -249,7 +249,8 @@ struct yh_context {
   float            last_ms = 0;
   int              last_launches = 0;
   int              last_nsamples = 0;   // samples of the launch the item costs come from
-  unsigned         launches_of_state = 0;  // synchronous launches since yh_init_state (re-planning schedule)
+  unsigned         launches_of_image = 0;  // synchronous launches since this IMAGE (scene, resolution, sampler, bounces) was first initialised: the re-planning schedule. A
+                                           // re-initialised render of a known image is planned already (item_cost survives it) and goes on where the schedule was
   int              launch_shape = 0;  // decided from launches of at least 16 spp (shorter ones have flat, noisy item costs)
   int              last_shape = -1;   // the kernel the most recent launch ran (yh_launch_shape)
   bool             async_pending = false;  // an asynchronous launch whose time yh_synchronize has still to read

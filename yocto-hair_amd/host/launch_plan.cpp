@@ -458,9 +458,10 @@ void lay_out_first_round(const yh_context* ctx, std::vector<int>& items, int sha
 int replan_after_launch(yh_context* ctx, int nsamples) {
   // A pixel's samples are sequential, so the items that start last bound the launch; hair quadrants
   // cost 10-100x background ones. Re-planned after launches 1, 2, 4, 8, ... of a state: the relative
-  // costs of the items settle after the first launches (they are a property of the image), and the
-  // read-back, sort and upload are a few hundred microseconds of a 16 ms launch.
-  const unsigned li      = ++ctx->launches_of_state;
+  // costs of the items settle after the first launches (they are a property of the IMAGE — the count goes on over
+  // a yh_init_state of the same image, round 5: the bench's timed region re-planned five times in twenty steps otherwise),
+  // and the read-back, sort and upload are half a millisecond of a 16 ms launch.
+  const unsigned li      = ++ctx->launches_of_image;
   // (... and after the first launch long enough to settle the costs, whenever it comes: the kernel trials wait for it)
   const bool     refresh = (li & (li - 1)) == 0 || (!ctx->costs_settled && nsamples >= YH_TRIAL_SPP && ctx->state.shader == YH_SHADER_PATH);
   if (refresh) HIPCHK(ctx, hipMemcpy(ctx->item_cost.data(), ctx->d_tile_cost.p, ctx->item_cost.size() * 4, hipMemcpyDeviceToHost));

@@ -46,6 +46,7 @@ int yh_init_state(yh_context* ctx, const yh_trace_params* params) {
     return fail(ctx, YH_E_INVALID, "sampler unknown");  // get_trace_shader_func's throw (pt.cpp:1669)
   if (params->hair_exact && params->shader != YH_SHADER_PATH) return fail(ctx, YH_E_INVALID, "hair_exact exists for the path shader only");
   HIPCHK(ctx, hipSetDevice(ctx->device));
+  const bool same_work = ctx->have_state && ctx->params.shader == params->shader && ctx->params.bounces == params->bounces;  // (what the items' relative costs depend on besides the image)
   ctx->params = *params;
   // image size (pt.cpp:1933-1939)
   auto& cam = ctx->scene.camera;
@@ -111,7 +112,7 @@ int yh_init_state(yh_context* ctx, const yh_trace_params* params) {
   s.accum = (yhd_float4*)ctx->d_accum.p, s.tiles = (const int*)ctx->d_tiles.p;
   s.launch_shape = first_shape;
   s.num_tiles = (int)tiles.size(), s.width = w, s.height = h, s.tiles_x = tx;
-  ctx->launches_of_state = 0;
+  if (new_image || !same_work) ctx->launches_of_image = 0;
   s.samples_done = 0, s.bounces = params->bounces, s.clamp = params->clamp, s.shader = params->shader;
   s.shard_rank = ctx->rank, s.shard_world = ctx->world;
   ctx->have_state = true;
@@ -130,7 +131,7 @@ int yh_init_state(yh_context* ctx, const yh_trace_params* params) {
     HIPCHK(ctx, hipMemcpy(ctx->d_rng_state.p, st.data(), npix * 8, hipMemcpyHostToDevice));
     HIPCHK(ctx, hipMemsetAsync(ctx->d_accum.p, 0, npix * 16, ctx->stream));
     YH_WAIT(ctx);
-    ctx->state.samples_done = 0, ctx->launches_of_state = 0, ctx->last_shape = -1, ctx->last_ms = 0, ctx->last_launches = 0;
+    ctx->state.samples_done = 0, ctx->launches_of_image = 0, ctx->last_shape = -1, ctx->last_ms = 0, ctx->last_launches = 0;
     ctx->have_costs = true;  // the launches that follow are planned: their times rank the kernels
   }
   return YH_OK;
