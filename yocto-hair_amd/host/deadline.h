@@ -5,6 +5,8 @@
 // the CLIs print the error and exit(1) like print_fatal (apps/yscenetrace/yscenetrace.cpp:225-226,273). No restart, no re-exec: a
 // caller that wants a retry starts a fresh process.
 //
+// (A launch of the usual length never gets that far: host/trace_launch.cpp first asks hipStreamQuery in a spin for as long as the context's launches have
+// been taking, 50 ms at most — nothing blocks, nothing can hang — and only a wait that outlasts it goes through the forms below.)
 // Two forms. BoundedCall (what the library uses): the blocking wait itself — hipStreamSynchronize, which notices the end of a launch
 // within microseconds — runs on a worker thread of the context and the caller waits for it on a condition variable with the deadline;
 // polling hipEventQuery between sleeps (wait_until, the first form of round 5) cost 0.6 ms per 16 ms step in detection latency

@@ -11,21 +11,25 @@ int wait_for_launch(yh_context* ctx) {
   const int    device  = ctx->device;
   hipStream_t  stream  = ctx->stream;
   int          e       = 0;
-  // The worker SPINS on the launch's end event for as long as launches of this context have been taking (at most 50 ms), then blocks:
-  // the blocking wait of the HIP runtime sleeps on an interrupt and wakes up tens of microseconds after the kernel has ended — for the
-  // bench's 15 ms launches that is most of what the library adds to a step (profiles/r05/bounded_wait_overhead.txt).
-  hipEvent_t   ev_end  = ctx->ev1;
-  const double spin_s  = std::min(0.050, 1.25e-3 * (double)ctx->last_ms + 0.001);
+  // The blocking wait of the HIP runtime sleeps on an interrupt and wakes up tens of microseconds after the kernel has ended — for the bench's
+  // 15 ms launches that was most of what the library added to a step (profiles/r05/bounded_wait_overhead.txt) — so the wait first SPINS for as
+  // long as launches of this context have been taking (at most 50 ms, never past the deadline)
+  // ... and for that long THIS thread asks the stream itself (hipStreamQuery: nothing blocks, nothing can hang): a launch of the usual length is
+  // over before the question stops being asked, and the two thread hand-overs to the worker and back never happen.
+  const double spin_s  = std::min(std::min(0.050, timeout), 1.25e-3 * (double)ctx->last_ms + 0.001);
+  {
+    const auto t0 = std::chrono::steady_clock::now();
+    while (true) {
+      const hipError_t q = hipStreamQuery(stream);
+      if (q == hipSuccess) return YH_OK;
+      if (q != hipErrorNotReady) return fail(ctx, YH_E_DEVICE, "hipStreamQuery: %s", hipGetErrorString(q));
+      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > spin_s) break;
+    }
+  }
   const int    rc      = ctx->sync_call.run(
-      [device, stream, ev_end, spin_s]() {
+      [device, stream]() {
         hipError_t se = hipSetDevice(device);
-        if (se != hipSuccess) return (int)se;
-        if (spin_s > 0) {
-          const auto t0 = std::chrono::steady_clock::now();
-          while (hipEventQuery(ev_end) == hipErrorNotReady)
-            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > spin_s) break;
-        }
-        return (int)hipStreamSynchronize(stream);
+        return (int)(se != hipSuccess ? se : hipStreamSynchronize(stream));
       },
       timeout, &e);
   if (rc == yhh::WAIT_EXPIRED) {
