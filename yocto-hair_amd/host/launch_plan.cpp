@@ -463,7 +463,9 @@ int replan_after_launch(yh_context* ctx, int nsamples) {
   // and the read-back, sort and upload are half a millisecond of a 16 ms launch.
   const unsigned li      = ++ctx->launches_of_image;
   // (... and after the first launch long enough to settle the costs, whenever it comes: the kernel trials wait for it)
-  const bool     refresh = (li & (li - 1)) == 0 || (!ctx->costs_settled && nsamples >= YH_TRIAL_SPP && ctx->state.shader == YH_SHADER_PATH);
+  // (... and after EVERY launch long enough for the half millisecond to be under one per cent of it: k_stream's per-wave shares are corrected by the re-plan,
+  // and a dense image's launches take a hundred times what it costs)
+  const bool     refresh = (li & (li - 1)) == 0 || ctx->last_ms >= 50.0f || (!ctx->costs_settled && nsamples >= YH_TRIAL_SPP && ctx->state.shader == YH_SHADER_PATH);
   if (refresh) HIPCHK(ctx, hipMemcpy(ctx->item_cost.data(), ctx->d_tile_cost.p, ctx->item_cost.size() * 4, hipMemcpyDeviceToHost));
   if (refresh) ctx->last_nsamples = nsamples;
   if (refresh && ctx->last_shape == 5)  // an item that ran as octets reports the time of its two halves, 2 x 0.74 of what it costs as a quad
@@ -601,8 +603,10 @@ static bool deal_shares_by_speed(yh_context* ctx, std::vector<int>& items, int P
     return (ctx->stream_speed.empty() ? 1.0 : ctx->stream_speed[std::min(round_of(w), ctx->stream_speed.size() - 1)]) * (ctx->st_wave_speed.size() == waves ? (double)ctx->st_wave_speed[w] : 1.0);
   };
   for (size_t w = 0; w < waves; w++) ssum += speed_of(w);
-  struct Share { std::vector<int> items; std::vector<double> cost; };
-  std::vector<Share> share(waves);
+  // (flat arrays, `cap` places per wave: this runs after every launch of a dense image, and four thousand pairs of small vectors were most of its five milliseconds)
+  std::vector<int>      share_items(waves * (size_t)cap);
+  std::vector<double>   share_cost(waves * (size_t)cap);
+  std::vector<int>      share_n(waves, 0);
   std::vector<std::pair<double, uint32_t>> heap(waves);  // (remaining budget, wave): max-heap
   for (size_t w = 0; w < waves; w++) heap[w] = {total * speed_of(w) / ssum, (uint32_t)w};
   std::make_heap(heap.begin(), heap.end());
@@ -611,17 +615,18 @@ static bool deal_shares_by_speed(yh_context* ctx, std::vector<int>& items, int P
     std::pop_heap(heap.begin(), heap.end());
     auto top = heap.back();
     heap.pop_back();
-    share[top.second].items.push_back(by_cost[i].second), share[top.second].cost.push_back(by_cost[i].first);
+    const size_t at = (size_t)top.second * (size_t)cap + (size_t)share_n[top.second]++;
+    share_items[at] = by_cost[i].second, share_cost[at] = by_cost[i].first;
     top.first -= by_cost[i].first;
-    if ((int)share[top.second].items.size() < cap) heap.push_back(top), std::push_heap(heap.begin(), heap.end());
+    if (share_n[top.second] < cap) heap.push_back(top), std::push_heap(heap.begin(), heap.end());
   }
   std::vector<int> begin(waves + 1, 0), out;
   std::vector<double> out_cost;
-  out.reserve(n), out_cost.reserve(n);
+  out.reserve(n + 3 * waves), out_cost.reserve(n + 3 * waves);
   for (size_t w = 0; w < waves; w++) {
     begin[w] = (int)out.size();
-    out.insert(out.end(), share[w].items.begin(), share[w].items.end());
-    out_cost.insert(out_cost.end(), share[w].cost.begin(), share[w].cost.end());
+    out.insert(out.end(), share_items.begin() + w * cap, share_items.begin() + w * cap + share_n[w]);
+    out_cost.insert(out_cost.end(), share_cost.begin() + w * cap, share_cost.begin() + w * cap + share_n[w]);
     while ((out.size() - (size_t)begin[w]) % 4 != 0) out.push_back(-1), out_cost.push_back(0.0);  // a take is four entries (csrc/stream.hip): -1 = no item
   }
   begin[waves] = (int)out.size();
