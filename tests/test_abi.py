@@ -277,6 +277,24 @@ def test_launch_deadline_logic(tmp_path):
     assert out.returncode == 0 and "all checks passed" in out.stdout, out.stdout + out.stderr
 
 
+def test_codegen_check_knows_two_round_trips_when_it_sees_them():
+    """tools/check_codegen.py also guards k_stream's step against the regression round 5 found in the assembly: a wait between the step's
+    buffer loads that an earlier one of them has to satisfy = two dependent memory round trips per step (the first form of the cooperative
+    leaves: -15 % instructions, 0 % time). The checker's rule on two hand-made instruction streams."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_codegen", os.path.join(ROOT, "tools", "check_codegen.py"))
+    cc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cc)
+    own = ["\tbuffer_load_dwordx4 v[%d:%d], v10, s[68:71], 0 offen offset:%d" % (16 + 4 * k, 19 + 4 * k, 16 * k) for k in range(8)]
+    seg = ["\tbuffer_load_dwordx4 v[8:11], v12, s[68:71], 0 offen", "\tbuffer_load_dwordx4 v[12:15], v12, s[68:71], 0 offen offset:16"]
+    good = own + ["\tds_write_b64 v9, v[88:89]", "\ts_waitcnt lgkmcnt(0)", "\ts_waitcnt vmcnt(8)"] + seg + ["\ts_waitcnt vmcnt(2)", "\tv_sub_f32_e32 v1, v16, v2"]
+    assert cc.loads_in_one_round_trip(good) == (10, None)
+    bad = seg + ["\ts_load_dwordx2 s[4:5], s[34:35], 0x440", "\ts_waitcnt vmcnt(0) lgkmcnt(0)"] + own + ["\ts_waitcnt vmcnt(0)"]
+    n, line = cc.loads_in_one_round_trip(bad)
+    assert n == 10 and line == "s_waitcnt vmcnt(0) lgkmcnt(0)"
+    assert cc.loads_in_one_round_trip(["\tv_mov_b32_e32 v0, 0"]) == (0, None)
+
+
 def test_traversal_loops_do_not_spill():
     """The traversal loop of the product kernels (plain k_trace in both launch shapes, plain k_stream) must not contain
     scratch instructions: a spill reload there stalls every step of every ray (0.75-0.8x on the dense configs), and

@@ -7,7 +7,8 @@ and whether the register allocator puts one there changes with unrelated edits o
 Loop membership comes from LLVM's own block annotations ("in Loop: Header=BBn_m Depth=d", "Parent Loop ..."), not
 from the layout: the block placement may put a loop's latch above its header.
 usage: tools/check_codegen.py [--strict] [--loops]
-  --strict: exit 1 when a traversal loop of a product kernel touches scratch
+  --strict: exit 1 when a traversal loop of a product kernel touches scratch, or when k_stream's step makes two dependent memory round trips
+            (a wait between its buffer loads that an earlier one of them has to satisfy)
   --loops:  list every other loop of >= 100 vector instructions too
   env YH_EXTRA_FLAGS="-D...": look at a developer variant"""
 import os, re, subprocess, sys, tempfile
@@ -83,6 +84,28 @@ def loops_of(body):
     return res
 
 
+def loads_in_one_round_trip(body):
+    """k_stream's step (csrc/dev_lane.h: lane_step, COOP) issues its loads as BUFFER loads, the lane's own node first, the segment it tests for
+    the wave behind the exchange: ONE memory round trip. body: the lines of the kernel. Returns (number of buffer loads, offending line or None): a
+    wait between the first and the last of them that lets fewer loads stay in flight than have been issued makes the later loads wait for the
+    earlier ones — two dependent round trips per step, which is what the first form of the cooperative leaves did (profiles/r05/coop_line_leaves.txt)."""
+    idx = [k for k, l in enumerate(body) if re.match(r"\s+buffer_load_dword", l)]
+    if not idx:
+        return 0, None
+    issued = 0
+    for k in range(idx[0], idx[-1] + 1):
+        l = body[k]
+        if re.match(r"\s+buffer_load_dword", l):
+            issued += 1
+            continue
+        m = re.match(r"\s+s_waitcnt\b(.*)", l)
+        if m:
+            v = re.search(r"vmcnt\((\d+)\)", m.group(1))
+            if v and int(v.group(1)) < issued:
+                return len(idx), l.strip()
+    return len(idx), None
+
+
 def kernels(src):
     with tempfile.NamedTemporaryFile(suffix=".s") as f:
         subprocess.run([hipcc(), *FLAGS, "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, os.path.join(CSRC, src), "-o", f.name],
@@ -96,7 +119,9 @@ def kernels(src):
         i = text.find("\n" + name + ":")
         if i < 0:
             continue
-        loops = loops_of(text[i:text.find(".end_amdhsa_kernel", i)].split("\n"))
+        body  = text[i:text.find(".end_amdhsa_kernel", i)].split("\n")
+        loops = loops_of(body)
+        info["buffer_loads"], info["serialising_wait"] = loads_in_one_round_trip(body)
         # traversal loops = the step loops of the BVH walk: a few hundred vector instructions around the 16-byte loads
         # of a node / leaf record (the sample and item loops around them hold thousands)
         info["loops"] = loops
@@ -121,6 +146,15 @@ if __name__ == "__main__":
                 if product and r["scratch"] > allowed:
                     flag, bad = "   <-- spill traffic in a traversal loop", bad + 1
                 print(f"    loop {h:10s} depth {r['depth']}: {r['valu']:4d} VALU {r['salu']:4d} SALU {r['lds']:3d} LDS {r['vmem']:3d} VMEM, {r['scratch']} scratch ops{flag}")
+            if "k_stream" in name:
+                if k["buffer_loads"] == 0:
+                    print("    the step's buffer loads were not found   <-- the check needs a look")
+                    bad += 1 if product else 0
+                elif k["serialising_wait"]:
+                    print(f"    {k['buffer_loads']} buffer loads, and `{k['serialising_wait']}` between them   <-- the step makes two dependent memory round trips")
+                    bad += 1 if product else 0
+                else:
+                    print(f"    {k['buffer_loads']} buffer loads of the step in one round trip (no wait between them that an earlier one has to satisfy)")
             if product and not k["trav"]:
                 print("    no traversal loop found   <-- the heuristic needs a look")
                 bad += 1
