@@ -61,7 +61,7 @@ CONFIGS = {
     "C4": dict(scene="hair-curls", resolution=1280, spp=4096, kw={}),
 }
 # What the headline line reports next to C1 (config.other_configs): BASELINE.json configs[2..4], C2 at the middle of its beta_m sweep
-OTHER_CONFIGS = [("C2", {"beta_m": 0.25}, 8), ("C3", {}, 8), ("C4", {}, 8)]  # (config, scene overrides, launches the spp are cut into)
+OTHER_CONFIGS = [("C2", {"beta_m": 0.25}, 8, False), ("C3", {}, 8, True), ("C4", {}, 8, True)]  # (config, scene overrides, launches the spp are cut into, project shard 0 of 8)
 KERNELS = {0: "k_trace<512 x 4>", 1: "k_trace<256 x 5>", 2: "k_trace<512 x 4, 8-wide nodes>", 3: "k_stream", 4: "k_trace<256 x 4, octets>",
            5: "k_trace_sbs<512 x 4>: quads + the top items as octets, one launch", 6: "k_trace<256 x 4, 16 lanes per path>", 7: "k_trace<256 x 4, octets, leaf pairs>",
            8: "k_trace<256 x 4, 16 lanes per path, leaf groups>"}
@@ -458,7 +458,7 @@ def main():
             elapsed, kernel_ms = t.tolist()
         return width, height, elapsed, kernel_ms, p
 
-    def other_config(name, kw, steps):
+    def other_config(name, kw, steps, project8=False):
         """One more BASELINE config on this GPU at its FULL sample count, with its own warm-up (its kernel trials stay out of
         the timed steps): value, ms per step, the kernel chosen and its roofline against the committed work counts and
         counter passes. The scene replaces the context's; the caller is done with the headline scene."""
@@ -498,9 +498,21 @@ def main():
                     o_parity = parity_field(np, oimgs[0], oimgs[1], ca, cb, ospp)
                 except Exception as e:  # never at the expense of the throughput numbers
                     o_parity = {"error": str(e)}
+            # what ONE GPU of eight would take on this config (its shard rendered alone here, as config.projected_strong_scaling does for the headline):
+            # C3 / C4 are the configs BASELINE.json pairs with 8 GPUs
+            proj8 = None
+            if project8 and a.project_scaling:
+                try:
+                    ctx.set_shard(0, 8)
+                    pw, ph, pel, _, _ = timed_run(c["resolution"], spps, 0, warm_spps=[96, 96, 96])
+                    proj8 = {"n_gpus": 8, "shard": "0 of 8", "seconds": round(pel, 4), "value_if_every_gpu_takes_this_long": round(pw * ph * c["spp"] / pel / 1e6, 1),
+                             "kernel": KERNELS.get(ctx.launch_shape(), "?"), "launches_in_timed_steps": sum(ctx_launches)}
+                except Exception as e:  # never at the expense of the throughput numbers
+                    proj8 = {"error": str(e)}
+                ctx.set_shard(0, 1)
             return {"workload": f"{name}: {c['scene']} {w}x{h} x {c['spp']} spp" + "".join(f" {k} {v:g}" for k, v in kw.items()),
                     "value": round(w * h * c["spp"] / el / 1e6, 2), "unit": "Msamples/s", "steps": steps, "ms_per_step": round(el * 1e3 / steps, 3),
-                    "kernel": KERNELS.get(shape, "?"), "launch_shape": shape, "launches_in_timed_steps": launches,
+                    "kernel": KERNELS.get(shape, "?"), "launch_shape": shape, "launches_in_timed_steps": launches, "projected_8_gpus": proj8,
                     "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                                  "traffic": traffic, "traffic_unit": "GB per launch", "traffic_source": pmc["source"] if pmc else why,
                                  "avg_launch_ms": round(launch_s * 1e3, 3), "algorithmic_bytes_per_sample": round(bps, 1), "work_counts_from": src,
@@ -635,9 +647,9 @@ def main():
     others = None
     if rank == 0 and world == 1 and headline and a.other_configs:
         others = {}
-        for oname, okw, osteps in OTHER_CONFIGS:
+        for oname, okw, osteps, oproj in OTHER_CONFIGS:
             try:
-                others[oname] = other_config(oname, okw, osteps)
+                others[oname] = other_config(oname, okw, osteps, oproj)
             except Exception as e:  # never at the expense of the reported line
                 others[oname] = {"error": str(e)}
 
@@ -729,7 +741,8 @@ def main():
         if others:
             out["config"]["other_configs"] = {
                 "what": "BASELINE.json configs[2..4] on this GPU after the headline run, each at its FULL sample count in 8 launches with its own "
-                        "warm-up (three 96-sample launches: the kernel trials); roofline as for the headline (committed work counts / counter passes)",
+                        "warm-up (three 96-sample launches: the kernel trials); roofline as for the headline (committed work counts / counter passes); "
+                        "projected_8_gpus (C3, C4): shard 0 of 8 of the config rendered alone here, as projected_strong_scaling does for the headline",
                 "runs": others}
         if e2e:
             out["config"]["end_to_end"] = e2e
@@ -742,6 +755,39 @@ def main():
             out["parity"] = shard_check
         if cpu is not None and world == 1:
             out["cpu_baseline"] = cpu
+        # ---- every config's number as SCALARS of `config` (a record that keeps only scalars of the nested objects still shows all four configs and the
+        # 8-GPU projections), and once more as `summary`, the LAST key of the line (a record that keeps only the tail of the line shows them too) -------
+        flat = {}
+        if others:
+            for oname, r in others.items():
+                k = oname.lower()
+                if "error" in r:
+                    flat[k + "_error"] = r["error"][:100]
+                    continue
+                flat[k + "_msamples"], flat[k + "_frac"], flat[k + "_launch_shape"] = r["value"], r["roofline"]["frac"], r["launch_shape"]
+                flat[k + "_launches_in_timed_steps"] = r["launches_in_timed_steps"]
+                if isinstance(r.get("parity"), dict) and "ratio_to_floor" in r["parity"]:
+                    flat[k + "_parity_ratio"], flat[k + "_parity_spp"] = r["parity"]["ratio_to_floor"], r["parity"]["spp"]
+                    flat[k + "_share_within_4_sigma"] = r["parity"]["share_within_4_sigma"]
+                if isinstance(r.get("cpu_baseline"), dict):
+                    flat[k + "_cpu_msamples"] = r["cpu_baseline"]["value"]
+                if isinstance(r.get("projected_8_gpus"), dict) and "seconds" in r["projected_8_gpus"]:
+                    flat[k + "_proj8_msamples"], flat[k + "_proj8_shard_s"] = r["projected_8_gpus"]["value_if_every_gpu_takes_this_long"], r["projected_8_gpus"]["seconds"]
+        for r in (projected or []):
+            if "seconds" in r:
+                flat[f"c1_proj{r['n_gpus']}_msamples"], flat[f"c1_proj{r['n_gpus']}_shard_s"] = r["value_if_every_gpu_takes_this_long"], r["seconds"]
+        if parity is not None:
+            flat["c1_parity_ratio"], flat["c1_parity_spp"], flat["c1_share_within_4_sigma"] = parity.get("ratio_to_floor"), parity.get("spp"), parity.get("share_within_4_sigma")
+        if e2e and "warm_trial_record" in e2e:
+            wm = e2e["warm_trial_record"]
+            flat["e2e_warm_total_wall_s"], flat["e2e_warm_msamples_whole_command"] = wm["total_wall_s"], wm["msamples_per_s_whole_command"]
+            flat["e2e_warm_bvh_and_upload_s"], flat["e2e_warm_sample_loop_s"] = wm.get("bvh_and_upload_s"), wm.get("sample_loop_s")
+            flat["e2e_warm_sample_loop_kernel_s"] = wm.get("sample_loop_kernel_s")
+            if "cold_trial_record" in e2e:
+                flat["e2e_cold_total_wall_s"] = e2e["cold_trial_record"]["total_wall_s"]
+        out["config"].update(flat)
+        out["summary"] = dict({"c1_msamples": out["value"], "c1_frac": out["roofline"]["frac"], "c1_launch_shape": shape_used, "n_gpus": world,
+                               "c1_cpu_msamples": cpu["value"] if cpu else None}, **flat)
         print(json.dumps(out), file=json_out, flush=True)
     if grouped:
         dist.barrier()

@@ -67,6 +67,15 @@ int main() {
     CHECK(launch_timeout_s() == 1800.0);
     setenv("YHAIR_LAUNCH_TIMEOUT_S", "soon", 1);
     CHECK(launch_timeout_s() == 1800.0);
+    setenv("YHAIR_LAUNCH_TIMEOUT_S", "1e12", 1);  // "never": clamped to what the wait's nanosecond clock can hold
+    CHECK(launch_timeout_s() == 1e8);
+    {  // ... and a healthy call under that deadline is DONE, not expired at once (an overflowed deadline lies in the past)
+      BoundedCall bc;
+      int         r = -1;
+      CHECK(bc.run([] { std::this_thread::sleep_for(std::chrono::milliseconds(80)); return 3; }, launch_timeout_s(), &r) == WAIT_DONE && r == 3 && !bc.expired());
+    }
+    setenv("YHAIR_LAUNCH_TIMEOUT_S", "inf", 1);
+    CHECK(launch_timeout_s() == 1e8);
     unsetenv("YHAIR_LAUNCH_TIMEOUT_S");
     CHECK(launch_timeout_s() == 1800.0);
   }

@@ -209,7 +209,11 @@ int yh_intersect_batch(yh_context* ctx, int n, const float* rays, int* object, i
   int         waves = 5;  // 91 registers without a spill: five waves per SIMD (6 and 8 spill 39 / 61 registers, measured slower)
   bool        lanes = n >= 65536 && lane_kernels_can_address(ctx);
   if (mode && !strcmp(mode, "quad")) lanes = false;
-  else if (mode && !strncmp(mode, "lane", 4)) lanes = true, waves = std::max(4, std::min(8, atoi(mode + 4)));
+  else if (mode && !strncmp(mode, "lane", 4)) {
+    if (!lane_kernels_can_address(ctx))  // (beyond 4 GB the buffer resource clamps and the loads return zeros: wrong hits, no error)
+      return fail(ctx, YH_E_INVALID, "YHAIR_INTERSECT=%s: the one-lane kernel reads the scene's trees through 32-bit byte offsets and this scene's exceed 4 GB", mode);
+    lanes = true, waves = std::max(4, std::min(8, atoi(mode + 4)));
+  }
   for (int i = 0; lanes && i < n; i++) lanes = rays[8 * (size_t)i + 6] == 1e-4f;
   HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   if (lanes) {

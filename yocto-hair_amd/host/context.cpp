@@ -16,7 +16,11 @@ int fail(yh_context* ctx, int code, const char* fmt, ...) {
   return code;
 }
 
+// (Both start with the BOUNDED wait for whatever the context has queued: freeing the old buffer is a device-synchronising hipFree and the copy a
+// blocking one on the null stream — behind a kernel of yh_trace_samples_async that never completes they would wait for ever, outside the
+// deadline include/yhair.h promises for every call that waits for the device.)
 int upload(yh_context* ctx, DevBuf& buf, const void* src, size_t bytes) {
+  YH_WAIT(ctx);
   buf.reset();
   size_t alloc = std::max<size_t>(bytes, 16);
   HIPCHK(ctx, hipMalloc(&buf.p, alloc));
@@ -24,7 +28,21 @@ int upload(yh_context* ctx, DevBuf& buf, const void* src, size_t bytes) {
   if (bytes) HIPCHK(ctx, hipMemcpy(buf.p, src, bytes, hipMemcpyHostToDevice));
   return YH_OK;
 }
+// The same into a buffer that is kept while it is large enough (no hipFree + hipMalloc per call: deal_shares_by_speed re-plans after every launch
+// of a dense image).
+int upload_keep(yh_context* ctx, DevBuf& buf, const void* src, size_t bytes) {
+  YH_WAIT(ctx);
+  if (!buf.p || buf.bytes < bytes) {
+    buf.reset();
+    const size_t alloc = std::max<size_t>(bytes + bytes / 4, 16);  // (room to grow: the list's length changes a little from plan to plan)
+    HIPCHK(ctx, hipMalloc(&buf.p, alloc));
+    buf.bytes = alloc;
+  }
+  if (bytes) HIPCHK(ctx, hipMemcpy(buf.p, src, bytes, hipMemcpyHostToDevice));
+  return YH_OK;
+}
 int alloc_zero(yh_context* ctx, DevBuf& buf, size_t bytes) {
+  YH_WAIT(ctx);
   buf.reset();
   size_t alloc = std::max<size_t>(bytes, 16);
   HIPCHK(ctx, hipMalloc(&buf.p, alloc));

@@ -279,6 +279,7 @@ struct yh_context {
   DevBuf           d_st_slots, d_st_medium, d_st_ovf, d_st_prof, d_st_wave_log, d_st_wave_begin, d_st_wave_fill, d_scene_copy;
   int              st_items = 0;         // work items of the list k_stream's hand-out was made for (deal_items_for_stream): what its launch geometry follows
   size_t           st_share_waves = 0;   // waves the per-wave shares of the work list were made for (0: none, everything through the cursor)
+  int              st_share_slots = 0;   // ... and the pool slots per wave (a share holds at most slots / 16 items)
   std::vector<int>    st_share_begin, st_share_items;  // host copy of the shares in effect: offsets per wave, items in list order
   std::vector<double> st_share_cost;                   // ... and the cost each item was planned with
   std::vector<unsigned long long> st_last_log;         // the last k_stream launch's stamps per wave {begin, end}
@@ -312,6 +313,7 @@ constexpr int    YH_TRIALS_MAX = 2;
 // ---- internal functions that cross translation units (defined in the file the comment above names) ----
 int fail(yh_context* ctx, int code, const char* fmt, ...);
 int upload(yh_context* ctx, DevBuf& buf, const void* src, size_t bytes);
+int upload_keep(yh_context* ctx, DevBuf& buf, const void* src, size_t bytes);  // ... into a buffer that is kept while it is large enough
 int alloc_zero(yh_context* ctx, DevBuf& buf, size_t bytes);
 yhd_float4 node_lo(const yhh::Node& n);
 yhd_float4 node_hi(const yhh::Node& n);

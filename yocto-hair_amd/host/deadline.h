@@ -127,7 +127,9 @@ inline double launch_timeout_s() {
   if (e && *e) {
     char*        end = nullptr;
     const double v   = strtod(e, &end);
-    if (end != e && v > 0) return v;
+    // (clamped: duration<double> -> the condition variable's integer nanoseconds overflows above ~9.2e9 s, and a deadline in the past would
+    // poison a healthy context at its first long wait; 1e8 s = three years is "never")
+    if (end != e && v > 0) return v < 1e8 ? v : 1e8;
   }
   return 1800.0;
 }

@@ -630,9 +630,9 @@ static bool deal_shares_by_speed(yh_context* ctx, std::vector<int>& items, int P
     while ((out.size() - (size_t)begin[w]) % 4 != 0) out.push_back(-1), out_cost.push_back(0.0);  // a take is four entries (csrc/stream.hip): -1 = no item
   }
   begin[waves] = (int)out.size();
-  if (upload(ctx, ctx->d_st_wave_begin, begin.data(), begin.size() * 4) != YH_OK) return false;
+  if (upload_keep(ctx, ctx->d_st_wave_begin, begin.data(), begin.size() * 4) != YH_OK) return false;
   ctx->stream_pool.wave_begin = (const int*)ctx->d_st_wave_begin.p;
-  ctx->st_share_waves         = waves;
+  ctx->st_share_waves         = waves, ctx->st_share_slots = P;
   ctx->st_share_begin = begin, ctx->st_share_items = out, ctx->st_share_cost = out_cost;  // what the next feedback reads the launch against
   items.swap(out);
   ctx->state.num_groups = 1, ctx->state.group_begin[0] = (int)items.size(), ctx->state.group_begin[1] = (int)items.size();  // nothing is left for the cursor
@@ -648,7 +648,7 @@ void deal_items_for_stream(yh_context* ctx, std::vector<int>& items) {
   int  P = 0, grid = 0;
   bool one = false;
   ctx->state.num_groups = 1, ctx->state.group_begin[0] = 0, ctx->state.group_begin[1] = (int)items.size();
-  ctx->stream_pool.wave_begin = nullptr, ctx->st_share_waves = 0;
+  ctx->stream_pool.wave_begin = nullptr, ctx->st_share_waves = 0, ctx->st_share_slots = 0;
   ctx->st_items = (int)items.size();  // the geometry of k_stream's launches follows the ITEMS of the list, not its entries (a shared-out list is padded)
   if (items.empty() || !stream_geometry(ctx, (int)items.size(), &P, &grid, nullptr, &one)) return;
   if (one && deal_shares_by_speed(ctx, items, P, grid)) return;

@@ -76,6 +76,8 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
   if (!ctx) return YH_E_INVALID;
   if (!sd) return fail(ctx, YH_E_INVALID, "scene is NULL");
   HIPCHK(ctx, hipSetDevice(ctx->device));
+  if (ctx->poisoned) return fail(ctx, YH_E_DEVICE, "a launch of this context exceeded its deadline: the context refuses further work, destroy it");
+  YH_WAIT(ctx);  // (an asynchronous launch may still be reading the scene this call replaces: wait for it, within the deadline)
   if (sd->num_objects <= 0) return fail(ctx, YH_E_INVALID, "scene has no objects");
   if (sd->num_environments > YH_MAX_ENVS) return fail(ctx, YH_E_INVALID, "more than %d environments", YH_MAX_ENVS);
   // YHAIR_TIMING=1: stage times of the upload on stderr

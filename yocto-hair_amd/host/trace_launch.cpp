@@ -50,6 +50,7 @@ int yh_init_state(yh_context* ctx, const yh_trace_params* params) {
     return fail(ctx, YH_E_INVALID, "sampler unknown");  // get_trace_shader_func's throw (pt.cpp:1669)
   if (params->hair_exact && params->shader != YH_SHADER_PATH) return fail(ctx, YH_E_INVALID, "hair_exact exists for the path shader only");
   HIPCHK(ctx, hipSetDevice(ctx->device));
+  YH_WAIT(ctx);  // (an asynchronous launch may still be running on the buffers this call replaces: wait for it, within the deadline)
   const bool same_work = ctx->have_state && ctx->params.shader == params->shader && ctx->params.bounces == params->bounces;  // (what the items' relative costs depend on besides the image)
   ctx->params = *params;
   // image size (pt.cpp:1933-1939)
@@ -145,10 +146,27 @@ int yh_init_state(yh_context* ctx, const yh_trace_params* params) {
 int stream_impl(yh_context* ctx, int nsamples, bool sync) {
   int  P = 0, grid = 0, lds_bytes = 0;
   bool one_generation = false;
+  if (!lane_kernels_can_address(ctx))
+    return fail(ctx, YH_E_INVALID, "k_stream (launch shape 3) reads the scene's trees through 32-bit byte offsets and this scene's exceed 4 GB: the quad kernels render it");
   if (!stream_geometry(ctx, ctx->st_items > 0 ? ctx->st_items : ctx->state.num_tiles, &P, &grid, &lds_bytes, &one_generation))
     return fail(ctx, YH_E_DEVICE, "k_stream cannot run with its LDS layout on this device");
   const int     wpb    = yhk_stream_block_threads() / 64;
-  const size_t  waves  = (size_t)grid * wpb, slots = waves * P;
+  size_t        waves  = (size_t)grid * wpb;
+  // The per-wave shares of the work list (deal_shares_by_speed) are made for ONE launch geometry — a wave count and a pool size — and the
+  // cursor then starts behind the whole list: launched with another geometry (YHAIR_ST_WAVES / YHAIR_ST_SLOTS changed between the plan and
+  // the launch), waves beyond the plan's would find nothing, shares beyond the pool's slots would be dropped, and samples_done would still
+  // advance over pixels nobody rendered. So: a mismatch re-deals the list for the geometry of THIS launch; if that does not settle it, the
+  // launch is refused — never a list the waves cannot reach.
+  if (ctx->stream_pool.wave_begin && (ctx->st_share_waves != waves || ctx->st_share_slots != P)) {
+    if (int wrc = wait_for_launch(ctx)) return wrc;
+    if (int rc = upload_work_items(ctx)) return rc;
+    if (!stream_geometry(ctx, ctx->st_items > 0 ? ctx->st_items : ctx->state.num_tiles, &P, &grid, &lds_bytes, &one_generation))
+      return fail(ctx, YH_E_DEVICE, "k_stream cannot run with its LDS layout on this device");
+    waves = (size_t)grid * wpb;
+    if (ctx->stream_pool.wave_begin && (ctx->st_share_waves != waves || ctx->st_share_slots != P))
+      return fail(ctx, YH_E_STATE, "k_stream: the work list was shared out for %zu waves of %d slots and the launch has %zu of %d", ctx->st_share_waves, ctx->st_share_slots, waves, P);
+  }
+  const size_t  slots  = waves * P;
   // overflow of the per-lane LDS stack windows (dev_lane.h): a main ray plus a light-pdf ray above it
   const int    ovf_entries = 2 * std::max(8, ctx->stack_need);
   const size_t ovf_words   = waves * (size_t)ovf_entries * 64;
@@ -184,13 +202,12 @@ int stream_impl(yh_context* ctx, int nsamples, bool sync) {
   if (ctx->d_st_wave_log.bytes < waves * 16)
     if ((rc = alloc_zero(ctx, ctx->d_st_wave_log, waves * 16))) return rc;
   ctx->stream_pool.wave_log = (unsigned long long*)ctx->d_st_wave_log.p;
-  if (ctx->stream_pool.wave_begin && ctx->st_share_waves != waves) ctx->stream_pool.wave_begin = nullptr;
   ctx->stream_pool.wave_fill = nullptr;
   if (ctx->stream_pool.wave_begin) {
     if (ctx->d_st_wave_fill.bytes < waves * 4)
       if ((rc = alloc_zero(ctx, ctx->d_st_wave_fill, waves * 4))) return rc;
     ctx->stream_pool.wave_fill = (int*)ctx->d_st_wave_fill.p;
-  }  // (shares made for another geometry: the list is then taken through the cursor, which starts behind them — cannot happen while both come from stream_geometry)
+  }
   if (!ctx->d_scene_copy.p) {  // the scene table in device memory, for the kernel's out-of-line callees
     if ((rc = upload(ctx, ctx->d_scene_copy, &ctx->scene, sizeof(yhd_scene)))) return rc;
   }
