@@ -277,6 +277,47 @@ def test_launch_deadline_logic(tmp_path):
     assert out.returncode == 0 and "all checks passed" in out.stdout, out.stdout + out.stderr
 
 
+def test_eight_cold_ranks_share_one_trial_record(tmp_path):
+    """Eight cold ranks on one node, rehearsed on CPU: tests/cpp/test_trial_ranks.cpp compiles the REAL
+    host/launch_plan.cpp with the device mocked and drives its trial bookkeeping for eight ranks (threads) against ONE trials_v2.txt.
+    cold: concurrent O_APPEND writers, every rank ends with a complete record, no trial inside any rank's timed steps
+    (launches_in_timed_steps == steps), tied candidates settle on one kernel on all ranks. Then this test damages the file the ways a node can
+    — a torn line (a rank killed inside its write), a damaged line, a second record for one key whose winner differs (two runs that disagreed:
+    the last line counts), a torn line without its newline at the end of the file — and a second process (warm) must run no trial at all,
+    one launch per request, write nothing, and pick the kernels the surviving lines name."""
+    exe, cache = str(tmp_path / "test_trial_ranks"), str(tmp_path / "cache")
+    os.makedirs(cache)
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-pthread", "-D__HIP_PLATFORM_AMD__", "-Wno-unused-function", "-I/opt/rocm/include",
+                           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "yocto-hair_amd", "host"),
+                           os.path.join(ROOT, "tests", "cpp", "test_trial_ranks.cpp"), "-o", exe, "-ldl"])
+    out = subprocess.run([exe, "cold", cache], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "all checks passed" in out.stdout, out.stdout + out.stderr
+    path = os.path.join(cache, "trials_v2.txt")
+    lines = open(path).read().splitlines()
+    assert len(lines) == 8 * 42
+
+    def line_of(rank):  # the record of shard `rank` of 8 of the 720 x 720 image of scene 0xC1
+        hits = [l for l in lines if f"|{0xC1:016x}|720|720|{rank}|8|8 =" in l]
+        assert len(hits) == 1
+        return hits[0]
+
+    def with_time(line, shape, factor):
+        key, _, rest = line.partition(" =")
+        pairs, _, tail = rest.partition(" ;")
+        pairs = pairs.split()
+        ms, n = pairs[shape].split(":")
+        pairs[shape] = f"{float(ms) * factor:.9g}:{n}"
+        return key + " = " + " ".join(pairs) + " ;" + tail
+
+    with open(path, "a") as f:
+        f.write(line_of(3)[: len(line_of(3)) * 6 // 10] + "\n")      # torn: a rank died inside its write — the earlier line of the key stands
+        f.write(with_time(line_of(4), 8, -1.5) + "\n")               # damaged: a negative time is not a record
+        f.write(with_time(line_of(5), 8, 1.3) + "\n")                # a later run measured the leaf-group form 30 % slower: the LAST line counts -> shape 6
+        f.write(with_time(line_of(6), 8, 1.3).rpartition(" ;")[0])    # ... and the same for rank 6, but torn at the very end of the file (no tail, no newline): ignored
+    out = subprocess.run([exe, "warm", cache, "5:6"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "all checks passed" in out.stdout, out.stdout + out.stderr
+
+
 def test_codegen_check_knows_two_round_trips_when_it_sees_them():
     """tools/check_codegen.py also guards k_stream's step against the regression round 5 found in the assembly: a wait between the step's
     buffer loads that an earlier one of them has to satisfy = two dependent memory round trips per step (the first form of the cooperative
