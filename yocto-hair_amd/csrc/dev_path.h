@@ -339,6 +339,39 @@ YH_DEV float sample_lights_pdf(const trace_ctx& tc, f3 position, f3 direction) {
   return pdf;
 }
 
+#if YH_LANE
+// sample_lights_pdf OUT OF LINE for k_stream<GENERAL> (one lane per path, big lights possible): inlined — twice, path_step calls it from its volume
+// and its surface branch — the lights' loop with a whole traversal loop inside (the pdf walk of a big light: up to a hundred
+// intersect_instance_bvh rays, pt.cpp:1315-1334) was what pushed that kernel's shading stage into scratch: 278 spilled registers and scratch
+// instructions inside three of its loops. As a function of its own it has its own register budget; the caller pays one
+// call per bounce. Everything by value, as lane_trace_exact: the caller's stack state stays in registers.
+struct lane_lights_pdf_result {
+  float pdf;
+  int   base;  // the stack's window base afterwards (sp is back where it was)
+};
+__device__ __attribute__((noinline)) lane_lights_pdf_result lane_lights_pdf_general(const yhd_scene* sc, const YH_LDS v4f* lds_scene, const YH_LDS v4f* lds_lights,
+    const YH_LDS float* lds_envtab, YH_LDS unsigned int* lds, unsigned int* ovf, int sp, int base, f3 position, f3 direction) {
+  trace_ctx tc;
+  tc.sc = sc, tc.sc_dev = sc, tc.lds_stack = nullptr, tc.lds_scene = lds_scene, tc.stats = nullptr;
+  tc.lds_lights = lds_lights, tc.lds_envtab = lds_envtab, tc.lds_mats = nullptr;
+  lane_stack s;
+  s.lds = lds, s.ovf = ovf, s.sp = sp, s.base = base;
+  tc.ls = &s;
+  const float pdf = sample_lights_pdf<false, 64, true>(tc, position, direction);
+  return lane_lights_pdf_result{pdf, s.base};
+}
+template <bool GENERAL>
+YH_DEV float lane_lights_pdf(const trace_ctx& tc, f3 position, f3 direction) {
+  if constexpr (GENERAL) {
+    const lane_lights_pdf_result r = lane_lights_pdf_general(tc.sc_dev, tc.lds_scene, tc.lds_lights, tc.lds_envtab, tc.ls->lds, tc.ls->ovf, tc.ls->sp, tc.ls->base, position, direction);
+    tc.ls->base = r.base;
+    return r.pdf;
+  } else {
+    return sample_lights_pdf<false, 64, false>(tc, position, direction);
+  }
+}
+#endif
+
 // State of one path in flight (the locals of trace_path, pt.cpp:1383-1387).
 struct path_t {
   ray_t ray;
@@ -349,6 +382,11 @@ struct path_t {
   // otherwise, so it never holds more than one medium. Used by GENERAL kernels only.
   bool   in_medium;
   vsdf_t medium;
+#if YH_LANE
+  // one lane per path (k_stream): the medium stays in the path's slot — path_step reads it where the free flight needs it and medium_crossing
+  // writes it when the path enters one — instead of travelling through the whole shading code in seven registers (dead in the hair stage)
+  yhd_float4* medium_mem;
+#endif
 };
 
 // End of one bounce (pt.cpp:1499-1507): weight check, Russian roulette, bounce count.
@@ -402,6 +440,10 @@ YH_DEV void medium_crossing(const yhd_scene& sc, path_t& ps, const yhd_material&
     }
     ps.medium.scatter    = ld3(mat.vol_scatter) * eval_texture(sc, mat.scattering_tex, false, tu, tv);
     ps.medium.anisotropy = mat.vol_anisotropy;
+#if YH_LANE
+    ps.medium_mem[0] = yhd_float4{ps.medium.density.x, ps.medium.density.y, ps.medium.density.z, ps.medium.anisotropy};
+    ps.medium_mem[1] = yhd_float4{ps.medium.scatter.x, ps.medium.scatter.y, ps.medium.scatter.z, 0.0f};
+#endif
   }
   ps.in_medium = !ps.in_medium;
 }
@@ -422,6 +464,12 @@ YH_DEV bool path_step(const trace_ctx& tc, path_t& ps, const hit_t& isec, rng_t&
   }
   f3 outgoing = -ps.ray.d;
   if (GENERAL && ps.in_medium) {
+#if YH_LANE
+    {
+      const yhd_float4 m0 = ps.medium_mem[0], m1 = ps.medium_mem[1];
+      ps.medium.density = f3{m0.x, m0.y, m0.z}, ps.medium.anisotropy = m0.w, ps.medium.scatter = f3{m1.x, m1.y, m1.z};
+    }
+#endif
     // free flight inside the medium (pt.cpp:1403-1414); g++ draws rd before rl
     float rd = rand1f(rng), rl = rand1f(rng);
     float dist = sample_transmittance(ps.medium.density, isec.distance, rl, rd);
@@ -444,7 +492,11 @@ YH_DEV bool path_step(const trace_ctx& tc, path_t& ps, const hit_t& isec, rng_t&
       }
       f3    f         = eval_scattering(ps.medium, outgoing, incoming);
       float pdf       = sample_scattering_pdf(ps.medium, outgoing, incoming);
+#if YH_LANE
+      float light_pdf = lane_lights_pdf<GENERAL>(tc, position, incoming);
+#else
       float light_pdf = sample_lights_pdf<COUNT, STRIDE, GENERAL>(tc, position, incoming);
+#endif
       ps.weight = ps.weight * (f / (0.5f * pdf + 0.5f * light_pdf));
       ps.ray    = mkray(position, incoming);
       if (COUNT) tc.stats->c_rest += clock64() - k0;
@@ -563,7 +615,11 @@ YH_DEV bool path_step(const trace_ctx& tc, path_t& ps, const hit_t& isec, rng_t&
     }
   }
   if (COUNT) k3 = clock64(), tc.stats->c_eval += k3 - k2;
+#if YH_LANE
+  float light_pdf = lane_lights_pdf<GENERAL>(tc, position, incoming);
+#else
   float light_pdf = sample_lights_pdf<COUNT, STRIDE, GENERAL>(tc, position, incoming);
+#endif
   ps.weight = ps.weight * (brdfcos / (0.5f * brdf_pdf + 0.5f * light_pdf));
   if (general) medium_crossing(sc, ps, mat, normal, outgoing, incoming, ctex, etex_x, tu, tv);
   ps.ray    = mkray(position, incoming);

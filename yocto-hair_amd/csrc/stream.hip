@@ -35,6 +35,9 @@ using namespace yhd;
 
 #define YH_ST_BLOCK 256
 #define YH_ST_WAVES 4        /* waves per SIMD the register allocator must allow (5 = 96 registers puts 28 spill instructions into the step loop: profiles/r05/coop_line_leaves.txt) */
+#ifndef YH_ST_WAVES_GENERAL
+#define YH_ST_WAVES_GENERAL 4 /* ... of the GENERAL variant (surface lobes, volumes, textures, big lights) */
+#endif
 #define YH_ST_WAVE_LDS(P) (64 * YH_LSTACK * 4 + 64 * 8 + 6 * (P) * 2) /* LDS of one wave */
 #define YH_REFILL_LANES 16   /* idle lanes of a wave before the (divergent) refill code runs */
 #define YH_SUSPEND_LANES 16  /* ray list dry and at most this many lanes busy: go shading. The default of yhd_stream::suspend_lanes, which the host sets:
@@ -284,10 +287,7 @@ __global__ __launch_bounds__(YH_ST_BLOCK, WAVES) void k_stream(const yhd_scene s
         ps.weight   = f3{w.x, w.y, w.z}, ps.radiance = f3{rad.x, rad.y, rad.z};
         const int fl = __float_as_int(d.w);
         ps.bounce = fl & 255, ps.hit = (fl & 256) != 0, ps.in_medium = (fl & 512) != 0;
-        if (GENERAL && ps.in_medium) {
-          yhd_float4 m0 = pl.medium[2 * g], m1 = pl.medium[2 * g + 1];
-          ps.medium.density = f3{m0.x, m0.y, m0.z}, ps.medium.anisotropy = m0.w, ps.medium.scatter = f3{m1.x, m1.y, m1.z};
-        }
+        ps.medium_mem = GENERAL ? pl.medium + 2 * g : nullptr;  // (read and written where path_step needs it: dev_path.h)
         hit_t isec;
         isec.object = h.x, isec.slot = h.y, isec.u = __int_as_float(h.z), isec.v = __int_as_float(h.w), isec.distance = o.w;
         isec = lane_hit_retest(tc, isec, act == A_HAIR, ps.ray.o, ps.ray.d);  // (hair batches hold the hits on lines: their uv from the test itself, dev_lane.h)
@@ -302,10 +302,6 @@ __global__ __launch_bounds__(YH_ST_BLOCK, WAVES) void k_stream(const yhd_scene s
         if (alive) {
           SLOT_RAY_O(pl, g)  = yhd_float4{ps.ray.o.x, ps.ray.o.y, ps.ray.o.z, 0.0f};
           SLOT_WEIGHT(pl, g) = yhd_float4{ps.weight.x, ps.weight.y, ps.weight.z, 0.0f};
-          if (GENERAL && ps.in_medium) {
-            pl.medium[2 * g]     = yhd_float4{ps.medium.density.x, ps.medium.density.y, ps.medium.density.z, ps.medium.anisotropy};
-            pl.medium[2 * g + 1] = yhd_float4{ps.medium.scatter.x, ps.medium.scatter.y, ps.medium.scatter.z, 0.0f};
-          }
         } else {
           SLOT_HIT(pl, g).x = H_ENDED;
         }
@@ -547,7 +543,7 @@ int yhk_intersect_lanes(const yhd_scene* sc, const yhd_scene* sc_dev, int n, con
 typedef void (*stream_kernel_t)(const yhd_scene, const yhd_scene*, const yhd_state, int, const yhd_stream);
 static stream_kernel_t stream_kernel(bool general, bool prof = false) {
   if (prof && !general) return k_stream<false, YH_ST_WAVES, true>;
-  return general ? k_stream<true, YH_ST_WAVES, false> : k_stream<false, YH_ST_WAVES, false>;
+  return general ? k_stream<true, YH_ST_WAVES_GENERAL, false> : k_stream<false, YH_ST_WAVES, false>;
 }
 int yhk_stream_block_threads(void) { return YH_ST_BLOCK; }
 int yhk_stream_lds_bytes(int tables_f4, int slots_per_wave) {

@@ -522,11 +522,14 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
   ctx->have_costs = false, ctx->costs_settled = false, ctx->dense = -1, ctx->chain = -1, ctx->chain16 = -1;
   for (double& t : ctx->shape_ms) t = 0;
   for (int& t : ctx->shape_trials) t = 0;
+  lap("scene table, fingerprint");
   wide_build_start(ctx);  // the wide collapses in the background: ready by the time a kernel that needs them is tried
   ctx->trials_from_disk = false;
   // the kernels over 4-wide nodes — quads and one lane per path alike — read the trees from the lane blob (yh_device.h): made
   // here, on the device, from the arrays just uploaded (two streaming kernels per shape, about a millisecond)
-  return ensure_lane_blob(ctx);
+  const int brc = ensure_lane_blob(ctx);
+  lap("lane blob (device)");
+  return brc;
 }
 
 void wide_build_join(yh_context* ctx) {
@@ -556,9 +559,18 @@ void wide_build_start(yh_context* ctx) {  // (ctx->host_trees must stay untouche
 // when a kernel that traverses them is about to run for the first time (launch shapes 4, 5, 6, 7).
 int ensure_wide_nodes(yh_context* ctx) {
   if (ctx->wide_built) return YH_OK;
+  const bool timing = getenv("YHAIR_TIMING") && atoi(getenv("YHAIR_TIMING")) != 0;
+  auto       t_last = std::chrono::steady_clock::now();
+  auto       lap    = [&](const char* what) {
+    if (!timing) return;
+    auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[yhair] wide nodes: %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+    t_last = now;
+  };
   YH_WAIT(ctx);  // (a queued launch may be reading the object records)
   if (!ctx->wide_job) wide_build_start(ctx);  // (normally started by yh_upload_scene)
   wide_build_join(ctx);
+  lap("wait for the collapses");
   const size_t ns = ctx->host_trees.size();
   std::vector<std::vector<yhh::WideNode8>>&  w8  = ctx->wide_job->w8;
   std::vector<std::vector<yhh::WideNode16>>& w16 = ctx->wide_job->w16;
@@ -604,7 +616,9 @@ int ensure_wide_nodes(yh_context* ctx) {
           }
       }
     };
+    lap("concatenate");
     rewrite(nodes8, base8, U8, 8), rewrite(nodes16, base16, U16, 16);
+    lap("absolute references");
     DevBuf bigger;
     if ((rc = alloc_zero(ctx, bigger, (size_t)total * 32))) return rc;
     HIPCHK(ctx, hipMemcpy(bigger.p, ctx->d_lane_blob.p, (size_t)ctx->lane_units * 32, hipMemcpyDeviceToDevice));
@@ -618,6 +632,7 @@ int ensure_wide_nodes(yh_context* ctx) {
     }
   }
   HIPCHK(ctx, hipMemcpy(ctx->d_objects.p, ctx->host_objects.data(), ctx->host_objects.size() * sizeof(yhd_object), hipMemcpyHostToDevice));
+  lap("bigger blob: malloc + copies");
   ctx->d_scene_copy.reset();  // (the copy of the scene table in device memory is made again at its next use)
   ctx->wide_built = true;
   ctx->wide_job.reset();

@@ -51,6 +51,14 @@ int yh_init_state(yh_context* ctx, const yh_trace_params* params) {
   if (params->hair_exact && params->shader != YH_SHADER_PATH) return fail(ctx, YH_E_INVALID, "hair_exact exists for the path shader only");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   YH_WAIT(ctx);  // (an asynchronous launch may still be running on the buffers this call replaces: wait for it, within the deadline)
+  const bool timing = getenv("YHAIR_TIMING") && atoi(getenv("YHAIR_TIMING")) != 0;
+  auto       t_last = std::chrono::steady_clock::now();
+  auto       lap    = [&](const char* what) {
+    if (!timing) return;
+    auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[yhair] init_state: %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+    t_last = now;
+  };
   const bool same_work = ctx->have_state && ctx->params.shader == params->shader && ctx->params.bounces == params->bounces;  // (what the items' relative costs depend on besides the image)
   ctx->params = *params;
   // image size (pt.cpp:1933-1939)
@@ -73,6 +81,7 @@ int yh_init_state(yh_context* ctx, const yh_trace_params* params) {
     Rng r   = make_rng(params->seed, (uint64_t)seq);
     st[i] = r.state, inc[i] = r.inc;
   }
+  lap("pixel streams (host)");
   int tx = tiles_of(w), ty = tiles_of(h);
   ctx->num_tiles_total = tx * ty;
   auto& owned = ctx->owned;
@@ -121,6 +130,7 @@ int yh_init_state(yh_context* ctx, const yh_trace_params* params) {
   s.samples_done = 0, s.bounces = params->bounces, s.clamp = params->clamp, s.shader = params->shader;
   s.shard_rank = ctx->rank, s.shard_world = ctx->world;
   ctx->have_state = true;
+  lap("work list, buffers, copies");
   if (new_image) trials_load(ctx);  // what this process already measured on this scene, image and shard
   // Probe: the first launch of a new image has no item costs and would hand its work items out in image order,
   // 25-60 % slower than a planned launch (hair quadrants cost 10-100x background ones and bound the launch when
@@ -138,6 +148,7 @@ int yh_init_state(yh_context* ctx, const yh_trace_params* params) {
     YH_WAIT(ctx);
     ctx->state.samples_done = 0, ctx->launches_of_image = 0, ctx->last_shape = -1, ctx->last_ms = 0, ctx->last_launches = 0;
     ctx->have_costs = true;  // the launches that follow are planned: their times rank the kernels
+    lap("probe launch + plan");
   }
   return YH_OK;
 }

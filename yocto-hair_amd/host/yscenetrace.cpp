@@ -100,11 +100,13 @@ int main(int argc, const char* argv[]) {
     int    launches = 0, requests = 0;
     for (int sample = 0; sample < params.samples;) {
       int n = save_batch ? 1 : std::min(spp_per_launch, params.samples - sample);
+      const double r0 = secs();
       ptr::trace_samples(state.get(), scene.get(), camera, params, n, save_batch);
       sample += n, requests++;
       float ms = 0;
       int   l  = 0;
       if (yh_last_trace_ms(yhair::detail::context(), &ms, &l) == YH_OK) kernel_ms += ms, launches += l;  // (context 0; the others run beside it)
+      if (timing && getenv("YHAIR_TIMING")) fprintf(stderr, "[yhair] request %d: %d spp, %.2f ms wall, %.2f ms of kernels in %d launch(es)\n", requests, n, (secs() - r0) * 1e3, ms, l);
       if (save_batch) {  // cli.cpp:259-267: "<stem>-s<sample><ext>"
         auto dot_pos = imfilename.rfind('.');
         auto stem = imfilename.substr(0, dot_pos), ext = dot_pos == std::string::npos ? "" : imfilename.substr(dot_pos);
