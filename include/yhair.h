@@ -396,6 +396,11 @@ int yh_bvh_build_wide(int n, const float* boxes, int width, float* slots);
  * shapes of 32 768 primitives and more). Same arguments and result as yh_bvh_build;
  * the two are compared node for node in the tests.                            */
 int yh_bvh_build_gpu(yh_context* ctx, int n, const float* boxes, float* nodes, int* primitives);
+/* ... and its wide collapse made on the GPU too (csrc/bvh_gpu.hip: what yh_upload_scene runs for EVERY shape since round 6 — the host's
+ * collapse_wide* of yh_bvh_build_wide are the restatement it is tested against). Same arguments and result as yh_bvh_build_wide, in the form the
+ * traversal kernels read: a child's ref is the index of its FIRST SLOT (width x the child node's index), and for width 4 bits 8-11 of `axes`
+ * hold the occupied slots.                                                                                                              */
+int yh_bvh_build_wide_gpu(yh_context* ctx, int n, const float* boxes, int width, float* slots);
 
 /* One surface lobe (kind = YH_LOBE_*) of yocto_math.h:1513-1620 (implementation
  * 4427-4755): eval_* (value times |cos|), sample_*_pdf and sample_* in one

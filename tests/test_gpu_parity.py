@@ -222,6 +222,40 @@ def test_device_bvh_build_is_the_reference_tree(ctx, yh, name, kw):
     sf.close()
 
 
+@pytest.mark.parametrize("n", [1, 3, 5, 37, 4099, 200000])
+def test_device_wide_collapses_are_the_host_collapses(ctx, yh, n):
+    """Round 6: yh_upload_scene makes the 4- / 8- / 16-wide nodes ON THE DEVICE (csrc/bvh_gpu.hip: a flag pass, a scan and one kernel per width write them
+    straight into the array the traversal kernels read). Against the host's collapse_wide / _wide8 / _wide16 (host/bvh_build.cpp, themselves checked
+    against the binary traversal's visiting order in tests/test_abi.py), slot for slot and bit for bit: the same boxes, the same leaf references, a
+    child's reference = width x the host's child index (the device writes the child's first slot), the same split axes; for width 4 the occupied-slot bits."""
+    rng = np.random.default_rng(n)
+    lo = rng.uniform(-1, 1, (n, 3)).astype(np.float32)
+    boxes = np.concatenate([lo, lo + rng.uniform(0.001, 0.05, (n, 3)).astype(np.float32)], axis=1)
+    boxes[: n // 3, 3:] = boxes[: n // 3, :3] + np.float32(0.01)  # (many equal extents: ties in the split's choice of axis)
+    lib = yh.load()
+    for width in (4, 8, 16):
+        nh = lib.yh_bvh_build_wide(n, yh.fptr(boxes), width, None)
+        host = np.zeros((nh, width, 8), np.float32)
+        assert lib.yh_bvh_build_wide(n, yh.fptr(boxes), width, yh.fptr(host)) == nh
+        nd = lib.yh_bvh_build_wide_gpu(ctx.h, n, yh.fptr(boxes), width, None)
+        assert nd == nh, f"width {width}: {nd} wide nodes on the device, {nh} on the host"
+        dev = np.zeros((nh, width, 8), np.float32)
+        assert lib.yh_bvh_build_wide_gpu(ctx.h, n, yh.fptr(boxes), width, yh.fptr(dev)) == nh
+        assert np.array_equal(host[..., :6].view(np.uint32), dev[..., :6].view(np.uint32)), f"width {width}: child boxes differ"
+        href, dref = host[..., 6].view(np.uint32).astype(np.int64), dev[..., 6].view(np.uint32).astype(np.int64)
+        empty, leaf = href == 0xFFFFFFFF, (href >> 30) == 3
+        node = ~empty & ~leaf
+        assert np.array_equal(dref[empty | leaf], href[empty | leaf]), f"width {width}: empty / leaf references differ"
+        assert np.array_equal(dref[node], href[node] * width), f"width {width}: child references differ"
+        haxes, daxes = host[..., 7].view(np.uint32), dev[..., 7].view(np.uint32)
+        if width == 4:
+            assert np.array_equal(daxes & 0xFF, haxes & 0xFF)
+            occ = ((~empty).astype(np.uint32) << np.arange(4, dtype=np.uint32)).sum(axis=1)
+            assert np.array_equal((daxes >> 8) & 0xF, np.broadcast_to(occ[:, None], daxes.shape))
+        else:
+            assert np.array_equal(daxes, haxes)
+
+
 def test_empty_and_invalid_batches(ctx, yh):
     z = np.zeros((0, 3), np.float32)
     assert ctx.hair_eval(np.zeros((0, 30), np.float32), z, z).shape == (0, 3)
@@ -728,6 +762,40 @@ def test_per_pixel_error_within_k_sigma(ctx, oracle, yh, name, kw):
     assert share16 >= 0.99, f"16 spp: {share16:.4f} of pixels within {K_SIGMA} sigma (relRMSE {err16:.4f})"
     share64, err64 = _k_sigma_share(ctx, osc, yh, res, 64, None, seeds=(961748941, 12345, 777, 31337))
     assert share64 >= 0.99, f"64 spp: {share64:.4f} of pixels within {K_SIGMA} sigma (relRMSE {err64:.4f})"
+    osc.close(), sf.close()
+
+
+@pytest.mark.parametrize("exact", [False, True], ids=["fast-bsdf", "exact-bsdf"])
+@pytest.mark.parametrize("name,kw", [("straight-hair", dict(scale=0.05)), ("curly-hair", dict(scale=0.05)), ("hair-curls", dict(scale=0.05))],
+                         ids=["straight-hair", "curly-hair", "hair-curls"])
+def test_dense_hair_has_no_mean_shift_at_high_spp(ctx, oracle, yh, name, kw, exact):
+    """The bias estimator of tools/parity_vs_spp.py as a test. The path-following ratio relRMSE(gpu, ref) / seed floor GROWS with
+    the sample count on dense hair — what per-pixel stream decorrelation predicts (a device path that leaves the reference's shifts every later draw
+    of that pixel's one PCG32 stream) and what a small bias of the fast BSDF arithmetic would also look like. What tells them apart: decorrelated
+    estimates have the same MEAN. At 512 spp (32 x the spp of the path-following bar) the mean radiance over the pixels that see the model, two seeds
+    pooled, must agree with the oracle's within 3 standard errors of the difference (pixels are independent streams: SE = std of the per-pixel
+    differences / sqrt(n)) — for the default arithmetic and for the exact one; a bias of 0.5 % of the radiance would be ~ 5 SE here."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from parity_vs_spp import mean_shift
+    sf = yh.SceneFile(scene_path(name, **kw))
+    ctx.upload_scene(sf.desc)
+    osc = oracle.scene(sf.desc)
+    res, spp = 48, 512
+    gpu, ref = [], []
+    for sd in (961748941, 12345):
+        p = yh.TraceParams.default(resolution=res, seed=sd, hair_exact=exact)
+        ctx.init_state(p)
+        ctx.trace_samples(spp)
+        gpu.append(ctx.download().astype(np.float64))
+        ref.append(osc.render(yh.TraceParams.default(resolution=res, seed=sd), spp).astype(np.float64))
+    mask = (ref[0][..., 3] > 0) & (ref[1][..., 3] > 0)
+    assert mask.sum() > 500, "the check image should mostly see hair"
+    ms = mean_shift((gpu[0][..., :3] + gpu[1][..., :3]) / 2, (ref[0][..., :3] + ref[1][..., :3]) / 2, mask)
+    lum = ms["luminance"]
+    assert lum["se"] < 5e-3, f"the estimator is too noisy to say anything: SE {lum['se']:.2e}"
+    assert abs(lum["rel_shift"]) <= 3.0 * lum["se"], f"mean radiance over {ms['pixels']} pixels differs by {lum['rel_shift']:+.3e} = {lum['shift_in_se']:+.2f} standard errors ({lum['se']:.2e})"
+    for c in "rgb":
+        assert abs(ms[c]["rel_shift"]) <= 4.0 * ms[c]["se"], f"channel {c}: {ms[c]['rel_shift']:+.3e} against SE {ms[c]['se']:.2e}"
     osc.close(), sf.close()
 
 

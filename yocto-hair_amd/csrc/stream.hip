@@ -46,15 +46,23 @@ using namespace yhd;
 // (tuned in rounds 2 and 4, profiles/r02/k_stream_sweep_slots_suspend.txt, profiles/r04/k_stream_tuning_after_blob.txt; the other
 // scheduling policy, items taken sixteen slots at a time and the field-by-field pool layout are closed A/Bs of the same records)
 
-// Fields of a path slot (yh_device.h: yhd_path_slot, eight 16-byte fields in one 128-byte line).
+// Fields of a path slot (yh_device.h: yhd_path_slot): eight 16-byte fields in one 128-byte line, GROUPED BY WHO WRITES THEM into the line's four 32-byte
+// sectors (round 6) — a stage that retires a ray dirties one sector, a shaded bounce two, not the whole line: the pool is 20 x the L2s, so a line is
+// written back between two stages that touch it, and what leaves the L2 is its dirty sectors.
+//   sector 0   ray origin | ray direction                                   written by: finish (a new camera ray), shade (the next ray of a live path)
+//   sector 1   weight.xyz, flags | rng state lo, hi, traversal steps so far  ...        finish, shade (every bounce)
+//   sector 2   hit: object, leaf slot, u, v | distance, steps of this ray    ...        the trace stage, when it retires the ray (publish); shade: object = H_ENDED
+//   sector 3   radiance.xyz, pixel | samples left, work item, rng inc lo, hi ...        items (a new pixel), finish (a new sample), shade only when the bounce met an emitter
 #define SLOT_F4(pl, g, k) (((yhd_float4*)&(pl).slots[g])[k])
+#define SLOT_I4(pl, g, k) (((yhd_int4*)&(pl).slots[g])[k])
 #define SLOT_RAY_O(pl, g) SLOT_F4(pl, g, 0)
 #define SLOT_RAY_D(pl, g) SLOT_F4(pl, g, 1)
-#define SLOT_WEIGHT(pl, g) SLOT_F4(pl, g, 2)
-#define SLOT_RADIANCE(pl, g) SLOT_F4(pl, g, 3)
-#define SLOT_HIT(pl, g) (*(yhd_int4*)&SLOT_F4(pl, g, 4))
-#define SLOT_RNG(pl, g) (*(yhd_int4*)&SLOT_F4(pl, g, 5))
-#define SLOT_META(pl, g) (*(yhd_int4*)&SLOT_F4(pl, g, 6))
+#define SLOT_WEIGHT(pl, g) SLOT_F4(pl, g, 2) /* .w = int bits: path_flags */
+#define SLOT_RNGW(pl, g) SLOT_I4(pl, g, 3)   /* rng state lo, hi, traversal steps of the pixel's rays so far (a scheduling hint), - */
+#define SLOT_HIT(pl, g) SLOT_I4(pl, g, 4)
+#define SLOT_HIT2(pl, g) SLOT_I4(pl, g, 5)   /* distance (float bits), steps of the ray just traced, -, - */
+#define SLOT_RADIANCE(pl, g) SLOT_F4(pl, g, 6) /* .w = int bits: the pixel */
+#define SLOT_OWN(pl, g) SLOT_I4(pl, g, 7)    /* samples left to start, work item, rng inc lo, hi */
 
 // Progress: a trace stage that leaves with rays suspended (<= suspend_lanes busy lanes, something pending) must be
 // followed by a stage that consumes what is pending — the scheduler flushes partial batches when fewer than 64 rays are at
@@ -75,12 +83,12 @@ YH_DEV int list_push(YH_LDS unsigned short* list, int n, bool pred, int value) {
 // Closest hit of a finished ray into its slot, RAW as the traversal keeps it (dev_lane.h: the shading stage applies lane_hit
 // to the batch it shades, once per hit instead of in every step that retires a ray); returns what it hit.
 YH_DEV int publish(const yhd_stream& pl, size_t g, const hit_t& hit, bool hit_lines, unsigned int steps) {
-  SLOT_HIT(pl, g)                 = yhd_int4{hit.object, hit.slot, __float_as_int(hit.u), __float_as_int(hit.v)};
-  ((float*)&SLOT_RAY_O(pl, g))[3] = hit.distance;
-  // steps of this ray: a scheduling hint of the pixel's work item, added to the pixel's total by the stage that
-  // takes the path next (NOT an atomic add here: device-scope atomics execute at the memory side and drop the
-  // slot's line from L2 — measured 1.6x on the whole kernel)
-  ((unsigned int*)&SLOT_F4(pl, g, 7))[0] = steps;
+  // ONE sector of the slot's line: the hit and, next to it, its distance and the steps of this ray — a scheduling hint of the pixel's work item,
+  // added to the pixel's total by the stage that takes the path next (NOT an atomic add here: device-scope atomics execute at the memory side
+  // and drop the slot's line from L2 — measured 1.6x on the whole kernel)
+  SLOT_HIT(pl, g)  = yhd_int4{hit.object, hit.slot, __float_as_int(hit.u), __float_as_int(hit.v)};
+  ((float*)&SLOT_HIT2(pl, g))[0]        = hit.distance;
+  ((unsigned int*)&SLOT_HIT2(pl, g))[1] = steps;
   return hit.object < 0 ? K_MISS : (hit_lines ? K_HAIR : K_SURF);
 }
 YH_DEV int path_flags(const path_t& ps) { return (ps.bounce & 255) | (ps.hit ? 256 : 0) | (ps.in_medium ? 512 : 0); }
@@ -185,8 +193,9 @@ __global__ __launch_bounds__(YH_ST_BLOCK, WAVES) void k_stream(const yhd_scene s
         sl                = l_free[n_free - 1 - lane_rank(m)];
         const size_t   g  = base + sl;
         const uint64_t rs = st.rng_state[pixel], ri = st.rng_inc[pixel];
-        SLOT_META(pl, g)        = yhd_int4{pixel, nsamples, item, 0};
-        SLOT_RNG(pl, g)         = yhd_int4{(int)(unsigned)rs, (int)(unsigned)(rs >> 32), (int)(unsigned)ri, (int)(unsigned)(ri >> 32)};
+        SLOT_RADIANCE(pl, g)    = yhd_float4{0.0f, 0.0f, 0.0f, __int_as_float(pixel)};
+        SLOT_OWN(pl, g)         = yhd_int4{nsamples, item, (int)(unsigned)ri, (int)(unsigned)(ri >> 32)};
+        SLOT_RNGW(pl, g)        = yhd_int4{(int)(unsigned)rs, (int)(unsigned)(rs >> 32), 0, 0};
         SLOT_HIT(pl, g)         = yhd_int4{H_NEW, 0, 0, 0};
       }
       n_free -= (int)__popcll(m);
@@ -222,28 +231,28 @@ __global__ __launch_bounds__(YH_ST_BLOCK, WAVES) void k_stream(const yhd_scene s
       if (PROF) p_batch = (unsigned long long)cnt;
       bool next = false, freed = false;
       if (on) {
-        const size_t   g  = base + sl;
-        const yhd_int4 mt = SLOT_META(pl, g);
-        const int      h  = SLOT_HIT(pl, g).x, p = mt.x, left = mt.y;
-        unsigned int   work = (unsigned int)mt.w;
-        if (h == H_MISS) work += ((const unsigned int*)&SLOT_F4(pl, g, 7))[0];  // the ray that missed (see publish)
+        const size_t     g   = base + sl;
+        const yhd_float4 rad = SLOT_RADIANCE(pl, g);
+        const yhd_int4   own = SLOT_OWN(pl, g), rw = SLOT_RNGW(pl, g);
+        const int        h = SLOT_HIT(pl, g).x, p = __float_as_int(rad.w), left = own.x;
+        unsigned int     work = (unsigned int)rw.z;
+        if (h == H_MISS) work += (unsigned int)SLOT_HIT2(pl, g).y;  // the ray that missed (see publish)
         if (h != H_NEW) {  // trace_sample's tail (pt.cpp:1683-1688)
-          yhd_float4 rad = SLOT_RADIANCE(pl, g), d = SLOT_RAY_D(pl, g);
-          path_t     ps;
+          const yhd_float4 w = SLOT_WEIGHT(pl, g);
+          path_t           ps;
           ps.radiance = f3{rad.x, rad.y, rad.z};
-          ps.hit      = (__float_as_int(d.w) & 256) != 0;
+          ps.hit      = (__float_as_int(w.w) & 256) != 0;
           if (h == H_MISS) {  // pt.cpp:1397-1400
-            yhd_float4 w = SLOT_WEIGHT(pl, g);
-            ps.radiance  = ps.radiance + f3{w.x, w.y, w.z} * eval_environment<false>(tc, f3{d.x, d.y, d.z});
+            const yhd_float4 d = SLOT_RAY_D(pl, g);
+            ps.radiance        = ps.radiance + f3{w.x, w.y, w.z} * eval_environment<false>(tc, f3{d.x, d.y, d.z});
           }
           yhd_float4 acc = st.accum[p];
           path_end(ps, st.clamp, acc);
           st.accum[p] = acc;
         }
-        const yhd_int4 r4 = SLOT_RNG(pl, g);
-        rng_t          rng;
-        rng.state = (uint64_t)(unsigned)r4.x | ((uint64_t)(unsigned)r4.y << 32);
-        rng.inc   = (uint64_t)(unsigned)r4.z | ((uint64_t)(unsigned)r4.w << 32);
+        rng_t rng;
+        rng.state = (uint64_t)(unsigned)rw.x | ((uint64_t)(unsigned)rw.y << 32);
+        rng.inc   = (uint64_t)(unsigned)own.z | ((uint64_t)(unsigned)own.w << 32);
         if (left > 0) {  // the pixel's next sample (trace_sample, pt.cpp:1676-1682)
           float lu = rand1f(rng), lv = rand1f(rng);
           float pu = rand1f(rng), pv = rand1f(rng);
@@ -252,16 +261,15 @@ __global__ __launch_bounds__(YH_ST_BLOCK, WAVES) void k_stream(const yhd_scene s
           cam.lens = lds_cam[12], cam.film_x = lds_cam[13], cam.film_y = lds_cam[14], cam.focus = lds_cam[15], cam.aperture = lds_cam[16];
           ray_t r = sample_camera_lane(cam, p % st.width, p / st.width, st.width, st.height, pu, pv, lu, lv);
           SLOT_RAY_O(pl, g)    = yhd_float4{r.o.x, r.o.y, r.o.z, 0.0f};
-          SLOT_RAY_D(pl, g)    = yhd_float4{r.d.x, r.d.y, r.d.z, __int_as_float(0)};
-          SLOT_WEIGHT(pl, g)   = yhd_float4{1.0f, 1.0f, 1.0f, 0.0f};
-          SLOT_RADIANCE(pl, g) = yhd_float4{0.0f, 0.0f, 0.0f, 0.0f};
-          SLOT_RNG(pl, g)      = yhd_int4{(int)(unsigned)rng.state, (int)(unsigned)(rng.state >> 32), r4.z, r4.w};
-          SLOT_META(pl, g).y   = left - 1;
-          SLOT_META(pl, g).w   = (int)work;
+          SLOT_RAY_D(pl, g)    = yhd_float4{r.d.x, r.d.y, r.d.z, 0.0f};
+          SLOT_WEIGHT(pl, g)   = yhd_float4{1.0f, 1.0f, 1.0f, __int_as_float(0)};
+          SLOT_RNGW(pl, g)     = yhd_int4{(int)(unsigned)rng.state, (int)(unsigned)(rng.state >> 32), (int)work, 0};
+          SLOT_RADIANCE(pl, g) = yhd_float4{0.0f, 0.0f, 0.0f, rad.w};
+          SLOT_OWN(pl, g)      = yhd_int4{left - 1, own.y, own.z, own.w};
           next           = true;
         } else {  // the pixel has all its samples: hand its stream back, report its work, free the slot
           st.rng_state[p] = rng.state;
-          if (work) atomicAdd(&st.tile_cost[mt.z], work);
+          if (work) atomicAdd(&st.tile_cost[own.y], work);
           freed = true;
         }
       }
@@ -280,28 +288,29 @@ __global__ __launch_bounds__(YH_ST_BLOCK, WAVES) void k_stream(const yhd_scene s
       bool alive = false;
       if (on) {
         const size_t g = base + sl;
-        yhd_float4 o = SLOT_RAY_O(pl, g), d = SLOT_RAY_D(pl, g), w = SLOT_WEIGHT(pl, g), rad = SLOT_RADIANCE(pl, g);
-        yhd_int4   h = SLOT_HIT(pl, g), r4 = SLOT_RNG(pl, g);
+        const yhd_float4 o = SLOT_RAY_O(pl, g), d = SLOT_RAY_D(pl, g), w = SLOT_WEIGHT(pl, g), rad = SLOT_RADIANCE(pl, g);
+        const yhd_int4   h = SLOT_HIT(pl, g), h2 = SLOT_HIT2(pl, g), rw = SLOT_RNGW(pl, g), own = SLOT_OWN(pl, g);
         path_t     ps;
         ps.ray      = ray_t{f3{o.x, o.y, o.z}, f3{d.x, d.y, d.z}, ray_eps, flt_max};
         ps.weight   = f3{w.x, w.y, w.z}, ps.radiance = f3{rad.x, rad.y, rad.z};
-        const int fl = __float_as_int(d.w);
+        const int fl = __float_as_int(w.w);
         ps.bounce = fl & 255, ps.hit = (fl & 256) != 0, ps.in_medium = (fl & 512) != 0;
         ps.medium_mem = GENERAL ? pl.medium + 2 * g : nullptr;  // (read and written where path_step needs it: dev_path.h)
         hit_t isec;
-        isec.object = h.x, isec.slot = h.y, isec.u = __int_as_float(h.z), isec.v = __int_as_float(h.w), isec.distance = o.w;
+        isec.object = h.x, isec.slot = h.y, isec.u = __int_as_float(h.z), isec.v = __int_as_float(h.w), isec.distance = __int_as_float(h2.x);
         isec = lane_hit_retest(tc, isec, act == A_HAIR, ps.ray.o, ps.ray.d);  // (hair batches hold the hits on lines: their uv from the test itself, dev_lane.h)
         rng_t rng;
-        rng.state = (uint64_t)(unsigned)r4.x | ((uint64_t)(unsigned)r4.y << 32);
-        rng.inc   = (uint64_t)(unsigned)r4.z | ((uint64_t)(unsigned)r4.w << 32);
+        rng.state = (uint64_t)(unsigned)rw.x | ((uint64_t)(unsigned)rw.y << 32);
+        rng.inc   = (uint64_t)(unsigned)own.z | ((uint64_t)(unsigned)own.w << 32);
         alive     = path_step<false, 64, GENERAL>(tc, ps, isec, rng, st.bounces);
-        SLOT_META(pl, g).w += (int)((const unsigned int*)&SLOT_F4(pl, g, 7))[0];  // the steps of the ray just shaded
-        SLOT_RNG(pl, g)      = yhd_int4{(int)(unsigned)rng.state, (int)(unsigned)(rng.state >> 32), r4.z, r4.w};
-        SLOT_RADIANCE(pl, g) = yhd_float4{ps.radiance.x, ps.radiance.y, ps.radiance.z, 0.0f};
-        SLOT_RAY_D(pl, g)    = yhd_float4{ps.ray.d.x, ps.ray.d.y, ps.ray.d.z, __int_as_float(path_flags(ps))};
-        if (alive) {
-          SLOT_RAY_O(pl, g)  = yhd_float4{ps.ray.o.x, ps.ray.o.y, ps.ray.o.z, 0.0f};
-          SLOT_WEIGHT(pl, g) = yhd_float4{ps.weight.x, ps.weight.y, ps.weight.z, 0.0f};
+        // sector 1, every bounce: weight + flags | the stream's state + the steps of the ray just shaded
+        SLOT_WEIGHT(pl, g) = yhd_float4{ps.weight.x, ps.weight.y, ps.weight.z, __int_as_float(path_flags(ps))};
+        SLOT_RNGW(pl, g)   = yhd_int4{(int)(unsigned)rng.state, (int)(unsigned)(rng.state >> 32), rw.z + h2.y, 0};
+        // sector 3 only when the bounce met an emitter (an area light, or a textured emission): the radiance is otherwise what it was
+        if (ps.radiance.x != rad.x || ps.radiance.y != rad.y || ps.radiance.z != rad.z) SLOT_RADIANCE(pl, g) = yhd_float4{ps.radiance.x, ps.radiance.y, ps.radiance.z, rad.w};
+        if (alive) {  // sector 0: the next ray
+          SLOT_RAY_O(pl, g) = yhd_float4{ps.ray.o.x, ps.ray.o.y, ps.ray.o.z, 0.0f};
+          SLOT_RAY_D(pl, g) = yhd_float4{ps.ray.d.x, ps.ray.d.y, ps.ray.d.z, 0.0f};
         } else {
           SLOT_HIT(pl, g).x = H_ENDED;
         }
@@ -394,9 +403,10 @@ __global__ __launch_bounds__(64) void k_stream_seed(const yhd_state st, int nsam
     if (valid && n + lane_rank(m) < pl.slots_per_wave) {  // (the host sizes the pool for the largest share)
       const size_t   g  = base + (size_t)(n + lane_rank(m));
       const uint64_t rs = st.rng_state[pixel], ri = st.rng_inc[pixel];
-      SLOT_META(pl, g)  = yhd_int4{pixel, nsamples, item, 0};
-      SLOT_RNG(pl, g)   = yhd_int4{(int)(unsigned)rs, (int)(unsigned)(rs >> 32), (int)(unsigned)ri, (int)(unsigned)(ri >> 32)};
-      SLOT_HIT(pl, g)   = yhd_int4{H_NEW, 0, 0, 0};
+      SLOT_RADIANCE(pl, g) = yhd_float4{0.0f, 0.0f, 0.0f, __int_as_float(pixel)};
+      SLOT_OWN(pl, g)      = yhd_int4{nsamples, item, (int)(unsigned)ri, (int)(unsigned)(ri >> 32)};
+      SLOT_RNGW(pl, g)     = yhd_int4{(int)(unsigned)rs, (int)(unsigned)(rs >> 32), 0, 0};
+      SLOT_HIT(pl, g)      = yhd_int4{H_NEW, 0, 0, 0};
     }
     n += (int)__popcll(m);
   }

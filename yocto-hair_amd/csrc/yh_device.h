@@ -226,16 +226,17 @@ typedef struct yhd_state {
 
 // Path pool of the streaming integrator (csrc/stream.hip): one lane per path, `slots_per_wave` slots owned by
 // each WAVEFRONT (no workgroup-level synchronisation), SoA over the slots.
-// One path slot = one 128-byte cache line: a stage touches one line per path, not one per field.
+// One path slot = one 128-byte cache line: a stage touches one line per path, not one per field. The fields are grouped by WRITER into the line's
+// four 32-byte sectors (round 6; csrc/stream.hip: SLOT_*), so that a stage dirties the sectors it owns and not the line.
 typedef struct yhd_path_slot {
-  yhd_float4 ray_o;     // origin.xyz; w = distance of the closest hit
-  yhd_float4 ray_d;     // direction.xyz; w = int bits: bounce | hit << 8 | in_medium << 9
-  yhd_float4 weight;    // path weight.xyz
-  yhd_float4 radiance;  // radiance collected so far .xyz
-  yhd_int4   hit;       // object (-1 miss, -2 path ended in shading, -3 new pixel), leaf slot, u bits, v bits
-  yhd_int4   rng;       // the pixel's PCG32 stream while it owns the slot: state lo, hi, inc lo, hi
-  yhd_int4   meta;      // pixel, samples left to start, work item, traversal steps so far
-  yhd_int4   pad;
+  yhd_float4 ray_o;     // sector 0: origin.xyz
+  yhd_float4 ray_d;     //           direction.xyz
+  yhd_float4 weight;    // sector 1: path weight.xyz; w = int bits: bounce | hit << 8 | in_medium << 9
+  yhd_int4   rngw;      //           the pixel's PCG32 state lo, hi; traversal steps of the pixel's rays so far (scheduling hint)
+  yhd_int4   hit;       // sector 2: object (-1 miss, -2 path ended in shading, -3 new pixel), leaf slot, u bits, v bits
+  yhd_int4   hit2;      //           distance bits of the closest hit, steps of the ray just traced
+  yhd_float4 radiance;  // sector 3: radiance collected so far .xyz; w = int bits: the pixel
+  yhd_int4   own;       //           samples left to start, work item, the stream's inc lo, hi
 } yhd_path_slot;
 typedef struct yhd_stream {
   yhd_path_slot* slots;

@@ -116,6 +116,31 @@ int yh_bvh_build_gpu(yh_context* ctx, int n, const float* boxes, float* nodes, i
   return (int)tree.nodes.size();
 }
 
+int yh_bvh_build_wide_gpu(yh_context* ctx, int n, const float* boxes, int width, float* slots) {
+  if (!ctx || n < 1 || !boxes || (width != 4 && width != 8 && width != 16)) return YH_E_INVALID;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  YH_WAIT(ctx);
+  const int L = width == 4 ? 2 : width == 8 ? 3 : 4;
+  DevBuf    d_boxes, d_nodes, d_pid, d_flag, d_widx, d_out;
+  int       rc;
+  if ((rc = upload(ctx, d_boxes, boxes, (size_t)n * 24))) return rc;
+  if ((rc = alloc_zero(ctx, d_nodes, ((size_t)2 * n + 1) * 32)) || (rc = alloc_zero(ctx, d_pid, (size_t)n * 4))) return rc;
+  int num_nodes = 0, levels = 0, level_first[130], count = 0;
+  int e = yhk_bvh_build_resident(n, (const float*)d_boxes.p, (float*)d_nodes.p, (int*)d_pid.p, &num_nodes, &levels, level_first, ctx->stream);
+  if (e) return fail(ctx, YH_E_DEVICE, "device BVH build: %s", hipGetErrorString((hipError_t)e));
+  if ((rc = alloc_zero(ctx, d_flag, ((size_t)num_nodes + 1) * 4)) || (rc = alloc_zero(ctx, d_widx, ((size_t)num_nodes + 1) * 4))) return rc;
+  e = yhk_wide_index(num_nodes, (const float*)d_nodes.p, levels, level_first, L, (unsigned int*)d_flag.p, (unsigned int*)d_widx.p, &count, ctx->stream);
+  if (e) return fail(ctx, YH_E_DEVICE, "wide-node index: %s", hipGetErrorString((hipError_t)e));
+  if (slots) {
+    if ((rc = alloc_zero(ctx, d_out, (size_t)count * width * 32))) return rc;
+    e = yhk_wide_collapse(L, num_nodes, (const float*)d_nodes.p, (const unsigned int*)d_flag.p, (const unsigned int*)d_widx.p, 1, 0, 0, d_out.p, ctx->stream);
+    if (e) return fail(ctx, YH_E_DEVICE, "wide collapse: %s", hipGetErrorString((hipError_t)e));
+    YH_WAIT(ctx);
+    HIPCHK(ctx, hipMemcpy(slots, d_out.p, (size_t)count * width * 32, hipMemcpyDeviceToHost));
+  }
+  return count;
+}
+
 int yh_bvh_build_wide(int n, const float* boxes, int width, float* slots) {
   if (n < 0 || (n && !boxes) || (width != 4 && width != 8 && width != 16)) return YH_E_INVALID;
   std::vector<yhh::Box> b((size_t)n);

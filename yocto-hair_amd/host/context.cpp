@@ -101,7 +101,6 @@ yh_context* yh_create(int device) {
 
 void yh_destroy(yh_context* ctx) {
   if (!ctx) return;
-  if (ctx->wide_job && ctx->wide_job->th.joinable()) ctx->wide_job->th.join();
   if (ctx->poisoned) return;  // a launch exceeded its deadline (wait_for_launch): the device may still be running it — synchronising or freeing would wait for it; the process is expected to end
   destroy_communicators(ctx);
   (void)hipSetDevice(ctx->device);

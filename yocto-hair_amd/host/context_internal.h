@@ -69,6 +69,12 @@ int yhk_hair_pdf(int, const float*, const float*, const float*, float*, hipStrea
 int yhk_hair_sample(int, const float*, const float*, const float*, float*, hipStream_t);
 int yhk_intersect(const yhd_scene*, int, const float*, int*, int*, float*, float*, hipStream_t);
 int yhk_bvh_build_gpu(int n, const float* boxes, float* nodes8, int* primitives, int* num_nodes, int* depth, hipStream_t);
+// csrc/bvh_gpu.hip, device in / device out (yh_upload_scene): bounds, the tree, the leaf records and the wide collapses of one shape
+int yhk_prim_boxes(int lines, int n, const float* pos, const float* radius, const int* idx, float* boxes, hipStream_t);
+int yhk_bvh_build_resident(int n, const float* d_boxes, float* d_nodes, int* d_pid, int* num_nodes, int* levels, int* level_first, hipStream_t);
+int yhk_leaf_records(int lines, int n, const int* pid, const float* pos, const float* nrm, const float* radius, const int* idx, void* prims_out, hipStream_t);
+int yhk_wide_index(int num_nodes, const float* d_nodes, int levels, const int* level_first, int L, unsigned int* d_flag, unsigned int* d_widx, int* count, hipStream_t);
+int yhk_wide_collapse(int L, int num_nodes, const float* d_nodes, const unsigned int* d_flag, const unsigned int* d_widx, int lines, long long node_off, long long test_off, void* blob, hipStream_t);
 int yhk_curves_to_lines(int, const float*, const float*, const float*, int, float*, float*, float*, int*, hipStream_t);
 int yhk_surface_lobe(int, int, const float*, const float*, const float*, const float*, const float*, float*, hipStream_t);
 int yhk_surface_bsdf(int, const void*, const float*, const float*, const float*, const float*, float*, hipStream_t);
@@ -196,15 +202,6 @@ void parallel_for(int n, F&& fn) {
 }
 
 constexpr int YH_SHAPES = 9;  // launch shapes: 0, 1 k_trace (4-wide nodes) | 2 (was: quads over 8-wide nodes; not built) | 3 k_stream | 4 k_trace with octets | 5 quads and octets side by side | 6 k_trace with sixteen lanes per path | 7 octets with leaf pairs | 8 sixteen lanes with leaf groups
-// The 8- and 16-wide collapses of a scene's trees take a tenth of a second of host time for a million-segment hair
-// model; the kernels that need them are chosen after the first launches. yh_upload_scene starts them in the background,
-// ensure_wide_nodes (host/scene_upload.cpp) waits for them — so the first launch of a wide kernel does not pay for them.
-struct WideBuild {
-  std::thread                               th;
-  std::vector<std::vector<yhh::WideNode8>>  w8;
-  std::vector<std::vector<yhh::WideNode16>> w16;
-  std::vector<int>                          d8, d16;
-};
 struct yh_context {
   int         device = 0;
   hipStream_t stream = nullptr;
@@ -222,17 +219,9 @@ struct yh_context {
   DevBuf    d_nodes, d_prims, d_vpos, d_elems, d_objects, d_materials, d_scene_nodes,
       d_scene_prims, d_light_cdf, d_env_texels, d_light_table, d_env_tab;
   int       stack_need = 0, stack_need8 = 0, stack_need16 = 0;
-  // The 8- and 16-wide node arrays (launch shapes 4, 6, 7) are built and uploaded at their first use (ensure_wide_nodes):
-  // an image that never runs those kernels pays neither the collapses nor the memory. Until then the host keeps the
-  // shapes' binary trees and the object records.
-  bool                     wide_built = false;
-  std::unique_ptr<struct WideBuild> wide_job;  // the collapses of host_trees, started in the background by yh_upload_scene
-  std::vector<yhh::Tree>   host_trees;    // per shape (emptied once the wide arrays exist)
-  std::vector<yhd_object>  host_objects;  // as uploaded; wbox_min[3] / wbox_max[3] = the wide arrays' bases once built
-  std::vector<int>         object_shape;  // shape index of every object
   // the one-lane kernels' copy of the trees (yhd_scene::lane_blob): laid out at upload, filled on the device at the first
   // launch of k_stream / k_intersect_lanes (ensure_lane_blob)
-  struct LaneShape { int kind, node_base, num_nodes, prim_base, num_prims; long long node_off, test_off; };  // offsets in 32-byte units
+  struct LaneShape { int kind, num_nodes, prim_base, num_prims; long long node_off, test_off, node_off8, node_off16; };  // offsets in 32-byte units: the shape's 4- / 8- / 16-wide nodes and its test records
   std::vector<LaneShape>   lane_shapes;
   long long                lane_units = 0;
   DevBuf                   d_lane_blob;
@@ -337,8 +326,6 @@ bool lane_kernels_can_address(const yh_context* ctx);  // launch_plan.cpp: the l
 int stream_geometry(const yh_context* ctx, int num_items, int* slots_per_wave, int* grid_blocks, int* lds_out, bool* single_generation = nullptr);
 void note_stream_wave_log(yh_context* ctx, const unsigned long long* log, size_t waves);
 void deal_items_for_stream(yh_context* ctx, std::vector<int>& items);
-void wide_build_join(yh_context* ctx);
-void wide_build_start(yh_context* ctx);
 int ensure_wide_nodes(yh_context* ctx);
 int ensure_lane_blob(yh_context* ctx);
 int build_bvh_device(yh_context* ctx, const std::vector<yhh::Box>& boxes, yhh::Tree& tree);

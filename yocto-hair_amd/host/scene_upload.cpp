@@ -2,10 +2,20 @@
 // (8- / 16-wide nodes, the lane blob).
 #include "context_internal.h"
 
+#include <atomic>
+
 // The material-only part of eval_hair_brdf (ext.cpp:131-172) plus the
 // per-lobe constants the kernels use (dev_hair.h). Same libm as the reference
 // (this runs on the host), so these values are bit-identical to what the
 // reference recomputes at every hit.
+// a plain device allocation owned by `buf`
+static int dev_alloc(yh_context* ctx, DevBuf& buf, size_t bytes) {
+  buf.reset();
+  HIPCHK(ctx, hipMalloc(&buf.p, std::max<size_t>(bytes, 16)));
+  buf.bytes = std::max<size_t>(bytes, 16);
+  return YH_OK;
+}
+
 void make_material(const yh_material& m, yhd_material& d) {
   memset(&d, 0, sizeof(d));
   memcpy(d.emission, m.emission, 12);
@@ -89,107 +99,132 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
     fprintf(stderr, "[yhair] upload: %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
     t_last = now;
   };
-  // ---- per-shape BVHs and flattened arrays --------------------------------
+  // ---- per-shape BVHs and leaf-ordered records ---------------------------------------------------------------------------
+  // BIG shapes (>= 32 768 primitives: the hair) never leave the device (round 6): their vertex arrays cross PCIe once, as they are, and
+  // bounds, the reference's tree (csrc/bvh_gpu.hip), the leaf-ordered records and — below — the wide collapses are made there. SMALL shapes
+  // (the configs' sphere and lights) are built on the host as before (microseconds) and their trees and records uploaded into the same arrays;
+  // the collapses are the device's for both. YHAIR_BVH=host: every shape the small way.
   struct ShapeInfo {
-    int kind, node_base, prim_base, vert_base, elem_base, has_normals, depth;
-    int node8_base, depth8;  // the same tree collapsed three levels at a time (yhd_scene::nodes8)
-    int node16_base, depth16;  // ... and four (yhd_scene::nodes16)
+    int kind, prim_base, vert_base, elem_base, has_normals, depth;
+    int depth8, depth16;  // depths of the same tree collapsed three / four levels at a time
     yhh::Box root;
-    int num_nodes, num_prims;
+    int num_prims;
+    int num_nodes = 0, levels = 1;   // the binary tree on the device: node count, levels, first node of every level
+    int level_first[130] = {0};
+    int wide_count[3] = {0, 0, 0};   // its 4- / 8- / 16-wide nodes
+    std::vector<yhd_float4> host_prims;  // SMALL shapes: their leaf records on the host too (the LDS light table is made from them)
   };
   std::vector<ShapeInfo>  info(sd->num_shapes);
-  std::vector<yhd_float4> nodes, prims, vpos;
-  wide_build_join(ctx), ctx->wide_job.reset();  // (a previous scene's collapses may still be running on the trees replaced below)
-  ctx->wide_built = false;
-  ctx->host_trees.assign((size_t)sd->num_shapes, yhh::Tree{});
+  std::vector<DevBuf>     d_tree(sd->num_shapes);  // binary nodes per shape (8 floats each), until the collapses are made
+  std::vector<yhd_float4> vpos;
   std::vector<float>      vtex;  // 2 per vertex, zeros for shapes without texture coordinates
   std::vector<yhd_int4>   elems;
-  {  // one allocation per array: growing them shape by shape would re-copy the hair every time
-    size_t np = 0, nv = 0, ne = 0;
-    for (int si = 0; si < sd->num_shapes; si++) {
-      auto& s = sd->shapes[si];
-      bool  lines = s.num_lines > 0;
-      size_t nel = (size_t)std::max(0, lines ? s.num_lines : s.num_triangles);
-      np += nel * (lines ? 4 : 6), nv += (size_t)std::max(0, s.num_vertices), ne += nel;
-    }
-    prims.reserve(np), vpos.reserve(nv), vtex.reserve(2 * nv), elems.reserve(ne), nodes.reserve(ne * 6);
-  }
+  size_t total_prim_f4 = 0;
   for (int si = 0; si < sd->num_shapes; si++) {
     auto& s = sd->shapes[si];
     if (s.num_vertices <= 0 || !s.positions) return fail(ctx, YH_E_INVALID, "shape %d has no vertices", si);
-    bool lines = s.num_lines > 0;
+    const bool lines = s.num_lines > 0;
     if (!lines && s.num_triangles <= 0) return fail(ctx, YH_E_INVALID, "shape %d has no lines or triangles", si);
-    int nel = lines ? s.num_lines : s.num_triangles;
+    const int nel = lines ? s.num_lines : s.num_triangles;
     // a leaf reference packs its first record into 27 bits (host/bvh_build.cpp: count << 27 | start)
     if (nel >= (1 << 27)) return fail(ctx, YH_E_INVALID, "shape %d has %d elements (limit %d)", si, nel, (1 << 27) - 1);
-    const int* idx = lines ? s.lines : s.triangles;
-    for (int k = 0; k < nel * (lines ? 2 : 3); k++)
-      if (idx[k] < 0 || idx[k] >= s.num_vertices) return fail(ctx, YH_E_INVALID, "shape %d: vertex index out of range", si);
-    auto& I       = info[si];
-    I.kind        = lines ? YH_KIND_LINES : YH_KIND_TRIANGLES;
-    I.node_base   = (int)nodes.size() / 8;
-    I.prim_base   = (int)prims.size();
-    I.vert_base   = (int)vpos.size();
-    I.elem_base   = (int)elems.size();
-    I.has_normals = s.normals != nullptr;
-    auto pos = [&](int v) { return ld3(s.positions + 3 * (size_t)v); };
-    auto rad = [&](int v) { return s.radius ? s.radius[v] : 0.001f; };  // add_radius, sceneio.cpp:390
-    std::vector<yhh::Box> boxes(nel);
-    parallel_for(nel, [&](int e) {
-      if (lines) {  // line_bounds (math.h:3037-3040)
-        int a = idx[2 * e], b = idx[2 * e + 1];
-        F3  p0 = pos(a), p1 = pos(b);
-        float r0 = rad(a), r1 = rad(b);
-        float lo0[3] = {p0.x - r0, p0.y - r0, p0.z - r0}, lo1[3] = {p1.x - r1, p1.y - r1, p1.z - r1};
-        float hi0[3] = {p0.x + r0, p0.y + r0, p0.z + r0}, hi1[3] = {p1.x + r1, p1.y + r1, p1.z + r1};
-        for (int k = 0; k < 3; k++) boxes[e].min[k] = fmin_(lo0[k], lo1[k]), boxes[e].max[k] = fmax_(hi0[k], hi1[k]);
-      } else {  // triangle_bounds (math.h:3041-3044)
-        const float* p0 = s.positions + 3 * (size_t)idx[3 * e];
-        const float* p1 = s.positions + 3 * (size_t)idx[3 * e + 1];
-        const float* p2 = s.positions + 3 * (size_t)idx[3 * e + 2];
-        for (int k = 0; k < 3; k++) {
-          boxes[e].min[k] = fmin_(p0[k], fmin_(p1[k], p2[k]));
-          boxes[e].max[k] = fmax_(p0[k], fmax_(p1[k], p2[k]));
-        }
-      }
-    });
-    lap("primitive bounds");
-    yhh::Tree tree;
-    // big shapes: the same tree, built on the device (YHAIR_BVH=host forces the host builder)
-    static const bool host_only = getenv("YHAIR_BVH") && !strcmp(getenv("YHAIR_BVH"), "host");
+    info[si].kind = lines ? YH_KIND_LINES : YH_KIND_TRIANGLES, info[si].num_prims = nel, info[si].has_normals = s.normals != nullptr;
+    info[si].prim_base = (int)total_prim_f4;
+    total_prim_f4 += (size_t)nel * (lines ? 4 : 6);
+  }
+  if (total_prim_f4 > (size_t)std::numeric_limits<int>::max()) return fail(ctx, YH_E_INVALID, "scene too large for 32-bit record offsets (%zu primitive float4)", total_prim_f4);
+  int rc;
+  ctx->d_prims.reset(), ctx->d_nodes.reset(), ctx->d_lane_blob.reset();  // (nothing of this context is running: waited for above)
+  if ((rc = dev_alloc(ctx, ctx->d_prims, total_prim_f4 * 16))) return rc;
+  lap("validation, record array");
+  static const bool host_only = getenv("YHAIR_BVH") && !strcmp(getenv("YHAIR_BVH"), "host");
+  for (int si = 0; si < sd->num_shapes; si++) {
+    auto&      s     = sd->shapes[si];
+    auto&      I     = info[si];
+    const bool lines = I.kind == YH_KIND_LINES;
+    const int  nel   = I.num_prims;
+    const int* idx   = lines ? s.lines : s.triangles;
+    {  // (a parallel pass: 3.2 M indices of a hair model)
+      std::atomic<bool> bad{false};
+      parallel_for(nel * (lines ? 2 : 3), [&](int k) {
+        if (idx[k] < 0 || idx[k] >= s.num_vertices) bad = true;
+      });
+      if (bad) return fail(ctx, YH_E_INVALID, "shape %d: vertex index out of range", si);
+    }
+    I.vert_base = (int)vpos.size(), I.elem_base = (int)elems.size();
+    yhd_float4* d_recs = (yhd_float4*)ctx->d_prims.p + I.prim_base;
     if (nel >= 32768 && !host_only) {
-      int rc = build_bvh_device(ctx, boxes, tree);
-      if (rc) return rc;
+      // ---- on the device ----
+      const size_t nv = (size_t)s.num_vertices;
+      DevBuf d_pos, d_nrm, d_rad, d_idx, d_boxes, d_pid;
+      auto h2d = [&](DevBuf& buf, const void* src, size_t bytes) -> int {
+        if (int arc = dev_alloc(ctx, buf, bytes)) return arc;
+        HIPCHK(ctx, hipMemcpyAsync(buf.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        return YH_OK;
+      };
+      if ((rc = h2d(d_pos, s.positions, nv * 12))) return rc;
+      if (s.radius && (rc = h2d(d_rad, s.radius, nv * 4))) return rc;
+      if ((rc = h2d(d_idx, idx, (size_t)nel * (lines ? 8 : 12)))) return rc;
+      if ((rc = dev_alloc(ctx, d_boxes, (size_t)nel * 24))) return rc;
+      if ((rc = dev_alloc(ctx, d_pid, (size_t)nel * 4))) return rc;
+      if ((rc = dev_alloc(ctx, d_tree[si], ((size_t)2 * nel + 1) * 32))) return rc;
+      int e = yhk_prim_boxes(lines ? 1 : 0, nel, (const float*)d_pos.p, (const float*)d_rad.p, (const int*)d_idx.p, (float*)d_boxes.p, ctx->stream);
+      if (e) return fail(ctx, YH_E_DEVICE, "primitive bounds: %s", hipGetErrorString((hipError_t)e));
+      // (the normals' copy is queued behind the kernels that do not need it: it travels while the tree is built)
+      if (s.normals && (rc = h2d(d_nrm, s.normals, nv * 12))) return rc;
+      e = yhk_bvh_build_resident(nel, (const float*)d_boxes.p, (float*)d_tree[si].p, (int*)d_pid.p, &I.num_nodes, &I.levels, I.level_first, ctx->stream);
+      if (e) return fail(ctx, YH_E_DEVICE, "device BVH build: %s", hipGetErrorString((hipError_t)e));
+      lap("device: bounds + reference tree");
+      e = yhk_leaf_records(lines ? 1 : 0, nel, (const int*)d_pid.p, (const float*)d_pos.p, (const float*)d_nrm.p, (const float*)d_rad.p, (const int*)d_idx.p, d_recs, ctx->stream);
+      if (e) return fail(ctx, YH_E_DEVICE, "leaf records: %s", hipGetErrorString((hipError_t)e));
+      float root8[8];
+      HIPCHK(ctx, hipMemcpyAsync(root8, d_tree[si].p, 32, hipMemcpyDeviceToHost, ctx->stream));
+      YH_WAIT(ctx);  // (the vertex arrays go out of scope)
+      memcpy(I.root.min, root8, 12), memcpy(I.root.max, root8 + 3, 12);
+      lap("device: leaf records");
     } else {
-      yhh::build_bvh(tree, boxes);
-    }
-    lap("build_bvh (reference tree)");
-    std::vector<yhh::WideNode> wide;
-    I.depth = yhh::collapse_wide(tree, wide);
-    lap("collapse to 4-wide");
-    {  // depths of the 8- and 16-wide collapses (built at first use, ensure_wide_nodes): a wide node stands for every
-       // internal binary node at a level that is a multiple of 3 (4), so the wide depth is 1 + deepest internal level / 3 (4)
-      std::vector<int> level(tree.nodes.size(), 0);
-      int deepest = 0;
-      for (size_t n = 0; n < tree.nodes.size(); n++)
-        if (tree.nodes[n].internal) {
-          deepest = std::max(deepest, level[n]);
-          level[(size_t)tree.nodes[n].start] = level[(size_t)tree.nodes[n].start + 1] = level[n] + 1;
+      // ---- on the host (small shapes) ----
+      auto pos = [&](int v) { return ld3(s.positions + 3 * (size_t)v); };
+      auto rad = [&](int v) { return s.radius ? s.radius[v] : 0.001f; };  // add_radius, sceneio.cpp:390
+      std::vector<yhh::Box> boxes(nel);
+      parallel_for(nel, [&](int e) {
+        if (lines) {  // line_bounds (math.h:3037-3040)
+          int a = idx[2 * e], b = idx[2 * e + 1];
+          F3  p0 = pos(a), p1 = pos(b);
+          float r0 = rad(a), r1 = rad(b);
+          float lo0[3] = {p0.x - r0, p0.y - r0, p0.z - r0}, lo1[3] = {p1.x - r1, p1.y - r1, p1.z - r1};
+          float hi0[3] = {p0.x + r0, p0.y + r0, p0.z + r0}, hi1[3] = {p1.x + r1, p1.y + r1, p1.z + r1};
+          for (int k = 0; k < 3; k++) boxes[e].min[k] = fmin_(lo0[k], lo1[k]), boxes[e].max[k] = fmax_(hi0[k], hi1[k]);
+        } else {  // triangle_bounds (math.h:3041-3044)
+          const float* p0 = s.positions + 3 * (size_t)idx[3 * e];
+          const float* p1 = s.positions + 3 * (size_t)idx[3 * e + 1];
+          const float* p2 = s.positions + 3 * (size_t)idx[3 * e + 2];
+          for (int k = 0; k < 3; k++) {
+            boxes[e].min[k] = fmin_(p0[k], fmin_(p1[k], p2[k]));
+            boxes[e].max[k] = fmax_(p0[k], fmax_(p1[k], p2[k]));
+          }
         }
-      I.depth8 = 1 + deepest / 3, I.depth16 = 1 + deepest / 4;
-      I.node8_base = I.node16_base = 0;
-    }
-    I.root = tree.nodes[0].bbox, I.num_nodes = (int)wide.size(), I.num_prims = nel;
-    {
-      size_t at = nodes.size();
-      nodes.resize(at + wide.size() * 8);
-      memcpy(&nodes[at], wide.data(), wide.size() * sizeof(yhh::WideNode));
-    }
-    auto nrm = [&](int v) { return s.normals ? ld3(s.normals + 3 * (size_t)v) : F3{0, 0, 0}; };
-    {  // leaf-ordered records (yh_device.h), filled in parallel
-      const size_t per = lines ? 4 : 6, at = prims.size();
-      prims.resize(at + per * (size_t)nel);
-      yhd_float4* out = prims.data() + at;
+      });
+      yhh::Tree tree;
+      yhh::build_bvh(tree, boxes);
+      // the tree as the device builder leaves it: 8 floats per node (yhh::Node has that layout byte for byte), the first node of every level
+      static_assert(sizeof(yhh::Node) == 32 && offsetof(yhh::Node, start) == 24 && offsetof(yhh::Node, num) == 28 && offsetof(yhh::Node, internal) == 30 && offsetof(yhh::Node, axis) == 31,
+          "yhh::Node is the device's node record");
+      {
+        std::vector<int> level(tree.nodes.size(), 0);
+        for (size_t n = 0; n < tree.nodes.size(); n++)
+          if (tree.nodes[n].internal) level[(size_t)tree.nodes[n].start] = level[(size_t)tree.nodes[n].start + 1] = level[n] + 1;
+        I.num_nodes = (int)tree.nodes.size(), I.levels = level.empty() ? 1 : level.back() + 1;  // (breadth-first numbering: levels are contiguous, the last node is on the last one)
+        if (I.levels > 128) return fail(ctx, YH_E_INVALID, "shape %d: tree of %d levels", si, I.levels);
+        for (int l = 0; l <= I.levels; l++) I.level_first[l] = I.num_nodes;
+        for (size_t n = tree.nodes.size(); n-- > 0;) I.level_first[level[n]] = (int)n;
+      }
+      if ((rc = upload(ctx, d_tree[si], tree.nodes.data(), tree.nodes.size() * 32))) return rc;
+      I.root = tree.nodes[0].bbox;
+      auto nrm = [&](int v) { return s.normals ? ld3(s.normals + 3 * (size_t)v) : F3{0, 0, 0}; };
+      const size_t per = lines ? 4 : 6;
+      I.host_prims.resize(per * (size_t)nel);
+      yhd_float4* out = I.host_prims.data();
       parallel_for(nel, [&](int slot) {
         int   e = tree.primitives[slot];
         float ew;
@@ -207,6 +242,13 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
           r[3] = {n0.x, n0.y, n0.z, 0}, r[4] = {n1.x, n1.y, n1.z, 0}, r[5] = {n2.x, n2.y, n2.z, 0};
         }
       });
+      HIPCHK(ctx, hipMemcpy(d_recs, I.host_prims.data(), I.host_prims.size() * 16, hipMemcpyHostToDevice));
+      lap("host: small shape");
+    }
+    {  // depths of the wide trees: a W-wide node stands for every internal binary node at a level that is a multiple of log2 W, so the wide
+       // depth is 1 + deepest internal level / log2 W (what collapse_wide / _wide8 / _wide16 return). The last level holds leaves only.
+      const int deepest = std::max(0, I.levels - 2);
+      I.depth = 1 + deepest / 2, I.depth8 = 1 + deepest / 3, I.depth16 = 1 + deepest / 4;
     }
     {
       // Per-vertex positions and per-element indices are read on the device only to sample a point
@@ -217,13 +259,14 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
       if (!per_vertex) {
         I.vert_base = 0, I.elem_base = 0;
       } else {
+        auto pos = [&](int v) { return ld3(s.positions + 3 * (size_t)v); };
         const size_t at = vpos.size();
         vpos.resize(at + (size_t)s.num_vertices);
         vtex.resize(2 * (at + (size_t)s.num_vertices), 0.0f);
         if (s.texcoords) memcpy(&vtex[2 * at], s.texcoords, sizeof(float) * 2 * (size_t)s.num_vertices);
         parallel_for(s.num_vertices, [&](int v) {
           F3 p = pos(v);
-          vpos[at + (size_t)v] = {p.x, p.y, p.z, lines ? rad(v) : 0.0f};
+          vpos[at + (size_t)v] = {p.x, p.y, p.z, lines ? (s.radius ? s.radius[v] : 0.001f) : 0.0f};
         });
         const size_t ea = elems.size();
         elems.resize(ea + (size_t)nel);
@@ -233,25 +276,54 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
         });
       }
     }
-    lap("leaf records + vertex arrays");
-    ctx->host_trees[(size_t)si] = std::move(tree);
   }
-  // ---- layout of the one-lane kernels' copy of the trees (yh_device.h: lane_blob): test records first, nodes behind ----
+  // ---- the wide collapses: the index of every wide node (one flag pass + one scan per width), then the layout of the ONE array the traversal
+  // kernels read (yh_device.h: lane_blob, 32-byte units): [test records of every shape][4-wide nodes][8-wide nodes][16-wide nodes] ----
+  std::vector<DevBuf> d_wflag((size_t)sd->num_shapes * 3), d_widx((size_t)sd->num_shapes * 3);
+  for (int si = 0; si < sd->num_shapes; si++)
+    for (int w = 0; w < 3; w++) {
+      auto&  I = info[si];
+      DevBuf &f = d_wflag[(size_t)si * 3 + w], &x = d_widx[(size_t)si * 3 + w];
+      if ((rc = dev_alloc(ctx, f, ((size_t)I.num_nodes + 1) * 4))) return rc;
+      if ((rc = dev_alloc(ctx, x, ((size_t)I.num_nodes + 1) * 4))) return rc;
+      int e = yhk_wide_index(I.num_nodes, (const float*)d_tree[si].p, I.levels, I.level_first, 2 + w, (unsigned int*)f.p, (unsigned int*)x.p, &I.wide_count[w], ctx->stream);
+      if (e) return fail(ctx, YH_E_DEVICE, "wide-node index: %s", hipGetErrorString((hipError_t)e));
+    }
   ctx->lane_shapes.assign((size_t)sd->num_shapes, yh_context::LaneShape{});
+  long long U8 = 0, U16 = 0, blob_units = 0;
   {
     long long at = 0;
     for (int si = 0; si < sd->num_shapes; si++) {
       auto& L = ctx->lane_shapes[(size_t)si];
-      L.kind = info[si].kind, L.node_base = info[si].node_base, L.num_nodes = info[si].num_nodes, L.prim_base = info[si].prim_base, L.num_prims = info[si].num_prims;
+      L.kind = info[si].kind, L.num_nodes = info[si].wide_count[0], L.prim_base = info[si].prim_base, L.num_prims = info[si].num_prims;
       L.test_off = at, at += (long long)L.num_prims * (L.kind == YH_KIND_LINES ? 1 : 2);
     }
     at = (at + 3) / 4 * 4 + 4;  // (nodes on 128-byte lines; four units of slack behind the last test record: a leaf step reads 64 bytes)
     if (at >= (1ll << 27)) return fail(ctx, YH_E_INVALID, "scene too large for 27-bit leaf offsets (%lld test-record units)", at);
-    for (int si = 0; si < sd->num_shapes; si++) ctx->lane_shapes[(size_t)si].node_off = at, at += 4ll * info[si].num_nodes;
-    if (at >= (1ll << 30)) return fail(ctx, YH_E_INVALID, "scene too large for 30-bit node offsets (%lld units)", at);
-    ctx->lane_units = at + 4;
+    for (int si = 0; si < sd->num_shapes; si++) ctx->lane_shapes[(size_t)si].node_off = at, at += 4ll * info[si].wide_count[0];
+    ctx->lane_units = at + 4;  // what the one-lane kernels address (32-bit byte offsets: launch_plan.cpp: lane_kernels_can_address)
+    U8 = (ctx->lane_units + 3) / 4 * 4, at = U8;
+    for (int si = 0; si < sd->num_shapes; si++) ctx->lane_shapes[(size_t)si].node_off8 = at, at += 8ll * info[si].wide_count[1];
+    U16 = at;
+    for (int si = 0; si < sd->num_shapes; si++) ctx->lane_shapes[(size_t)si].node_off16 = at, at += 16ll * info[si].wide_count[2];
+    blob_units = at + 4;
+    if (blob_units >= (1ll << 30)) return fail(ctx, YH_E_INVALID, "scene too large for 30-bit node offsets (%lld units)", blob_units);
+    (void)U16;
   }
-  ctx->d_lane_blob.reset();
+  if ((rc = alloc_zero(ctx, ctx->d_lane_blob, (size_t)blob_units * 32))) return rc;
+  for (int si = 0; si < sd->num_shapes; si++) {
+    auto& L = ctx->lane_shapes[(size_t)si];
+    auto& I = info[si];
+    int e = yhk_lane_blob_shape(nullptr, (const yhd_float4*)ctx->d_prims.p, (yhd_float4*)ctx->d_lane_blob.p, L.kind, 0, 0, L.prim_base, L.num_prims, L.node_off, L.test_off, ctx->stream);
+    const long long offs[3] = {L.node_off, L.node_off8, L.node_off16};
+    for (int w = 0; w < 3 && !e; w++)
+      e = yhk_wide_collapse(2 + w, I.num_nodes, (const float*)d_tree[si].p, (const unsigned int*)d_wflag[(size_t)si * 3 + w].p, (const unsigned int*)d_widx[(size_t)si * 3 + w].p,
+          L.kind == YH_KIND_LINES ? 1 : 0, offs[w], L.test_off, ctx->d_lane_blob.p, ctx->stream);
+    if (e) return fail(ctx, YH_E_DEVICE, "wide collapse: %s", hipGetErrorString((hipError_t)e));
+  }
+  YH_WAIT(ctx);
+  d_tree.clear(), d_wflag.clear(), d_widx.clear();
+  lap("device: wide collapses, blob");
   // ---- objects and the scene-level BVH (pt.cpp:792-814) -------------------
   std::vector<yhd_object> objects(sd->num_objects);
   std::vector<yhh::Box>   obj_boxes(sd->num_objects);
@@ -263,9 +335,10 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
     auto& d = objects[oi];
     memcpy(d.frame, o.frame, 48);
     inverse_frame(o.frame, true, d.inv_frame);
-    d.kind = I.kind, d.node_base = I.node_base, d.prim_base = I.prim_base, d.vert_base = I.vert_base;
+    d.kind = I.kind, d.node_base = 0, d.prim_base = I.prim_base, d.vert_base = I.vert_base;
     d.elem_base = I.elem_base, d.has_normals = I.has_normals, d.material = o.material, d.has_texcoords = sd->shapes[o.shape].texcoords != nullptr;
-    d.lane_root = (int)ctx->lane_shapes[(size_t)o.shape].node_off, d.lane_test = (int)ctx->lane_shapes[(size_t)o.shape].test_off, d.lane_root8 = d.lane_root16 = 0;
+    const auto& LS = ctx->lane_shapes[(size_t)o.shape];
+    d.lane_root = (int)LS.node_off, d.lane_test = (int)LS.test_off, d.lane_root8 = (int)LS.node_off8, d.lane_root16 = (int)LS.node_off16;
     // transform_bbox (math.h:3174-3185)
     const yhh::Box& b = I.root;
     float lo[3] = {std::numeric_limits<float>::max(), std::numeric_limits<float>::max(), std::numeric_limits<float>::max()};
@@ -282,13 +355,11 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
       float ext = fmax_(fmax_(hi[0] - lo[0], hi[1] - lo[1]), hi[2] - lo[2]);
       float eps = 1e-3f * ext + 1e-5f;
       for (int k = 0; k < 3; k++) d.wbox_min[k] = lo[k] - eps, d.wbox_max[k] = hi[k] + eps;
-      d.wbox_min[3] = d.wbox_max[3] = 0;  // (int bits) the shape's first 8- / 16-wide node once those arrays exist (ensure_wide_nodes)
+      d.wbox_min[3] = d.wbox_max[3] = 0;
     }
   }
   // array offsets on the device are 32-bit float4 indices
-  if (prims.size() > (size_t)std::numeric_limits<int>::max() || nodes.size() > (size_t)std::numeric_limits<int>::max() ||
-      vpos.size() > (size_t)std::numeric_limits<int>::max())
-    return fail(ctx, YH_E_INVALID, "scene too large for 32-bit record offsets (%zu primitive, %zu node float4)", prims.size(), nodes.size());
+  if (vpos.size() > (size_t)std::numeric_limits<int>::max()) return fail(ctx, YH_E_INVALID, "scene too large for 32-bit vertex offsets (%zu)", vpos.size());
   yhh::Tree scene_tree;
   yhh::build_bvh(scene_tree, obj_boxes);
   std::vector<yhd_float4> scene_nodes;
@@ -373,7 +444,8 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
   for (int li : small_lights) {
     auto& L  = sc.lights[li];
     auto& I  = info[sd->objects[L.object].shape];
-    const yhd_float4* rec = prims.data() + I.prim_base;
+    if (I.host_prims.empty()) return fail(ctx, YH_E_INVALID, "light %d: a small light's shape was not built on the host", li);  // (cannot happen: <= 4 triangles)
+    const yhd_float4* rec = I.host_prims.data();
     L.small_base = (int)light_table.size();
     yhd_float4 b0{I.root.min[0], I.root.min[1], I.root.min[2], 0}, b1{I.root.max[0], I.root.max[1], I.root.max[2], light_cdf[(size_t)L.cdf_base + L.cdf_count - 1]};
     memcpy(&b0.w, &L.cdf_count, 4);
@@ -439,15 +511,9 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
   }
   lap("objects, materials, lights");
   // ---- upload ------------------------------------------------------------
-  int rc;
-  if ((rc = upload(ctx, ctx->d_nodes, nodes.data(), nodes.size() * 16))) return rc;
-  if ((rc = upload(ctx, ctx->d_prims, prims.data(), prims.size() * 16))) return rc;
   if ((rc = upload(ctx, ctx->d_vpos, vpos.data(), vpos.size() * 16))) return rc;
   if ((rc = upload(ctx, ctx->d_elems, elems.data(), elems.size() * 16))) return rc;
   if ((rc = upload(ctx, ctx->d_objects, objects.data(), objects.size() * sizeof(yhd_object)))) return rc;
-  ctx->host_objects = objects;
-  ctx->object_shape.resize((size_t)sd->num_objects);
-  for (int oi = 0; oi < sd->num_objects; oi++) ctx->object_shape[(size_t)oi] = sd->objects[oi].shape;
   if ((rc = upload(ctx, ctx->d_materials, materials.data(), materials.size() * sizeof(yhd_material)))) return rc;
   if ((rc = upload(ctx, ctx->d_scene_nodes, scene_nodes.data(), scene_nodes.size() * 16))) return rc;
   std::vector<int> scene_prims_padded = scene_tree.primitives;
@@ -461,7 +527,7 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
   if ((rc = upload(ctx, ctx->d_tex_texels, tex_texels.data(), tex_texels.size() * 16))) return rc;
   if ((rc = upload(ctx, ctx->d_vtex, vtex.data(), vtex.size() * 4))) return rc;
   lap("hipMalloc + H2D copies");
-  sc.nodes = (const yhd_float4*)ctx->d_nodes.p, sc.prims = (const yhd_float4*)ctx->d_prims.p;
+  sc.nodes = nullptr, sc.prims = (const yhd_float4*)ctx->d_prims.p;  // (the 4-wide node array of rounds 1-5 exists only inside the lane blob)
   sc.vpos = (const yhd_float4*)ctx->d_vpos.p;
   sc.elems = (const yhd_int4*)ctx->d_elems.p;
   sc.objects = (const yhd_object*)ctx->d_objects.p, sc.materials = (const yhd_material*)ctx->d_materials.p;
@@ -471,15 +537,16 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
   sc.light_table = (const yhd_float4*)ctx->d_light_table.p, sc.light_table_f4 = (int)light_table.size();
   sc.env_tab = (const float*)ctx->d_env_tab.p;
   sc.stack_entries = std::max(8, (ctx->stack_need + 7) / 8 * 8);
-  sc.stack_entries8 = std::max(8, (ctx->stack_need8 + 7) / 8 * 8);  // (the 8- / 16-wide nodes join the lane blob at their first use: ensure_wide_nodes)
+  sc.stack_entries8 = std::max(8, (ctx->stack_need8 + 7) / 8 * 8);
   sc.stack_entries16 = std::max(8, (ctx->stack_need16 + 7) / 8 * 8);
-  sc.lane_blob = nullptr, sc.lane_blob_units = 0;  // made at the end of this function: ensure_lane_blob
+  sc.lane_blob = (const yhd_float4*)ctx->d_lane_blob.p, sc.lane_blob_units = blob_units;
   sc.textures = (const yhd_texture*)ctx->d_textures.p, sc.tex_texels = (const yhd_float4*)ctx->d_tex_texels.p;
   sc.vtex = (const float*)ctx->d_vtex.p;
   memcpy(sc.camera.frame, sd->camera.frame, 48);
   sc.camera.lens = sd->camera.lens, sc.camera.film_x = sd->camera.film[0], sc.camera.film_y = sd->camera.film[1];
   sc.camera.focus = sd->camera.focus, sc.camera.aperture = sd->camera.aperture;
-  sc.num_nodes_total = (int)(nodes.size() / 8), sc.num_prim_f4 = (int)prims.size();
+  sc.num_nodes_total = 0, sc.num_prim_f4 = (int)total_prim_f4;
+  for (auto& I : info) sc.num_nodes_total += I.wide_count[0];
   sc.general_materials = general_materials;
   {  // scene-level LDS table: objects (YH_OBJECT_F4 = 11 float4 each), scene BVH nodes (2 float4 each), primitive ids; up to 10 KB = 46
      // objects (a scene with more runs the GENERAL kernel variants, which read the table from memory)
@@ -522,142 +589,16 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
   ctx->have_costs = false, ctx->costs_settled = false, ctx->dense = -1, ctx->chain = -1, ctx->chain16 = -1;
   for (double& t : ctx->shape_ms) t = 0;
   for (int& t : ctx->shape_trials) t = 0;
-  lap("scene table, fingerprint");
-  wide_build_start(ctx);  // the wide collapses in the background: ready by the time a kernel that needs them is tried
   ctx->trials_from_disk = false;
-  // the kernels over 4-wide nodes — quads and one lane per path alike — read the trees from the lane blob (yh_device.h): made
-  // here, on the device, from the arrays just uploaded (two streaming kernels per shape, about a millisecond)
-  const int brc = ensure_lane_blob(ctx);
-  lap("lane blob (device)");
-  return brc;
-}
-
-void wide_build_join(yh_context* ctx) {
-  if (ctx->wide_job && ctx->wide_job->th.joinable()) ctx->wide_job->th.join();
-}
-void wide_build_start(yh_context* ctx) {  // (ctx->host_trees must stay untouched until wide_build_join)
-  wide_build_join(ctx);
-  ctx->wide_job.reset(new WideBuild());
-  WideBuild*                    job   = ctx->wide_job.get();
-  const std::vector<yhh::Tree>* trees = &ctx->host_trees;
-  const size_t                  ns    = trees->size();
-  job->w8.resize(ns), job->w16.resize(ns), job->d8.assign(ns, 0), job->d16.assign(ns, 0);
-  job->th = std::thread([job, trees, ns] {
-    std::vector<std::thread> pool;
-    for (size_t si = 0; si < ns; si++) {
-      pool.emplace_back([job, trees, si] { job->d8[si] = yhh::collapse_wide8((*trees)[si], job->w8[si]); });
-      pool.emplace_back([job, trees, si] { job->d16[si] = yhh::collapse_wide16((*trees)[si], job->w16[si]); });
-      if (pool.size() >= 8) {
-        for (auto& t : pool) t.join();
-        pool.clear();
-      }
-    }
-    for (auto& t : pool) t.join();
-  });
-}
-// The 8- and 16-wide collapses of the shapes' trees (host/bvh_build.h), built, uploaded and wired into the object records
-// when a kernel that traverses them is about to run for the first time (launch shapes 4, 5, 6, 7).
-int ensure_wide_nodes(yh_context* ctx) {
-  if (ctx->wide_built) return YH_OK;
-  const bool timing = getenv("YHAIR_TIMING") && atoi(getenv("YHAIR_TIMING")) != 0;
-  auto       t_last = std::chrono::steady_clock::now();
-  auto       lap    = [&](const char* what) {
-    if (!timing) return;
-    auto now = std::chrono::steady_clock::now();
-    fprintf(stderr, "[yhair] wide nodes: %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
-    t_last = now;
-  };
-  YH_WAIT(ctx);  // (a queued launch may be reading the object records)
-  if (!ctx->wide_job) wide_build_start(ctx);  // (normally started by yh_upload_scene)
-  wide_build_join(ctx);
-  lap("wait for the collapses");
-  const size_t ns = ctx->host_trees.size();
-  std::vector<std::vector<yhh::WideNode8>>&  w8  = ctx->wide_job->w8;
-  std::vector<std::vector<yhh::WideNode16>>& w16 = ctx->wide_job->w16;
-  std::vector<int>&                          d8 = ctx->wide_job->d8, &d16 = ctx->wide_job->d16;
-  {  // the LDS stacks were sized at upload from the depths these collapses were expected to have
-    int m8 = 0, m16 = 0;
-    for (size_t si = 0; si < ns; si++) m8 = std::max(m8, d8[si]), m16 = std::max(m16, d16[si]);
-    if (7 * m8 > ctx->stack_need8 || 15 * m16 > ctx->stack_need16)
-      return fail(ctx, YH_E_INVALID, "wide trees deeper than their traversal stacks were sized for (%d / %d levels)", m8, m16);
-  }
-  std::vector<int>        base8(ns), base16(ns);
-  std::vector<yhd_float4> nodes8, nodes16;
-  for (size_t si = 0; si < ns; si++) {
-    base8[si] = (int)(nodes8.size() / 16), base16[si] = (int)(nodes16.size() / 32);
-    size_t at = nodes8.size();
-    nodes8.resize(at + w8[si].size() * 16);
-    if (!w8[si].empty()) memcpy(&nodes8[at], w8[si].data(), w8[si].size() * sizeof(yhh::WideNode8));
-    at = nodes16.size();
-    nodes16.resize(at + w16[si].size() * 32);
-    if (!w16[si].empty()) memcpy(&nodes16[at], w16[si].data(), w16[si].size() * sizeof(yhh::WideNode16));
-  }
-  if (nodes8.size() > (size_t)std::numeric_limits<int>::max() || nodes16.size() > (size_t)std::numeric_limits<int>::max())
-    return fail(ctx, YH_E_INVALID, "scene too large for 32-bit wide-node offsets");
-  int rc;
-  {
-    // The wide nodes join the lane blob (yh_device.h) behind what it holds, with ABSOLUTE references: a child node's offset in
-    // the blob (32-byte units: 8 per 8-wide node, 16 per 16-wide one), a leaf's first test record. The blob is made anew with
-    // room for them (device-to-device copy of the old one).
-    const long long U8 = (ctx->lane_units + 3) / 4 * 4, U16 = U8 + (long long)(nodes8.size() / 2), total = U16 + (long long)(nodes16.size() / 2) + 4;
-    if (total >= (1ll << 30)) return fail(ctx, YH_E_INVALID, "scene too large for 30-bit node offsets with its wide nodes (%lld units)", total);
-    auto rewrite = [&](std::vector<yhd_float4>& nodes, const std::vector<int>& base, long long U, int slots) {
-      for (size_t si = 0; si < ns; si++) {
-        const auto&  L   = ctx->lane_shapes[si];
-        const size_t n0  = (size_t)base[si], n1 = si + 1 < ns ? (size_t)base[si + 1] : nodes.size() / (2 * (size_t)slots);
-        for (size_t n = n0; n < n1; n++)
-          for (int q = 0; q < slots; q++) {
-            unsigned ref;
-            memcpy(&ref, &nodes[(n * (size_t)slots + (size_t)q) * 2 + 1].z, 4);
-            if (ref == 0xFFFFFFFFu) continue;
-            if ((ref & 0xC0000000u) == 0xC0000000u) ref = (ref & 0xF8000000u) | (unsigned)(L.test_off + (long long)(ref & 0x07FFFFFFu) * (L.kind == YH_KIND_LINES ? 1 : 2));
-            else ref = (unsigned)(U + (long long)slots * ((long long)base[si] + (long long)ref));
-            memcpy(&nodes[(n * (size_t)slots + (size_t)q) * 2 + 1].z, &ref, 4);
-          }
-      }
-    };
-    lap("concatenate");
-    rewrite(nodes8, base8, U8, 8), rewrite(nodes16, base16, U16, 16);
-    lap("absolute references");
-    DevBuf bigger;
-    if ((rc = alloc_zero(ctx, bigger, (size_t)total * 32))) return rc;
-    HIPCHK(ctx, hipMemcpy(bigger.p, ctx->d_lane_blob.p, (size_t)ctx->lane_units * 32, hipMemcpyDeviceToDevice));
-    if (!nodes8.empty()) HIPCHK(ctx, hipMemcpy((char*)bigger.p + (size_t)U8 * 32, nodes8.data(), nodes8.size() * 16, hipMemcpyHostToDevice));
-    if (!nodes16.empty()) HIPCHK(ctx, hipMemcpy((char*)bigger.p + (size_t)U16 * 32, nodes16.data(), nodes16.size() * 16, hipMemcpyHostToDevice));
-    std::swap(ctx->d_lane_blob.p, bigger.p), std::swap(ctx->d_lane_blob.bytes, bigger.bytes);
-    ctx->scene.lane_blob = (const yhd_float4*)ctx->d_lane_blob.p, ctx->scene.lane_blob_units = total;
-    for (size_t oi = 0; oi < ctx->host_objects.size(); oi++) {
-      const size_t si = (size_t)ctx->object_shape[oi];
-      ctx->host_objects[oi].lane_root8 = (int)(U8 + 8ll * base8[si]), ctx->host_objects[oi].lane_root16 = (int)(U16 + 16ll * base16[si]);
-    }
-  }
-  HIPCHK(ctx, hipMemcpy(ctx->d_objects.p, ctx->host_objects.data(), ctx->host_objects.size() * sizeof(yhd_object), hipMemcpyHostToDevice));
-  lap("bigger blob: malloc + copies");
-  ctx->d_scene_copy.reset();  // (the copy of the scene table in device memory is made again at its next use)
-  ctx->wide_built = true;
-  ctx->wide_job.reset();
-  ctx->host_trees.clear(), ctx->host_trees.shrink_to_fit();
+  lap("scene table, fingerprint");
   return YH_OK;
 }
 
-// The trees as every traversal kernel reads them (yh_device.h: yhd_scene::lane_blob: test records 32 B per segment / 64 B per triangle,
-// then the 4-wide nodes with absolute references), made on the device from the node and primitive arrays at the end of
-// yh_upload_scene; the 4-wide node array it was made from is freed afterwards (no kernel reads it).
-int ensure_lane_blob(yh_context* ctx) {
-  if (ctx->scene.lane_blob) return YH_OK;
-  int rc;
-  if ((rc = alloc_zero(ctx, ctx->d_lane_blob, (size_t)ctx->lane_units * 32))) return rc;
-  for (auto& L : ctx->lane_shapes) {
-    int e = yhk_lane_blob_shape(ctx->scene.nodes, ctx->scene.prims, (yhd_float4*)ctx->d_lane_blob.p, L.kind, L.node_base, L.num_nodes, L.prim_base,
-        L.num_prims, L.node_off, L.test_off, ctx->stream);
-    if (e) return fail(ctx, YH_E_DEVICE, "lane blob build: %s", hipGetErrorString((hipError_t)e));
-  }
-  YH_WAIT(ctx);
-  ctx->scene.lane_blob = (const yhd_float4*)ctx->d_lane_blob.p, ctx->scene.lane_blob_units = ctx->lane_units;
-  ctx->d_nodes.reset(), ctx->scene.nodes = nullptr;
-  ctx->d_scene_copy.reset();  // (the scene table in device memory is made again at its next use)
-  return YH_OK;
-}
+// (Rounds 3-5 made the 8- / 16-wide nodes at the first launch of a kernel that reads them — host collapses in a background thread, their references
+// rewritten and the array re-allocated — and the lane blob at the end of the upload from a 4-wide node array: all of it is made on the device inside
+// yh_upload_scene now, csrc/bvh_gpu.hip; these remain as the places where a launch says what it is about to read.)
+int ensure_wide_nodes(yh_context* ctx) { return ctx->scene.lane_blob ? YH_OK : fail(ctx, YH_E_STATE, "no scene"); }
+int ensure_lane_blob(yh_context* ctx) { return ctx->scene.lane_blob ? YH_OK : fail(ctx, YH_E_STATE, "no scene"); }
 
 // The same tree built on the device (csrc/bvh_gpu.hip): fills `tree` like yhh::build_bvh.
 int build_bvh_device(yh_context* ctx, const std::vector<yhh::Box>& boxes, yhh::Tree& tree) {

@@ -16,6 +16,8 @@
 #include <cstring>
 #include <string>
 
+#include <thread>
+
 #include "yscene_cli.h"
 
 int main(int argc, const char* argv[]) {
@@ -71,6 +73,18 @@ int main(int argc, const char* argv[]) {
     auto secs = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
     double t_last = 0, ph_load, ph_convert, ph_bvh, ph_lights, ph_state, ph_render, ph_download, ph_save;
     auto   lap = [&]() { double now = secs(), d = now - t_last; t_last = now; return d; };
+    // the device contexts in a thread of their own while the scene file is read: creating the first one initialises the HIP runtime (a tenth of a second,
+    // profiles/r06/e2e_laps_before.txt: it used to be the first thing init_state waited for); a failure is reported by the caller that needs them
+    std::thread warm_contexts([] {
+      try {
+        (void)yhair::detail::require_contexts();
+      } catch (...) {
+      }
+    });
+    struct Joiner {
+      std::thread& t;
+      ~Joiner() { if (t.joinable()) t.join(); }
+    } join_warm{warm_contexts};
     auto ioscene = yh_scene_load(filename.c_str(), camera_name.c_str(), error, sizeof(error));
     if (!ioscene) print_fatal(error);
     ph_load = lap();
@@ -81,6 +95,7 @@ int main(int argc, const char* argv[]) {
     yh_scene_free(ioscene);
     ph_convert = lap();
 
+    warm_contexts.join();
     ptr::init_bvh(scene.get(), params);  // flattens the scene graph and uploads it: yh_upload_scene = BVH build + records + copies
     ph_bvh = lap();
     ptr::init_lights(scene.get(), params);

@@ -160,6 +160,7 @@ _SIGS = {
     "yh_bvh_build_gpu": (C.c_int, [C.c_void_p, C.c_int, c_float_p, c_float_p, c_int_p]),
     "yh_bvh_build": (C.c_int, [C.c_int, c_float_p, c_float_p, c_int_p]),
     "yh_bvh_build_wide": (C.c_int, [C.c_int, c_float_p, C.c_int, c_float_p]),
+    "yh_bvh_build_wide_gpu": (C.c_int, [C.c_void_p, C.c_int, c_float_p, C.c_int, c_float_p]),
     "yh_surface_lobe_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_float_p, c_float_p, c_float_p, c_float_p,
                                         c_float_p, c_float_p]),
     "yh_surface_bsdf_batch": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Material), c_float_p, c_float_p, c_float_p,
