@@ -140,6 +140,7 @@ def end_to_end(scene_json, resolution, spp, cpu_rate_msamples):
         env = dict(os.environ, YHAIR_CACHE_DIR=os.path.join(work, "cache"))
         env.pop("YHAIR_NO_DISK_CACHE", None), env.pop("YHAIR_SHAPE", None)
         for key in ("cold_trial_record", "warm_trial_record"):
+            time.sleep(1.0)  # (a process that starts within milliseconds of the end of another GPU process waits ~ 0.15 s in its first HIP call for the driver to finish with the old one: profiles/r06/e2e_laps_after.txt)
             t0 = time.time()
             r = subprocess.run([exe, scene_json, "-r", str(resolution), "-s", str(spp), "-o", os.path.join(work, "out.pfm"), "--timing"], env=env, capture_output=True, text=True, timeout=300)
             wall = time.time() - t0

@@ -7,8 +7,9 @@ and whether the register allocator puts one there changes with unrelated edits o
 Loop membership comes from LLVM's own block annotations ("in Loop: Header=BBn_m Depth=d", "Parent Loop ..."), not
 from the layout: the block placement may put a loop's latch above its header.
 usage: tools/check_codegen.py [--strict] [--loops]
-  --strict: exit 1 when a traversal loop of a product kernel touches scratch, or when k_stream's step makes two dependent memory round trips
-            (a wait between its buffer loads that an earlier one of them has to satisfy)
+  --strict: exit 1 when a traversal loop of a product kernel touches scratch, when k_stream's step makes two dependent memory round trips
+            (a wait between its buffer loads that an earlier one of them has to satisfy), or when an inner loop (>= 100 vector instructions) of the
+            GENERAL k_stream or of an out-of-line device function holds a scratch instruction
   --loops:  list every other loop of >= 100 vector instructions too
   env YH_EXTRA_FLAGS="-D...": look at a developer variant"""
 import os, re, subprocess, sys, tempfile
@@ -115,6 +116,12 @@ def kernels(src):
     for m in re.finditer(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)\n(?:.*\n)*?\s+\.sgpr_spill_count:\s+(\d+)\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)\n(?:.*\n)*?\s+\.vgpr_spill_count:\s+(\d+)", text):
         meta[m.group(1)] = dict(scratch_bytes=int(m.group(2)), sgpr_spills=int(m.group(3)), vgprs=int(m.group(4)), vgpr_spills=int(m.group(5)))
     out = {}
+    # the out-of-line device functions of the file (noinline callees: their loops have a register budget of their own)
+    funcs = {}
+    for m in re.finditer(r"^(_ZN3yhd\w+):\s*; @", text, re.M):
+        end = text.find(".Lfunc_end", m.end())
+        funcs[m.group(1)] = loops_of(text[m.start():end].split("\n"))
+    out["__functions__"] = funcs
     for name, info in meta.items():
         i = text.find("\n" + name + ":")
         if i < 0:
@@ -133,7 +140,9 @@ def kernels(src):
 if __name__ == "__main__":
     bad = 0
     for src, pat in (("kernels.hip", r"k_traceILb0ELb[01]E"), ("wide.hip", r"k_trace_sbsILb[01]E"), ("exact.hip", r"k_trace_exact"), ("stream.hip", r"k_streamILb[01]ELi\dELb0")):
-        for name, k in sorted(kernels(src).items()):
+        ks = kernels(src)
+        funcs = ks.pop("__functions__", {})
+        for name, k in sorted(ks.items()):
             if not re.search(pat, name):
                 continue
             product = ("k_traceILb0ELb0" in name or "k_trace_sbsILb0" in name or "k_streamILb0" in name or "k_trace_exactILb0" in name)  # the plain variants every BASELINE config runs
@@ -155,6 +164,15 @@ if __name__ == "__main__":
                     bad += 1 if product else 0
                 else:
                     print(f"    {k['buffer_loads']} buffer loads of the step in one round trip (no wait between them that an earlier one has to satisfy)")
+            if "k_streamILb1" in name:
+                # the GENERAL k_stream (round 6): no scratch instruction inside any INNER loop of 100 vector instructions or more
+                # (depth >= 2: the stages' loops; the depth-1 loop is the scheduler around the whole kernel, where the stages' few spills live)
+                inner = {h: r for h, r in k["loops"].items() if r["valu"] >= 100 and r["depth"] >= 2}
+                dirty = {h: r["scratch"] for h, r in inner.items() if r["scratch"]}
+                print(f"    {len(inner)} inner loops of >= 100 vector instructions, scratch instructions inside them: {dirty if dirty else 'none'}")
+                if dirty:
+                    print("    <-- the GENERAL k_stream has spill traffic inside a loop again")
+                    bad += 1
             if product and not k["trav"]:
                 print("    no traversal loop found   <-- the heuristic needs a look")
                 bad += 1
@@ -162,4 +180,10 @@ if __name__ == "__main__":
                 for h, r in k["loops"].items():
                     if r["valu"] >= 100 and h not in k["trav"]:
                         print(f"    (loop {h:10s} depth {r['depth']}: {r['valu']:5d} VALU {r['salu']:5d} SALU, {r['scratch']} scratch ops)")
+        for fname, loops in sorted(funcs.items()):  # the noinline callees of this file: every loop of 100 vector instructions or more
+            big = {h: r for h, r in loops.items() if r["valu"] >= 100}
+            dirty = {h: r["scratch"] for h, r in big.items() if r["scratch"]}
+            print(f"{fname[:64]:64s} out of line: {len(big)} loops of >= 100 vector instructions, scratch instructions inside them: {dirty if dirty else 'none'}")
+            if dirty and "lane_trace_exact" not in fname:  # (lane_trace_exact: the compare-and-select form for axis-parallel rays, one ray in millions: known, not on any config's path)
+                bad += 1
     sys.exit(1 if (bad and "--strict" in sys.argv) else 0)

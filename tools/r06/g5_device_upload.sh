@@ -7,7 +7,7 @@ S=$(python3 -c "
 import sys; sys.path.insert(0,'tools'); import make_scenes
 print(make_scenes.ensure_scene('sphere-hairblock','/tmp/yhair_scenes',scale=1.0))" | tail -1)
 export YHAIR_CACHE_DIR=/tmp/yh_e2e_cache; rm -rf $YHAIR_CACHE_DIR
-for k in cold warm warm2; do
+for k in cold warm warm2; do sleep 2
   echo "--- $k" | tee -a $out/e2e_laps.txt
   ( time YHAIR_TIMING=1 yocto-hair_amd/yscenetrace $S -r 720 -s 1536 -o /tmp/out.pfm --timing ) 2>&1 | grep -v amdgpu.ids | tee -a $out/e2e_laps.txt
 done

@@ -148,15 +148,20 @@ YH_DEV hit_t lane_hit(const trace_ctx& tc, hit_t raw, bool hit_lines, float hit_
 YH_DEV hit_t lane_hit_retest(const trace_ctx& tc, hit_t raw, bool hit_lines, f3 ro, f3 rd) {
   if (raw.object >= 0 && hit_lines) {
     frame inv;
+    int   prim_base, lane_test;
     if (tc.lds_scene) {
       const YH_LDS v4f* ob = tc.lds_scene + YH_OBJECT_F4 * raw.object;
       v4f a = ob[3], b = ob[4], c = ob[5];
       inv.x = {a.x, a.y, a.z}, inv.y = {a.w, b.x, b.y}, inv.z = {b.z, b.w, c.x}, inv.o = {c.y, c.z, c.w};
+      prim_base = __float_as_int(ob[6].z), lane_test = __float_as_int(ob[10].y);
     } else {
-      inv = ldframe(tc.sc->objects[raw.object].inv_frame);
+      const yhd_object& o = tc.sc->objects[raw.object];
+      inv = ldframe(o.inv_frame), prim_base = o.prim_base, lane_test = o.lane_test;
     }
     const f3          lo = transform_point(inv, ro), ld = transform_vector(inv, rd);
-    const yhd_float4* a  = tc.sc->lane_blob + 2 * (size_t)raw.slot;
+    // the segment's {p0, r0}{p1, r1} from its LEAF RECORD (yhd_scene::prims: the blob's test record is a copy of these 32 bytes): the shading stage that
+    // follows reads the same record for the tangents (eval_hit), so a shaded hair hit costs one cache line, not one of the blob's and one of the records'
+    const yhd_float4* a  = tc.sc->prims + (size_t)prim_base + 4 * (size_t)(raw.slot - lane_test);
     const v4f         A = ldg4(a), B = ldg4(a + 1);
     float ss, d2, rr, dist;
     (void)intersect_line_raw(lo, ld, dot(ld, ld), ray_eps, flt_max, xyz(A), xyz(B), A.w, B.w, ss, d2, rr, dist);

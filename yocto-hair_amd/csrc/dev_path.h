@@ -457,11 +457,15 @@ YH_DEV bool path_step(const trace_ctx& tc, path_t& ps, const hit_t& isec, rng_t&
   const yhd_scene& sc = *tc.sc;
   unsigned long long k0 = 0, k1 = 0, k2 = 0, k3 = 0;
   if (COUNT) k0 = clock64();
+#if YH_LANE
+  if (isec.object < 0) return false;  // (k_stream's shading stages take hits only: a ray that missed goes to its finish stage, which looks the environment up)
+#else
   if (isec.object < 0) {
     ps.radiance = ps.radiance + ps.weight * eval_environment<COUNT>(tc, ps.ray.d);
     if (COUNT) tc.stats->c_rest += clock64() - k0;
     return false;
   }
+#endif
   f3 outgoing = -ps.ray.d;
   if (GENERAL && ps.in_medium) {
 #if YH_LANE

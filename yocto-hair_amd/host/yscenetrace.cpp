@@ -86,7 +86,10 @@ int main(int argc, const char* argv[]) {
       ~Joiner() { if (t.joinable()) t.join(); }
     } join_warm{warm_contexts};
     auto ioscene = yh_scene_load(filename.c_str(), camera_name.c_str(), error, sizeof(error));
-    if (!ioscene) print_fatal(error);
+    if (!ioscene) {
+      warm_contexts.join();  // (print_fatal exits: never while the other thread is inside the HIP runtime's initialisation)
+      print_fatal(error);
+    }
     ph_load = lap();
     printf("load scene: %.2fs\n", ph_load);
 
