@@ -256,6 +256,42 @@ def test_device_wide_collapses_are_the_host_collapses(ctx, yh, n):
             assert np.array_equal(daxes, haxes)
 
 
+@pytest.mark.parametrize("name,kw", [("lobes", dict(scale=0.05)), ("textured", dict(scale=0.05)), ("hair-curls", dict(scale=0.05)), ("crowd", dict(scale=0.05))],
+                         ids=["lobes", "textured", "hair-curls", "crowd"])
+def test_upload_on_the_device_equals_the_upload_on_the_host(ctx, yh, name, kw, monkeypatch):
+    """Round 6: yh_upload_scene makes a big shape's bounds, tree and leaf records on the device and every shape's wide nodes there (csrc/bvh_gpu.hip).
+    YHAIR_BVH=device sends EVERY shape that way — triangle meshes with and without normals, textured ones, two-triangle lights, instanced hair —
+    and YHAIR_BVH=host none: closest hits (object, element, uv, distance) of 60 000 rays and a 4-spp image must be the same bits either way, for the
+    quad kernels and for the sixteen-lane form (its 16-wide nodes)."""
+    sf = yh.SceneFile(scene_path(name, **kw))
+    rng = np.random.default_rng(5)
+    n = 60000
+    d = rng.normal(size=(n, 3))
+    rays = np.concatenate([rng.uniform(-1.5, 1.5, (n, 3)) + [0, 1.0, 3.0], d / np.linalg.norm(d, axis=1, keepdims=True) * [1, 1, -1],
+                           np.full((n, 1), 1e-4), np.full((n, 1), 3.4e38)], axis=1).astype(np.float32)
+    got = {}
+    for mode in ("host", "device"):
+        monkeypatch.setenv("YHAIR_BVH", mode)
+        ctx.upload_scene(sf.desc)
+        hits = ctx.intersect(rays)
+        imgs = []
+        for shape in ("1", "8"):
+            monkeypatch.setenv("YHAIR_SHAPE", shape)
+            ctx.init_state(yh.TraceParams.default(resolution=64))
+            ctx.trace_samples(4)
+            imgs.append(ctx.download())
+        monkeypatch.delenv("YHAIR_SHAPE")
+        got[mode] = (hits, imgs)
+    monkeypatch.delenv("YHAIR_BVH")
+    assert (got["host"][0][0] >= 0).mean() > 0.02, "the rays should hit something"
+    for a, b in zip(got["host"][0], got["device"][0]):
+        assert np.array_equal(a, b), "closest hits differ between the host-side and the device-side upload"
+    for a, b in zip(got["host"][1], got["device"][1]):
+        assert np.array_equal(a, b), "images differ between the host-side and the device-side upload"
+    assert np.array_equal(got["host"][1][0], got["host"][1][1]), "quads and the sixteen-lane form render different pixels"
+    sf.close()
+
+
 def test_empty_and_invalid_batches(ctx, yh):
     z = np.zeros((0, 3), np.float32)
     assert ctx.hair_eval(np.zeros((0, 30), np.float32), z, z).shape == (0, 3)

@@ -137,7 +137,8 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
   ctx->d_prims.reset(), ctx->d_nodes.reset(), ctx->d_lane_blob.reset();  // (nothing of this context is running: waited for above)
   if ((rc = dev_alloc(ctx, ctx->d_prims, total_prim_f4 * 16))) return rc;
   lap("validation, record array");
-  static const bool host_only = getenv("YHAIR_BVH") && !strcmp(getenv("YHAIR_BVH"), "host");
+  const char* bvh_env   = getenv("YHAIR_BVH");  // developer switch, read per upload: "host" = every shape the small way, "device" = every shape on the device
+  const bool  host_only = bvh_env && !strcmp(bvh_env, "host"), device_all = bvh_env && !strcmp(bvh_env, "device");
   for (int si = 0; si < sd->num_shapes; si++) {
     auto&      s     = sd->shapes[si];
     auto&      I     = info[si];
@@ -153,7 +154,7 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
     }
     I.vert_base = (int)vpos.size(), I.elem_base = (int)elems.size();
     yhd_float4* d_recs = (yhd_float4*)ctx->d_prims.p + I.prim_base;
-    if (nel >= 32768 && !host_only) {
+    if ((nel >= 32768 || device_all) && !host_only) {
       // ---- on the device ----
       const size_t nv = (size_t)s.num_vertices;
       DevBuf d_pos, d_nrm, d_rad, d_idx, d_boxes, d_pid;
@@ -444,7 +445,10 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
   for (int li : small_lights) {
     auto& L  = sc.lights[li];
     auto& I  = info[sd->objects[L.object].shape];
-    if (I.host_prims.empty()) return fail(ctx, YH_E_INVALID, "light %d: a small light's shape was not built on the host", li);  // (cannot happen: <= 4 triangles)
+    if (I.host_prims.empty()) {  // (a shape made on the device — YHAIR_BVH=device: a light of <= 4 triangles is otherwise a small shape): its few records back
+      I.host_prims.resize((size_t)6 * L.cdf_count);
+      HIPCHK(ctx, hipMemcpy(I.host_prims.data(), (const yhd_float4*)ctx->d_prims.p + I.prim_base, I.host_prims.size() * 16, hipMemcpyDeviceToHost));
+    }
     const yhd_float4* rec = I.host_prims.data();
     L.small_base = (int)light_table.size();
     yhd_float4 b0{I.root.min[0], I.root.min[1], I.root.min[2], 0}, b1{I.root.max[0], I.root.max[1], I.root.max[2], light_cdf[(size_t)L.cdf_base + L.cdf_count - 1]};
