@@ -399,7 +399,7 @@ __global__ void k_wide_flags(int num_nodes, const float* nodes, LevelTable lt, i
 }
 // One thread per wide node: its W slots {min.xyz, max.x}{max.yz, ref, axes} at blob + 32 * (node_off + W * index + slot), references ABSOLUTE
 // (a child wide node's first slot in the blob; a leaf = tag | count << 27 | its first test record) as the traversal kernels read them
-// (what csrc/stream.hip: k_lane_nodes and ensure_wide_nodes' host pass made of the host's collapses until round 5). W = 4: bits 8-11 of the
+// (what a device pass over the host's 4-wide collapse and a host pass over its 8- / 16-wide ones made until round 5). W = 4: bits 8-11 of the
 // axes word = the occupied slots (dev_lane.h).
 template <int L>
 __global__ void k_wide_collapse(int num_nodes, const float* nodes, const unsigned int* flag, const unsigned int* widx, int lines,

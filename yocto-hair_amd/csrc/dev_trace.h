@@ -294,7 +294,7 @@ YH_DEV void count_quad(unsigned int& slot) {
 // select form throughout. Results are identical either way; only axis-parallel rays take the
 // second pass.
 // Nodes and leaf test records are read from yhd_scene::lane_blob (yh_device.h: ONE array in 32-byte units with absolute references —
-// the 4-wide nodes, and the 8- / 16-wide ones once ensure_wide_nodes has appended them): one base and one address form for
+// the 4-wide nodes and the 8- / 16-wide ones behind them, all made at yh_upload_scene): one base and one address form for
 // whatever a quad, an octet or a group of sixteen holds. (Until round 4 the kernels read `nodes` / `nodes8` / `nodes16` + `prims`;
 // the A/B halves, the resumable PHASE form, the cache-line touches of pushed children and the quad form over 8-wide nodes are
 // closed experiments: profiles/r05/pruned_experiments.patch holds their code, profiles/r02-r04 their numbers.)

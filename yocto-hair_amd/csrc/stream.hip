@@ -482,9 +482,8 @@ __global__ __launch_bounds__(256, WAVES) void k_intersect_lanes(const yhd_scene 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// The one-lane kernels' copy of a shape's tree (yh_device.h: yhd_scene::lane_blob), made from the arrays the quad kernels
-// read: the ray-test halves of the leaf-ordered primitive records, and the 4-wide nodes with absolute references and a
-// bit per occupied slot. HBM-streaming, one thread per record.
+// The test records of the traversal kernels' array (yh_device.h: yhd_scene::lane_blob): the ray-test halves of the leaf-ordered
+// primitive records, one thread per record, HBM-streaming. (The nodes of that array are written by csrc/bvh_gpu.hip: k_wide_collapse.)
 // ---------------------------------------------------------------------------------------------------------------
 __global__ void k_lane_tests(const yhd_float4* __restrict__ prims, yhd_float4* __restrict__ out, int kind, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -496,34 +495,11 @@ __global__ void k_lane_tests(const yhd_float4* __restrict__ prims, yhd_float4* _
     out[4 * (size_t)i + 3] = yhd_float4{0, 0, 0, 0};
   }
 }
-__global__ void k_lane_nodes(const yhd_float4* __restrict__ nodes, yhd_float4* __restrict__ out, int kind, int n, unsigned int node_off,
-    unsigned int test_off) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  yhd_float4   s[8];
-  unsigned int occupied = 0;
-  for (int k = 0; k < 8; k++) s[k] = nodes[8 * (size_t)i + k];
-  for (int q = 0; q < 4; q++) {
-    unsigned int ref = __float_as_uint(s[2 * q + 1].z);
-    if (ref == YH_NONE) continue;
-    occupied |= 1u << q;
-    if ((ref & YH_TAG_MASK) == YH_TAG_LEAF) ref = (ref & 0xF8000000u) | (test_off + (ref & 0x07FFFFFFu) * (kind == YH_KIND_LINES ? 1u : 2u));
-    else ref = node_off + 4u * ref;  // child wide nodes were shape-local indices
-    s[2 * q + 1].z = __uint_as_float(ref);
-  }
-  for (int q = 0; q < 4; q++) s[2 * q + 1].w = __uint_as_float((__float_as_uint(s[2 * q + 1].w) & 0xFFu) | (occupied << 8));
-  for (int k = 0; k < 8; k++) out[8 * (size_t)i + k] = s[k];
-}
-
 extern "C" {
 
-int yhk_lane_blob_shape(const yhd_float4* nodes, const yhd_float4* prims, yhd_float4* blob, int kind, int node_base, int num_nodes, int prim_base,
-    int num_prims, long long node_off, long long test_off, hipStream_t stream) {
+int yhk_lane_tests(const yhd_float4* prims, yhd_float4* blob, int kind, int prim_base, int num_prims, long long test_off, hipStream_t stream) {
   if (num_prims > 0)
     hipLaunchKernelGGL(k_lane_tests, dim3((num_prims + 255) / 256), dim3(256), 0, stream, prims + prim_base, blob + 2 * test_off, kind, num_prims);
-  if (num_nodes > 0)
-    hipLaunchKernelGGL(k_lane_nodes, dim3((num_nodes + 255) / 256), dim3(256), 0, stream, nodes + 8 * (size_t)node_base, blob + 2 * node_off, kind, num_nodes,
-        (unsigned int)node_off, (unsigned int)test_off);
   return (int)hipGetLastError();
 }
 

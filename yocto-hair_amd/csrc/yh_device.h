@@ -36,7 +36,7 @@ typedef struct yhd_object {
   float frame[12];      // object -> world
   float inv_frame[12];  // inverse(frame, non_rigid = true), pt.cpp:1012-1013
   int   kind;           // YH_KIND_*
-  int   node_base;      // first BVH node of the shape in `nodes`
+  int   node_base;      // (unused since round 6: the trees exist only in lane_blob; kept so that the LDS copy of the record keeps its layout)
   int   prim_base;      // first leaf-ordered record of the shape (float4 units)
   int   vert_base;      // first vertex in vpos / vtex (shapes that need them, host/scene_upload.cpp)
   int   elem_base;      // first element in elems
@@ -50,7 +50,7 @@ typedef struct yhd_object {
   // the shape's place in yhd_scene::lane_blob (the one-lane kernels' copy of the trees, dev_lane.h), in 32-byte units:
   // its root node and its first test record
   int   lane_root, lane_test;
-  int   lane_root8, lane_root16;  // ... and the roots of its 8- / 16-wide trees there, once those exist (ensure_wide_nodes)
+  int   lane_root8, lane_root16;  // ... and the roots of its 8- / 16-wide trees there
 } yhd_object;
 #define YH_OBJECT_F4 11 /* sizeof(yhd_object) / 16 */
 
@@ -133,7 +133,7 @@ typedef struct yhd_camera {
 
 typedef struct yhd_scene {
   // geometry
-  const yhd_float4* nodes;      // 8 float4 per 4-wide node, shape-local references: the source of the lane blob below (freed once that is made: NULL)
+  const yhd_float4* nodes;      // NULL since round 6: the node arrays exist only inside lane_blob (below); the field keeps the struct's layout
   const yhd_float4* prims;      // leaf-ordered records (4 or 6 float4 each)
   const yhd_float4* vpos;       // per vertex {pos, radius}
   const yhd_int4*   elems;      // per element vertex indices (shape-local)
@@ -171,21 +171,19 @@ typedef struct yhd_scene {
   int               env_tab_k, env_tab_stride;
   int               lds_materials;   // materials staged in LDS (all of them, or 0 when they are too many)
   // the same trees with THREE binary levels per node (host/bvh_build.h: WideNode8, 256 B: YH_MODE_OCT, dev_trace.h) and with FOUR
-  // (WideNode16, 512 B: YH_MODE_HEX) live in the lane blob below, behind the 4-wide nodes, once a kernel that reads them is about
-  // to run (host/scene_upload.cpp: ensure_wide_nodes); traversal stack depths per ray over them (up to 7 / 15 pushes per node):
+  // (WideNode16, 512 B: YH_MODE_HEX) live in the lane blob below, behind the 4-wide nodes; traversal stack depths per ray over them
+  // (up to 7 / 15 pushes per node):
   int               stack_entries8;
   int               stack_entries16;
-  // The one-lane kernels' copy of the shape trees (k_stream, k_intersect_lanes; dev_lane.h), ONE array addressed in
-  // 32-byte units so that whatever a lane holds — node or leaf — is fetched from lane_blob + 32 * offset with the same
-  // eight 16-byte loads:
+  // THE TREES AS EVERY TRAVERSAL KERNEL READS THEM: ONE array addressed in 32-byte units, so that whatever a lane, a quad, an octet or a
+  // group of sixteen holds — node or leaf — is fetched from lane_blob + 32 * offset:
   //   test records  a hair segment = 32 B {p0.xyz, r0} {p1.xyz, r1} (the ray-test half of its yhd_scene::prims record),
   //                 a triangle = 64 B {p0}{p1}{p2}{-}; both in the shape's leaf order
-  //   nodes         the 4-wide nodes of yhd_scene::nodes (128 B, same boxes, same axes word + a bit per occupied slot in
-  //                 bits 8-11) with ABSOLUTE references: a child node's offset in the blob, or
-  //                 YH_TAG_LEAF | count << 27 | offset of the leaf's first test record
-  // Built on the device from nodes / prims (host/scene_upload.cpp: ensure_lane_blob, at yh_upload_scene). When the 8- / 16-wide
-  // nodes are made (ensure_wide_nodes) they join the array behind the 4-wide ones (256 / 512 B each, same slot format, absolute
-  // references too), so that the octet and sixteen-lane forms address nodes and leaves like the quad form does.
+  //   nodes         4-wide (128 B: two levels of the reference's binary tree; the axes word + a bit per occupied slot in bits 8-11), then
+  //                 8-wide (256 B, three levels), then 16-wide (512 B, four levels); slot = {min.xyz, max.x}{max.yz, ref, axes};
+  //                 references ABSOLUTE: a child node's first slot in the blob, or YH_TAG_LEAF | count << 27 | the leaf's first test record
+  // Made on the device inside yh_upload_scene (csrc/bvh_gpu.hip: k_wide_collapse; csrc/stream.hip: k_lane_tests) from the binary tree and
+  // the leaf records; the one-lane kernels read the part up to the end of the 4-wide nodes through 32-bit byte offsets.
   const yhd_float4* lane_blob;
   long long         lane_blob_units;
 } yhd_scene;

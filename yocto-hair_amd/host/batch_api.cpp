@@ -249,7 +249,6 @@ int yh_intersect_batch(yh_context* ctx, int n, const float* rays, int* object, i
     auto         dcur        = (int*)s.out(16);
     auto         dovf        = (unsigned int*)s.out((size_t)grid * 4 * ovf_entries * 64 * 4);
     if (s.rc) return s.rc;
-    if (int rcb = ensure_lane_blob(ctx)) return rcb;
     if (!ctx->d_scene_copy.p) {
       int rc = upload(ctx, ctx->d_scene_copy, &ctx->scene, sizeof(yhd_scene));
       if (rc) return rc;

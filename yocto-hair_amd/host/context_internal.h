@@ -52,8 +52,7 @@ int yhk_trace_sbs_occupancy(int lds_bytes, int general);
 int yhk_trace_lds_bytes(const yhd_scene* sc, int shape);
 int yhk_stack_entries(void);
 int yhk_stream(const yhd_scene*, const yhd_scene* sc_dev, const yhd_state*, int, const yhd_stream*, int grid_blocks, hipStream_t);
-int yhk_lane_blob_shape(const yhd_float4* nodes, const yhd_float4* prims, yhd_float4* blob, int kind, int node_base, int num_nodes, int prim_base,
-    int num_prims, long long node_off, long long test_off, hipStream_t);
+int yhk_lane_tests(const yhd_float4* prims, yhd_float4* blob, int kind, int prim_base, int num_prims, long long test_off, hipStream_t);
 int yhk_stream_block_threads(void);
 int yhk_stream_lds_bytes(int tables_f4, int slots_per_wave);
 int yhk_stream_occupancy(int lds_bytes, int general);
@@ -216,11 +215,10 @@ struct yh_context {
   // scene
   bool      have_scene = false;
   yhd_scene scene{};
-  DevBuf    d_nodes, d_prims, d_vpos, d_elems, d_objects, d_materials, d_scene_nodes,
+  DevBuf    d_prims, d_vpos, d_elems, d_objects, d_materials, d_scene_nodes,
       d_scene_prims, d_light_cdf, d_env_texels, d_light_table, d_env_tab;
   int       stack_need = 0, stack_need8 = 0, stack_need16 = 0;
-  // the one-lane kernels' copy of the trees (yhd_scene::lane_blob): laid out at upload, filled on the device at the first
-  // launch of k_stream / k_intersect_lanes (ensure_lane_blob)
+  // where every shape's test records and nodes sit in the traversal kernels' array (yhd_scene::lane_blob), made at yh_upload_scene
   struct LaneShape { int kind, num_nodes, prim_base, num_prims; long long node_off, test_off, node_off8, node_off16; };  // offsets in 32-byte units: the shape's 4- / 8- / 16-wide nodes and its test records
   std::vector<LaneShape>   lane_shapes;
   long long                lane_units = 0;
@@ -326,8 +324,6 @@ bool lane_kernels_can_address(const yh_context* ctx);  // launch_plan.cpp: the l
 int stream_geometry(const yh_context* ctx, int num_items, int* slots_per_wave, int* grid_blocks, int* lds_out, bool* single_generation = nullptr);
 void note_stream_wave_log(yh_context* ctx, const unsigned long long* log, size_t waves);
 void deal_items_for_stream(yh_context* ctx, std::vector<int>& items);
-int ensure_wide_nodes(yh_context* ctx);
-int ensure_lane_blob(yh_context* ctx);
 int build_bvh_device(yh_context* ctx, const std::vector<yhh::Box>& boxes, yhh::Tree& tree);
 int stream_impl(yh_context* ctx, int nsamples, bool sync);
 int trace_impl(yh_context* ctx, int nsamples, bool counted, bool sync);

@@ -1,5 +1,5 @@
-// scene_upload.cpp — yh_upload_scene = init_bvh + init_lights (pt.cpp:755-818,1695-1740) and the arrays made at first use
-// (8- / 16-wide nodes, the lane blob).
+// scene_upload.cpp — yh_upload_scene = init_bvh + init_lights (pt.cpp:755-818,1695-1740): everything a launch reads is made here, big shapes
+// entirely on the device (csrc/bvh_gpu.hip); nothing is deferred to a first launch (rounds 3-5 built the 8- / 16-wide nodes there).
 #include "context_internal.h"
 
 #include <atomic>
@@ -134,7 +134,7 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
   }
   if (total_prim_f4 > (size_t)std::numeric_limits<int>::max()) return fail(ctx, YH_E_INVALID, "scene too large for 32-bit record offsets (%zu primitive float4)", total_prim_f4);
   int rc;
-  ctx->d_prims.reset(), ctx->d_nodes.reset(), ctx->d_lane_blob.reset();  // (nothing of this context is running: waited for above)
+  ctx->d_prims.reset(), ctx->d_lane_blob.reset();  // (nothing of this context is running: waited for above)
   if ((rc = dev_alloc(ctx, ctx->d_prims, total_prim_f4 * 16))) return rc;
   lap("validation, record array");
   const char* bvh_env   = getenv("YHAIR_BVH");  // developer switch, read per upload: "host" = every shape the small way, "device" = every shape on the device
@@ -315,7 +315,7 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
   for (int si = 0; si < sd->num_shapes; si++) {
     auto& L = ctx->lane_shapes[(size_t)si];
     auto& I = info[si];
-    int e = yhk_lane_blob_shape(nullptr, (const yhd_float4*)ctx->d_prims.p, (yhd_float4*)ctx->d_lane_blob.p, L.kind, 0, 0, L.prim_base, L.num_prims, L.node_off, L.test_off, ctx->stream);
+    int e = yhk_lane_tests((const yhd_float4*)ctx->d_prims.p, (yhd_float4*)ctx->d_lane_blob.p, L.kind, L.prim_base, L.num_prims, L.test_off, ctx->stream);
     const long long offs[3] = {L.node_off, L.node_off8, L.node_off16};
     for (int w = 0; w < 3 && !e; w++)
       e = yhk_wide_collapse(2 + w, I.num_nodes, (const float*)d_tree[si].p, (const unsigned int*)d_wflag[(size_t)si * 3 + w].p, (const unsigned int*)d_widx[(size_t)si * 3 + w].p,
@@ -597,12 +597,6 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
   lap("scene table, fingerprint");
   return YH_OK;
 }
-
-// (Rounds 3-5 made the 8- / 16-wide nodes at the first launch of a kernel that reads them — host collapses in a background thread, their references
-// rewritten and the array re-allocated — and the lane blob at the end of the upload from a 4-wide node array: all of it is made on the device inside
-// yh_upload_scene now, csrc/bvh_gpu.hip; these remain as the places where a launch says what it is about to read.)
-int ensure_wide_nodes(yh_context* ctx) { return ctx->scene.lane_blob ? YH_OK : fail(ctx, YH_E_STATE, "no scene"); }
-int ensure_lane_blob(yh_context* ctx) { return ctx->scene.lane_blob ? YH_OK : fail(ctx, YH_E_STATE, "no scene"); }
 
 // The same tree built on the device (csrc/bvh_gpu.hip): fills `tree` like yhh::build_bvh.
 int build_bvh_device(yh_context* ctx, const std::vector<yhh::Box>& boxes, yhh::Tree& tree) {

@@ -198,7 +198,6 @@ int stream_impl(yh_context* ctx, int nsamples, bool sync) {
   }
   ctx->stream_pool.slots_per_wave = P, ctx->stream_pool.ovf_entries = ovf_entries, ctx->stream_pool.total_slots = (long long)ctx->st_slots;
   ctx->stream_pool.suspend_lanes  = one_generation ? 8 : 16;  // (csrc/stream.hip: YH_SUSPEND_LANES)
-  if ((rc = ensure_lane_blob(ctx))) return rc;
   const bool prof = getenv("YHAIR_ST_PROF") && atoi(getenv("YHAIR_ST_PROF")) != 0;  // developer switch: per-stage counters on stderr
   if (prof) {
     if ((rc = alloc_zero(ctx, ctx->d_st_prof, 64 * 8))) return rc;
@@ -357,8 +356,6 @@ int trace_impl(yh_context* ctx, int nsamples, bool counted, bool sync) {
     if (int wrc = wait_for_launch(ctx)) return wrc;
     if (int rc = upload_work_items(ctx)) return rc;
   }
-  if (shape >= 4)
-    if (int rc = ensure_wide_nodes(ctx)) return rc;
   ctx->last_shape = shape, ctx->last_counted = counted, ctx->planned_settled = ctx->costs_settled;
   if (shape == 3) return stream_impl(ctx, nsamples, sync);
   if (shape == 2) return fail(ctx, YH_E_INVALID, "launch shape 2 (quads over 8-wide nodes) was a developer kernel and is not built (profiles/r03/w8_oct_ab.txt)");
