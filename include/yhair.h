@@ -206,10 +206,13 @@ const char* yh_version(void);
  * two-level BVH (reference-identical binary middle-split tree, so that
  * closest-hit results, including exact-t ties, match the reference), the
  * area-light triangle CDFs and the environment texel CDF, precomputes inverse
- * object frames and per-material hair constants, and uploads everything.
+ * object frames and per-material hair constants, and uploads everything. Shapes of 32 768 primitives and more are built ON THE
+ * DEVICE from their vertex arrays as they are (bounds, tree, leaf-ordered records), and every shape's tree is collapsed there into
+ * the 4- / 8- / 16-wide nodes the kernels traverse (csrc/bvh_gpu.hip): the call returns with everything a launch will read in
+ * place (1.6 M hair segments: 41 ms); the host arrays are borrowed for the call only.
  * LIMITS (YH_E_INVALID with a message beyond them): a shape holds fewer than 2^27 elements; the traversal kernels address a
  * scene's trees as one array of 32-byte units with 27-bit leaf references and 30-bit node references — a line segment takes one
- * unit, a triangle two, a 4-wide node four — i.e. about 134 M segments or 67 M triangles in ALL shapes together (instances share
+ * unit, a triangle two, a 4- / 8- / 16-wide node four / eight / sixteen — i.e. about 134 M segments or 67 M triangles in ALL shapes together (instances share
  * their shape); at most 4 environments and 16 lights. Scenes of more than ~46 objects or 24 materials run the GENERAL
  * kernel variants (their tables do not fit the LDS budget): slower, same pixels. The one-lane kernels (the streaming integrator
  * of dense hair, large closest-hit batches) address that array with 32-bit byte offsets: beyond 4 GB of it (about fifty million
