@@ -278,6 +278,42 @@ def valu_block(pmc):
             "source": pmc.get("source")}
 
 
+def summary_scalars(others, projected, parity, e2e):
+    """Every config's value, roofline fraction, parity ratio, CPU rate and 8-GPU projection, and the whole command's wall clock, as ONE flat dict of
+    scalars: what bench.py adds to `config` and repeats as the line's last key `summary` (the driver's record keeps the scalars of
+    the nested objects and the tail of the line — in round 5 two of the four configs' values were in no driver-written record).
+    others: config.other_configs.runs or None; projected: projected_strong_scaling's runs or None; parity: the headline's parity field or None;
+    e2e: config.end_to_end or None. A leg that failed contributes `<config>_error`, a leg that did not run contributes nothing."""
+    flat = {}
+    for oname, r in (others or {}).items():
+        k = oname.lower()
+        if "error" in r:
+            flat[k + "_error"] = str(r["error"])[:100]
+            continue
+        flat[k + "_msamples"], flat[k + "_frac"], flat[k + "_launch_shape"] = r["value"], r["roofline"]["frac"], r["launch_shape"]
+        flat[k + "_launches_in_timed_steps"] = r["launches_in_timed_steps"]
+        if isinstance(r.get("parity"), dict) and "ratio_to_floor" in r["parity"]:
+            flat[k + "_parity_ratio"], flat[k + "_parity_spp"] = r["parity"]["ratio_to_floor"], r["parity"]["spp"]
+            flat[k + "_share_within_4_sigma"] = r["parity"]["share_within_4_sigma"]
+        if isinstance(r.get("cpu_baseline"), dict):
+            flat[k + "_cpu_msamples"] = r["cpu_baseline"]["value"]
+        if isinstance(r.get("projected_8_gpus"), dict) and "seconds" in r["projected_8_gpus"]:
+            flat[k + "_proj8_msamples"], flat[k + "_proj8_shard_s"] = r["projected_8_gpus"]["value_if_every_gpu_takes_this_long"], r["projected_8_gpus"]["seconds"]
+    for r in (projected or []):
+        if "seconds" in r:
+            flat[f"c1_proj{r['n_gpus']}_msamples"], flat[f"c1_proj{r['n_gpus']}_shard_s"] = r["value_if_every_gpu_takes_this_long"], r["seconds"]
+    if parity is not None:
+        flat["c1_parity_ratio"], flat["c1_parity_spp"], flat["c1_share_within_4_sigma"] = parity.get("ratio_to_floor"), parity.get("spp"), parity.get("share_within_4_sigma")
+    if e2e and "warm_trial_record" in e2e:
+        wm = e2e["warm_trial_record"]
+        flat["e2e_warm_total_wall_s"], flat["e2e_warm_msamples_whole_command"] = wm["total_wall_s"], wm["msamples_per_s_whole_command"]
+        flat["e2e_warm_bvh_and_upload_s"], flat["e2e_warm_sample_loop_s"] = wm.get("bvh_and_upload_s"), wm.get("sample_loop_s")
+        flat["e2e_warm_sample_loop_kernel_s"] = wm.get("sample_loop_kernel_s")
+        if "cold_trial_record" in e2e:
+            flat["e2e_cold_total_wall_s"] = e2e["cold_trial_record"]["total_wall_s"]
+    return flat
+
+
 def spawn_ranks(n):
     """Bare `bench.py --gpus N`: N rank processes of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as the
     launcher would set them). The parent never touches the GPU; it waits, ends the others when one fails, and
@@ -758,34 +794,7 @@ def main():
             out["cpu_baseline"] = cpu
         # ---- every config's number as SCALARS of `config` (a record that keeps only scalars of the nested objects still shows all four configs and the
         # 8-GPU projections), and once more as `summary`, the LAST key of the line (a record that keeps only the tail of the line shows them too) -------
-        flat = {}
-        if others:
-            for oname, r in others.items():
-                k = oname.lower()
-                if "error" in r:
-                    flat[k + "_error"] = r["error"][:100]
-                    continue
-                flat[k + "_msamples"], flat[k + "_frac"], flat[k + "_launch_shape"] = r["value"], r["roofline"]["frac"], r["launch_shape"]
-                flat[k + "_launches_in_timed_steps"] = r["launches_in_timed_steps"]
-                if isinstance(r.get("parity"), dict) and "ratio_to_floor" in r["parity"]:
-                    flat[k + "_parity_ratio"], flat[k + "_parity_spp"] = r["parity"]["ratio_to_floor"], r["parity"]["spp"]
-                    flat[k + "_share_within_4_sigma"] = r["parity"]["share_within_4_sigma"]
-                if isinstance(r.get("cpu_baseline"), dict):
-                    flat[k + "_cpu_msamples"] = r["cpu_baseline"]["value"]
-                if isinstance(r.get("projected_8_gpus"), dict) and "seconds" in r["projected_8_gpus"]:
-                    flat[k + "_proj8_msamples"], flat[k + "_proj8_shard_s"] = r["projected_8_gpus"]["value_if_every_gpu_takes_this_long"], r["projected_8_gpus"]["seconds"]
-        for r in (projected or []):
-            if "seconds" in r:
-                flat[f"c1_proj{r['n_gpus']}_msamples"], flat[f"c1_proj{r['n_gpus']}_shard_s"] = r["value_if_every_gpu_takes_this_long"], r["seconds"]
-        if parity is not None:
-            flat["c1_parity_ratio"], flat["c1_parity_spp"], flat["c1_share_within_4_sigma"] = parity.get("ratio_to_floor"), parity.get("spp"), parity.get("share_within_4_sigma")
-        if e2e and "warm_trial_record" in e2e:
-            wm = e2e["warm_trial_record"]
-            flat["e2e_warm_total_wall_s"], flat["e2e_warm_msamples_whole_command"] = wm["total_wall_s"], wm["msamples_per_s_whole_command"]
-            flat["e2e_warm_bvh_and_upload_s"], flat["e2e_warm_sample_loop_s"] = wm.get("bvh_and_upload_s"), wm.get("sample_loop_s")
-            flat["e2e_warm_sample_loop_kernel_s"] = wm.get("sample_loop_kernel_s")
-            if "cold_trial_record" in e2e:
-                flat["e2e_cold_total_wall_s"] = e2e["cold_trial_record"]["total_wall_s"]
+        flat = summary_scalars(others, projected, parity, e2e)
         out["config"].update(flat)
         out["summary"] = dict({"c1_msamples": out["value"], "c1_frac": out["roofline"]["frac"], "c1_launch_shape": shape_used, "n_gpus": world,
                                "c1_cpu_msamples": cpu["value"] if cpu else None}, **flat)

@@ -50,3 +50,48 @@ def test_committed_counter_passes_describe_the_committed_device_code():
     if stale:  # visible, not fatal: the device code was edited after the passes — bench.py then reports `traffic: null, traffic_source: "stale: ..."`
         import pytest
         pytest.xfail(f"counter passes taken on other device code: {stale}; retake with tools/profile_configs.sh + tools/traffic_from_pmc.py")
+
+
+def test_the_lines_scalars_and_summary_carry_every_config():
+    """the driver's record keeps the scalars of `config` and the tail of the line. bench.summary_scalars on the shape of a real
+    line (profiles/r06/bench_C1_driver_flags.json): every config's value / fraction / parity ratio, the 8-GPU projections and the whole command's
+    wall clock come out as scalars; a failed leg is an `_error` string and nothing else of it; a leg that did not run leaves no key; and in the
+    committed line `summary` is the LAST key and fits the few KB a tail keeps."""
+    line = json.loads(open(os.path.join(ROOT, "profiles", "r06", "bench_C1_driver_flags.json")).read().strip().splitlines()[-1])
+    cfg = line["config"]
+    flat = bench.summary_scalars(cfg["other_configs"]["runs"], cfg["projected_strong_scaling"]["runs"], line["parity"], cfg["end_to_end"])
+    for k in ("c2_msamples", "c3_msamples", "c4_msamples", "c2_frac", "c3_frac", "c4_frac", "c2_parity_ratio", "c3_parity_ratio", "c4_parity_ratio",
+              "c1_proj8_msamples", "c3_proj8_msamples", "c4_proj8_msamples", "c1_parity_ratio", "e2e_warm_total_wall_s", "e2e_warm_msamples_whole_command"):
+        assert isinstance(flat[k], (int, float)) and flat[k] > 0, k
+    assert all(not isinstance(v, (dict, list)) for v in flat.values())
+    assert flat["c3_msamples"] == cfg["other_configs"]["runs"]["C3"]["value"] and flat["c1_proj8_msamples"] == cfg["projected_strong_scaling"]["runs"][-1]["value_if_every_gpu_takes_this_long"]
+    # the committed line itself: the scalars are in `config`, `summary` repeats them and closes the line
+    assert list(line)[-1] == "summary" and len(json.dumps(line["summary"])) < 3000
+    for k, v in flat.items():
+        assert cfg[k] == v and line["summary"][k] == v, k
+    # a failed leg, a leg that did not run
+    broken = bench.summary_scalars({"C2": {"error": "x" * 500}, "C3": cfg["other_configs"]["runs"]["C3"]}, [{"error": "boom"}], None, {"error": "no exe"})
+    assert broken["c2_error"] == "x" * 100 and "c2_msamples" not in broken and broken["c3_msamples"] == flat["c3_msamples"]
+    assert not any(k.startswith(("c1_proj", "c1_parity", "e2e_")) for k in broken)
+    assert bench.summary_scalars(None, None, None, None) == {}
+
+
+def test_the_mean_shift_estimator_sees_a_bias_and_not_the_noise():
+    """tools/parity_vs_spp.mean_shift: on synthetic images — independent per-pixel noise around a common mean — the relative shift of
+    the mean radiance is within a few standard errors of zero, its standard error is the noise over sqrt(n), and a 1 % bias on top shows as many SE."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from parity_vs_spp import mean_shift
+    rng = np.random.default_rng(3)
+    truth = rng.uniform(0.2, 1.0, (96, 96, 3))
+    ref = truth + rng.normal(0, 0.05, truth.shape)
+    gpu = truth + rng.normal(0, 0.05, truth.shape)
+    mask = np.ones(truth.shape[:2], bool)
+    mask[:8] = False
+    ms = mean_shift(gpu, ref, mask)
+    assert ms["pixels"] == 88 * 96
+    assert abs(ms["luminance"]["shift_in_se"]) < 3.5 and 3e-4 < ms["luminance"]["se"] < 2e-3
+    biased = mean_shift(gpu * 1.01, ref, mask)
+    assert biased["luminance"]["shift_in_se"] > 8 and abs(biased["luminance"]["rel_shift"] - 0.01) < 3 * biased["luminance"]["se"] + 1e-3
+    for c in "rgb":
+        assert abs(ms[c]["rel_shift"]) < 4 * ms[c]["se"] and biased[c]["rel_shift"] > 5 * biased[c]["se"]
