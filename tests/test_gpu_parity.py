@@ -305,6 +305,41 @@ def test_empty_and_invalid_batches(ctx, yh):
     c2.close()
 
 
+def test_a_failed_upload_leaves_a_context_without_a_scene(yh):
+    """yh_upload_scene replaces the device arrays of the previous scene as it goes (round 6: the records and the trees are made on the device): a call that
+    fails half-way — here a vertex index out of range in the LAST shape, found after the first shapes were built — must leave a context that refuses to
+    render ("before yh_upload_scene"), never one whose scene table points at freed arrays; and a good upload afterwards renders as a fresh context does."""
+    import ctypes as C
+    c = yh.Context(0)
+    sf = yh.SceneFile(scene_path("hair-curls", scale=0.05))
+    c.upload_scene(sf.desc)
+    p = yh.TraceParams.default(resolution=48)
+    c.init_state(p)
+    c.trace_samples(2)
+    want = c.download()
+    d = sf.desc.contents
+    shapes = (yh.Shape * d.num_shapes)(*[d.shapes[i] for i in range(d.num_shapes)])
+    last = shapes[d.num_shapes - 1]
+    tri = last.num_triangles > 0
+    n = (last.num_triangles * 3) if tri else (last.num_lines * 2)
+    idx = np.ctypeslib.as_array(last.triangles if tri else last.lines, shape=(n,)).copy()
+    idx[n // 2] = last.num_vertices  # one past the end
+    if tri:
+        last.triangles = idx.ctypes.data_as(C.POINTER(C.c_int))
+    else:
+        last.lines = idx.ctypes.data_as(C.POINTER(C.c_int))
+    bad = yh.SceneDesc.from_buffer_copy(d)
+    bad.shapes = shapes
+    assert c.lib.yh_upload_scene(c.h, C.byref(bad)) == yh.YH_E_INVALID and b"out of range" in c.lib.yh_last_error(c.h)
+    assert c.lib.yh_trace_samples(c.h, 1) == yh.YH_E_STATE and b"before" in c.lib.yh_last_error(c.h)
+    assert c.lib.yh_init_state(c.h, p) == yh.YH_E_STATE
+    c.upload_scene(sf.desc)
+    c.init_state(p)
+    c.trace_samples(2)
+    assert np.array_equal(c.download(), want)
+    c.close(), sf.close()
+
+
 @pytest.mark.parametrize("which", [0, 1, 2, 3])
 def test_reference_selftests_pass_on_device(ctx, which):
     """white_furnace, white_furnace_sampled, sampling_weights, sampling_consistency

@@ -134,6 +134,10 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
   }
   if (total_prim_f4 > (size_t)std::numeric_limits<int>::max()) return fail(ctx, YH_E_INVALID, "scene too large for 32-bit record offsets (%zu primitive float4)", total_prim_f4);
   int rc;
+  // From here on the previous scene's device arrays are being replaced: a call that fails half-way must leave a context WITHOUT a scene (every launch
+  // then says "before yh_upload_scene"), never one whose scene table points at freed arrays.
+  ctx->have_scene = false, ctx->have_state = false;
+  ctx->scene.lane_blob = nullptr, ctx->scene.prims = nullptr;
   ctx->d_prims.reset(), ctx->d_lane_blob.reset();  // (nothing of this context is running: waited for above)
   if ((rc = dev_alloc(ctx, ctx->d_prims, total_prim_f4 * 16))) return rc;
   lap("validation, record array");
