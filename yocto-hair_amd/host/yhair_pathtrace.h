@@ -302,6 +302,12 @@ inline void set_triangles(shape* s, const std::vector<vec3i>& v) { s->triangles 
 inline void set_positions(shape* s, const std::vector<vec3f>& v) { s->positions = v; }
 inline void set_normals(shape* s, const std::vector<vec3f>& v) { s->normals = v; }
 inline void set_radius(shape* s, const std::vector<float>& v) { s->radius = v; }
+// (the same taking a temporary: the reference's signatures copy; a caller that hands over a vector it no longer needs — a loader — moves it: 60 MB for a hair model)
+inline void set_lines(shape* s, std::vector<vec2i>&& v) { s->lines = std::move(v); }
+inline void set_triangles(shape* s, std::vector<vec3i>&& v) { s->triangles = std::move(v); }
+inline void set_positions(shape* s, std::vector<vec3f>&& v) { s->positions = std::move(v); }
+inline void set_normals(shape* s, std::vector<vec3f>&& v) { s->normals = std::move(v); }
+inline void set_radius(shape* s, std::vector<float>&& v) { s->radius = std::move(v); }
 inline void set_frame(environment* e, const frame3f& f) { e->frame = f; }
 inline void set_emission(environment* e, const vec3f& em, texture* tex = nullptr) { e->emission = em, e->emission_tex = tex; }
 

@@ -66,10 +66,10 @@ inline ptr::camera* init_scene(ptr::scene* scene, const yh_scene_desc* d) {
   for (int i = 0; i < d->num_shapes; i++) {
     auto& s = d->shapes[i];
     auto  o = ptr::add_shape(scene);
-    auto  v3 = [](const float* p, int n) {
-      std::vector<vec3f> v(n);
-      if (n) memcpy(v.data(), p, sizeof(float) * 3 * n);
-      return v;
+    auto  v3 = [](const float* p, int n) {  // (one pass: no zero fill before the copy)
+      static_assert(sizeof(vec3f) == 12, "vec3f is three floats");
+      const vec3f* q = (const vec3f*)p;
+      return std::vector<vec3f>(q, q + n);
     };
     ptr::set_positions(o, v3(s.positions, s.num_vertices));
     if (s.normals) ptr::set_normals(o, v3(s.normals, s.num_vertices));
@@ -79,16 +79,8 @@ inline ptr::camera* init_scene(ptr::scene* scene, const yh_scene_desc* d) {
       memcpy((void*)tc.data(), s.texcoords, sizeof(float) * 2 * (size_t)s.num_vertices);
       ptr::set_texcoords(o, tc);
     }
-    if (s.num_lines) {
-      std::vector<vec2i> l(s.num_lines);
-      memcpy(l.data(), s.lines, sizeof(int) * 2 * s.num_lines);
-      ptr::set_lines(o, l);
-    }
-    if (s.num_triangles) {
-      std::vector<vec3i> t(s.num_triangles);
-      memcpy(t.data(), s.triangles, sizeof(int) * 3 * s.num_triangles);
-      ptr::set_triangles(o, t);
-    }
+    if (s.num_lines) ptr::set_lines(o, std::vector<vec2i>((const vec2i*)s.lines, (const vec2i*)s.lines + s.num_lines));
+    if (s.num_triangles) ptr::set_triangles(o, std::vector<vec3i>((const vec3i*)s.triangles, (const vec3i*)s.triangles + s.num_triangles));
     shapes.push_back(o);
   }
   for (int i = 0; i < d->num_objects; i++) {
