@@ -102,7 +102,7 @@ int yh_upload_scene(yh_context* ctx, const yh_scene_desc* sd) {
   // ---- per-shape BVHs and leaf-ordered records ---------------------------------------------------------------------------
   // BIG shapes (>= 32 768 primitives: the hair) never leave the device (round 6): their vertex arrays cross PCIe once, as they are, and
   // bounds, the reference's tree (csrc/bvh_gpu.hip), the leaf-ordered records and — below — the wide collapses are made there. SMALL shapes
-  // (the configs' sphere and lights) are built on the host as before (microseconds) and their trees and records uploaded into the same arrays;
+  // (the configs' sphere and lights: 10 ms together) are built on the host as before and their trees and records uploaded into the same arrays;
   // the collapses are the device's for both. YHAIR_BVH=host: every shape the small way.
   struct ShapeInfo {
     int kind, prim_base, vert_base, elem_base, has_normals, depth;
